@@ -1,0 +1,197 @@
+/*
+ * cnc_hip.h — C ABI of libcnc_hip.so, the MI355X (gfx950) implementation of the CNC hot path.
+ *
+ * Every entry point replaces one function of the reference's three pybind/torch extensions
+ * (`_gridencoder`, `pack_and_align`, `nerfacc.csrc`); the reference interface each one stands in
+ * for is cited next to it (paths relative to the reference checkout).  The ABI is plain C:
+ * raw DEVICE pointers, sizes and a HIP stream (passed as void*, i.e. a hipStream_t; NULL = the
+ * legacy default stream).  No torch types, no allocation inside the library, no globals: all
+ * calls are re-entrant and stream-ordered (asynchronous; nothing here synchronises the device).
+ *
+ * Ownership: the caller owns every buffer.  Where the reference's host wrapper allocates its
+ * result (torch::zeros / torch::empty inside the extension), the host-side mirror in
+ * cnc_amd/backends/ allocates with torch and passes the pointer down, so the Python-visible
+ * behaviour (callee returns a fresh tensor) is unchanged.
+ *
+ * Return value: CNC_OK (0) or a negative CNC_ERR_* code; cnc_error_string() gives the text the
+ * Python mirror raises as RuntimeError (the reference raises RuntimeError via TORCH_CHECK /
+ * std::runtime_error for the same conditions).
+ *
+ * Arithmetic policy (shared with oracle/): all float math is IEEE fp32 with contraction OFF,
+ * except the handful of sites where nvcc's default -fmad=true fuses a same-type multiply into
+ * the following add; those use an explicit fmaf (listed in DESIGN.md "Arithmetic policy").
+ */
+#ifndef CNC_HIP_H
+#define CNC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNC_OK                 0
+#define CNC_ERR_INVALID_VALUE -1   /* bad size / null pointer / unsupported n_features or num_dim */
+#define CNC_ERR_UNSUPPORTED   -2   /* valid in the reference, not built here (e.g. half tables)  */
+#define CNC_ERR_LAUNCH        -3   /* hipGetLastError() != hipSuccess after the launch           */
+
+/* element type tags for the few polymorphic entry points */
+#define CNC_F32 0
+
+/* flags for cnc_grid_encode_{forward,backward} */
+#define CNC_FLAG_NONE        0u
+#define CNC_FLAG_STE_BINARY  1u   /* treat table value v as (v >= 0 ? +1 : -1) while gathering:
+                                     fuses STE_binary.forward (examples/radiance_fields/ngp.py:22-31)
+                                     into the gather so the 4-7 full-table elementwise passes of the
+                                     reference disappear.  In backward, also applies the STE mask
+                                     |v| <= 1 (ngp.py:33-39) to the scattered gradient.            */
+
+const char* cnc_error_string(int code);
+int         cnc_abi_version(void);              /* bumps when a signature below changes */
+
+/* ------------------------------------------------------------------------------------------
+ * Hash-grid encoder  —  replaces gridencoder/src/gridencoder.h:12-54 (bindings.cpp:5-9)
+ * ---------------------------------------------------------------------------------------- */
+
+/* grid_encode_forward (gridencoder.h:12-22, gridencoder.cu:752-806; kernel_grid :96-396).
+ *   inputs      [N, D] f32 in [0,1]          embeddings [rows, F] f32
+ *   offsets     [L+1] i32 (absolute rows; may be a slice of a longer table, ngp.py:90)
+ *   resolutions [L] i32                      outputs    [L, N, F] f32 (level-major, :131)
+ *   binary_vxl  NULL or bool[Rb^D]           min_level_id NULL or i32 [N] (per-point level window)
+ *   dy_dx       NULL (reference never passes it: ngp.py:58-60,84) — non-NULL => CNC_ERR_UNSUPPORTED
+ *   PV is accepted and ignored, as in the reference (gridencoder.cu:304-308).                  */
+int cnc_grid_encode_forward(const float* inputs, const float* embeddings,
+                            const int32_t* offsets, const int32_t* resolutions,
+                            float* outputs,
+                            uint32_t N, uint32_t D, uint32_t F, uint32_t L,
+                            uint32_t Rb, float PV,
+                            float* dy_dx, const uint8_t* binary_vxl, const int32_t* min_level_id,
+                            uint32_t flags, void* stream);
+
+/* grid_encode_backward (gridencoder.h:24-36, gridencoder.cu:808-866; kernel_grid_backward :399-585).
+ *   grad [L, N, F] f32;  grad_embeddings [rows, F] f32, ACCUMULATED into (caller zero-fills,
+ *   ngp.py:129).  dy_dx / grad_inputs must be NULL (dead path in the reference).               */
+int cnc_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings,
+                             const int32_t* offsets, const int32_t* resolutions,
+                             float* grad_embeddings,
+                             uint32_t N, uint32_t D, uint32_t F, uint32_t L, uint32_t Rb,
+                             const float* dy_dx, float* grad_inputs,
+                             const uint8_t* binary_vxl, const int32_t* min_level_id,
+                             uint32_t flags, void* stream);
+
+/* cnt_np_embed (gridencoder.h:39-44, gridencoder.cu:873-970): ±1 vote counts of the finest 3-D
+ * level projected on a plane.  inputs i16 [N,3]; embeddings_clip [hashmap_size, F] f32;
+ * outputs [res-2, res-2, F, 2] f32, ACCUMULATED into (caller zero-fills, utils_bpp_acc.py:39).
+ * axis 0|1|2 = xy|xz|yz.                                                                       */
+int cnc_cnt_np_embed(const int16_t* inputs, const float* embeddings_clip, float* outputs,
+                     uint32_t N, uint32_t resolution, uint32_t F, uint32_t hashmap_size,
+                     uint32_t axis, void* stream);
+
+/* cnt_np_embed_backward (gridencoder.h:47-54, gridencoder.cu:972-1087).
+ * outputs_sum [res-2,res-2,F,1]; grad [res-2,res-2,F,2]; grad_embeddings accumulated into.     */
+int cnc_cnt_np_embed_backward(const int16_t* inputs, const float* embeddings_clip,
+                              const float* outputs_sum, const float* grad, float* grad_embeddings,
+                              uint32_t N, uint32_t resolution, uint32_t F, uint32_t hashmap_size,
+                              uint32_t axis, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Context-model aligner — replaces my_cuda_backen/aligner.cpp:4-79 (pack_and_align module)
+ * ---------------------------------------------------------------------------------------- */
+
+/* query_mask_3D (aligner.cpp:37-52, aligner_kernel.cu:4-80,161-242,328-367).
+ *   points i16 [N, D] (D = 2 or 3), binary_vxl bool[Rb^D], mask i16 [N], overlap i32 [N].      */
+int cnc_query_mask_3D(const int16_t* points, uint32_t D, const uint8_t* binary_vxl, uint32_t Rb,
+                      int16_t* mask, int32_t* overlap, int32_t resolution, uint32_t N,
+                      void* stream);
+
+/* query_mask_3D_qlist (aligner.cpp:54-71, aligner_kernel.cu:82-158,244-326,370-409):
+ * per-point resolution list i64 [N].                                                           */
+int cnc_query_mask_3D_qlist(const int16_t* points, uint32_t D, const uint8_t* binary_vxl,
+                            uint32_t Rb, int16_t* mask, int32_t* overlap,
+                            const int64_t* resolution_list, uint32_t N, void* stream);
+
+/* align_and_pack_forward (aligner.cpp:4-18, aligner_kernel.cu:413-495): ragged -> padded.
+ *   feat [T, F] f32, cnt i64 [N], cumsum i64 [N+1] -> packed [N, M, F] f32, every element
+ *   written (pad value V); `dim` only selected a launch shape in the reference and is ignored. */
+int cnc_align_and_pack_forward(const float* feat, const int64_t* cnt, const int64_t* cumsum,
+                               float* packed, uint32_t N, uint32_t M, uint32_t F, float V,
+                               void* stream);
+
+/* align_and_pack_backward (aligner.cpp:20-35, aligner_kernel.cu:498-565): dL_packed [N,M,F] ->
+ * dL_feat [T, F]; rows not covered by any (i, j<cnt[i]) keep the caller's zero fill.           */
+int cnc_align_and_pack_backward(const float* dL_packed, const int64_t* cnt, const int64_t* cumsum,
+                                float* dL_feat, uint32_t N, uint32_t M, uint32_t F,
+                                void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Occupancy-grid marcher — replaces nerfacc/cuda/csrc/nerfacc.cpp:41-66 (grid.cu)
+ * ---------------------------------------------------------------------------------------- */
+
+/* ray_aabb_intersect (grid.cu:320-349,513-555; utils_grid.cuh:11-56).
+ *   rays_o, rays_d [n_rays,3]; aabbs [n_aabbs,6] -> t_mins, t_maxs f32 [n_rays,n_aabbs],
+ *   hits bool [n_rays,n_aabbs].                                                                */
+int cnc_ray_aabb_intersect(const float* rays_o, const float* rays_d, const float* aabbs,
+                           int32_t n_rays, int32_t n_aabbs, float near_plane, float far_plane,
+                           float miss_value, float* t_mins, float* t_maxs, uint8_t* hits,
+                           void* stream);
+
+/* One launch of traverse_grids_kernel (grid.cu:68-318).  The reference's host function
+ * (grid.cu:356-510) runs it twice (count, cumsum+alloc, fill) or once with over-allocation; the
+ * allocation/cumsum stays on the host side of this ABI (cnc_amd/backends/nerfacc_cuda.py).
+ * A segment group is "absent" when its chunk_cnts pointer is NULL (compute_intervals /
+ * compute_samples == false).  first_pass != 0: only chunk_cnts are written.                    */
+typedef struct {
+    float*   vals;          /* [n_edges]  */
+    int64_t* chunk_starts;  /* [n_rays]   */
+    int64_t* chunk_cnts;    /* [n_rays]   */
+    int64_t* ray_indices;   /* [n_edges]  */
+    uint8_t* is_left;       /* [n_edges] or NULL */
+    uint8_t* is_right;      /* [n_edges] or NULL */
+    uint8_t* is_valid;      /* [n_edges] or NULL */
+} cnc_ray_segments_t;       /* device-pointer view of RaySegmentsSpec, data_spec.hpp:6-13 */
+
+int cnc_traverse_grids(const float* rays_o, const float* rays_d, const uint8_t* rays_mask,
+                       int32_t n_rays,
+                       const uint8_t* binaries, int32_t n_grids, int32_t resx, int32_t resy,
+                       int32_t resz, const float* aabbs,
+                       const uint8_t* hits, const float* t_sorted, const int64_t* t_indices,
+                       const float* near_planes, const float* far_planes,
+                       float step_size, float cone_angle, int32_t traverse_steps_limit,
+                       int32_t first_pass,
+                       const cnc_ray_segments_t* intervals, const cnc_ray_segments_t* samples,
+                       float* terminate_planes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-ray segmented scans — replaces nerfacc/cuda/csrc/nerfacc.cpp:8-39 (scan.cu)
+ * ---------------------------------------------------------------------------------------- */
+
+/* inclusive_sum / exclusive_sum (scan.cu:9-128).  chunk_starts/cnts i64 [n_rays];
+ * inputs/outputs f32 [n_edges].  backward != 0 scans each chunk right-to-left (scan.cu:42-55). */
+int cnc_inclusive_sum(const int64_t* chunk_starts, const int64_t* chunk_cnts, const float* inputs,
+                      float* outputs, uint32_t n_rays, int64_t n_edges, int32_t normalize,
+                      int32_t backward, void* stream);
+int cnc_exclusive_sum(const int64_t* chunk_starts, const int64_t* chunk_cnts, const float* inputs,
+                      float* outputs, uint32_t n_rays, int64_t n_edges, int32_t normalize,
+                      int32_t backward, void* stream);
+/* inclusive_prod_forward / exclusive_prod_forward (scan.cu:130-170, 224-264). */
+int cnc_inclusive_prod_forward(const int64_t* chunk_starts, const int64_t* chunk_cnts,
+                               const float* inputs, float* outputs, uint32_t n_rays,
+                               int64_t n_edges, void* stream);
+int cnc_exclusive_prod_forward(const int64_t* chunk_starts, const int64_t* chunk_cnts,
+                               const float* inputs, float* outputs, uint32_t n_rays,
+                               int64_t n_edges, void* stream);
+/* inclusive_prod_backward / exclusive_prod_backward (scan.cu:172-222, 266-304):
+ * grad_inputs = reverse-scan-sum(grad_outputs * outputs) / max(inputs, 1e-10).                 */
+int cnc_inclusive_prod_backward(const int64_t* chunk_starts, const int64_t* chunk_cnts,
+                                const float* inputs, const float* outputs,
+                                const float* grad_outputs, float* grad_inputs, uint32_t n_rays,
+                                int64_t n_edges, void* stream);
+int cnc_exclusive_prod_backward(const int64_t* chunk_starts, const int64_t* chunk_cnts,
+                                const float* inputs, const float* outputs,
+                                const float* grad_outputs, float* grad_inputs, uint32_t n_rays,
+                                int64_t n_edges, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNC_HIP_H */
