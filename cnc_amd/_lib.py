@@ -1,0 +1,97 @@
+"""ctypes binding of libcnc_hip.so — the only way the package reaches a kernel.
+
+There is no CPU fallback: if the library is missing or a tensor is not on the GPU the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcnc_hip.so")
+_lib = None
+
+_vp, _u32, _i32, _i64, _f32 = C.c_void_p, C.c_uint32, C.c_int32, C.c_int64, C.c_float
+
+
+class RaySegments(C.Structure):
+    """cnc_ray_segments_t (include/cnc_hip.h)."""
+    _fields_ = [("vals", _vp), ("chunk_starts", _vp), ("chunk_cnts", _vp), ("ray_indices", _vp),
+                ("is_left", _vp), ("is_right", _vp), ("is_valid", _vp)]
+
+
+# name -> argtypes, in the order of include/cnc_hip.h
+SIGNATURES = {
+    "cnc_grid_encode_forward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _u32, _vp],
+    "cnc_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _vp],
+    "cnc_cnt_np_embed": [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp],
+    "cnc_cnt_np_embed_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp],
+    "cnc_query_mask_3D": [_vp, _u32, _vp, _u32, _vp, _vp, _i32, _u32, _vp],
+    "cnc_query_mask_3D_qlist": [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u32, _vp],
+    "cnc_align_and_pack_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp],
+    "cnc_align_and_pack_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp],
+    "cnc_ray_aabb_intersect": [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
+    "cnc_traverse_grids": [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                           _f32, _f32, _i32, _i32, C.POINTER(RaySegments), C.POINTER(RaySegments), _vp, _vp],
+    "cnc_inclusive_sum": [_vp, _vp, _vp, _vp, _u32, _i64, _i32, _i32, _vp],
+    "cnc_exclusive_sum": [_vp, _vp, _vp, _vp, _u32, _i64, _i32, _i32, _vp],
+    "cnc_inclusive_prod_forward": [_vp, _vp, _vp, _vp, _u32, _i64, _vp],
+    "cnc_exclusive_prod_forward": [_vp, _vp, _vp, _vp, _u32, _i64, _vp],
+    "cnc_inclusive_prod_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _i64, _vp],
+    "cnc_exclusive_prod_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _i64, _vp],
+}
+
+CNC_FLAG_STE_BINARY = 1
+
+
+def lib() -> C.CDLL:
+    """Load libcnc_hip.so (built by `python -m cnc_amd.build`); raise if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+                "Build it with `python -m cnc_amd.build`.")
+        L = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        L.cnc_error_string.argtypes = [C.c_int]
+        L.cnc_error_string.restype = C.c_char_p
+        L.cnc_abi_version.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what}: {lib().cnc_error_string(rc).decode()}")
+
+
+def ptr(t):
+    """Device pointer of an optional tensor."""
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# TORCH_CHECK-style argument checks of the reference's host wrappers
+def check_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+
+
+def check_contiguous(t, name):
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+
+
+def check_input(t, name):
+    check_cuda(t, name)
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")

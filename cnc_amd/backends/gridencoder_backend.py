@@ -1,0 +1,128 @@
+"""Drop-in for the reference's `_gridencoder` extension (gridencoder/src/bindings.cpp:5-9).
+
+Same function names, positional arguments and error behaviour as gridencoder/src/gridencoder.h:12-54:
+the caller owns every buffer, results are written in place, nothing is returned, RuntimeError on
+non-CUDA / non-contiguous / wrong-dtype tensors.  Kernels run on the current torch stream.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+from .._lib import check, check_contiguous, check_cuda, ptr, stream
+
+_FLOATING = (torch.float32, torch.float16, torch.float64)
+
+
+def _check_floating(t, name):
+    if t.dtype not in _FLOATING:
+        raise RuntimeError(f"{name} must be a floating tensor")
+
+
+def _check_int(t, name):
+    if t.dtype != torch.int32:
+        raise RuntimeError(f"{name} must be an int tensor")
+
+
+def _require_f32(t, name):
+    # gridencoder.cu:790 also dispatches half/double tables; the CNC drivers never enable
+    # autocast (train_CNC_nerf_synthetic.py:211,362 use GradScaler only), so only fp32 is built.
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: libcnc_hip builds the fp32 path only (got {t.dtype})")
+
+
+def _common_checks(named):
+    for name, t in named:
+        check_cuda(t, name)
+    for name, t in named:
+        check_contiguous(t, name)
+
+
+def grid_encode_forward(inputs, embeddings, offsets_list, resolutions_list, outputs, N, num_dim,
+                        n_features, n_levels, max_level, Rb, PV, dy_dx=None, binary_vxl=None,
+                        min_level_id=None, *, ste_binary=False):
+    _common_checks([("inputs", inputs), ("embeddings", embeddings), ("offsets_list", offsets_list),
+                    ("resolutions_list", resolutions_list), ("outputs", outputs)])
+    _check_floating(inputs, "inputs")
+    _check_floating(embeddings, "embeddings")
+    _check_int(offsets_list, "offsets_list")
+    _check_int(resolutions_list, "resolutions_list")
+    _check_floating(outputs, "outputs")
+    for name, t in (("inputs", inputs), ("embeddings", embeddings), ("outputs", outputs)):
+        _require_f32(t, name)
+    if n_features not in (1, 2, 4, 8, 16, 32):
+        raise RuntimeError("GridEncoding: n_fearures must be 1, 2, 4, 8, 16 or 32.")
+    if num_dim not in (1, 2, 3):
+        raise RuntimeError("GridEncoding: num_dim must be 1, 2, 3.")
+    if binary_vxl is not None:
+        binary_vxl = binary_vxl.contiguous()
+    rc = _lib.lib().cnc_grid_encode_forward(
+        ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list), ptr(outputs),
+        int(N), int(num_dim), int(n_features), int(n_levels), int(Rb), float(PV), ptr(dy_dx),
+        ptr(binary_vxl), ptr(min_level_id), _lib.CNC_FLAG_STE_BINARY if ste_binary else 0, stream())
+    check(rc, "grid_encode_forward")
+
+
+def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_list, grad_embeddings,
+                         N, num_dim, n_features, n_levels, max_level, Rb, dy_dx=None,
+                         grad_inputs=None, binary_vxl=None, min_level_id=None, *, ste_binary=False):
+    _common_checks([("grad", grad), ("inputs", inputs), ("embeddings", embeddings),
+                    ("offsets_list", offsets_list), ("resolutions_list", resolutions_list),
+                    ("grad_embeddings", grad_embeddings)])
+    _check_floating(grad, "grad")
+    _check_floating(inputs, "inputs")
+    _check_floating(embeddings, "embeddings")
+    _check_int(offsets_list, "offsets_list")
+    _check_int(resolutions_list, "resolutions_list")
+    _check_floating(grad_embeddings, "grad_embeddings")
+    for name, t in (("grad", grad), ("inputs", inputs), ("embeddings", embeddings),
+                    ("grad_embeddings", grad_embeddings)):
+        _require_f32(t, name)
+    if n_features not in (1, 2, 4, 8, 16, 32):
+        raise RuntimeError("GridEncoding: n_fearures must be 1, 2, 4, 8, 16 or 32.")
+    if num_dim not in (1, 2, 3):
+        raise RuntimeError("GridEncoding: num_dim must be 1, 2, 3.")
+    if binary_vxl is not None:
+        binary_vxl = binary_vxl.contiguous()
+    rc = _lib.lib().cnc_grid_encode_backward(
+        ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
+        ptr(grad_embeddings), int(N), int(num_dim), int(n_features), int(n_levels), int(Rb),
+        ptr(dy_dx), ptr(grad_inputs), ptr(binary_vxl), ptr(min_level_id),
+        _lib.CNC_FLAG_STE_BINARY if ste_binary else 0, stream())
+    check(rc, "grid_encode_backward")
+
+
+def cnt_np_embed(inputs, embeddings_clip, outputs, N, resolution, n_features, hashmap_size, axis):
+    _common_checks([("inputs", inputs), ("embeddings_clip", embeddings_clip), ("outputs", outputs)])
+    _check_floating(embeddings_clip, "embeddings_clip")
+    _check_floating(outputs, "outputs")
+    if inputs.dtype != torch.int16:
+        raise RuntimeError("expected scalar type Short for inputs")   # data_ptr<short>() mismatch
+    _require_f32(embeddings_clip, "embeddings_clip")
+    _require_f32(outputs, "outputs")
+    if n_features not in (1, 2, 4, 8, 16, 32):
+        raise RuntimeError("GridEncoding: n_features must be 1, 2, 4, 8, 16 or 32.")
+    rc = _lib.lib().cnc_cnt_np_embed(ptr(inputs), ptr(embeddings_clip), ptr(outputs), int(N),
+                                     int(resolution), int(n_features), int(hashmap_size), int(axis),
+                                     stream())
+    check(rc, "cnt_np_embed")
+
+
+def cnt_np_embed_backward(inputs, embeddings_clip, outputs_sum, grad, grad_embeddings, N,
+                          resolution, n_features, hashmap_size, axis):
+    _common_checks([("inputs", inputs), ("embeddings_clip", embeddings_clip),
+                    ("outputs_sum", outputs_sum), ("grad", grad),
+                    ("grad_embeddings", grad_embeddings)])
+    for name, t in (("embeddings_clip", embeddings_clip), ("outputs_sum", outputs_sum),
+                    ("grad", grad), ("grad_embeddings", grad_embeddings)):
+        _check_floating(t, name)
+        _require_f32(t, name)
+    if inputs.dtype != torch.int16:
+        raise RuntimeError("expected scalar type Short for inputs")
+    if n_features not in (1, 2, 4, 8, 16, 32):
+        raise RuntimeError("GridEncoding: n_features must be 1, 2, 4, 8, 16 or 32.")
+    rc = _lib.lib().cnc_cnt_np_embed_backward(ptr(inputs), ptr(embeddings_clip), ptr(outputs_sum),
+                                              ptr(grad), ptr(grad_embeddings), int(N),
+                                              int(resolution), int(n_features), int(hashmap_size),
+                                              int(axis), stream())
+    check(rc, "cnt_np_embed_backward")

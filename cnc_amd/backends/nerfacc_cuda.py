@@ -1,0 +1,218 @@
+"""Drop-in for the reference's `nerfacc.csrc` extension (nerfacc/cuda/csrc/nerfacc.cpp:100-129):
+ray_aabb_intersect, traverse_grids, the six segmented scans and the RaySegmentsSpec record.
+
+The callee allocates and returns tensors on the inputs' device, like the reference's host
+functions; the allocation / cumsum logic of grid.cu:356-510 and data_spec.hpp:53-106 lives here
+(torch ops), the kernels behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from .._lib import RaySegments, check, check_input, ptr, stream
+
+
+class RaySegmentsSpec:
+    """Mirror of RaySegmentsSpec (data_spec.hpp:6-13 / nerfacc.cpp:120-128): undefined tensors
+    read as None from Python."""
+
+    __slots__ = ("vals", "is_left", "is_right", "is_valid", "chunk_starts", "chunk_cnts",
+                 "ray_indices")
+
+    def __init__(self):
+        for k in self.__slots__:
+            setattr(self, k, None)
+
+    # data_spec.hpp:62-84
+    def memalloc_data(self, size, alloc_masks=True, zero_init=True, alloc_valid=False):
+        assert self.chunk_cnts is not None and self.vals is None
+        dev = self.chunk_cnts.device
+        mk = torch.zeros if zero_init else torch.empty
+        self.vals = mk(size, dtype=torch.float32, device=dev)
+        self.ray_indices = mk(size, dtype=torch.int64, device=dev)
+        if alloc_masks:
+            self.is_left = mk(size, dtype=torch.bool, device=dev)
+            self.is_right = mk(size, dtype=torch.bool, device=dev)
+        if alloc_valid:
+            self.is_valid = torch.zeros(size, dtype=torch.bool, device=dev)
+
+    # data_spec.hpp:86-96 (the .item() is the reference's host sync too)
+    def memalloc_data_from_chunk(self, alloc_masks=True, zero_init=True, alloc_valid=False):
+        assert self.chunk_cnts is not None and self.chunk_starts is None
+        cumsum = torch.cumsum(self.chunk_cnts, 0, dtype=self.chunk_cnts.dtype)
+        n_edges = int(cumsum[-1].item()) if cumsum.numel() else 0
+        self.chunk_starts = cumsum - self.chunk_cnts
+        self.memalloc_data(n_edges, alloc_masks, zero_init, alloc_valid)
+
+    # data_spec.hpp:99-106
+    def compute_chunk_start(self):
+        if self.chunk_cnts is None:
+            return
+        cumsum = torch.cumsum(self.chunk_cnts, 0, dtype=self.chunk_cnts.dtype)
+        self.chunk_starts = cumsum - self.chunk_cnts
+
+    def _view(self) -> RaySegments:
+        return RaySegments(ptr(self.vals), ptr(self.chunk_starts), ptr(self.chunk_cnts),
+                           ptr(self.ray_indices), ptr(self.is_left), ptr(self.is_right),
+                           ptr(self.is_valid))
+
+
+def ray_aabb_intersect(rays_o, rays_d, aabbs, near_plane, far_plane, miss_value):
+    n_rays, n_aabbs = rays_o.shape[0], aabbs.shape[0]
+    for name, t in (("rays_o", rays_o), ("rays_d", rays_d), ("aabbs", aabbs)):
+        check_input(t, name)
+    t_mins = torch.empty((n_rays, n_aabbs), dtype=rays_o.dtype, device=rays_o.device)
+    t_maxs = torch.empty((n_rays, n_aabbs), dtype=rays_o.dtype, device=rays_o.device)
+    hits = torch.empty((n_rays, n_aabbs), dtype=torch.bool, device=rays_o.device)
+    rc = _lib.lib().cnc_ray_aabb_intersect(ptr(rays_o), ptr(rays_d), ptr(aabbs), n_rays, n_aabbs,
+                                           float(near_plane), float(far_plane), float(miss_value),
+                                           ptr(t_mins), ptr(t_maxs), ptr(hits), stream())
+    check(rc, "ray_aabb_intersect")
+    return [t_mins, t_maxs, hits]
+
+
+def traverse_grids(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits,
+                   near_planes, far_planes, step_size, cone_angle, compute_intervals,
+                   compute_samples, compute_terminate_planes, traverse_steps_limit, over_allocate):
+    """grid.cu:356-510."""
+    if over_allocate and not traverse_steps_limit > 0:
+        raise RuntimeError("traverse_steps_limit must be > 0 when over_allocate is true")
+    for name, t in (("rays_o", rays_o), ("rays_d", rays_d), ("rays_mask", rays_mask),
+                    ("binaries", binaries), ("aabbs", aabbs), ("t_sorted", t_sorted),
+                    ("t_indices", t_indices), ("hits", hits), ("near_planes", near_planes),
+                    ("far_planes", far_planes)):
+        check_input(t, name)
+    n_rays = rays_o.shape[0]
+    n_grids = binaries.shape[0]
+    dev = rays_o.device
+    L = _lib.lib()
+    intervals, samples = RaySegmentsSpec(), RaySegmentsSpec()
+    terminate_planes = (torch.empty(n_rays, dtype=rays_o.dtype, device=dev)
+                        if compute_terminate_planes else None)
+
+    def launch(mask, first_pass, term):
+        iv, sm = intervals._view(), samples._view()
+        rc = L.cnc_traverse_grids(ptr(rays_o), ptr(rays_d), ptr(mask), n_rays, ptr(binaries),
+                                  n_grids, binaries.shape[1], binaries.shape[2], binaries.shape[3],
+                                  ptr(aabbs), ptr(hits), ptr(t_sorted), ptr(t_indices),
+                                  ptr(near_planes), ptr(far_planes), float(step_size),
+                                  float(cone_angle), int(traverse_steps_limit), int(first_pass),
+                                  C.byref(iv), C.byref(sm), ptr(term), stream())
+        check(rc, "traverse_grids")
+
+    if over_allocate:
+        # single pass into an upper-bound allocation (grid.cu:400-440)
+        if compute_intervals:
+            intervals.chunk_cnts = torch.full((n_rays,), traverse_steps_limit * 2, dtype=torch.int64,
+                                              device=dev) * rays_mask
+            intervals.memalloc_data_from_chunk(True, True)
+        if compute_samples:
+            samples.chunk_cnts = torch.full((n_rays,), traverse_steps_limit, dtype=torch.int64,
+                                            device=dev) * rays_mask
+            samples.memalloc_data_from_chunk(False, True, True)
+        launch(rays_mask, 0, terminate_planes)
+        intervals.compute_chunk_start()
+        samples.compute_chunk_start()
+    else:
+        # count, allocate exactly, fill (grid.cu:441-507); note: rays_mask is NOT applied here
+        if compute_intervals:
+            intervals.chunk_cnts = torch.empty(n_rays, dtype=torch.int64, device=dev)
+        if compute_samples:
+            samples.chunk_cnts = torch.empty(n_rays, dtype=torch.int64, device=dev)
+        launch(None, 1, None)
+        if compute_intervals:
+            intervals.memalloc_data_from_chunk(True, True)
+        if compute_samples:
+            samples.memalloc_data_from_chunk(False, False, True)
+        launch(None, 0, terminate_planes)
+    return intervals, samples, terminate_planes
+
+
+def _scan_checks(chunk_starts, chunk_cnts, inputs):
+    check_input(chunk_starts, "chunk_starts")
+    check_input(chunk_cnts, "chunk_cnts")
+    check_input(inputs, "inputs")
+    if chunk_starts.dim() != 1 or chunk_cnts.dim() != 1 or inputs.dim() != 1 \
+            or chunk_starts.shape[0] != chunk_cnts.shape[0]:
+        raise RuntimeError("Expected 1-D chunk_starts/chunk_cnts of equal length and 1-D inputs")
+
+
+def _sum(fn_name, chunk_starts, chunk_cnts, inputs, normalize, backward):
+    _scan_checks(chunk_starts, chunk_cnts, inputs)
+    outputs = torch.empty_like(inputs)
+    if inputs.shape[0] == 0:
+        return outputs
+    rc = getattr(_lib.lib(), fn_name)(ptr(chunk_starts), ptr(chunk_cnts), ptr(inputs), ptr(outputs),
+                                      chunk_cnts.shape[0], inputs.shape[0], int(bool(normalize)),
+                                      int(bool(backward)), stream())
+    check(rc, fn_name)
+    return outputs
+
+
+def inclusive_sum(chunk_starts, chunk_cnts, inputs, normalize, backward):
+    return _sum("cnc_inclusive_sum", chunk_starts, chunk_cnts, inputs, normalize, backward)
+
+
+def exclusive_sum(chunk_starts, chunk_cnts, inputs, normalize, backward):
+    return _sum("cnc_exclusive_sum", chunk_starts, chunk_cnts, inputs, normalize, backward)
+
+
+def _prod_fwd(fn_name, chunk_starts, chunk_cnts, inputs):
+    _scan_checks(chunk_starts, chunk_cnts, inputs)
+    outputs = torch.empty_like(inputs)
+    if inputs.shape[0] == 0:
+        return outputs
+    rc = getattr(_lib.lib(), fn_name)(ptr(chunk_starts), ptr(chunk_cnts), ptr(inputs), ptr(outputs),
+                                      chunk_cnts.shape[0], inputs.shape[0], stream())
+    check(rc, fn_name)
+    return outputs
+
+
+def inclusive_prod_forward(chunk_starts, chunk_cnts, inputs):
+    return _prod_fwd("cnc_inclusive_prod_forward", chunk_starts, chunk_cnts, inputs)
+
+
+def exclusive_prod_forward(chunk_starts, chunk_cnts, inputs):
+    return _prod_fwd("cnc_exclusive_prod_forward", chunk_starts, chunk_cnts, inputs)
+
+
+def _prod_bwd(fn_name, chunk_starts, chunk_cnts, inputs, outputs, grad_outputs):
+    _scan_checks(chunk_starts, chunk_cnts, inputs)
+    check_input(grad_outputs, "grad_outputs")
+    grad_inputs = torch.empty_like(grad_outputs)
+    if inputs.shape[0] == 0:
+        return grad_inputs
+    rc = getattr(_lib.lib(), fn_name)(ptr(chunk_starts), ptr(chunk_cnts), ptr(inputs),
+                                      ptr(outputs.contiguous()), ptr(grad_outputs),
+                                      ptr(grad_inputs), chunk_cnts.shape[0], inputs.shape[0],
+                                      stream())
+    check(rc, fn_name)
+    return grad_inputs
+
+
+def inclusive_prod_backward(chunk_starts, chunk_cnts, inputs, outputs, grad_outputs):
+    return _prod_bwd("cnc_inclusive_prod_backward", chunk_starts, chunk_cnts, inputs, outputs,
+                     grad_outputs)
+
+
+def exclusive_prod_backward(chunk_starts, chunk_cnts, inputs, outputs, grad_outputs):
+    return _prod_bwd("cnc_exclusive_prod_backward", chunk_starts, chunk_cnts, inputs, outputs,
+                     grad_outputs)
+
+
+def _not_built(name):
+    def f(*a, **k):
+        raise NotImplementedError(
+            f"{name}: outside the CNC hot path (never called by examples/train_CNC_*.py); "
+            "not built in cnc_amd")
+    return f
+
+
+# bound by the reference module but unused by CNC
+importance_sampling = _not_built("importance_sampling")
+searchsorted = _not_built("searchsorted")
+opencv_lens_undistortion = _not_built("opencv_lens_undistortion")
+opencv_lens_undistortion_fisheye = _not_built("opencv_lens_undistortion_fisheye")

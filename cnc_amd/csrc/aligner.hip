@@ -1,0 +1,176 @@
+// aligner.hip — context-model aligner for gfx950: occupancy-box query (mask + overlap volume)
+// and ragged <-> padded packing of per-vertex features by hash slot.
+//
+// Stands in for my_cuda_backen/aligner_kernel.cu (query_mask_3D_kernel_* :4-326,
+// align_and_pack_{forward,backward}_kernel :413-516) behind include/cnc_hip.h.
+//
+// Both are HBM-bound integer/byte kernels:
+//   * query: 6 B in + 6 B out per vertex (+8 B for the per-point resolution list); the 2 MiB
+//     occupancy grid stays resident in L2.  One lane per vertex, outputs written coalesced.
+//   * pack: the padded [N, M, F] tensor is written once with consecutive lanes on consecutive
+//     floats of a row (reference: one thread per element on a (2,128,1) block, i.e. strided).
+#include "common.hpp"
+
+namespace cnc {
+
+template <uint32_t D, bool QLIST>
+__global__ __launch_bounds__(256) void k_query_mask(const int16_t* __restrict__ points,
+                                                    const uint8_t* __restrict__ vxl, uint32_t Rb,
+                                                    int16_t* __restrict__ mask,
+                                                    int32_t* __restrict__ overlap,
+                                                    int32_t resolution,
+                                                    const int64_t* __restrict__ res_list,
+                                                    uint32_t N)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float Rb_re = 1.0f / (float)(int)Rb;
+    const float R = QLIST ? (float)res_list[i] : (float)resolution;
+    const float scale_re = 1.0f / (R - 2.0f);
+
+    float    pn[D];
+    uint32_t lo[D], hi[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++)
+        box_range((float)points[(size_t)i * D + d], scale_re, Rb, lo[d], hi[d], pn[d]);
+
+    bool  m = false;
+    float area = 0;
+    for (uint32_t a = lo[0]; a <= hi[0]; a++) {
+        const float ra = fminf(__builtin_fmaf((float)(int)a, Rb_re, Rb_re), pn[0] + scale_re);
+        const float la = fmaxf((float)(int)a * Rb_re, pn[0] - scale_re);
+        const float oa = ra - la;
+        for (uint32_t b = lo[1]; b <= hi[1]; b++) {
+            const float rb = fminf(__builtin_fmaf((float)(int)b, Rb_re, Rb_re), pn[1] + scale_re);
+            const float lb = fmaxf((float)(int)b * Rb_re, pn[1] - scale_re);
+            const float ob = rb - lb;
+            if constexpr (D == 2) {
+                const bool mt = vxl[a * Rb + b] != 0;
+                m |= mt;
+                if (mt) area = __builtin_fmaf(oa, ob, area);
+            } else {
+                const float oab = oa * ob;
+                for (uint32_t c = lo[2]; c <= hi[2]; c++) {
+                    const float rc = fminf(__builtin_fmaf((float)(int)c, Rb_re, Rb_re), pn[2] + scale_re);
+                    const float lc = fmaxf((float)(int)c * Rb_re, pn[2] - scale_re);
+                    const float oc = rc - lc;
+                    const bool  mt = vxl[(a * Rb + b) * Rb + c] != 0;
+                    m |= mt;
+                    if (mt) area = __builtin_fmaf(oab, oc, area);
+                }
+            }
+        }
+    }
+    const float Rbf = (float)(int)Rb;
+    area = area * Rbf * Rbf;
+    if constexpr (D == 3) area = area * Rbf;
+    mask[i] = (int16_t)m;
+    overlap[i] = (int32_t)(area * 1000);
+}
+
+// packed[i][j][k] = j < cnt[i] ? feat[cumsum[i]+j][k] : V.  One lane per float of the output.
+__global__ __launch_bounds__(256) void k_pack_fwd(const float* __restrict__ feat,
+                                                  const int64_t* __restrict__ cnt,
+                                                  const int64_t* __restrict__ cumsum,
+                                                  float* __restrict__ packed, uint32_t N,
+                                                  uint32_t M, uint32_t F, float V)
+{
+    const uint64_t total = (uint64_t)N * M * F;
+    const uint64_t row_len = (uint64_t)M * F;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i = (uint32_t)(e / row_len);
+        const uint32_t r = (uint32_t)(e - (uint64_t)i * row_len);
+        const uint32_t j = r / F;
+        packed[e] = ((int64_t)(j + 1) > cnt[i]) ? V : feat[(size_t)cumsum[i] * F + r];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack_bwd(const float* __restrict__ dpacked,
+                                                  const int64_t* __restrict__ cnt,
+                                                  const int64_t* __restrict__ cumsum,
+                                                  float* __restrict__ dfeat, uint32_t N,
+                                                  uint32_t M, uint32_t F)
+{
+    const uint64_t total = (uint64_t)N * M * F;
+    const uint64_t row_len = (uint64_t)M * F;
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t i = (uint32_t)(e / row_len);
+        const uint32_t r = (uint32_t)(e - (uint64_t)i * row_len);
+        const uint32_t j = r / F;
+        if ((int64_t)(j + 1) > cnt[i]) continue;
+        dfeat[(size_t)cumsum[i] * F + r] = dpacked[e];
+    }
+}
+
+static uint32_t stream_grid(uint64_t total)
+{
+    const uint64_t want = (total + 255) / 256;
+    const uint64_t cap = 256ull * 16;   // 256 CUs x 16 blocks; grid-stride the rest
+    return (uint32_t)(want < cap ? (want ? want : 1) : cap);
+}
+
+}  // namespace cnc
+
+using namespace cnc;
+
+static int query_mask_impl(const int16_t* points, uint32_t D, const uint8_t* vxl, uint32_t Rb,
+                           int16_t* mask, int32_t* overlap, int32_t resolution,
+                           const int64_t* res_list, uint32_t N, void* stream)
+{
+    if (N == 0) return CNC_OK;
+    if (!points || !vxl || !mask || !overlap || Rb == 0) return CNC_ERR_INVALID_VALUE;
+    const dim3 grid(div_up(N, 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 2) {
+        if (res_list) hipLaunchKernelGGL((k_query_mask<2, true>), grid, block, 0, s, points, vxl, Rb, mask, overlap, resolution, res_list, N);
+        else hipLaunchKernelGGL((k_query_mask<2, false>), grid, block, 0, s, points, vxl, Rb, mask, overlap, resolution, res_list, N);
+    } else if (D == 3) {
+        if (res_list) hipLaunchKernelGGL((k_query_mask<3, true>), grid, block, 0, s, points, vxl, Rb, mask, overlap, resolution, res_list, N);
+        else hipLaunchKernelGGL((k_query_mask<3, false>), grid, block, 0, s, points, vxl, Rb, mask, overlap, resolution, res_list, N);
+    } else {
+        return CNC_ERR_INVALID_VALUE;   // reference: switch (num_dim) has only cases 2 and 3
+    }
+    return launch_status();
+}
+
+extern "C" int cnc_query_mask_3D(const int16_t* points, uint32_t D, const uint8_t* binary_vxl,
+                                 uint32_t Rb, int16_t* mask, int32_t* overlap, int32_t resolution,
+                                 uint32_t N, void* stream)
+{
+    return query_mask_impl(points, D, binary_vxl, Rb, mask, overlap, resolution, nullptr, N, stream);
+}
+
+extern "C" int cnc_query_mask_3D_qlist(const int16_t* points, uint32_t D,
+                                       const uint8_t* binary_vxl, uint32_t Rb, int16_t* mask,
+                                       int32_t* overlap, const int64_t* resolution_list,
+                                       uint32_t N, void* stream)
+{
+    if (N != 0 && !resolution_list) return CNC_ERR_INVALID_VALUE;
+    return query_mask_impl(points, D, binary_vxl, Rb, mask, overlap, 0, resolution_list, N, stream);
+}
+
+extern "C" int cnc_align_and_pack_forward(const float* feat, const int64_t* cnt,
+                                          const int64_t* cumsum, float* packed, uint32_t N,
+                                          uint32_t M, uint32_t F, float V, void* stream)
+{
+    const uint64_t total = (uint64_t)N * M * F;
+    if (total == 0) return CNC_OK;
+    if (!feat || !cnt || !cumsum || !packed) return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_pack_fwd, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       feat, cnt, cumsum, packed, N, M, F, V);
+    return launch_status();
+}
+
+extern "C" int cnc_align_and_pack_backward(const float* dL_packed, const int64_t* cnt,
+                                           const int64_t* cumsum, float* dL_feat, uint32_t N,
+                                           uint32_t M, uint32_t F, void* stream)
+{
+    const uint64_t total = (uint64_t)N * M * F;
+    if (total == 0) return CNC_OK;
+    if (!dL_packed || !cnt || !cumsum || !dL_feat) return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_pack_bwd, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       dL_packed, cnt, cumsum, dL_feat, N, M, F);
+    return launch_status();
+}

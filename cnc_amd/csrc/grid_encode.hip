@@ -1,0 +1,588 @@
+// grid_encode.hip — multiresolution hash-grid encoder for gfx950 (MI355X).
+//
+// Stands in for gridencoder/src/gridencoder.cu of the reference (kernel_grid :96-396,
+// kernel_grid_backward :399-585, cnt_np_embed{,_backward} :873-1087) behind the C ABI of
+// include/cnc_hip.h.  Design notes:
+//   * A table row is F floats.  A row is fetched by G = F/V adjacent lanes, V = min(F,4) floats
+//     (<= 16 B, one global_load_dwordx4) per lane, so one wave-instruction touches 64/G rows and
+//     the G lanes of a row land in one 16B-aligned span of a single cache line.  No lane ever
+//     needs another lane's data: each lane owns V output features for all 2^D corners.
+//   * Level-major launch (blockIdx.y = level slot) as in the reference, so at any moment the chip
+//     is gathering from one level's table (<= 16 MiB at T=2^19, F=8): coarse levels live in L2,
+//     fine ones in the 256 MiB Infinity Cache.  outputs are [L, N, F]: a wave stores 1 KiB
+//     contiguous.
+//   * All 2^D row addresses are formed first, then all gathers are issued back-to-back (8
+//     independent dwordx4 loads in flight per lane), then the weighted sum runs in the
+//     reference's corner order so results are bit-identical to the CPU oracle.
+//   * Optional STE fusion (CNC_FLAG_STE_BINARY): sign() is applied to the gathered values, which
+//     removes the reference's separate full-table STE_binary passes (ngp.py:22-39,244-245).
+#include "common.hpp"
+
+namespace cnc {
+
+template <uint32_t V> struct vecf;
+template <> struct vecf<1> { using type = float; };
+template <> struct vecf<2> { using type = float2; };
+template <> struct vecf<4> { using type = float4; };
+
+template <uint32_t V>
+__device__ __forceinline__ void load_vec(const float* __restrict__ p, float (&v)[V])
+{
+    using T = typename vecf<V>::type;
+    T t = *reinterpret_cast<const T*>(p);
+    const float* f = reinterpret_cast<const float*>(&t);
+#pragma unroll
+    for (uint32_t i = 0; i < V; i++) v[i] = f[i];
+}
+
+template <uint32_t V>
+__device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&v)[V])
+{
+    using T = typename vecf<V>::type;
+    T t;
+    float* f = reinterpret_cast<float*>(&t);
+#pragma unroll
+    for (uint32_t i = 0; i < V; i++) f[i] = v[i];
+    *reinterpret_cast<T*>(p) = t;
+}
+
+// Corner set-up for one (point, level): weights, validity and row indices.
+// Mirrors gridencoder.cu:166-291 (forward) / :443-562 (backward).
+template <uint32_t D, bool VXL>
+struct Corners {
+    static constexpr uint32_t C = 1u << D;
+    float    w[C];
+    uint32_t row[C];
+    bool     valid[C];
+    float    wn_re;
+
+    __device__ __forceinline__ void setup(const float (&x)[D], uint32_t R, uint32_t hs,
+                                          uint32_t Rb, const uint8_t* __restrict__ vxl)
+    {
+        float    pos[D];
+        uint32_t g[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            float p = x[d] * (float)(R - 2);   // float*float, rounded
+            p = p + 0.5f;                      // == (float)((double)p + 0.5)
+            const float fl = floorf(p);
+            g[d] = (uint32_t)fl;
+            pos[d] = p - fl;
+        }
+        float wn = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < C; i++) {
+            float    wi = 1;
+            uint32_t q[D];
+            bool     border = false;
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                if ((i & (1u << d)) == 0) {
+                    wi *= 1 - pos[d];
+                    q[d] = g[d];
+                } else {
+                    wi *= pos[d];
+                    q[d] = min(g[d] + 1, R - 1);
+                }
+                border |= (q[d] == 0) | (q[d] == R - 1);
+            }
+            bool ok = !border;
+            if constexpr (VXL) {
+                // the reference evaluates the box for every corner; its result only matters
+                // for non-border ones, so skip the (expensive) scan otherwise
+                if (ok) ok = box_any<D>(q, R, Rb, vxl);
+            }
+            w[i] = wi;
+            valid[i] = ok;
+            row[i] = ok ? grid_row<D>(q, hs, R) : 0u;
+            wn += ok ? wi : 0.0f;
+        }
+        if (wn == 0) wn = 1e-9f;   // (float)(0.0 + 1e-9)
+        wn_re = 1.0f / wn;         // == (float)(1.0 / (double)wn)
+    }
+};
+
+template <uint32_t D>
+__device__ __forceinline__ bool load_point(const float* __restrict__ inputs, uint32_t b,
+                                           float (&x)[D])
+{
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        x[d] = inputs[(size_t)b * D + d];
+        oob |= (x[d] < 0) | (x[d] > 1);
+    }
+    return !oob;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <uint32_t D, uint32_t F, bool VXL, bool STE>
+__global__ __launch_bounds__(256) void k_grid_encode_fwd(
+    const float* __restrict__ inputs, const float* __restrict__ emb,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
+    float* __restrict__ out, uint32_t N, uint32_t Rb, const uint8_t* __restrict__ vxl,
+    const int32_t* __restrict__ min_level_id)
+{
+    constexpr uint32_t V = F < 4 ? F : 4;
+    constexpr uint32_t G = F / V;
+    constexpr uint32_t C = 1u << D;
+
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = t / G;
+    const uint32_t h = t % G;
+    if (b >= N) return;
+    const uint32_t slot = blockIdx.y;
+    const uint32_t level = slot + (min_level_id ? (uint32_t)min_level_id[b] : 0u);
+
+    float* o = out + ((size_t)slot * N + b) * F + h * V;
+    float  acc[V];
+#pragma unroll
+    for (uint32_t k = 0; k < V; k++) acc[k] = 0;
+
+    float x[D];
+    if (!load_point<D>(inputs, b, x)) {   // out of [0,1]: zeros (gridencoder.cu:134-158)
+        store_vec<V>(o, acc);
+        return;
+    }
+    const uint32_t off = (uint32_t)offsets[level];
+    const uint32_t hs = (uint32_t)offsets[level + 1] - off;
+    const uint32_t R = (uint32_t)resolutions[level];
+    const float* table = emb + (size_t)off * F + h * V;
+
+    Corners<D, VXL> c;
+    c.setup(x, R, hs, Rb, vxl);
+
+    float v[C][V];
+#pragma unroll
+    for (uint32_t i = 0; i < C; i++) {
+        if (c.valid[i]) {
+            load_vec<V>(table + (size_t)c.row[i] * F, v[i]);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < V; k++) v[i][k] = 0;
+        }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < C; i++) {
+        const float tw = c.w[i] * c.wn_re;
+#pragma unroll
+        for (uint32_t k = 0; k < V; k++) {
+            float e = v[i][k];
+            if constexpr (STE) e = (e >= 0) ? 1.0f : -1.0f;
+            acc[k] = c.valid[i] ? __builtin_fmaf(tw, e, acc[k]) : acc[k];
+        }
+    }
+    store_vec<V>(o, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, generic fallback (row wider than a wave: C*F > 64): one lane per (point, 16-B chunk),
+// hardware fp32 atomics (global_atomic_add_f32, no CAS loop).
+// ---------------------------------------------------------------------------------------------
+template <uint32_t D, uint32_t F, bool VXL, bool STE>
+__global__ __launch_bounds__(256) void k_grid_encode_bwd_simple(
+    const float* __restrict__ grad, const float* __restrict__ inputs,
+    const float* __restrict__ emb, const int32_t* __restrict__ offsets,
+    const int32_t* __restrict__ resolutions, float* __restrict__ grad_emb, uint32_t N,
+    uint32_t Rb, const uint8_t* __restrict__ vxl, const int32_t* __restrict__ min_level_id)
+{
+    constexpr uint32_t V = F < 4 ? F : 4;
+    constexpr uint32_t G = F / V;
+    constexpr uint32_t C = 1u << D;
+
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = t / G;
+    const uint32_t h = t % G;
+    if (b >= N) return;
+    const uint32_t slot = blockIdx.y;
+    const uint32_t level = slot + (min_level_id ? (uint32_t)min_level_id[b] : 0u);
+
+    float x[D];
+    if (!load_point<D>(inputs, b, x)) return;   // gridencoder.cu:435-440
+
+    float g[V];
+    load_vec<V>(grad + ((size_t)slot * N + b) * F + h * V, g);
+
+    const uint32_t off = (uint32_t)offsets[level];
+    const uint32_t hs = (uint32_t)offsets[level + 1] - off;
+    const uint32_t R = (uint32_t)resolutions[level];
+    const size_t base = (size_t)off * F + h * V;
+
+    Corners<D, VXL> c;
+    c.setup(x, R, hs, Rb, vxl);
+
+#pragma unroll
+    for (uint32_t i = 0; i < C; i++) {
+        if (!c.valid[i]) continue;
+        const float  tw = c.w[i] * c.wn_re;
+        const size_t at = base + (size_t)c.row[i] * F;
+        float keep[V];
+        if constexpr (STE) {   // STE_binary.backward: pass gradient only where |param| <= 1
+            float e[V];
+            load_vec<V>(emb + at, e);
+#pragma unroll
+            for (uint32_t k = 0; k < V; k++) keep[k] = (e[k] >= -1.0f && e[k] <= 1.0f) ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < V; k++) {
+            if constexpr (STE) {
+                if (keep[k] == 0.f) continue;
+            }
+            unsafeAtomicAdd(grad_emb + at + k, tw * g[k]);
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// backward, run-aggregated scatter (the hot path).
+//
+// Measured on MI355X (tools/atomic_probe.hip): the L2 atomic path retires ~21 G requests/s, where
+// a request is one (wave-instruction, 64-byte-aligned segment) pair, independent of how many of
+// its 16 dwords are touched; same-address lanes inside one instruction serialise.  So the cost of
+// the scatter is the number of row-requests, and the kernel is built to minimise that:
+//   * phase A (lane = point): corner set-up once per (point, level); weights, gradient row,
+//     absolute table rows and the cell key go to LDS.
+//   * consecutive points that fall in the same cell of this level (ray-marched samples do, for
+//     all but the finest levels) form a run; runs are found with a ballot prefix over head flags.
+//   * phase B (lane = (corner, feature), C*F lanes per run): the run's C x F gradient block
+//     sum_p w_p[c] * g_p[f] is accumulated from LDS (broadcast reads), then ONE atomic
+//     instruction updates all C rows x F features: 8 lanes per 32-B row, and the two x-neighbour
+//     rows sit on adjacent lanes so they share a request whenever they share a 64-B segment.
+// ---------------------------------------------------------------------------------------------
+template <uint32_t D, uint32_t F, bool VXL, bool STE>
+__global__ __launch_bounds__(256) void k_grid_encode_bwd(
+    const float* __restrict__ grad, const float* __restrict__ inputs,
+    const float* __restrict__ emb, const int32_t* __restrict__ offsets,
+    const int32_t* __restrict__ resolutions, float* __restrict__ grad_emb, uint32_t N,
+    uint32_t Rb, const uint8_t* __restrict__ vxl, const int32_t* __restrict__ min_level_id)
+{
+    constexpr uint32_t C = 1u << D;
+    constexpr uint32_t SLOTS = C * F;           // lanes per run in phase B (<= 64)
+    constexpr uint32_t GROUPS = 256 / SLOTS;    // runs processed concurrently by the block
+    constexpr uint32_t V = F < 4 ? F : 4;
+    static_assert(SLOTS <= 64, "use k_grid_encode_bwd_simple");
+
+    __shared__ float    s_tw[256][C];
+    __shared__ float    s_g[256][F];
+    __shared__ uint32_t s_row[256][C];
+    __shared__ uint64_t s_key[256];
+    __shared__ uint16_t s_run_start[257];
+    __shared__ uint8_t  s_valid[256];
+    __shared__ uint32_t s_wave_heads[4];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = blockIdx.x * 256 + tid;
+    const uint32_t slot = blockIdx.y;
+
+    // ---- phase A ----
+    uint64_t key = ~0ull;   // out-of-range / padding points: no contribution
+    uint32_t validmask = 0;
+    {
+        float x[D];
+        bool  in_range = false;
+        if (b < N) in_range = load_point<D>(inputs, b, x);
+        if (in_range) {
+            const uint32_t level = slot + (min_level_id ? (uint32_t)min_level_id[b] : 0u);
+            const uint32_t off = (uint32_t)offsets[level];
+            const uint32_t hs = (uint32_t)offsets[level + 1] - off;
+            const uint32_t R = (uint32_t)resolutions[level];
+            Corners<D, VXL> c;
+            c.setup(x, R, hs, Rb, vxl);
+            uint64_t cell = 0;
+#pragma unroll
+            for (uint32_t d = D; d-- > 0;) {
+                float p = x[d] * (float)(R - 2);
+                p = p + 0.5f;
+                cell = cell * R + (uint32_t)floorf(p);
+            }
+            key = ((uint64_t)level << 52) | cell;
+#pragma unroll
+            for (uint32_t i = 0; i < C; i++) {
+                s_tw[tid][i] = c.valid[i] ? c.w[i] * c.wn_re : 0.0f;
+                s_row[tid][i] = off + c.row[i];
+                validmask |= (c.valid[i] ? 1u : 0u) << i;
+            }
+            const float* gp = grad + ((size_t)slot * N + b) * F;
+#pragma unroll
+            for (uint32_t k = 0; k < F; k += V) {
+                float gv[V];
+                load_vec<V>(gp + k, gv);
+#pragma unroll
+                for (uint32_t j = 0; j < V; j++) s_g[tid][k + j] = gv[j];
+            }
+        }
+        s_key[tid] = key;
+        s_valid[tid] = (uint8_t)validmask;
+    }
+    __syncthreads();
+
+    // ---- run detection: head = first point of a run of equal (level, cell) keys ----
+    const bool     head = (tid == 0) || (s_key[tid - 1] != key);
+    const uint64_t hb = __ballot(head);
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    if (lane == 0) s_wave_heads[wave] = (uint32_t)__popcll(hb);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) {
+        const uint32_t h = s_wave_heads[w];
+        before += (w < wave) ? h : 0u;
+        total += h;
+    }
+    if (head) s_run_start[before + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull))] = (uint16_t)tid;
+    if (tid == 0) s_run_start[total] = 256;
+    __syncthreads();
+
+    // ---- phase B ----
+    const uint32_t grp = tid / SLOTS, l = tid % SLOTS;
+    const uint32_t c = l / F, f = l % F;
+    for (uint32_t r = grp; r < total; r += GROUPS) {
+        const uint32_t p0 = s_run_start[r], p1 = s_run_start[r + 1];
+        if (!((s_valid[p0] >> c) & 1u)) continue;
+        float acc = 0;
+        for (uint32_t p = p0; p < p1; p++) acc += s_tw[p][c] * s_g[p][f];
+        const size_t at = (size_t)s_row[p0][c] * F + f;
+        if constexpr (STE) {   // STE_binary.backward: pass gradient only where |param| <= 1
+            const float e = emb[at];
+            if (!(e >= -1.0f && e <= 1.0f)) continue;
+        }
+        unsafeAtomicAdd(grad_emb + at, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cnt_np_embed: per fine-level vertex, vote +1 / -1 of each feature into the 2-D projection
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cnt_loc(const int16_t* __restrict__ p, uint32_t R, uint32_t F,
+                                        uint32_t axis, uint32_t (&q)[3], uint32_t& loc)
+{
+    q[0] = (uint32_t)(int32_t)p[0];
+    q[1] = (uint32_t)(int32_t)p[1];
+    q[2] = (uint32_t)(int32_t)p[2];
+    const uint32_t scale = R - 2;
+    bool inside = true;
+#pragma unroll
+    for (int d = 0; d < 3; d++) inside &= !(q[d] <= 0 || q[d] >= R - 1);
+    const uint32_t u = axis == 2 ? q[1] : q[0];
+    const uint32_t w = axis == 0 ? q[1] : q[2];
+    loc = (u - 1) * scale * F * 2 + (w - 1) * F * 2;
+    return inside;
+}
+
+template <uint32_t F>
+__global__ __launch_bounds__(256) void k_cnt_np_embed(const int16_t* __restrict__ inputs,
+                                                      const float* __restrict__ emb,
+                                                      float* __restrict__ out, uint32_t N,
+                                                      uint32_t R, uint32_t hs, uint32_t axis)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= N) return;
+    uint32_t q[3], loc;
+    if (!cnt_loc(inputs + (size_t)b * 3, R, F, axis, q, loc)) return;
+    const float* row = emb + (size_t)grid_row<3>(q, hs, R) * F;
+#pragma unroll
+    for (uint32_t ch = 0; ch < F; ch++) {
+        const bool pos = (double)row[ch] > 0.9;   // float vs double literal, gridencoder.cu:909
+        unsafeAtomicAdd(out + loc + ch * 2 + (pos ? 0 : 1), 1.0f);
+    }
+}
+
+template <uint32_t F>
+__global__ __launch_bounds__(256) void k_cnt_np_embed_bwd(
+    const int16_t* __restrict__ inputs, const float* __restrict__ emb,
+    const float* __restrict__ out_sum, const float* __restrict__ grad,
+    float* __restrict__ grad_emb, uint32_t N, uint32_t R, uint32_t hs, uint32_t axis)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= N) return;
+    uint32_t q[3], loc;
+    if (!cnt_loc(inputs + (size_t)b * 3, R, F, axis, q, loc)) return;
+    const size_t   at = (size_t)grid_row<3>(q, hs, R) * F;
+    const uint32_t half = loc / 2;
+#pragma unroll
+    for (uint32_t ch = 0; ch < F; ch++) {
+        const float gv = 1 / out_sum[half + ch];
+        const bool  pos = (double)emb[at + ch] > 0.9;
+        const float contrib = pos ? gv * grad[loc + ch * 2 + 0] : -gv * grad[loc + ch * 2 + 1];
+        unsafeAtomicAdd(grad_emb + at + ch, contrib);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------------------------
+struct EncArgs {
+    const float*   inputs;
+    const float*   emb;
+    const int32_t* offsets;
+    const int32_t* resolutions;
+    float*         out;        // forward: outputs; backward: grad_embeddings
+    const float*   grad;       // backward only
+    uint32_t       N, L, Rb;
+    const uint8_t* vxl;
+    const int32_t* mli;
+    hipStream_t    stream;
+};
+
+template <uint32_t D, uint32_t F, bool VXL, bool STE>
+static void launch_fwd(const EncArgs& a)
+{
+    constexpr uint32_t V = F < 4 ? F : 4, G = F / V;
+    const dim3 grid(div_up(a.N * G, 256), a.L, 1);
+    hipLaunchKernelGGL((k_grid_encode_fwd<D, F, VXL, STE>), grid, dim3(256), 0, a.stream,
+                       a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N, a.Rb, a.vxl, a.mli);
+}
+
+template <uint32_t D, uint32_t F, bool VXL, bool STE>
+static void launch_bwd(const EncArgs& a)
+{
+    if constexpr ((1u << D) * F <= 64) {
+        const dim3 grid(div_up(a.N, 256), a.L, 1);
+        hipLaunchKernelGGL((k_grid_encode_bwd<D, F, VXL, STE>), grid, dim3(256), 0, a.stream,
+                           a.grad, a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N, a.Rb,
+                           a.vxl, a.mli);
+    } else {
+        constexpr uint32_t V = F < 4 ? F : 4, G = F / V;
+        const dim3 grid(div_up(a.N * G, 256), a.L, 1);
+        hipLaunchKernelGGL((k_grid_encode_bwd_simple<D, F, VXL, STE>), grid, dim3(256), 0,
+                           a.stream, a.grad, a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N,
+                           a.Rb, a.vxl, a.mli);
+    }
+}
+
+template <bool BWD, uint32_t D, uint32_t F>
+static void dispatch_flags(const EncArgs& a, bool ste)
+{
+    const bool vxl = a.vxl != nullptr;
+#define CNC_GO(VX, ST)                                   \
+    do {                                                 \
+        if constexpr (BWD) launch_bwd<D, F, VX, ST>(a);  \
+        else launch_fwd<D, F, VX, ST>(a);                \
+    } while (0)
+    if (vxl && ste) CNC_GO(true, true);
+    else if (vxl) CNC_GO(true, false);
+    else if (ste) CNC_GO(false, true);
+    else CNC_GO(false, false);
+#undef CNC_GO
+}
+
+template <bool BWD, uint32_t D>
+static int dispatch_F(const EncArgs& a, uint32_t F, bool ste)
+{
+    switch (F) {
+    case 1: dispatch_flags<BWD, D, 1>(a, ste); break;
+    case 2: dispatch_flags<BWD, D, 2>(a, ste); break;
+    case 4: dispatch_flags<BWD, D, 4>(a, ste); break;
+    case 8: dispatch_flags<BWD, D, 8>(a, ste); break;
+    case 16: dispatch_flags<BWD, D, 16>(a, ste); break;
+    case 32: dispatch_flags<BWD, D, 32>(a, ste); break;
+    default: return CNC_ERR_INVALID_VALUE;   // "n_fearures must be 1, 2, 4, 8, 16 or 32"
+    }
+    return CNC_OK;
+}
+
+template <bool BWD>
+static int dispatch_D(const EncArgs& a, uint32_t D, uint32_t F, bool ste)
+{
+    switch (D) {
+    case 1: return dispatch_F<BWD, 1>(a, F, ste);
+    case 2: return dispatch_F<BWD, 2>(a, F, ste);
+    case 3: return dispatch_F<BWD, 3>(a, F, ste);
+    default: return CNC_ERR_INVALID_VALUE;   // "num_dim must be 1, 2, 3"
+    }
+}
+
+}  // namespace cnc
+
+using namespace cnc;
+
+extern "C" int cnc_grid_encode_forward(const float* inputs, const float* embeddings,
+                                       const int32_t* offsets, const int32_t* resolutions,
+                                       float* outputs, uint32_t N, uint32_t D, uint32_t F,
+                                       uint32_t L, uint32_t Rb, float PV, float* dy_dx,
+                                       const uint8_t* binary_vxl, const int32_t* min_level_id,
+                                       uint32_t flags, void* stream)
+{
+    (void)PV;
+    if (dy_dx) return CNC_ERR_UNSUPPORTED;
+    if (N == 0 || L == 0) return CNC_OK;
+    if (!inputs || !embeddings || !offsets || !resolutions || !outputs) return CNC_ERR_INVALID_VALUE;
+    EncArgs a{inputs, embeddings, offsets, resolutions, outputs, nullptr, N, L, Rb,
+              binary_vxl, min_level_id, (hipStream_t)stream};
+    const int rc = dispatch_D<false>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
+    return rc != CNC_OK ? rc : launch_status();
+}
+
+extern "C" int cnc_grid_encode_backward(const float* grad, const float* inputs,
+                                        const float* embeddings, const int32_t* offsets,
+                                        const int32_t* resolutions, float* grad_embeddings,
+                                        uint32_t N, uint32_t D, uint32_t F, uint32_t L,
+                                        uint32_t Rb, const float* dy_dx, float* grad_inputs,
+                                        const uint8_t* binary_vxl, const int32_t* min_level_id,
+                                        uint32_t flags, void* stream)
+{
+    if (dy_dx || grad_inputs) return CNC_ERR_UNSUPPORTED;
+    if (N == 0 || L == 0) return CNC_OK;
+    if (!grad || !inputs || !embeddings || !offsets || !resolutions || !grad_embeddings)
+        return CNC_ERR_INVALID_VALUE;
+    EncArgs a{inputs, embeddings, offsets, resolutions, grad_embeddings, grad, N, L, Rb,
+              binary_vxl, min_level_id, (hipStream_t)stream};
+    const int rc = dispatch_D<true>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
+    return rc != CNC_OK ? rc : launch_status();
+}
+
+#define CNC_F_SWITCH(F, CALL)                         \
+    switch (F) {                                      \
+    case 1: { constexpr uint32_t FF = 1; CALL; } break;   \
+    case 2: { constexpr uint32_t FF = 2; CALL; } break;   \
+    case 4: { constexpr uint32_t FF = 4; CALL; } break;   \
+    case 8: { constexpr uint32_t FF = 8; CALL; } break;   \
+    case 16: { constexpr uint32_t FF = 16; CALL; } break; \
+    case 32: { constexpr uint32_t FF = 32; CALL; } break; \
+    default: return CNC_ERR_INVALID_VALUE;            \
+    }
+
+extern "C" int cnc_cnt_np_embed(const int16_t* inputs, const float* embeddings_clip,
+                                float* outputs, uint32_t N, uint32_t resolution, uint32_t F,
+                                uint32_t hashmap_size, uint32_t axis, void* stream)
+{
+    if (N == 0) return CNC_OK;
+    if (!inputs || !embeddings_clip || !outputs || axis > 2) return CNC_ERR_INVALID_VALUE;
+    CNC_F_SWITCH(F, hipLaunchKernelGGL((k_cnt_np_embed<FF>), dim3(div_up(N, 256)), dim3(256), 0,
+                                       (hipStream_t)stream, inputs, embeddings_clip, outputs, N,
+                                       resolution, hashmap_size, axis));
+    return launch_status();
+}
+
+extern "C" int cnc_cnt_np_embed_backward(const int16_t* inputs, const float* embeddings_clip,
+                                         const float* outputs_sum, const float* grad,
+                                         float* grad_embeddings, uint32_t N, uint32_t resolution,
+                                         uint32_t F, uint32_t hashmap_size, uint32_t axis,
+                                         void* stream)
+{
+    if (N == 0) return CNC_OK;
+    if (!inputs || !embeddings_clip || !outputs_sum || !grad || !grad_embeddings || axis > 2)
+        return CNC_ERR_INVALID_VALUE;
+    CNC_F_SWITCH(F, hipLaunchKernelGGL((k_cnt_np_embed_bwd<FF>), dim3(div_up(N, 256)), dim3(256), 0,
+                                       (hipStream_t)stream, inputs, embeddings_clip, outputs_sum,
+                                       grad, grad_embeddings, N, resolution, hashmap_size, axis));
+    return launch_status();
+}
+
+extern "C" const char* cnc_error_string(int code)
+{
+    switch (code) {
+    case CNC_OK: return "ok";
+    case CNC_ERR_INVALID_VALUE:
+        return "invalid argument (null pointer, bad size, n_features not in {1,2,4,8,16,32} or "
+               "num_dim not in {1,2,3})";
+    case CNC_ERR_UNSUPPORTED: return "argument combination not supported by libcnc_hip (dy_dx / grad_inputs)";
+    case CNC_ERR_LAUNCH: return "HIP kernel launch failed";
+    default: return "unknown error";
+    }
+}
+
+extern "C" int cnc_abi_version(void) { return 1; }

@@ -1,0 +1,291 @@
+// march.hip — ray/AABB slab test and occupancy-grid ray marching for gfx950.
+//
+// Stands in for nerfacc/cuda/csrc/grid.cu (ray_aabb_intersect_kernel :320-349,
+// traverse_grids_kernel :68-318) and include/utils_grid.cuh (:11-149) behind include/cnc_hip.h.
+//
+// One lane marches one ray (the traversal is a serial DDA whose every step depends on the
+// previous one).  What is shaped for CDNA4 here:
+//   * 64-thread workgroups: a wave retires as soon as its own 64 rays finish, instead of a
+//     512-thread block waiting for its slowest ray, and N_rays/64 workgroups keep 256 CUs busy
+//     even for an 8192-ray evaluation chunk;
+//   * the 2 MiB occupancy grid is read-only and L2-resident; rays arrive in image order so the
+//     lanes of a wave walk neighbouring cells;
+//   * per-ray outputs are written in (ray, t) order at chunk_starts[ray] exactly as the
+//     reference does, so the host mirror can reuse the reference's boolean-mask post-processing
+//     (nerfacc/estimators/occ_grid.py:188-189).
+#include "common.hpp"
+
+namespace cnc {
+
+__device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+__device__ __forceinline__ int   clampi(int f, int a, int b) { return max(a, min(f, b)); }
+__device__ __forceinline__ float calc_dt(float t, float cone, float dmin, float dmax)
+{
+    return clampf(t * cone, dmin, dmax);
+}
+
+// utils_grid.cuh:11-56
+__device__ __forceinline__ bool slab(const float* __restrict__ o, const float (&inv)[3],
+                                     const float* __restrict__ bb, float near, float far,
+                                     float& tmin_o, float& tmax_o)
+{
+    float tmin, tmax;
+    if (inv[0] >= 0) { tmin = (bb[0] - o[0]) * inv[0]; tmax = (bb[3] - o[0]) * inv[0]; }
+    else             { tmin = (bb[3] - o[0]) * inv[0]; tmax = (bb[0] - o[0]) * inv[0]; }
+#pragma unroll
+    for (int d = 1; d < 3; d++) {
+        float a, b;
+        if (inv[d] >= 0) { a = (bb[d] - o[d]) * inv[d];     b = (bb[3 + d] - o[d]) * inv[d]; }
+        else             { a = (bb[3 + d] - o[d]) * inv[d]; b = (bb[d] - o[d]) * inv[d]; }
+        if (tmin > b || a > tmax) return false;
+        if (a > tmin) tmin = a;
+        if (b < tmax) tmax = b;
+    }
+    if (tmax <= 0) return false;
+    tmin_o = fmaxf(tmin, near);
+    tmax_o = fminf(tmax, far);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_ray_aabb(const float* __restrict__ rays_o,
+                                                  const float* __restrict__ rays_d,
+                                                  const float* __restrict__ aabbs, int32_t n_rays,
+                                                  int32_t n_aabbs, float near, float far,
+                                                  float miss, float* __restrict__ t_mins,
+                                                  float* __restrict__ t_maxs,
+                                                  uint8_t* __restrict__ hits)
+{
+    const int32_t numel = n_rays * n_aabbs;
+    for (int32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < numel; t += blockDim.x * gridDim.x) {
+        const int32_t r = t / n_aabbs, a = t % n_aabbs;
+        const float inv[3] = {1.0f / rays_d[r * 3], 1.0f / rays_d[r * 3 + 1], 1.0f / rays_d[r * 3 + 2]};
+        float t0, t1;
+        const bool hit = slab(rays_o + (size_t)r * 3, inv, aabbs + a * 6, near, far, t0, t1);
+        t_mins[t] = hit ? t0 : miss;
+        t_maxs[t] = hit ? t1 : miss;
+        hits[t] = (uint8_t)hit;
+    }
+}
+
+struct Seg {
+    float*   vals;
+    int64_t* chunk_starts;
+    int64_t* chunk_cnts;
+    int64_t* ray_indices;
+    uint8_t* is_left;
+    uint8_t* is_right;
+    uint8_t* is_valid;
+};
+
+__global__ __launch_bounds__(64) void k_traverse(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const uint8_t* __restrict__ rays_mask, int32_t n_rays, const uint8_t* __restrict__ binaries,
+    int32_t n_grids, int32_t resx, int32_t resy, int32_t resz, const float* __restrict__ aabbs,
+    const uint8_t* __restrict__ hits, const float* __restrict__ t_sorted,
+    const int64_t* __restrict__ t_indices, const float* __restrict__ near_planes,
+    const float* __restrict__ far_planes, float step_size, float cone_angle, int32_t limit,
+    int32_t first_pass, Seg iv, Seg sm, float* __restrict__ terminate_planes)
+{
+    const float eps = 1e-6f;
+    const int   res[3] = {resx, resy, resz};
+    const bool  has_iv = iv.chunk_cnts != nullptr, has_sm = sm.chunk_cnts != nullptr;
+
+    for (int32_t tid = blockIdx.x * blockDim.x + threadIdx.x; tid < n_rays;
+         tid += blockDim.x * gridDim.x) {
+        if (rays_mask != nullptr && !rays_mask[tid]) continue;
+        if (has_iv && !first_pass && iv.chunk_cnts[tid] == 0) continue;
+        if (has_sm && !first_pass && sm.chunk_cnts[tid] == 0) continue;
+        int64_t cs_iv = 0, cs_sm = 0;
+        if (!first_pass) {
+            if (has_iv) cs_iv = iv.chunk_starts[tid];
+            if (has_sm) cs_sm = sm.chunk_starts[tid];
+        }
+        const float near_plane = near_planes[tid], far_plane = far_planes[tid];
+        const float o[3] = {rays_o[(size_t)tid * 3], rays_o[(size_t)tid * 3 + 1], rays_o[(size_t)tid * 3 + 2]};
+        const float dir[3] = {rays_d[(size_t)tid * 3], rays_d[(size_t)tid * 3 + 1], rays_d[(size_t)tid * 3 + 2]};
+        const float inv[3] = {1.0f / dir[0], 1.0f / dir[1], 1.0f / dir[2]};
+        const int32_t base_hits = tid * n_grids, base_t = tid * n_grids * 2;
+
+        int64_t n_iv = 0, n_sm = 0;
+        float   t_last = near_plane;
+        bool    continuous = false;
+
+        for (int32_t i = base_t; i < base_t + n_grids * 2 - 1; i++) {
+            const bool is_entering = t_indices[i] < n_grids;
+            int64_t    level = t_indices[i] % n_grids;
+            if (!hits[base_hits + level]) continue;
+            if (!is_entering) {
+                if (t_indices[i + 1] < n_grids) continue;
+                level = t_indices[i + 1] % n_grids;
+                if (!hits[base_hits + level]) continue;
+            }
+            const float this_tmin = fmaxf(t_sorted[i], near_plane);
+            const float this_tmax = fminf(t_sorted[i + 1], far_plane);
+            if (this_tmin >= this_tmax) continue;
+
+            if (!continuous) {
+                if (step_size <= 0.0f) {
+                    t_last = this_tmin;
+                } else {
+                    const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                    while (!(t_last + dt * 0.5f >= this_tmin)) t_last += dt;
+                }
+            }
+
+            const float* bb = aabbs + level * 6;
+            float tdist[3], delta[3];
+            int   step_i[3], cur[3], over[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {   // setup_traversal, utils_grid.cuh:59-118
+                const float resf = (float)res[a];
+                const float ext = bb[3 + a] - bb[a];
+                const float voxel = ext / resf;
+                const float rs = __builtin_fmaf(dir[a], this_tmin + eps, o[a]);
+                const float re = __builtin_fmaf(dir[a], this_tmax - eps, o[a]);
+                cur[a] = clampi((int)(((rs - bb[a]) / ext) * resf), 0, res[a] - 1);
+                const int fin = clampi((int)(((re - bb[a]) / ext) * resf), 0, res[a] - 1);
+                const int start_index = cur[a] + (dir[a] > 0 ? 1 : 0);
+                const float txyz = __builtin_fmaf(
+                    bb[a] + __builtin_fmaf((float)start_index, voxel, -rs), inv[a], this_tmin);
+                const bool  flat = dir[a] == 0.0f;
+                const float sf = flat ? 0.0f : (dir[a] > 0.0f ? 1.0f : -1.0f);
+                tdist[a] = flat ? this_tmax : txyz;
+                step_i[a] = (int)sf;
+                delta[a] = flat ? this_tmax : voxel * inv[a] * sf;
+                over[a] = fin + step_i[a];
+            }
+
+            while (limit <= 0 || n_sm < limit) {
+                float t_trav = fminf(tdist[0], fminf(tdist[1], tdist[2]));
+                t_trav = fminf(t_trav, this_tmax);
+                const int64_t cell = (int64_t)(cur[0] * res[1] * res[2] + cur[1] * res[2] + cur[2])
+                                     + level * res[0] * res[1] * res[2];
+                if (!binaries[cell]) {
+                    if (step_size <= 0.0f) {
+                        t_last = t_trav;
+                    } else {
+                        const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                        while (!(t_last + dt * 0.5f >= t_trav)) t_last += dt;
+                    }
+                    continuous = false;
+                } else {
+                    while (limit <= 0 || n_sm < limit) {
+                        float t_next;
+                        if (step_size <= 0.0f) {
+                            t_next = t_trav;
+                        } else {
+                            const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                            if (t_last + dt * 0.5f >= t_trav) break;
+                            t_next = t_last + dt;
+                        }
+                        if (has_iv) {
+                            if (!continuous) {
+                                if (!first_pass) {
+                                    const int64_t k = cs_iv + n_iv;
+                                    iv.vals[k] = t_last;
+                                    iv.ray_indices[k] = tid;
+                                    iv.is_left[k] = 1;
+                                    iv.vals[k + 1] = t_next;
+                                    iv.ray_indices[k + 1] = tid;
+                                    iv.is_right[k + 1] = 1;
+                                }
+                                n_iv += 2;
+                            } else {
+                                if (!first_pass) {
+                                    const int64_t k = cs_iv + n_iv;
+                                    iv.vals[k] = t_next;
+                                    iv.ray_indices[k] = tid;
+                                    iv.is_left[k - 1] = 1;
+                                    iv.is_right[k] = 1;
+                                }
+                                n_iv += 1;
+                            }
+                        }
+                        if (has_sm && !first_pass) {
+                            const int64_t k = cs_sm + n_sm;
+                            sm.vals[k] = (t_next + t_last) * 0.5f;
+                            sm.ray_indices[k] = tid;
+                            sm.is_valid[k] = 1;
+                        }
+                        n_sm++;
+                        continuous = true;
+                        t_last = t_next;
+                        if (t_next >= t_trav) break;
+                    }
+                }
+                // single_traversal, utils_grid.cuh:121-149 (strict '<' tie-break x, y, then z)
+                const int ax = (tdist[0] < tdist[1] && tdist[0] < tdist[2]) ? 0
+                               : (tdist[1] < tdist[2] ? 1 : 2);
+                bool done;
+                if (ax == 0)      { cur[0] += step_i[0]; tdist[0] += delta[0]; done = cur[0] == over[0]; }
+                else if (ax == 1) { cur[1] += step_i[1]; tdist[1] += delta[1]; done = cur[1] == over[1]; }
+                else              { cur[2] += step_i[2]; tdist[2] += delta[2]; done = cur[2] == over[2]; }
+                if (done) break;
+            }
+        }
+        if (terminate_planes != nullptr) terminate_planes[tid] = t_last;
+        if (has_iv) iv.chunk_cnts[tid] = n_iv;
+        if (has_sm) sm.chunk_cnts[tid] = n_sm;
+    }
+}
+
+static Seg to_seg(const cnc_ray_segments_t* s)
+{
+    Seg r{};
+    if (s) {
+        r.vals = s->vals; r.chunk_starts = s->chunk_starts; r.chunk_cnts = s->chunk_cnts;
+        r.ray_indices = s->ray_indices; r.is_left = s->is_left; r.is_right = s->is_right;
+        r.is_valid = s->is_valid;
+    }
+    return r;
+}
+
+}  // namespace cnc
+
+using namespace cnc;
+
+extern "C" int cnc_ray_aabb_intersect(const float* rays_o, const float* rays_d,
+                                      const float* aabbs, int32_t n_rays, int32_t n_aabbs,
+                                      float near_plane, float far_plane, float miss_value,
+                                      float* t_mins, float* t_maxs, uint8_t* hits, void* stream)
+{
+    const int64_t numel = (int64_t)n_rays * n_aabbs;
+    if (numel <= 0) return CNC_OK;
+    if (!rays_o || !rays_d || !aabbs || !t_mins || !t_maxs || !hits) return CNC_ERR_INVALID_VALUE;
+    const uint32_t blocks = (uint32_t)((numel + 255) / 256);
+    hipLaunchKernelGGL(k_ray_aabb, dim3(blocks < 65535u ? blocks : 65535u), dim3(256), 0,
+                       (hipStream_t)stream, rays_o, rays_d, aabbs, n_rays, n_aabbs, near_plane,
+                       far_plane, miss_value, t_mins, t_maxs, hits);
+    return launch_status();
+}
+
+extern "C" int cnc_traverse_grids(const float* rays_o, const float* rays_d,
+                                  const uint8_t* rays_mask, int32_t n_rays,
+                                  const uint8_t* binaries, int32_t n_grids, int32_t resx,
+                                  int32_t resy, int32_t resz, const float* aabbs,
+                                  const uint8_t* hits, const float* t_sorted,
+                                  const int64_t* t_indices, const float* near_planes,
+                                  const float* far_planes, float step_size, float cone_angle,
+                                  int32_t traverse_steps_limit, int32_t first_pass,
+                                  const cnc_ray_segments_t* intervals,
+                                  const cnc_ray_segments_t* samples, float* terminate_planes,
+                                  void* stream)
+{
+    if (n_rays <= 0) return CNC_OK;
+    if (!rays_o || !rays_d || !binaries || !aabbs || !hits || !t_sorted || !t_indices ||
+        !near_planes || !far_planes || n_grids <= 0)
+        return CNC_ERR_INVALID_VALUE;
+    const Seg iv = to_seg(intervals), sm = to_seg(samples);
+    if (!first_pass) {
+        if (iv.chunk_cnts && (!iv.vals || !iv.chunk_starts || !iv.ray_indices || !iv.is_left || !iv.is_right))
+            return CNC_ERR_INVALID_VALUE;
+        if (sm.chunk_cnts && (!sm.vals || !sm.chunk_starts || !sm.ray_indices || !sm.is_valid))
+            return CNC_ERR_INVALID_VALUE;
+    }
+    const uint32_t blocks = div_up((uint32_t)n_rays, 64);
+    hipLaunchKernelGGL(k_traverse, dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d,
+                       rays_mask, n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits,
+                       t_sorted, t_indices, near_planes, far_planes, step_size, cone_angle,
+                       traverse_steps_limit, first_pass, iv, sm, terminate_planes);
+    return launch_status();
+}

@@ -1,0 +1,198 @@
+"""GridEncoder — host-side mirror of the reference's hash-grid encoder module.
+
+Reference: examples/radiance_fields/ngp.py — `STE_binary` :22-39, `STE_multistep` :41-47,
+`_grid_encode` :49-165, `GridEncoder` :171-315 (`gridencoder/__init__.py:1` imports the class from
+an empty file; this module is what makes `from gridencoder import GridEncoder` real).
+
+Same constructor arguments, buffers (`offsets_list`, `resolutions_list`), parameter (`params`,
+U(-1e-4, 1e-4)) and the three entry points `forward`, `forward_diff_levels`,
+`forward_given_params`, with the same argument meaning and output layout `[..., L_calc * F]`.
+
+MI355X-first difference (opt-in per instance, `fused_ste=True`, the default): when
+`ste_binary=True` the reference materialises `STE_binary(params)` — 4-7 elementwise passes over the
+whole 128 MB table before every encoder call, and as many again in backward — and then gathers from
+the copy.  Here the sign is taken inside the gather kernel and the STE mask `|p| <= 1` inside the
+scatter kernel (CNC_FLAG_STE_BINARY), so the table is never copied.  The results are identical
+to the unfused path (tests/test_gridencoder_glue.py); `fused_ste=False` reproduces the reference's
+op-by-op dataflow.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from .backends import gridencoder_backend as _backend
+
+
+class STE_binary(Function):
+    """+1 where clamp(x,-1,1) >= 0 else -1; gradient passes where |x| <= 1 (ngp.py:22-39)."""
+
+    @staticmethod
+    def forward(ctx, input):
+        ctx.save_for_backward(input)
+        return torch.where(input >= 0, 1.0, -1.0).to(input.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (input,) = ctx.saved_tensors
+        return grad_output * ((input >= -1) & (input <= 1)).to(grad_output.dtype)
+
+
+class STE_multistep(Function):
+    """round(x*Q)/Q with identity gradient (ngp.py:41-47)."""
+
+    @staticmethod
+    def forward(ctx, input, Q):
+        return torch.round(input * Q) / Q
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output, None
+
+
+class _grid_encode(Function):
+    """Autograd wrapper of the encoder kernels (ngp.py:49-165).
+
+    `min_level_id` is either an int (scalar level window: the offset / resolution tables are
+    sliced, ngp.py:86-97) or an int32 tensor [N] (per-point window, ngp.py:98-109).
+    `ste` (extension) = take sign(embeddings) on the fly / mask the gradient with |e| <= 1.
+    """
+
+    @staticmethod
+    def forward(ctx, inputs, embeddings, offsets_list, resolutions_list, calc_grad_inputs=False,
+                min_level_id=None, n_levels_calc=1, binary_vxl=None, PV=0, ste=False):
+        inputs = inputs.contiguous()
+        if calc_grad_inputs:
+            # dead in the reference too (ngp.py:58-60)
+            raise AssertionError("calc_grad_inputs not applicable!")
+        Rb = 128
+        if binary_vxl is not None:
+            binary_vxl = binary_vxl.contiguous()
+            Rb = binary_vxl.shape[-1]
+            assert binary_vxl.dim() == inputs.shape[-1]
+        N, num_dim = inputs.shape
+        n_features = embeddings.shape[1]
+        embeddings = embeddings.contiguous()
+        outputs = torch.empty(n_levels_calc, N, n_features, device=inputs.device, dtype=embeddings.dtype)
+
+        scalar_window = isinstance(min_level_id, int)
+        if scalar_window:
+            max_level_id = min_level_id + n_levels_calc
+            offs = offsets_list[min_level_id:max_level_id + 1]
+            ress = resolutions_list[min_level_id:max_level_id]
+            mli = None
+        else:
+            offs, ress, mli = offsets_list, resolutions_list, min_level_id
+        _backend.grid_encode_forward(inputs, embeddings, offs, ress, outputs, N, num_dim, n_features,
+                                     n_levels_calc, 0, Rb, PV, None, binary_vxl, mli, ste_binary=ste)
+        # level-major [L, N, F] -> [N, L*F] (ngp.py:111)
+        outputs = outputs.permute(1, 0, 2).reshape(N, n_levels_calc * n_features)
+        ctx.save_for_backward(inputs, embeddings, offs, ress, binary_vxl, mli)
+        ctx.dims = (N, num_dim, n_features, n_levels_calc, Rb, ste)
+        return outputs
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, embeddings, offs, ress, binary_vxl, mli = ctx.saved_tensors
+        N, num_dim, n_features, n_levels_calc, Rb, ste = ctx.dims
+        grad = grad.view(N, n_levels_calc, n_features).permute(1, 0, 2).contiguous()
+        grad_embeddings = torch.zeros_like(embeddings)
+        _backend.grid_encode_backward(grad, inputs, embeddings, offs, ress, grad_embeddings, N,
+                                      num_dim, n_features, n_levels_calc, 0, Rb, None, None,
+                                      binary_vxl, mli, ste_binary=ste)
+        return None, grad_embeddings, None, None, None, None, None, None, None, None
+
+
+grid_encode = _grid_encode.apply
+
+
+class GridEncoder(nn.Module):
+    def __init__(self, num_dim=3, n_features=2,
+                 resolutions_list=(16, 23, 32, 46, 64, 92, 128, 184, 256, 368, 512, 736),
+                 log2_hashmap_size=19, ste_binary=False, ste_multistep=False, add_noise=False, Q=1,
+                 fused_ste=True):
+        super().__init__()
+        resolutions_list = torch.as_tensor(np.asarray(resolutions_list)).to(torch.int)
+        n_levels = resolutions_list.numel()
+        self.num_dim = num_dim
+        self.n_levels = n_levels
+        self.n_features = n_features
+        self.log2_hashmap_size = log2_hashmap_size
+        self.output_dim = n_levels * n_features
+        self.ste_binary = ste_binary
+        self.ste_multistep = ste_multistep
+        self.add_noise = add_noise
+        self.Q = Q
+        self.fused_ste = fused_ste
+
+        # rows per level = min(2^log2T, R^D) rounded up to a multiple of 8 (ngp.py:197-210)
+        self.max_params = 2 ** log2_hashmap_size
+        offsets = [0]
+        for R in resolutions_list.tolist():
+            rows = min(self.max_params, R ** num_dim)
+            offsets.append(offsets[-1] + int(np.ceil(rows / 8) * 8))
+        self.register_buffer("offsets_list", torch.from_numpy(np.array(offsets, dtype=np.int32)))
+        self.register_buffer("resolutions_list", resolutions_list)
+        self.n_params = self.offsets_list[-1] * n_features
+        self.params = nn.Parameter(torch.empty(offsets[-1], n_features))
+        self.reset_parameters()
+        self.n_output_dims = n_levels * n_features
+
+    def reset_parameters(self):
+        self.params.data.uniform_(-1e-4, 1e-4)
+
+    def __repr__(self):
+        return (f"GridEncoder: num_dim={self.num_dim} n_levels={self.n_levels} "
+                f"n_features={self.n_features} resolutions={self.resolutions_list.tolist()} "
+                f"log2_hashmap_size={self.log2_hashmap_size} params={tuple(self.params.shape)} "
+                f"ste_binary={self.ste_binary}")
+
+    # -- embeddings as the kernels should see them --------------------------------------------
+    def _embeddings(self, params, test_phase):
+        """Returns (table, ste_flag)."""
+        if self.ste_binary:
+            if self.fused_ste:
+                return params, True
+            return STE_binary.apply(params), False
+        if self.add_noise and not test_phase:
+            return params + (torch.rand_like(params) - 0.5) * (1 / self.Q), False
+        if self.ste_multistep or (self.add_noise and test_phase):
+            return STE_multistep.apply(params, self.Q), False
+        return params, False
+
+    def forward(self, inputs, min_level_id=None, max_level_id=None, test_phase=False,
+                outspace_params=None, binary_vxl=None, PV=0):
+        """inputs [..., num_dim] in [0,1] -> [..., L_calc * F] for levels [min_level_id, max_level_id)."""
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.num_dim)
+        params = self.params if outspace_params is None else outspace_params
+        embeddings, ste = self._embeddings(params, test_phase)
+        min_level_id = 0 if min_level_id is None else max(min_level_id, 0)
+        max_level_id = self.n_levels if max_level_id is None else min(max_level_id, self.n_levels)
+        n_levels_calc = max_level_id - min_level_id
+        outputs = grid_encode(inputs, embeddings, self.offsets_list, self.resolutions_list, False,
+                              min_level_id, n_levels_calc, binary_vxl, PV, ste)
+        return outputs.view(prefix_shape + [n_levels_calc * self.n_features])
+
+    def forward_diff_levels(self, inputs, min_level_id_list=None, n_levels_calc=1, test_phase=False,
+                            outspace_params=None, binary_vxl=None, PV=0):
+        """Per-point level window [min_level_id_list[i], +n_levels_calc) (ngp.py:265-297)."""
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.num_dim)
+        params = self.params if outspace_params is None else outspace_params
+        embeddings, ste = self._embeddings(params, test_phase)
+        outputs = grid_encode(inputs, embeddings, self.offsets_list, self.resolutions_list, False,
+                              min_level_id_list.contiguous(), n_levels_calc, binary_vxl, PV, ste)
+        return outputs.view(prefix_shape + [n_levels_calc * self.n_features])
+
+    def forward_given_params(self, inputs, offsets_list, resolutions_list, outspace_params=None,
+                             binary_vxl=None, PV=0):
+        """One dense 2-D level described by the caller's tables; no STE (ngp.py:299-315)."""
+        assert inputs.shape[-1] == 2
+        prefix_shape = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, 2)
+        outputs = grid_encode(inputs, outspace_params, offsets_list, resolutions_list, False, 0, 1,
+                              binary_vxl, PV, False)
+        return outputs.view(prefix_shape + [self.n_features])

@@ -1,0 +1,237 @@
+"""HIP hash-grid encoder (through the `_gridencoder` mirror -> C ABI) vs the CPU oracle.
+Forward: bit-exact.  Backward: fp32 atomics reorder the sum, so the bound is derived from the
+oracle's float64 shadow and the sum of |contributions| instead of a guessed tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ball_occupancy, make_grid
+
+pytestmark = pytest.mark.gpu
+
+RES3 = [6, 9, 14, 20, 31, 44]
+RES2 = [10, 18, 34, 66]
+
+
+def _points(N, D, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(0, 1, size=(N, D)).astype(np.float32)
+    if N >= 16:   # edge cases the reference handles explicitly
+        x[0] = 0.0
+        x[1] = 1.0
+        x[2, 0] = -1e-3           # out of range -> zeros, no gradient
+        x[3, D - 1] = 1.0 + 1e-3
+        x[4] = 0.5
+        x[5] = np.float32(1.0) - np.float32(2 ** -24)
+        x[6] = np.float32(2 ** -30)
+    return x
+
+
+def _fwd_gpu(dev, x, emb, offs, res, L, vxl=None, mli=None, ste=False):
+    from cnc_amd.backends import gridencoder_backend as be
+    t = lambda a, dt=None: None if a is None else torch.as_tensor(a, device=dev)
+    N, D = x.shape
+    F = emb.shape[1]
+    out = torch.empty((L, N, F), dtype=torch.float32, device=dev)
+    Rb = 128 if vxl is None else vxl.shape[-1]
+    be.grid_encode_forward(t(x), t(emb), t(offs), t(res), out, N, D, F, L, 0, Rb, 0.0, None,
+                           t(vxl), t(mli), ste_binary=ste)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _bwd_gpu(dev, g, x, emb, offs, res, vxl=None, mli=None, ste=False):
+    from cnc_amd.backends import gridencoder_backend as be
+    t = lambda a: None if a is None else torch.as_tensor(a, device=dev)
+    L, N, F = g.shape
+    D = x.shape[1]
+    ge = torch.zeros(emb.shape, dtype=torch.float32, device=dev)
+    Rb = 128 if vxl is None else vxl.shape[-1]
+    be.grid_encode_backward(t(g), t(x), t(emb), t(offs), t(res), ge, N, D, F, L, 0, Rb, None, None,
+                            t(vxl), t(mli), ste_binary=ste)
+    torch.cuda.synchronize()
+    return ge.cpu().numpy()
+
+
+@pytest.mark.parametrize("D", [2, 3])
+@pytest.mark.parametrize("F", [1, 2, 4, 8, 16, 32])
+def test_forward_bit_exact(cuda, oracle, D, F):
+    res = RES3 if D == 3 else RES2
+    offs, resl, emb = make_grid(res, 10, D, F, seed=F)
+    x = _points(3001, D, seed=D * 10 + F)
+    want = oracle.grid_encode_forward(x, emb, offs, resl)
+    got = _fwd_gpu(cuda, x, emb, offs, resl, len(res))
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+    assert np.all(got[:, 2] == 0) and np.all(got[:, 3] == 0)   # OOB points
+
+
+@pytest.mark.parametrize("D", [2, 3])
+@pytest.mark.parametrize("ste", [False, True])
+def test_forward_with_occupancy_mask(cuda, oracle, D, ste):
+    res = RES3 if D == 3 else RES2
+    offs, resl, emb = make_grid(res, 10, D, 8, seed=3)
+    vxl = ball_occupancy(16 if D == 3 else 32, D)
+    x = _points(2500, D, seed=5)
+    want = oracle.grid_encode_forward(x, emb, offs, resl, binary_vxl=vxl, ste_binary=ste)
+    got = _fwd_gpu(cuda, x, emb, offs, resl, len(res), vxl=vxl, ste=ste)
+    assert np.array_equal(got, want)
+
+
+def test_forward_level_window_slice_and_per_point_levels(cuda, oracle):
+    offs, resl, emb = make_grid(RES3, 10, 3, 4, seed=7)
+    vxl = ball_occupancy(16, 3)
+    x = _points(1777, 3, seed=8)
+    # scalar window: the reference slices the tables in Python (ngp.py:90-91)
+    lo, hi = 2, 5
+    want = oracle.grid_encode_forward(x, emb, offs[lo:hi + 1], resl[lo:hi], binary_vxl=vxl)
+    got = _fwd_gpu(cuda, x, emb, offs[lo:hi + 1].copy(), resl[lo:hi].copy(), hi - lo, vxl=vxl)
+    assert np.array_equal(got, want)
+    # per-point window (forward_diff_levels, ngp.py:265-297)
+    rng = np.random.default_rng(1)
+    mli = rng.integers(0, len(RES3) - 3 + 1, size=x.shape[0]).astype(np.int32)
+    want = oracle.grid_encode_forward(x, emb, offs, resl, n_levels_calc=3, binary_vxl=vxl, min_level_id=mli)
+    got = _fwd_gpu(cuda, x, emb, offs, resl, 3, vxl=vxl, mli=mli)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("N", [0, 1, 63, 64, 65, 257])
+def test_forward_ragged_sizes(cuda, oracle, N):
+    offs, resl, emb = make_grid(RES3, 10, 3, 8, seed=2)
+    x = np.random.default_rng(N).uniform(0, 1, size=(N, 3)).astype(np.float32)
+    got = _fwd_gpu(cuda, x, emb, offs, resl, len(RES3))
+    if N == 0:
+        assert got.shape == (len(RES3), 0, 8)
+        return
+    assert np.array_equal(got, oracle.grid_encode_forward(x, emb, offs, resl))
+
+
+def _check_bwd(got, want32, acc64, abs64, n_terms_max):
+    # |float-sum in any order - exact| <= (n-1) * eps * sum|terms|  (+ rounding of the terms)
+    eps = np.finfo(np.float32).eps
+    bound = (n_terms_max + 2) * eps * abs64 + 1e-30
+    assert np.all(np.abs(got.astype(np.float64) - acc64) <= bound)
+    # and the oracle's own fp32 serial sum obeys the same bound (sanity of the bound)
+    assert np.all(np.abs(want32.astype(np.float64) - acc64) <= bound)
+    untouched = abs64 == 0
+    assert np.all(got[untouched] == 0)
+
+
+@pytest.mark.parametrize("D,F", [(3, 8), (3, 2), (3, 1), (2, 8), (2, 4), (3, 16)])
+@pytest.mark.parametrize("ste", [False, True])
+def test_backward_against_float64_shadow(cuda, oracle, D, F, ste):
+    res = RES3 if D == 3 else RES2
+    offs, resl, emb = make_grid(res, 10, D, F, seed=11)
+    x = _points(2049, D, seed=12)
+    rng = np.random.default_rng(13)
+    g = rng.normal(size=(len(res), x.shape[0], F)).astype(np.float32)
+    want32, acc64 = oracle.grid_encode_backward(g, x, emb, offs, resl, ste_binary=ste, want_acc64=True)
+    _, abs64 = oracle.grid_encode_backward(np.abs(g), x, emb, offs, resl, ste_binary=ste, want_acc64=True)
+    got = _bwd_gpu(cuda, g, x, emb, offs, resl, ste=ste)
+    _check_bwd(got, want32, acc64, abs64, n_terms_max=x.shape[0] * 8)
+    if ste:
+        assert np.all(got[np.abs(emb) > 1] == 0)
+
+
+def test_backward_with_mask_and_per_point_levels(cuda, oracle):
+    offs, resl, emb = make_grid(RES3, 10, 3, 8, seed=21)
+    vxl = ball_occupancy(16, 3)
+    x = _points(1500, 3, seed=22)
+    rng = np.random.default_rng(23)
+    mli = rng.integers(0, len(RES3) - 3 + 1, size=x.shape[0]).astype(np.int32)
+    g = rng.normal(size=(3, x.shape[0], 8)).astype(np.float32)
+    want32, acc64 = oracle.grid_encode_backward(g, x, emb, offs, resl, binary_vxl=vxl, min_level_id=mli, want_acc64=True)
+    _, abs64 = oracle.grid_encode_backward(np.abs(g), x, emb, offs, resl, binary_vxl=vxl, min_level_id=mli, want_acc64=True)
+    got = _bwd_gpu(cuda, g, x, emb, offs, resl, vxl=vxl, mli=mli)
+    _check_bwd(got, want32, acc64, abs64, n_terms_max=x.shape[0] * 8)
+
+
+def test_backward_is_exact_without_collisions(cuda, oracle):
+    """One point per call -> every table entry receives at most one term per (level): the atomic
+    result must equal the oracle bit for bit."""
+    offs, resl, emb = make_grid(RES3, 12, 3, 8, seed=31)
+    x = np.array([[0.3137, 0.7211, 0.5523]], np.float32)
+    g = np.random.default_rng(32).normal(size=(len(RES3), 1, 8)).astype(np.float32)
+    want = oracle.grid_encode_backward(g, x, emb, offs, resl)
+    got = _bwd_gpu(cuda, g, x, emb, offs, resl)
+    assert np.array_equal(got, want)
+
+
+def test_linearity_and_partition_of_unity_full_size(cuda):
+    """BASELINE size (16 levels x 2^19 x F8, 2^20 points): properties that need no oracle.
+    (a) with an all-ones table every in-range point encodes to 1 (weights renormalised to 1);
+    (b) backward of an all-ones gradient deposits exactly N*L*F in total;
+    (c) encode is linear in the table."""
+    from cnc_amd.backends import gridencoder_backend as be
+    dev = cuda
+    res_list = [18, 24, 32, 44, 60, 82, 113, 155, 214, 296, 408, 563, 778, 1074, 1484, 2049]
+    offs, resl, _ = make_grid(res_list, 19, 3, 1, seed=0)
+    F, L, N = 8, 16, 1 << 20
+    rows = int(offs[-1])
+    assert rows == 6120776
+    gen = torch.Generator(device=dev).manual_seed(42)
+    x = torch.rand((N, 3), device=dev, generator=gen)
+    o_t, r_t = torch.as_tensor(offs, device=dev), torch.as_tensor(resl, device=dev)
+    ones = torch.ones((rows, F), device=dev)
+    out = torch.empty((L, N, F), device=dev)
+    be.grid_encode_forward(x, ones, o_t, r_t, out, N, 3, F, L, 0, 128, 0.0, None, None, None)
+    assert torch.all((out - 1).abs() <= 1e-6)
+    ge = torch.zeros((rows, F), device=dev)
+    be.grid_encode_backward(torch.ones_like(out), x, ones, o_t, r_t, ge, N, 3, F, L, 0, 128, None, None, None, None)
+    total = ge.double().sum().item()
+    assert abs(total - N * L * F) <= 1e-5 * N * L * F
+    a = torch.randn((rows, F), device=dev, generator=gen)
+    b = torch.randn((rows, F), device=dev, generator=gen)
+    oa, ob, oab = (torch.empty_like(out) for _ in range(3))
+    be.grid_encode_forward(x, a, o_t, r_t, oa, N, 3, F, L, 0, 128, 0.0, None, None, None)
+    be.grid_encode_forward(x, b, o_t, r_t, ob, N, 3, F, L, 0, 128, 0.0, None, None, None)
+    be.grid_encode_forward(x, a + b, o_t, r_t, oab, N, 3, F, L, 0, 128, 0.0, None, None, None)
+    assert torch.allclose(oab, oa + ob, atol=2e-5, rtol=0)
+
+
+def test_error_behaviour(cuda):
+    from cnc_amd.backends import gridencoder_backend as be
+    dev = cuda
+    offs, resl, emb = make_grid(RES3, 10, 3, 8)
+    x = torch.rand((8, 3), device=dev)
+    e = torch.as_tensor(emb, device=dev)
+    o, r = torch.as_tensor(offs, device=dev), torch.as_tensor(resl, device=dev)
+    out = torch.empty((len(RES3), 8, 8), device=dev)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        be.grid_encode_forward(x.cpu(), e, o, r, out, 8, 3, 8, len(RES3), 0, 128, 0.0, None, None, None)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        be.grid_encode_forward(x.t().contiguous().t(), e, o, r, out, 8, 3, 8, len(RES3), 0, 128, 0.0, None, None, None)
+    with pytest.raises(RuntimeError, match="int tensor"):
+        be.grid_encode_forward(x, e, o.long(), r, out, 8, 3, 8, len(RES3), 0, 128, 0.0, None, None, None)
+    with pytest.raises(RuntimeError, match="n_fearures"):
+        be.grid_encode_forward(x, e, o, r, out, 8, 3, 3, len(RES3), 0, 128, 0.0, None, None, None)
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+@pytest.mark.parametrize("F", [2, 8])
+def test_cnt_np_embed_forward_backward(cuda, oracle, axis, F):
+    from cnc_amd.backends import gridencoder_backend as be
+    dev = cuda
+    R, hs = 34, 2 ** 12
+    rng = np.random.default_rng(axis * 7 + F)
+    pts = rng.integers(0, R, size=(5000, 3)).astype(np.int16)   # includes border vertices (skipped)
+    emb = np.where(rng.uniform(size=(hs, F)) < 0.5, 1.0, -1.0).astype(np.float32)
+    emb[::7] *= 0.5   # values that are not +-1: 0.5 counts as "negative" (> 0.9 test)
+    want = oracle.cnt_np_embed(pts, emb, R, hs, axis)
+    out = torch.zeros((R - 2, R - 2, F, 2), device=dev)
+    be.cnt_np_embed(torch.as_tensor(pts, device=dev), torch.as_tensor(emb, device=dev), out,
+                    pts.shape[0], R, F, hs, axis)
+    got = out.cpu().numpy()
+    assert np.array_equal(got, want)            # integer-valued counts: exact in fp32
+    assert got.sum() == want.sum()
+    s = (want.sum(-1, keepdims=True) + 1e-6).astype(np.float32)
+    grad = rng.normal(size=want.shape).astype(np.float32)
+    want_g, acc = oracle.cnt_np_embed_backward(pts, emb, s, grad, R, hs, axis, want_acc64=True)
+    _, absacc = oracle.cnt_np_embed_backward(pts, emb, s, np.abs(grad), R, hs, axis, want_acc64=True)
+    ge = torch.zeros((hs, F), device=dev)
+    be.cnt_np_embed_backward(torch.as_tensor(pts, device=dev), torch.as_tensor(emb, device=dev),
+                             torch.as_tensor(s, device=dev), torch.as_tensor(grad, device=dev), ge,
+                             pts.shape[0], R, F, hs, axis)
+    got_g = ge.cpu().numpy()
+    bound = 64 * np.finfo(np.float32).eps * np.abs(absacc) + 1e-30
+    assert np.all(np.abs(got_g.astype(np.float64) - acc) <= bound)

@@ -1,0 +1,196 @@
+"""HIP marcher + scans (through the `nerfacc.cuda` mirror) vs the CPU oracle.  Counts, masks,
+indices and t-values are bit-exact; the scans keep the reference's 32-wide tile association, so
+they are bit-exact too."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ball_occupancy
+
+pytestmark = pytest.mark.gpu
+
+
+def _rays(n, seed, radius=4.0):
+    rng = np.random.default_rng(seed)
+    o = rng.normal(size=(n, 3))
+    o = (o / np.linalg.norm(o, axis=1, keepdims=True) * radius).astype(np.float32)
+    target = rng.uniform(-0.8, 0.8, size=(n, 3))
+    d = target - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    if n > 8:
+        o[0] = [0, 0, -4]; d[0] = [0, 0, 1]          # axis-aligned (two zero components)
+        o[1] = [0.3, -4, 0.1]; d[1] = [0, 1, 0]
+        o[2] = [4, 4, 4]; d[2] = [0.57735026, 0.57735026, 0.57735026]   # points away: miss
+        o[3] = [0.1, 0.2, 0.3]; d[3] = [1, 0, 0]     # origin inside the box
+    return o, d
+
+
+AABB = np.array([[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]], np.float32)
+
+
+def test_ray_aabb_intersect(cuda, oracle):
+    from cnc_amd.backends import nerfacc_cuda as nc
+    o, d = _rays(5000, 1)
+    aabbs = np.concatenate([AABB, AABB * 2, AABB * 0.25], 0)
+    for near, far, miss in ((-np.inf, np.inf, np.inf), (0.5, 4.2, -1.0)):
+        w0, w1, wh = oracle.ray_aabb_intersect(o, d, aabbs, near, far, miss)
+        g0, g1, gh = nc.ray_aabb_intersect(torch.as_tensor(o, device=cuda), torch.as_tensor(d, device=cuda),
+                                           torch.as_tensor(aabbs, device=cuda), near, far, miss)
+        assert np.array_equal(gh.cpu().numpy(), wh)
+        assert np.array_equal(g0.cpu().numpy(), w0)
+        assert np.array_equal(g1.cpu().numpy(), w1)
+        assert 0 < wh.sum() < wh.size
+
+
+def _traverse_gpu(dev, o, d, binaries, aabbs, **kw):
+    from cnc_amd.nerfacc.grid import traverse_grids
+    t = lambda a: None if a is None else torch.as_tensor(a, device=dev)
+    kw = {k: (t(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+    iv, sm, term = traverse_grids(t(o), t(d), t(binaries), t(aabbs), **kw)
+    torch.cuda.synchronize()
+    return iv, sm, term
+
+
+def _cmp_segments(iv, sm, term, oiv, osm, oterm, live=None):
+    assert np.array_equal(iv.packed_info[:, 1].cpu().numpy(), oiv["chunk_cnts"])
+    assert np.array_equal(iv.packed_info[:, 0].cpu().numpy(), oiv["chunk_starts"])
+    assert np.array_equal(sm.packed_info[:, 1].cpu().numpy(), osm["chunk_cnts"])
+    assert np.array_equal(iv.is_left.cpu().numpy(), oiv["is_left"])
+    assert np.array_equal(iv.is_right.cpu().numpy(), oiv["is_right"])
+    # terminate_planes is only written for rays the fill pass visits (grid.cu:100-106,310-311):
+    # skipped rays keep whatever torch.empty held, in the reference as here
+    if live is None:
+        live = osm["chunk_cnts"] > 0
+    assert np.array_equal(term.cpu().numpy()[live], oterm[live])
+
+
+@pytest.mark.parametrize("step,cone", [(5e-3, 0.0), (2e-2, 0.004), (0.0, 0.0)])
+def test_traverse_two_pass(cuda, oracle, step, cone):
+    occ = ball_occupancy(32, 3, radius=0.33, seed=4)[None]
+    o, d = _rays(3000, 7)
+    rng = np.random.default_rng(3)
+    near = (rng.uniform(size=o.shape[0]) * max(step, 1e-3)).astype(np.float32)   # stratified jitter
+    far = np.full(o.shape[0], 1e10, np.float32)
+    oiv, osm, oterm = oracle.traverse_grids(o, d, occ, AABB, near, far, step, cone)
+    iv, sm, term = _traverse_gpu(cuda, o, d, occ, AABB, near_planes=near, far_planes=far,
+                                 step_size=step, cone_angle=cone)
+    _cmp_segments(iv, sm, term, oiv, osm, oterm)
+    assert np.array_equal(iv.vals.cpu().numpy(), oiv["vals"])
+    assert np.array_equal(iv.ray_indices.cpu().numpy(), oiv["ray_indices"])
+    assert np.array_equal(sm.vals.cpu().numpy(), osm["vals"])
+    assert np.array_equal(sm.ray_indices.cpu().numpy(), osm["ray_indices"])
+    assert osm["chunk_cnts"].sum() > 10000 and (osm["chunk_cnts"] == 0).any()
+    # sortedness: ordered by ray, then by t
+    ri = sm.ray_indices.cpu().numpy()
+    assert np.all(np.diff(ri) >= 0)
+    v = sm.vals.cpu().numpy()
+    same = np.diff(ri) == 0
+    assert np.all(np.diff(v)[same] > 0)
+
+
+def test_traverse_over_allocate_iterative(cuda, oracle):
+    """The evaluation loop's form (examples/utils.py:395-478): bounded steps, over-allocation,
+    rays_mask, restart from the termination planes until every ray is done; the concatenation
+    of all rounds must equal one unbounded march."""
+    occ = ball_occupancy(32, 3, radius=0.33, seed=4)[None]
+    o, d = _rays(2000, 11)
+    n = o.shape[0]
+    t0, t1, hits = oracle.ray_aabb_intersect(o, d, AABB)
+    t_sorted = np.concatenate([t0, t1], -1)
+    t_indices = np.broadcast_to(np.arange(2, dtype=np.int64), (n, 2)).copy()
+    near = np.zeros(n, np.float32)
+    far = np.full(n, 1e10, np.float32)
+    mask = np.ones(n, bool)
+    limit = 24
+    totals = np.zeros(n, np.int64)
+    full_iv, full_sm, _ = oracle.traverse_grids(o, d, occ, AABB, near, far, 5e-3, 0.0)
+    for it in range(64):
+        if not mask.any():
+            break
+        oiv, osm, oterm = oracle.traverse_grids(o, d, occ, AABB, near, far, 5e-3, 0.0,
+                                                traverse_steps_limit=limit, over_allocate=True,
+                                                rays_mask=mask, t_sorted=t_sorted, t_indices=t_indices, hits=hits)
+        iv, sm, term = _traverse_gpu(cuda, o, d, occ, AABB, near_planes=near, far_planes=far,
+                                     step_size=5e-3, cone_angle=0.0, traverse_steps_limit=limit,
+                                     over_allocate=True, rays_mask=mask, t_sorted=t_sorted,
+                                     t_indices=t_indices, hits=hits)
+        _cmp_segments(iv, sm, term, oiv, osm, oterm, live=mask)
+        # over-allocated buffers: compare the values selected by the masks, as the caller does
+        gl, gr = iv.vals[iv.is_left].cpu().numpy(), iv.vals[iv.is_right].cpu().numpy()
+        assert np.array_equal(gl, oiv["vals"][oiv["is_left"]])
+        assert np.array_equal(gr, oiv["vals"][oiv["is_right"]])
+        assert np.array_equal(sm.ray_indices[sm.is_valid].cpu().numpy(), osm["ray_indices"][osm["is_valid"]])
+        cnt = osm["chunk_cnts"]
+        totals += cnt
+        near = np.where(mask, oterm, near).astype(np.float32)
+        mask = mask & (cnt == limit)
+    assert not mask.any()
+    # restarting the DDA from a termination plane recomputes the cell-boundary distances from a
+    # different origin, so a sample that sits on a boundary may flip: near-equality only
+    diff = np.abs(totals - full_sm["chunk_cnts"])
+    assert diff.max() <= 2 and (diff > 0).mean() < 0.05
+
+
+def test_traverse_multi_grid(cuda, oracle):
+    rng = np.random.default_rng(2)
+    occ = rng.uniform(size=(2, 16, 16, 16)) < 0.3
+    aabbs = np.concatenate([AABB * 0.5, AABB], 0)
+    o, d = _rays(1500, 5)
+    oiv, osm, oterm = oracle.traverse_grids(o, d, occ, aabbs, None, None, 1e-2, 0.0)
+    iv, sm, term = _traverse_gpu(cuda, o, d, occ, aabbs, step_size=1e-2, cone_angle=0.0)
+    _cmp_segments(iv, sm, term, oiv, osm, oterm)
+    assert np.array_equal(sm.vals.cpu().numpy(), osm["vals"])
+
+
+def _ragged(n_rays, seed, max_len=200):
+    rng = np.random.default_rng(seed)
+    cnt = rng.integers(0, max_len, size=n_rays).astype(np.int64)
+    cnt[rng.uniform(size=n_rays) < 0.3] = 0
+    cnt[0] = 33; cnt[1] = 32; cnt[2] = 1; cnt[3] = 64; cnt[4] = 1040
+    starts = (np.cumsum(cnt) - cnt).astype(np.int64)
+    x = rng.uniform(0.01, 1.0, size=int(cnt.sum())).astype(np.float32)
+    return starts, cnt, x
+
+
+@pytest.mark.parametrize("exclusive", [False, True])
+@pytest.mark.parametrize("backward", [False, True])
+@pytest.mark.parametrize("normalize", [False, True])
+def test_segmented_sums_bit_exact(cuda, oracle, exclusive, backward, normalize):
+    from cnc_amd.backends import nerfacc_cuda as nc
+    if backward and normalize:
+        pytest.skip("reference: backward does not support normalize (scan.cu:25-26)")
+    starts, cnt, x = _ragged(999, 3)
+    want = oracle.segmented_scan(x, starts, cnt, exclusive, prod=False, reverse=backward, normalize=normalize)
+    fn = nc.exclusive_sum if exclusive else nc.inclusive_sum
+    got = fn(torch.as_tensor(starts, device=cuda), torch.as_tensor(cnt, device=cuda),
+             torch.as_tensor(x, device=cuda), normalize, backward).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("exclusive", [False, True])
+def test_segmented_prods_bit_exact(cuda, oracle, exclusive):
+    from cnc_amd.backends import nerfacc_cuda as nc
+    starts, cnt, x = _ragged(500, 8, max_len=60)
+    x = (0.5 + x).astype(np.float32)
+    t = lambda a: torch.as_tensor(a, device=cuda)
+    want = oracle.segmented_scan(x, starts, cnt, exclusive, prod=True)
+    fwd = nc.exclusive_prod_forward if exclusive else nc.inclusive_prod_forward
+    got = fwd(t(starts), t(cnt), t(x)).cpu().numpy()
+    assert np.array_equal(got, want)
+    g = np.random.default_rng(1).normal(size=x.shape).astype(np.float32)
+    want_b = oracle.prod_backward(x, want, g, starts, cnt, exclusive)
+    bwd = nc.exclusive_prod_backward if exclusive else nc.inclusive_prod_backward
+    got_b = bwd(t(starts), t(cnt), t(x), t(want), t(g)).cpu().numpy()
+    assert np.array_equal(got_b, want_b)
+
+
+def test_scan_docstring_examples(cuda):
+    """Known answers from the reference docstrings (nerfacc/scan.py:36-39,78-81,127-130,170-173)."""
+    from cnc_amd.nerfacc import exclusive_prod, exclusive_sum, inclusive_prod, inclusive_sum
+    x = torch.tensor([1., 2., 3., 4., 5., 6., 7., 8., 9.], device=cuda)
+    pk = torch.tensor([[0, 2], [2, 3], [5, 4]], device=cuda)
+    assert inclusive_sum(x, pk).tolist() == [1., 3., 3., 7., 12., 6., 13., 21., 30.]
+    assert exclusive_sum(x, pk).tolist() == [0., 1., 0., 3., 7., 0., 6., 13., 21.]
+    assert inclusive_prod(x, pk).tolist() == [1., 2., 3., 12., 60., 6., 42., 336., 3024.]
+    assert exclusive_prod(x, pk).tolist() == [1., 1., 1., 3., 12., 1., 6., 42., 336.]
+    assert exclusive_sum(torch.empty(0, device=cuda), torch.zeros((3, 2), dtype=torch.long, device=cuda)).shape == (0,)

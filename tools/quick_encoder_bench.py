@@ -1,0 +1,49 @@
+"""Scratch timing of the encoder kernels on the BASELINE 16Lx2^19xF8 grid (not the judged bench)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from cnc_amd.backends import gridencoder_backend as be
+
+dev = torch.device("cuda:0")
+res_list = [18, 24, 32, 44, 60, 82, 113, 155, 214, 296, 408, 563, 778, 1074, 1484, 2049]
+offs = [0]
+for R in res_list:
+    offs.append(offs[-1] + int(np.ceil(min(2**19, R**3) / 8) * 8))
+F, L = 8, 16
+o_t = torch.tensor(offs, dtype=torch.int32, device=dev); r_t = torch.tensor(res_list, dtype=torch.int32, device=dev)
+torch.manual_seed(42)
+emb = torch.sign(torch.rand((offs[-1], F), device=dev) * 2 - 1)
+
+def ray_points(N):
+    # coherent: 64 consecutive samples along a ray, step 5e-3/3
+    nr = N // 256
+    o = torch.rand((nr, 1, 3), device=dev) * 0.3 + 0.2
+    d = torch.nn.functional.normalize(torch.randn((nr, 1, 3), device=dev), dim=-1)
+    t = torch.arange(256, device=dev).view(1, 256, 1) * (5e-3 / 3)
+    return (o + d * t).clamp(0, 1).reshape(-1, 3).contiguous()
+
+for name, N, gen in (("uniform 2^20", 1 << 20, None), ("uniform 2^22", 1 << 22, None), ("rays 2^22", 1 << 22, ray_points)):
+    x = gen(N) if gen else torch.rand((N, 3), device=dev)
+    out = torch.empty((L, N, F), device=dev)
+    ge = torch.zeros_like(emb)
+    for ste in (False, True):
+        for _ in range(3):
+            be.grid_encode_forward(x, emb, o_t, r_t, out, N, 3, F, L, 0, 128, 0.0, None, None, None, ste_binary=ste)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            be.grid_encode_forward(x, emb, o_t, r_t, out, N, 3, F, L, 0, 128, 0.0, None, None, None, ste_binary=ste)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print(f"fwd {name} ste={ste}: {ms:.3f} ms  {N/ms/1e6:.3f} Gsamples/s  alg {N*4620/ms/1e9:.2f} TB/s")
+    for _ in range(2):
+        be.grid_encode_backward(out, x, emb, o_t, r_t, ge, N, 3, F, L, 0, 128, None, None, None, None)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        be.grid_encode_backward(out, x, emb, o_t, r_t, ge, N, 3, F, L, 0, 128, None, None, None, None)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print(f"bwd {name}: {ms:.3f} ms  {N/ms/1e6:.3f} Gsamples/s  alg {N*8716/ms/1e9:.2f} TB/s")
