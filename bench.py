@@ -1,0 +1,245 @@
+#!/usr/bin/env python
+"""bench.py — CNC hot path on MI355X: march 800x800 rays through an occupancy grid, push every
+ray-sample through the 16-level x 2^19 x F8 hash-grid encoder (forward), scatter the gradient back
+(backward); at N>1 each rank does that for its own camera and the table gradient is all-reduced
+over RCCL.  Prints ONE JSON line (rank 0).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+metric: encoded ray-samples/s (BASELINE.json).  `value` counts every marched sample once per
+step and divides by the wall time of the WHOLE step (march + positions + encode fwd + encode bwd
+[+ all-reduce]); per-kernel rates are in `kernels`, the dominant kernel's roofline in `roofline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from cnc_amd import synthetic  # noqa: E402
+from cnc_amd.backends import gridencoder_backend as enc  # noqa: E402
+from cnc_amd.nerfacc import grid as ngrid  # noqa: E402
+
+F, L, D = 8, 16, 3
+LOG2_T = 19
+CHUNK = 1 << 20
+STEP_SIZE = 5e-3
+AABB = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
+HBM_PEAK = 8.0e12
+BYTES_FWD = 4 * D + L * (2 ** D) * F * 4 + L * F * 4            # 4,620 B / sample
+BYTES_BWD = 4 * D + L * F * 4 + 2 * L * (2 ** D) * F * 4        # 8,716 B / sample
+
+
+class Timed:
+    """HIP-event timing of kernel launches on torch's current stream (the stream the C ABI is
+    handed), accumulated per kernel name."""
+
+    def __init__(self):
+        self.pending = []
+        self.acc = {}
+
+    def launch(self, name, units, fn):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.pending.append((name, units, e0, e1))
+
+    def collect(self):
+        for name, units, e0, e1 in self.pending:
+            a = self.acc.setdefault(name, [0.0, 0, 0])
+            a[0] += e0.elapsed_time(e1) * 1e-3
+            a[1] += 1
+            a[2] += units
+        self.pending = []
+
+
+def build_workload(dev, rank):
+    offs = synthetic.level_offsets(synthetic.RES_16L, LOG2_T, D)
+    assert int(offs[-1]) == 6120776
+    g = torch.Generator(device="cpu").manual_seed(42)
+    table = torch.sign(torch.rand((int(offs[-1]), F), generator=g) * 2 - 1)   # post-STE values
+    table[table == 0] = 1
+    w = dict(
+        offsets=torch.as_tensor(offs, device=dev),
+        resolutions=torch.tensor(synthetic.RES_16L, dtype=torch.int32, device=dev),
+        table=table.to(dev),
+        binaries=synthetic.ball_binaries(128, AABB, 1.0, device=dev),
+        aabbs=torch.tensor([AABB], dtype=torch.float32, device=dev),
+    )
+    # one camera per rank on a circle (weak scaling: every GPU renders its own 800x800 view)
+    o, d = synthetic.pinhole_rays(800, 800, 0.6911, 4.0, azimuth=0.7 + 0.785398 * rank, elevation=0.5)
+    w["rays_o"], w["rays_d"] = o.to(dev), d.to(dev)
+    from cnc_amd.dist import GradBucket
+    w["table_param"] = torch.nn.Parameter(w["table"])
+    w["bucket"] = GradBucket([w["table_param"]])
+    w["grad_table"] = w["bucket"].views[0]
+    w["out"] = torch.empty((L, CHUNK, F), device=dev)
+    return w
+
+
+def step(w, timed, world):
+    """One pass of the hot path over one 800x800 frame.  Returns the number of ray-samples."""
+    rays_o, rays_d = w["rays_o"], w["rays_d"]
+    n_rays = rays_o.shape[0]
+    t0 = time.perf_counter()
+    box = {}
+
+    def march():
+        box["iv"], box["sm"], _ = ngrid.traverse_grids(rays_o, rays_d, w["binaries"], w["aabbs"],
+                                                       step_size=STEP_SIZE, cone_angle=0.0)
+    timed.launch("march(ray_aabb+traverse x2+cumsum)", n_rays, march)
+    sm = box["sm"]
+    S = sm.vals.shape[0]
+    # sample positions, normalised to the unit cube (radiance field's aabb mapping, ngp.py:518-519)
+    ri = sm.ray_indices
+    pos = rays_o[ri] + rays_d[ri] * sm.vals[:, None]
+    x = ((pos - w["aabbs"][0, :3]) / (w["aabbs"][0, 3:] - w["aabbs"][0, :3])).contiguous()
+
+    gt = w["grad_table"]
+    gt.zero_()                                         # zeros_like(embeddings), ngp.py:129
+    out = w["out"]
+    for s in range(0, S, CHUNK):
+        n = min(CHUNK, S - s)
+        xs = x[s:s + n]
+        o = out[:, :n, :] if n == CHUNK else out.view(-1)[: L * n * F].view(L, n, F)
+        timed.launch("grid_encode_forward", n, lambda: enc.grid_encode_forward(
+            xs, w["table"], w["offsets"], w["resolutions"], o, n, D, F, L, 0, 128, 0.0, None, None, None))
+        # the encoder output doubles as a resident, non-trivial upstream gradient [L, n, F]
+        timed.launch("grid_encode_backward", n, lambda: enc.grid_encode_backward(
+            o, xs, w["table"], w["offsets"], w["resolutions"], gt, n, D, F, L, 0, 128, None, None, None, None))
+    if world > 1:
+        # the only exchange of the path: one flat-bucket all-reduce of the table gradient
+        timed.launch("allreduce(grad_table)", gt.numel() * 4, lambda: w["bucket"].allreduce(average=True))
+    return S
+
+
+def cpu_baseline(w):
+    """Oracle (C port of the reference kernels, OpenMP) on the host cores: march + encode fwd + bwd
+    over forty image rows of the same frame (~1e7 ray-samples); bounded so the default run stays short."""
+    import oracle
+    oracle.build()
+    threads = oracle.max_threads()
+    n_rays_sub = 40 * 800   # forty image rows through the middle of the ball (~1e7 samples)
+    mid = 380 * 800
+    o = w["rays_o"][mid:mid + n_rays_sub].cpu().numpy()
+    d = w["rays_d"][mid:mid + n_rays_sub].cpu().numpy()
+    binaries = w["binaries"].cpu().numpy()
+    aabbs = w["aabbs"].cpu().numpy()
+    table = w["table"].cpu().numpy()
+    offs, res = w["offsets"].cpu().numpy(), w["resolutions"].cpu().numpy()
+    t0 = time.perf_counter()
+    _, sm, _ = oracle.traverse_grids(o, d, binaries, aabbs, None, None, STEP_SIZE, 0.0)
+    pos = o[sm["ray_indices"]] + d[sm["ray_indices"]] * sm["vals"][:, None]
+    x = ((pos - aabbs[0, :3]) / (aabbs[0, 3:] - aabbs[0, :3])).astype(np.float32)
+    S = x.shape[0]
+    y = oracle.grid_encode_forward(x, table, offs, res, threads=threads)
+    oracle.grid_encode_backward(y, x, table, offs, res, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": S / dt, "unit": "ray-samples/s", "cores": threads, "kind": "port",
+            "sample": f"{n_rays_sub} rays of the same frame -> {S} samples, march(1 thread)+encode fwd+bwd (OpenMP x{threads}), {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    w = build_workload(dev, rank)
+    timed = Timed()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(w, timed, world)
+    barrier()
+    timed.pending, timed.acc = [], {}
+    t0 = time.perf_counter()
+    samples = 0
+    for _ in range(args.steps):
+        samples += step(w, timed, world)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timed.collect()
+
+    tot = torch.tensor([float(samples), elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        s = tot[0:1].clone()
+        e = tot[1:2].clone()
+        torch.distributed.all_reduce(s, op=torch.distributed.ReduceOp.SUM)
+        torch.distributed.all_reduce(e, op=torch.distributed.ReduceOp.MAX)
+        samples_all, elapsed_max = s.item(), e.item()
+    else:
+        samples_all, elapsed_max = float(samples), elapsed
+
+    if rank == 0:
+        kernels = {}
+        for name, (secs, launches, units) in timed.acc.items():
+            kernels[name] = {"launches": launches, "avg_ms": secs / launches * 1e3,
+                             "units_per_s": units / secs}
+        kb = timed.acc["grid_encode_backward"]
+        kf = timed.acc["grid_encode_forward"]
+        # dominant kernel = the one with the most accumulated time in the timed region
+        dom_name, bytes_per, k = (("grid_encode_backward", BYTES_BWD, kb) if kb[0] >= kf[0]
+                                  else ("grid_encode_forward", BYTES_FWD, kf))
+        achieved = bytes_per * k[2] / k[0]      # algorithmic bytes / s, averaged over launches
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            traffic = json.load(open(tp)).get(dom_name)
+        roofline = {"kernel": dom_name, "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+                    "bytes_per_sample": bytes_per, "samples_per_launch": k[2] / k[1],
+                    "avg_launch_ms": k[0] / k[1] * 1e3}
+        other = {"kernel": "grid_encode_forward", "achieved": BYTES_FWD * kf[2] / kf[0] / 1e9,
+                 "frac": BYTES_FWD * kf[2] / kf[0] / HBM_PEAK, "bytes_per_sample": BYTES_FWD}
+        out = {
+            "metric": "ray-samples/s/GPU (16Lx2^19xF8 grid)", "value": samples_all / elapsed_max,
+            "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 800x800 rays/GPU marched (step 5e-3) through a 128^3 ball "
+                                   "occupancy, every sample encoded fwd+bwd on the 16Lx2^19xF8 hash grid"
+                                   + (", grad table all-reduced (RCCL)" if world > 1 else ""),
+                       "rays_per_gpu": 640000, "samples_per_step_rank0": samples // args.steps,
+                       "chunk": CHUNK, "table_rows": 6120776, "n_features": F, "levels": L},
+            "roofline": roofline, "roofline_forward": other, "kernels": kernels,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

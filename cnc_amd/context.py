@@ -1,0 +1,666 @@
+"""Context models + entropy estimate + codec for the binarised hash-grid embeddings.
+
+Host-side mirror of examples/utils_bpp_acc.py of the reference:
+    `_cnt_np_embed` :27-75, `encoder`/`decoder` :77-110, `align_and_pack` :113-139,
+    `CNC_context_models` :193-999 (tables :260-402, training pass :533-706, encode :709-865,
+    decode :867-999), `Bernoulli_entropy` :1002-1013.
+Same class / method names, argument meaning, return values and file naming, so the reference's
+drivers can call it unchanged.  The three passes share their per-level arithmetic here (the
+reference repeats it three times); every kernel call goes through the HIP mirrors
+(`_gridencoder`, `pack_and_align`), the entropy coder through libcnc_codec.so.
+
+Differences that do not change results:
+  * device is taken from the constructor (`device=`) instead of hard-coded 'cuda' module
+    globals (utils_bpp_acc.py:19-20), so the tables can be built and inspected on CPU;
+  * `align_and_pack(...).sum(dim=1)` — a padded [N, M, F] tensor (M up to 288) that is
+    immediately reduced — keeps the reference's dataflow for now (bit-identical means);
+  * random draws go through `self.rand_like` / `self.randperm` hooks (default torch) so tests
+    can replay the reference's CPU random stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as nnf
+from torch.autograd import Function
+
+from .backends import gridencoder_backend as _backend
+from .backends import pack_and_align
+from .gridencoder import STE_binary, STE_multistep
+
+_codec = None
+
+
+def _codec_lib():
+    global _codec
+    if _codec is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcnc_codec.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: build it with `python -m cnc_amd.build`")
+        L = C.CDLL(path)
+        L.cnc_rc_bound.restype = C.c_int64
+        L.cnc_rc_bound.argtypes = [C.c_int64]
+        L.cnc_rc_encode_pm1.restype = C.c_int64
+        L.cnc_rc_encode_pm1.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.cnc_rc_decode_pm1.restype = C.c_int
+        L.cnc_rc_decode_pm1.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+        _codec = L
+    return _codec
+
+
+def get_grid_index(hashmap_size, resolution, pos_grid):
+    """Row index of integer grid vertices (reference twin of the kernel's hash:
+    examples/utils.py:492-511).  Dense x + y*R + z*R^2 when the level fits, else xor of
+    coordinate*prime; int64 arithmetic, which equals the kernel's uint32 wrap-around for the
+    power-of-two table sizes hashed levels have."""
+    D = pos_grid.shape[-1]
+    pos = pos_grid.to(torch.long)
+    if resolution ** D <= hashmap_size:
+        idx = torch.zeros(pos.shape[:-1], dtype=torch.long, device=pos.device)
+        stride = 1
+        for d in range(D):
+            idx = idx + pos[..., d] * stride
+            stride *= resolution
+    else:
+        primes = (1, 2654435761, 805459861, 3674653429, 2097192037, 1434869437, 2165219737)
+        idx = pos[..., 0] * primes[0]
+        for d in range(1, D):
+            idx = idx ^ (pos[..., d] * primes[d])
+    return idx % hashmap_size
+
+
+class _cnt_np_embed(Function):
+    """Fraction of +1 votes of the finest 3-D level projected on a plane (utils_bpp_acc.py:27-75)."""
+
+    @staticmethod
+    def forward(ctx, inputs, embeddings, resolution, hashmap_size, axis):
+        axis_id = ("xy", "xz", "yz").index(axis)
+        N = inputs.shape[0]
+        n_features = embeddings.shape[-1]
+        assert inputs.shape[-1] == 3
+        inputs = inputs.to(torch.int16).contiguous()
+        embeddings = embeddings.contiguous()
+        scale = resolution - 2
+        pn_embed = torch.zeros([scale, scale, n_features, 2], device=inputs.device)
+        _backend.cnt_np_embed(inputs, embeddings, pn_embed, N, resolution, n_features, hashmap_size, axis_id)
+        pn_embed_sum = torch.sum(pn_embed, dim=-1, keepdim=True) + 1e-6
+        ctx.save_for_backward(inputs, embeddings, pn_embed_sum)
+        ctx.dims = (N, resolution, n_features, hashmap_size, axis_id)
+        return pn_embed / pn_embed_sum
+
+    @staticmethod
+    def backward(ctx, grad):
+        inputs, embeddings, pn_embed_sum = ctx.saved_tensors
+        N, resolution, n_features, hashmap_size, axis_id = ctx.dims
+        grad_embeddings = torch.zeros_like(embeddings)
+        _backend.cnt_np_embed_backward(inputs, embeddings, pn_embed_sum, grad.contiguous(),
+                                       grad_embeddings, N, resolution, n_features, hashmap_size, axis_id)
+        return None, grad_embeddings, None, None, None
+
+
+def encoder(x, p, file_name):
+    """Code x in {-1,+1} with P(x=+1)=p into `file_name` (.b); returns the size in bits
+    (utils_bpp_acc.py:77-93)."""
+    assert file_name[-2:] == ".b"
+    x = x.detach().to(torch.float32).cpu().contiguous().view(-1)
+    p = p.detach().to(torch.float32).cpu().contiguous().view(-1)
+    n = x.numel()
+    L = _codec_lib()
+    cap = int(L.cnc_rc_bound(n))
+    buf = np.empty(cap, dtype=np.uint8)
+    nbytes = L.cnc_rc_encode_pm1(p.data_ptr(), x.data_ptr(), n, buf.ctypes.data, cap)
+    if nbytes < 0:
+        raise RuntimeError("range coder: output buffer too small")
+    with open(file_name, "wb") as fout:
+        fout.write(buf[:nbytes].tobytes())
+    return int(nbytes) * 8
+
+
+def decoder(p, file_name):
+    """Inverse of `encoder`: returns float32 ±1 on p's device (utils_bpp_acc.py:95-110)."""
+    assert file_name[-2:] == ".b"
+    dvc = p.device
+    p = p.detach().to(torch.float32).cpu().contiguous().view(-1)
+    with open(file_name, "rb") as fin:
+        stream = np.frombuffer(fin.read(), dtype=np.uint8)
+    out = torch.empty(p.numel(), dtype=torch.float32)
+    _codec_lib().cnc_rc_decode_pm1(p.data_ptr(), p.numel(), stream.ctypes.data, stream.shape[0],
+                                   out.data_ptr())
+    return out.to(dvc)
+
+
+class align_and_pack(Function):
+    """Ragged [T, F] rows grouped by `unique_cnt` -> padded [N, max(cnt), F] (utils_bpp_acc.py:113-139)."""
+
+    @staticmethod
+    def forward(ctx, voxel_features, unique_cnt, V, dim=3):
+        voxel_features = voxel_features.contiguous()
+        unique_cnt = unique_cnt.contiguous()
+        cumsum = torch.cat([torch.zeros(1, dtype=unique_cnt.dtype, device=unique_cnt.device),
+                            torch.cumsum(unique_cnt, dim=0)])
+        N = unique_cnt.numel()
+        M = int(unique_cnt.max()) if N else 0          # host sync, as in the reference (:121)
+        F = voxel_features.shape[-1]
+        T = int(cumsum[-1])
+        packed = pack_and_align.align_and_pack_forward(voxel_features, unique_cnt, cumsum, N, M, F, 0.0, dim)
+        ctx.save_for_backward(voxel_features, unique_cnt, cumsum)
+        ctx.dims = (N, M, F, T, dim)
+        return packed
+
+    @staticmethod
+    def backward(ctx, dL_packed):
+        voxel_features, unique_cnt, cumsum = ctx.saved_tensors
+        N, M, F, T, dim = ctx.dims
+        d_feat = pack_and_align.align_and_pack_backward(dL_packed.contiguous(), voxel_features,
+                                                        unique_cnt, cumsum, N, M, F, T, dim)
+        return d_feat, None, None, None
+
+
+def my_meshgrid3D(start=(0, 0, 0), end=(1000, 1000, 1000), dtype=torch.int32, device="cuda"):
+    """[lx, ly, lz, 3] integer lattice (utils_bpp_acc.py:142-161)."""
+    if isinstance(start, int):
+        start, end = (start,) * 3, (end,) * 3
+    axes = [torch.arange(s, e, device=device, dtype=dtype) for s, e in zip(start, end)]
+    return torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=-1)
+
+
+class Bernoulli_entropy(nn.Module):
+    """bits of x in {-1,+1} under P(+1)=clamp(p, 1e-6, 1-1e-6) (utils_bpp_acc.py:1002-1013)."""
+
+    def forward(self, x, p):
+        p = torch.clamp(p, min=1e-6, max=1 - 1e-6)
+        pos_mask = (1 + x) / 2.0
+        neg_mask = (1 - x) / 2.0
+        return -torch.log2(p) * pos_mask + -torch.log2(1 - p) * neg_mask
+
+
+class CNC_context_models(nn.Module):
+    MAX_POINTS_NUM_TO_OOM = 20000000
+
+    def __init__(self, num_dim=3,
+                 resolutions_list=(16, 22, 31, 42, 57, 78, 106, 146, 199, 273, 374, 512),
+                 resolutions_list_2D=(128, 256, 512, 1024), log2_hashmap_size=19,
+                 log2_hashmap_size_2D=21, n_features=4, sample_num=20000, max_context_layer_num=3,
+                 ste_binary=False, ste_multistep=False, add_noise=False, Q=100, quantize_epoch=1000,
+                 Pg_level=-1, Pg_level_2D=-1, Rb=128, step_update=16, skip_levels_3D=(0, 1, 2, 3),
+                 skip_levels_2D=(0,), use_dimension_wise=True, use_overlap_area_pool=True,
+                 device="cuda", dimension_wise_resolution=514):
+        super().__init__()
+        dev = torch.device(device)
+        self.dev = dev
+        self.use_overlap_area_pool = use_overlap_area_pool
+        self.use_dimension_wise = use_dimension_wise
+        self.rand_like = torch.rand_like
+        self.randperm = torch.randperm
+
+        resolutions_list = torch.tensor(list(resolutions_list), device=dev)
+        resolutions_list_2D = torch.tensor(list(resolutions_list_2D), device=dev)
+        n_levels, n_levels_2D = resolutions_list.numel(), resolutions_list_2D.numel()
+        self.num_dim = num_dim
+        self.resolutions_list = resolutions_list
+        self.resolutions_list_2D = resolutions_list_2D
+        self.scales_list = (resolutions_list - 2).unsqueeze(-1)
+        self.scales_list_2D = (resolutions_list_2D - 2).unsqueeze(-1)
+        self.log2_hashmap_size = log2_hashmap_size
+        self.log2_hashmap_size_2D = log2_hashmap_size_2D
+        self.n_features = n_features
+        self.n_levels, self.n_levels_2D = n_levels, n_levels_2D
+        self.ste_binary, self.ste_multistep, self.add_noise = ste_binary, ste_multistep, add_noise
+        self.Q = Q
+        self.quantize_epoch = quantize_epoch
+        self.quantize_epoch_cnt = 0
+        if Pg_level == -1 or Pg_level >= n_levels:
+            Pg_level = n_levels
+        self.Pg_level = max(Pg_level, 1)
+        if Pg_level_2D == -1 or Pg_level_2D >= n_levels_2D:
+            Pg_level_2D = n_levels_2D
+        self.Pg_level_2D = max(Pg_level_2D, 1)
+        Pg_level = self.Pg_level
+        self.skip_levels_3D = skip_levels_3D
+        self.skip_levels_2D = skip_levels_2D
+        self.sample_num = sample_num
+        self.max_context_layer_num = max_context_layer_num
+
+        def offsets(res, T, D):
+            o = [0]
+            for R in res.tolist():
+                o.append(o[-1] + int(np.ceil(min(T, R ** D) / 8) * 8))
+            return torch.tensor(o, dtype=torch.long, device=dev)
+
+        max_params = 2 ** log2_hashmap_size
+        self.offsets_list = offsets(resolutions_list, max_params, num_dim)
+        self.offsets_list_2D = offsets(resolutions_list_2D, 2 ** log2_hashmap_size_2D, 2)
+        offsets_list = self.offsets_list
+
+        # finest level that is still stored densely (utils_bpp_acc.py:288-293)
+        self.n_levels_thresh = n_levels - 1
+        self.resolution_thresh = resolutions_list[-1]
+        for i in range(n_levels - 1):
+            if resolutions_list[i] ** num_dim <= max_params and resolutions_list[i + 1] ** num_dim > max_params:
+                self.n_levels_thresh = i + 1
+                self.resolution_thresh = resolutions_list[i] + 0.0
+
+        # per level: every grid vertex sorted by the hash slot it lands in (:296-335)
+        unique_value_list, cumsum_list, count_list, pos_sorted_list = [], [], [], []
+        zero = torch.zeros(1, dtype=torch.long, device=dev)
+        for i in reversed(range(Pg_level)):
+            R = int(resolutions_list[i].item())
+            pos_grid = my_meshgrid3D(0, R, device=dev).view(-1, 3)
+            indexes = get_grid_index(int(offsets_list[i + 1] - offsets_list[i]), R, pos_grid)
+            indexes_sorted, order = torch.sort(indexes, descending=False, dim=0)
+            pos_sorted = torch.index_select(pos_grid.to(torch.int16), dim=0, index=order)
+            unique_value, unique_cnt = torch.unique(indexes_sorted, return_counts=True)
+            if R <= self.resolution_thresh:
+                # dense levels: random slot order so a sampled window is spatially spread (:311-315)
+                shuffle = self.randperm(unique_value.nelement()).to(dev)
+                unique_value, pos_sorted, unique_cnt = unique_value[shuffle], pos_sorted[shuffle], unique_cnt[shuffle]
+            unique_value_list.insert(0, unique_value.to(torch.long))
+            cumsum_list.insert(0, torch.cat([zero, torch.cumsum(unique_cnt, dim=0)]).to(torch.long))
+            count_list.insert(0, unique_cnt)
+            pos_sorted_list.insert(0, pos_sorted)
+            del pos_grid, indexes, indexes_sorted, order
+        self.unique_value_list = unique_value_list
+        self.pos_grid_sorted_list = pos_sorted_list
+
+        lens = [c.numel() for c in cumsum_list]
+        self.unique_count_cumsum_list = torch.zeros([Pg_level, max(lens)], dtype=torch.long, device=dev)
+        self.unique_count_list = torch.zeros([Pg_level, max(lens)], dtype=torch.long, device=dev)
+        for i in range(Pg_level):
+            self.unique_count_cumsum_list[i, :lens[i]] = cumsum_list[i]
+            self.unique_count_list[i, :lens[i] - 1] = count_list[i]
+
+        # how many hash slots per level enter the per-step entropy estimate (:350-366)
+        hp = torch.tensor([lens[i] - 1 for i in range(Pg_level)], device=dev)
+        self.hashparams_num_levels = hp
+        self.sample_num_levels = self._sample_allocation(sample_num)
+        self.ttl_hashparams_num_levels = int(hp.sum().item())
+        coded = [n for n in range(n_levels) if n not in skip_levels_3D and n < Pg_level]
+        self.ttl_hashparams_num_valid_levels = int(sum(hp[n].item() for n in coded))
+        self.ttl_sample_num = int(self.sample_num_levels.sum().item())
+        self.ttl_sample_num_valid_levels = int(sum(self.sample_num_levels[n].item() for n in coded))
+
+        self.utils_rand = torch.rand(size=[Pg_level]).to(dev)
+        self.utils_nlevel_idx = torch.arange(Pg_level, device=dev)
+        self.utils_points_per_param_levels = [
+            ((resolutions_list[i] ** num_dim) / hp[i]).item() for i in range(Pg_level)]
+
+        ar = torch.arange(0, Rb, device=dev, dtype=torch.int32)
+        self.binary_vxl_2D_idx = torch.stack(torch.meshgrid(ar, ar, indexing="ij"), dim=-1)
+
+        self.context_model_3D = nn.Sequential(
+            nn.Linear(n_features * max_context_layer_num + 1, 32), nn.LeakyReLU(),
+            nn.Linear(32, 32), nn.LeakyReLU(),
+            nn.Linear(32, n_features),
+        ).to(dev)
+        heads = []
+        for n in range(1, self.Pg_level_2D):
+            ctx_layers = min(n, max_context_layer_num)
+            heads.append(nn.Sequential(
+                nn.Linear(n_features * (ctx_layers + int(use_dimension_wise)) + 1, n_features)))
+        self.context_model_2D = nn.Sequential(*heads).to(dev)
+        self.entropy_model = Bernoulli_entropy()
+
+        self.binary_vxl_len = Rb
+        self.dimension_wise_resolution = dimension_wise_resolution
+        self.init_binary_vxl_coords(scale=dimension_wise_resolution - 2)
+        self.step_update = step_update
+        self.idx_coords2_tmp = None
+        self.batched_inputs_list = None
+
+    # ------------------------------------------------------------------------------- helpers
+    def _sample_allocation(self, sample_num):
+        hp = self.hashparams_num_levels
+        alloc = torch.round(hp * (sample_num / hp.sum())).to(torch.long)
+        return hp if alloc[-1] > hp[-1] else alloc
+
+    def _query(self, points, binary_vxl, resolution=None, resolution_list=None):
+        N = points.shape[0]
+        mask = torch.zeros([N], dtype=torch.int16, device=points.device)
+        overlap = torch.zeros([N], dtype=torch.int32, device=points.device)
+        vxl = binary_vxl.squeeze(0).contiguous()
+        if resolution_list is None:
+            pack_and_align.query_mask_3D(points.contiguous(), vxl, mask, overlap, int(resolution), N)
+        else:
+            pack_and_align.query_mask_3D_qlist(points.contiguous(), vxl, mask, overlap,
+                                               resolution_list.contiguous(), N)
+        return mask.to(torch.bool), overlap
+
+    def query_binary_vxl(self, points_n_orig, binary_vxl, n, mem_save=False, verbose=False,
+                         return_overlap_area=False):
+        mask, overlap = self._query(points_n_orig, binary_vxl, resolution=self.resolutions_list[n])
+        return (mask, overlap) if return_overlap_area else mask
+
+    def query_binary_vxl_qlist(self, points_n_orig_list, binary_vxl, n_list, return_overlap_area=False):
+        mask, overlap = self._query(points_n_orig_list, binary_vxl,
+                                    resolution_list=self.resolutions_list[n_list])
+        return (mask, overlap) if return_overlap_area else mask
+
+    def fetch_2D_batches(self, binary_vxl_2D, n):
+        """All vertices of 2-D level n inside (or one ring around) occupied projected cells:
+        their hash rows and normalised positions (utils_bpp_acc.py:431-456)."""
+        Rb = binary_vxl_2D.shape[-1]
+        T = self.scales_list_2D[n] / Rb
+        assert T % 1 == 0
+        T = int(T)
+        R = self.resolutions_list_2D[n]
+        occ = self.binary_vxl_2D_idx.view(-1, 2)[binary_vxl_2D.reshape(-1) == 1]
+        occ = occ.view(-1, 1, 1, 2) * T
+        ar = torch.arange(0, T + 2, device=self.dev)
+        ring = torch.stack(torch.meshgrid(ar, ar, indexing="ij"), dim=-1).view(1, T + 2, T + 2, 2)
+        points_n_orig = (occ + ring + 0.0).to(torch.long)
+        indexes_2D = get_grid_index(int(self.offsets_list_2D[n + 1] - self.offsets_list_2D[n]),
+                                    int(R.item()), points_n_orig.view(-1, 2))
+        points_n = (points_n_orig - 0.5) / self.scales_list_2D[n].item()
+        return indexes_2D, points_n.view(-1, 2)
+
+    def get_STE_params(self, Encoding, mode="ste_binary"):
+        assert mode in ("ste_binary", "ste_multistep", "add_noise")
+        params = Encoding.params
+        if mode == "ste_binary":
+            return STE_binary.apply(params)
+        if mode == "ste_multistep":
+            return STE_multistep.apply(params, self.Q)
+        return params + (self.rand_like(params) - 0.5) * (1 / self.Q)
+
+    def get_BiRF_wentropy_leveln(self, params_q, n, offsets_list=None):
+        """Level frequency Pg_n = #(+1)/numel and the zero-order bit count (utils_bpp_acc.py:472-486)."""
+        if offsets_list is None:
+            offsets_list = self.offsets_list
+        level = params_q[offsets_list[n]:offsets_list[n + 1]]
+        ttl = level.numel()
+        s = torch.sum(level)
+        pos_num, neg_num = (ttl + s) / 2.0, (ttl - s) / 2.0
+        Pg_n = pos_num / ttl
+        bits = pos_num * (-torch.log2(Pg_n)) + neg_num * (-torch.log2(1 - Pg_n))
+        return Pg_n, bits, ttl
+
+    def init_binary_vxl_coords(self, scale=512):
+        t = scale // self.binary_vxl_len
+        resolution = scale + 2
+        self.idx_coord_base = my_meshgrid3D(-1, t + 1, device=self.dev).unsqueeze(0)
+        self.idx_coord_temp = my_meshgrid3D(0, self.binary_vxl_len, device=self.dev).view(-1, 1, 1, 1, 3)
+        self.pn_frac_offsets_list = torch.tensor([0, resolution * resolution], device=self.dev, dtype=torch.int32)
+        self.pn_frac_resolutions_list = torch.tensor([resolution], device=self.dev, dtype=torch.int32)
+
+    def get_idx_coords2(self, binary_vxl, resolution=None):
+        """Unique finest-level vertices inside / one ring around occupied cells (utils_bpp_acc.py:498-512)."""
+        resolution = self.dimension_wise_resolution if resolution is None else resolution
+        t = (resolution - 2) // self.binary_vxl_len
+        sel = self.idx_coord_temp[binary_vxl.squeeze(0).reshape(-1)]
+        coords = (sel * t + self.idx_coord_base).view(-1, 3) + 1
+        lin = coords[..., 0] * resolution * resolution + coords[..., 1] * resolution + coords[..., 2]
+        lin = torch.unique(lin, dim=0)
+        return torch.stack([lin // (resolution * resolution), (lin // resolution) % resolution,
+                            lin % resolution], dim=-1)
+
+    def get_pn_embed_frac(self, embeddings_3D_q, idx_coords2, resolution=None, axis="xy"):
+        resolution = self.dimension_wise_resolution if resolution is None else resolution
+        frac = _cnt_np_embed.apply(idx_coords2, embeddings_3D_q, resolution, 2 ** self.log2_hashmap_size, axis)
+        frac = frac[..., 0].permute(2, 0, 1).unsqueeze(0).contiguous()      # [1, F, R-2, R-2]
+        frac = nnf.pad(frac, pad=[1, 1, 1, 1])                              # ring of zeros
+        return frac.squeeze(0).permute(1, 2, 0).contiguous().view(-1, self.n_features)
+
+    @staticmethod
+    def _project(binary_vxl, axis):
+        return torch.any(binary_vxl.squeeze(0), dim={"xy": 2, "xz": 1, "yz": 0}[axis])
+
+    # ---- shared per-level arithmetic -------------------------------------------------------
+    def _mean_2D(self, Encoding_2D, n, points_n, Pg_n, binary_vxl_2D, pn_embed_frac, order,
+                 unique_cnt, outspace_params=None, detach_pn=False):
+        """P(+1) per distinct hash slot of 2-D level n: context = lower levels (+ dimension-wise
+        3-D vote fraction) -> linear head -> mean over the vertices colliding in the slot."""
+        ctx_layers = min(n, self.max_context_layer_num)
+        context = Encoding_2D(points_n, n - ctx_layers, n, outspace_params=outspace_params,
+                              binary_vxl=binary_vxl_2D, PV=0)
+        Pg_col = Pg_n.reshape(1, 1).repeat(context.shape[0], 1)
+        if self.use_dimension_wise:
+            context_pn = Encoding_2D.forward_given_params(points_n, self.pn_frac_offsets_list,
+                                                          self.pn_frac_resolutions_list,
+                                                          pn_embed_frac, binary_vxl_2D)
+            if detach_pn:
+                context_pn = context_pn.detach()
+            context = torch.cat([context, context_pn, Pg_col], dim=-1)
+        else:
+            context = torch.cat([context, Pg_col], dim=-1)
+        mean = self.context_model_2D[n - 1](context)
+        mean = torch.index_select(mean, dim=0, index=order)
+        mean = align_and_pack.apply(mean, unique_cnt, 0.0, 2)
+        return torch.sum(mean, dim=1) / unique_cnt.unsqueeze(-1)
+
+    def _fuse_3D(self, mean_pts, mask_cnt, overlap_w):
+        """Hash fusion: combine the per-vertex predictions of one slot (overlap-weighted or plain mean)."""
+        mean = align_and_pack.apply(mean_pts, mask_cnt, 0.0)
+        if self.use_overlap_area_pool:
+            return torch.sum(mean * overlap_w, dim=1)
+        return torch.sum(mean, dim=1) / mask_cnt.unsqueeze(-1)
+
+    def _slot_masks(self, mask, overlap, unique_cnt):
+        """Per slot: number of its vertices next to occupied space, whether any is, and the
+        normalised overlap weights of those vertices (utils_bpp_acc.py:668-682)."""
+        mask_packed = align_and_pack.apply(mask.unsqueeze(-1).to(torch.float), unique_cnt, 0)
+        per_slot = torch.sum(mask_packed[:, :, 0], dim=1)
+        mask_exist = per_slot > 0
+        mask_cnt = per_slot.to(torch.long)[mask_exist]
+        ov = torch.clamp(overlap[mask], min=1)
+        ov = align_and_pack.apply(ov.unsqueeze(-1).to(torch.float), mask_cnt, 0)
+        ov = ov / torch.sum(ov, dim=1, keepdim=True)
+        return mask_cnt, mask_exist, ov
+
+    def _chunks_3D(self, n):
+        """Slot ranges of level n so that one chunk holds <= MAX_POINTS_NUM_TO_OOM vertices
+        (:798-809).  The chunking is part of the bitstream (one .b file per chunk)."""
+        hp_n = int(self.hashparams_num_levels[n].item())
+        per = min(int(self.MAX_POINTS_NUM_TO_OOM // self.utils_points_per_param_levels[n]), hp_n)
+        steps = int(np.ceil(hp_n / per))
+        return [(sn, sn * per, min((sn + 1) * per, hp_n)) for sn in range(steps)]
+
+    def _level_chunk_3D(self, Encoding_xyz, n, v0, v1, Pg_n, binary_vxl, outspace_params):
+        """Context pass for slots [v0, v1) of coded 3-D level n (shared by encode and decode).
+        Returns (mean [num_valid, F], mask_exist, hash_rows [v1-v0])."""
+        p0 = self.unique_count_cumsum_list[n, v0]
+        p1 = self.unique_count_cumsum_list[n, v1]
+        points_n_orig = self.pos_grid_sorted_list[n][p0:p1]
+        points_n = (points_n_orig - 0.5) / self.scales_list[n, :]
+        mask, overlap = self.query_binary_vxl(points_n_orig, binary_vxl, n, return_overlap_area=True)
+        unique_cnt = self.unique_count_list[n, v0:v1]
+        mask_cnt, mask_exist, overlap_w = self._slot_masks(mask, overlap, unique_cnt)
+        ctx_layers = min(n, self.max_context_layer_num)
+        context = Encoding_xyz(points_n[mask], n - ctx_layers, n, outspace_params=outspace_params,
+                               binary_vxl=binary_vxl.squeeze(), PV=0)
+        context = torch.cat([context, Pg_n.reshape(1, 1).repeat(context.shape[0], 1)], dim=-1)
+        mean = self._fuse_3D(self.context_model_3D(context), mask_cnt, overlap_w)
+        rows = self.unique_value_list[n][v0:v1] + self.offsets_list[n]
+        return mean, mask_exist, rows
+
+    def _sorted_slots_2D(self, binary_vxl_2D, n):
+        indexes_2D, points_n = self.fetch_2D_batches(binary_vxl_2D, n)
+        indexes_sorted, order = torch.sort(indexes_2D, descending=False, dim=0)
+        unique_value, unique_cnt = torch.unique(indexes_sorted, return_counts=True)
+        return points_n, order, unique_value.to(torch.long) + self.offsets_list_2D[n], unique_cnt
+
+    def _coded_2D(self, n):
+        return not (n in self.skip_levels_2D or n >= self.Pg_level_2D)
+
+    def _coded_3D(self, n):
+        return not (n in self.skip_levels_3D or n >= self.Pg_level)
+
+    # ------------------------------------------------------------------------------- training
+    def forward_binary_vxl_mixPg_3D2D(self, Encoding_xyz, Encoding_xy, Encoding_xz, Encoding_yz,
+                                      binary_vxl=None, verbose=False, sample_num=None, step=0):
+        """Entropy estimate (bits per parameter) of the four binarised tables under the context
+        models; differentiable w.r.t. tables and context models (utils_bpp_acc.py:533-706)."""
+        params_q_xy = self.get_STE_params(Encoding_xy)
+        params_q_xz = self.get_STE_params(Encoding_xz)
+        params_q_yz = self.get_STE_params(Encoding_yz)
+        params_q_xyz = self.get_STE_params(Encoding_xyz)
+        ttl_bit_sum, ttl_num_sum = 0, 0
+        axes = ("xy", "xz", "yz")
+
+        refresh = step % self.step_update == 0
+        if refresh and self.use_dimension_wise:
+            self.idx_coords2_tmp = self.get_idx_coords2(binary_vxl)
+        idx_coords2 = self.idx_coords2_tmp
+        binary_2D = [self._project(binary_vxl, a) for a in axes]
+        if refresh:
+            self.batched_inputs_list = [
+                [self._sorted_slots_2D(binary_2D[k], n) for n in range(self.n_levels_2D) if self._coded_2D(n)]
+                for k in range(3)]
+
+        finest_3D = params_q_xyz[self.offsets_list[-2]:self.offsets_list[-1]]
+        for k, (Ec, p_q) in enumerate(zip((Encoding_xy, Encoding_xz, Encoding_yz),
+                                          (params_q_xy, params_q_xz, params_q_yz))):
+            pn_frac = (self.get_pn_embed_frac(finest_3D, idx_coords2, axis=axes[k])
+                       if self.use_dimension_wise else None)
+            batches = iter(self.batched_inputs_list[k])
+            for n in range(self.n_levels_2D):
+                Pg_n, bits_n, _ = self.get_BiRF_wentropy_leveln(p_q, n, self.offsets_list_2D)
+                if self._coded_2D(n):
+                    points_n, order, rows, unique_cnt = next(batches)
+                    mean = self._mean_2D(Ec, n, points_n, Pg_n, binary_2D[k], pn_frac, order, unique_cnt)
+                    bits_n = torch.sum(self.entropy_model(p_q[rows, :], mean))
+                ttl_bit_sum = ttl_bit_sum + bits_n
+            ttl_num_sum += p_q.numel()
+
+        # 3-D: a random contiguous window of hash slots per level (:619-634)
+        if sample_num is not None:
+            sample_num_levels = self._sample_allocation(sample_num)
+            ttl_sample_valid = sum(int(sample_num_levels[n].item()) for n in range(self.n_levels) if self._coded_3D(n))
+        else:
+            sample_num_levels, ttl_sample_valid = self.sample_num_levels, self.ttl_sample_num_valid_levels
+        v0s = torch.round((self.hashparams_num_levels - sample_num_levels) * self.rand_like(self.utils_rand)).to(torch.long)
+        v1s = v0s + sample_num_levels
+        p0s = self.unique_count_cumsum_list[self.utils_nlevel_idx, v0s]
+        p1s = self.unique_count_cumsum_list[self.utils_nlevel_idx, v1s]
+
+        pts_orig, pts_n, Pg_cols, lvl_ids, cnts, values_q = [], [], [], [], [], []
+        for n in range(self.n_levels):
+            Pg_n, bits_n, _ = self.get_BiRF_wentropy_leveln(params_q_xyz, n)
+            if not self._coded_3D(n):
+                ttl_bit_sum = ttl_bit_sum + bits_n
+                continue
+            po = self.pos_grid_sorted_list[n][p0s[n]:p1s[n]]
+            pts_orig.append(po)
+            pts_n.append((po - 0.5) / self.scales_list[n, :])
+            Pg_cols.append(Pg_n.reshape(1, 1).repeat(po.shape[0], 1))
+            lvl_ids.append(torch.full((po.shape[0],), n, dtype=torch.long, device=self.dev))
+            cnts.append(self.unique_count_list[n, v0s[n]:v1s[n]])
+            values_q.append(params_q_xyz[self.unique_value_list[n][v0s[n]:v1s[n]] + self.offsets_list[n]])
+
+        if pts_orig:
+            pts_orig, pts_n, Pg_cols = torch.cat(pts_orig), torch.cat(pts_n), torch.cat(Pg_cols)
+            lvl_ids, cnts, values_q = torch.cat(lvl_ids), torch.cat(cnts), torch.cat(values_q)
+            mask, overlap = self.query_binary_vxl_qlist(pts_orig, binary_vxl, lvl_ids, return_overlap_area=True)
+            mask_cnt, mask_exist, overlap_w = self._slot_masks(mask, overlap, cnts)
+            L = self.max_context_layer_num
+            context = Encoding_xyz.forward_diff_levels(pts_n[mask], lvl_ids[mask].to(torch.int) - L, L,
+                                                       binary_vxl=binary_vxl.squeeze(), PV=1001)
+            context = torch.cat([context, Pg_cols[mask]], dim=-1)
+            mean = self._fuse_3D(self.context_model_3D(context), mask_cnt, overlap_w)
+            bits = torch.sum(self.entropy_model(values_q[mask_exist], mean))
+            ttl_bit_sum = ttl_bit_sum + bits / ttl_sample_valid * self.ttl_hashparams_num_valid_levels
+
+        ttl_num_sum += params_q_xyz.numel()
+        bits_per_param = ttl_bit_sum / ttl_num_sum
+        return bits_per_param, ttl_bit_sum.item() / 8 / 1024 / 1024
+
+    # ------------------------------------------------------------------------------- encode
+    def encode_binary_vxl_mixPg_3D2D(self, Encoding_xyz, Encoding_xy, Encoding_xz, Encoding_yz,
+                                     binary_vxl=None, filename_prefix="b"):
+        """Arithmetic-code all four tables into {prefix}_{axis}{n}.b / {prefix}_3D{n}[_{chunk}].b.
+        Returns (Pgs_dict, estimated MB, coded MB) (utils_bpp_acc.py:709-865)."""
+        Pgs_dict = {}
+        params_q_xy = self.get_STE_params(Encoding_xy)
+        params_q_xz = self.get_STE_params(Encoding_xz)
+        params_q_yz = self.get_STE_params(Encoding_yz)
+        params_q_xyz = self.get_STE_params(Encoding_xyz)
+        F = self.n_features
+        ttl_bit_sum, encode_bits = 0, 0
+
+        idx_coords2 = self.get_idx_coords2(binary_vxl) if self.use_dimension_wise else None
+        finest_3D = params_q_xyz[self.offsets_list[-2]:self.offsets_list[-1]]
+        for Ec, p_q, axis in zip((Encoding_xy, Encoding_xz, Encoding_yz),
+                                 (params_q_xy, params_q_xz, params_q_yz), ("xy", "xz", "yz")):
+            binary_2D = self._project(binary_vxl, axis)
+            pn_frac = self.get_pn_embed_frac(finest_3D, idx_coords2, axis=axis) if self.use_dimension_wise else None
+            for n in range(self.n_levels_2D):
+                Pg_n, bits_n, _ = self.get_BiRF_wentropy_leveln(p_q, n, self.offsets_list_2D)
+                Pgs_dict[axis + str(n)] = Pg_n
+                fname = f"{filename_prefix}_{axis}{n}.b"
+                if not self._coded_2D(n):
+                    xs = p_q[self.offsets_list_2D[n]:self.offsets_list_2D[n + 1]].reshape(-1)
+                    ps = Pg_n.reshape(1).expand(xs.numel())
+                else:
+                    points_n, order, rows, unique_cnt = self._sorted_slots_2D(binary_2D, n)
+                    mean = self._mean_2D(Ec, n, points_n, Pg_n, binary_2D, pn_frac, order, unique_cnt, detach_pn=True)
+                    values_q = p_q[rows, :]
+                    bits_n = torch.sum(self.entropy_model(values_q, mean))
+                    xs = values_q.reshape(-1)
+                    ps = torch.clamp(mean, min=1e-6, max=1 - 1e-6).reshape(-1)
+                encode_bits += encoder(xs, ps, fname)
+                ttl_bit_sum = ttl_bit_sum + bits_n
+
+        for n in range(self.n_levels):
+            Pg_n, bits_n, _ = self.get_BiRF_wentropy_leveln(params_q_xyz, n)
+            Pgs_dict["3D" + str(n)] = Pg_n
+            if not self._coded_3D(n):
+                xs = params_q_xyz[self.offsets_list[n]:self.offsets_list[n + 1]].reshape(-1)
+                ps = Pg_n.reshape(1).expand(xs.numel())
+                encode_bits += encoder(xs, ps, f"{filename_prefix}_3D{n}.b")
+                ttl_bit_sum = ttl_bit_sum + bits_n
+                continue
+            for sn, v0, v1 in self._chunks_3D(n):
+                mean, mask_exist, rows = self._level_chunk_3D(Encoding_xyz, n, v0, v1, Pg_n, binary_vxl, None)
+                values_q = params_q_xyz[rows][mask_exist]
+                ttl_bit_sum = ttl_bit_sum + torch.sum(self.entropy_model(values_q, mean))
+                ps = torch.clamp(mean, min=1e-6, max=1 - 1e-6).reshape(-1)
+                encode_bits += encoder(values_q.reshape(-1), ps, f"{filename_prefix}_3D{n}_{sn}.b")
+        return Pgs_dict, ttl_bit_sum.item() / 8.0 / 1024 / 1024, encode_bits / 8.0 / 1024 / 1024
+
+    # ------------------------------------------------------------------------------- decode
+    def decode_binary_vxl_mixPg_3D2D(self, Encoding_xyz, Encoding_xy, Encoding_xz, Encoding_yz,
+                                     params_q_xyz_rec, params_q_xy_rec, params_q_xz_rec,
+                                     params_q_yz_rec, binary_vxl=None, Pgs_dict=None, filename_prefix="b"):
+        """Sequential inverse of encode: 3-D levels coarse to fine (each level's context reads the
+        already decoded lower levels), then the three planes (which need the decoded finest 3-D
+        level).  Rows never coded keep the caller's initial value (utils_bpp_acc.py:867-999)."""
+        F = self.n_features
+        with torch.no_grad():
+            for n in range(self.n_levels):
+                Pg_n = Pgs_dict["3D" + str(n)]
+                if not self._coded_3D(n):
+                    rows = int(self.offsets_list[n + 1] - self.offsets_list[n])
+                    sout = decoder(Pg_n.reshape(1).expand(rows * F), f"{filename_prefix}_3D{n}.b")
+                    params_q_xyz_rec[self.offsets_list[n]:self.offsets_list[n + 1]] = sout.view(rows, F)
+                    continue
+                for sn, v0, v1 in self._chunks_3D(n):
+                    mean, mask_exist, rows = self._level_chunk_3D(Encoding_xyz, n, v0, v1, Pg_n,
+                                                                  binary_vxl, params_q_xyz_rec)
+                    ps = torch.clamp(mean, min=1e-6, max=1 - 1e-6).reshape(-1)
+                    sout = decoder(ps, f"{filename_prefix}_3D{n}_{sn}.b")
+                    params_q_xyz_rec[rows[mask_exist]] = sout.view(*mean.shape)
+
+            idx_coords2 = self.get_idx_coords2(binary_vxl) if self.use_dimension_wise else None
+            finest_3D = params_q_xyz_rec[self.offsets_list[-2]:self.offsets_list[-1]]
+            for Ec, rec, axis in zip((Encoding_xy, Encoding_xz, Encoding_yz),
+                                     (params_q_xy_rec, params_q_xz_rec, params_q_yz_rec), ("xy", "xz", "yz")):
+                binary_2D = self._project(binary_vxl, axis)
+                pn_frac = self.get_pn_embed_frac(finest_3D, idx_coords2, axis=axis) if self.use_dimension_wise else None
+                for n in range(self.n_levels_2D):
+                    Pg_n = Pgs_dict[axis + str(n)]
+                    fname = f"{filename_prefix}_{axis}{n}.b"
+                    if not self._coded_2D(n):
+                        rows = int(self.offsets_list_2D[n + 1] - self.offsets_list_2D[n])
+                        sout = decoder(Pg_n.reshape(1).expand(rows * F), fname)
+                        rec[self.offsets_list_2D[n]:self.offsets_list_2D[n + 1]] = sout.view(rows, F)
+                        continue
+                    points_n, order, rows, unique_cnt = self._sorted_slots_2D(binary_2D, n)
+                    mean = self._mean_2D(Ec, n, points_n, Pg_n, binary_2D, pn_frac, order, unique_cnt,
+                                         outspace_params=rec, detach_pn=True)
+                    ps = torch.clamp(mean, min=1e-6, max=1 - 1e-6).reshape(-1)
+                    rec[rows, :] = decoder(ps, fname).view(-1, F)
+        return params_q_xyz_rec, params_q_xy_rec, params_q_xz_rec, params_q_yz_rec

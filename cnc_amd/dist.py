@@ -1,0 +1,115 @@
+"""Ray-sharded data parallelism: one process per GPU, RCCL over xGMI (torch.distributed 'nccl').
+
+The reference is single-GPU; this is the part of the north-star that has no
+reference code.  Rays are independent units, so ranks only ever exchange the gradient of the shared
+tables / MLPs: ONE flat bucket all-reduced once per step (161 MB fp32 for the reference composition
+at F=8) — sized for xGMI's point-to-point links (a single large ring transfer, not per-tensor calls).
+Replica state that must stay identical (occupancy grid, context-window RNG) is either seeded
+identically or broadcast from rank 0.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Initialise the default process group from the torchrun environment (no-op for world 1)."""
+    rank, local_rank, world = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) share of n units; the first n % world ranks get one extra."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class GradBucket:
+    """All gradients of a parameter list as views into ONE contiguous fp32 buffer, so a step's
+    exchange is a single all-reduce.  `bind()` points each param.grad at its slice (autograd then
+    accumulates in place), `allreduce()` sums across ranks and optionally averages."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev, dt = self.params[0].device, self.params[0].dtype
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
+        self.views = []
+        o = 0
+        for p in self.params:
+            assert p.device == dev and p.dtype == dt
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+
+    def bind(self) -> None:
+        for p, v in zip(self.params, self.views):
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+            p.grad = v
+
+    def zero(self) -> None:
+        self.flat.zero_()
+
+    def allreduce(self, average: bool = True, async_op: bool = False):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        if average and not async_op:
+            self.flat.div_(dist.get_world_size())
+        return work
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+
+def broadcast_module_buffers(module: torch.nn.Module, names: Iterable[str], src: int = 0) -> None:
+    """Keep replica state (e.g. OccGridEstimator.occs / .binaries) identical to rank `src`."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    for n in names:
+        t = getattr(module, n)
+        if t.dtype == torch.bool:
+            u = t.to(torch.uint8)
+            dist.broadcast(u, src)
+            setattr(module, n, u.to(torch.bool))
+        else:
+            dist.broadcast(t, src)
+
+
+def max_over_ranks(x: float, device) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(x: float, device) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())

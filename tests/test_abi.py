@@ -1,0 +1,79 @@
+"""CPU-only: the C-ABI libraries load and export every symbol the headers declare
+(no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cnc_[a-z0-9_A-Z]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from cnc_amd import build
+    return build.build_all()
+
+
+def test_hip_library_exports_every_declared_symbol(built):
+    lib = ctypes.CDLL(built[0])
+    names = _declared("cnc_hip.h")
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"libcnc_hip.so does not export {n}"
+    lib.cnc_abi_version.restype = ctypes.c_int
+    assert lib.cnc_abi_version() >= 1
+    lib.cnc_error_string.restype = ctypes.c_char_p
+    assert lib.cnc_error_string(0) == b"ok"
+    assert b"invalid" in lib.cnc_error_string(-1)
+
+
+def test_ctypes_signature_table_covers_the_header(built):
+    from cnc_amd import _lib
+    declared = set(_declared("cnc_hip.h")) - {"cnc_error_string", "cnc_abi_version"}
+    assert declared == set(_lib.SIGNATURES)
+    L = _lib.lib()
+    for n, argtypes in _lib.SIGNATURES.items():
+        assert getattr(L, n).argtypes == argtypes
+
+
+def test_codec_library_exports(built):
+    lib = ctypes.CDLL(built[1])
+    for n in _declared("cnc_codec.h"):
+        assert hasattr(lib, n)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under cnc_amd/ may import or load it."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "cnc_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(import|from)\s+oracle\b", txt, flags=re.M) or "libcnc_oracle" in txt:
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_mirrors_refuse_cpu_tensors():
+    """No CPU fallback: host tensors raise like the reference's CHECK_CUDA."""
+    import torch
+    from cnc_amd.backends import gridencoder_backend as be, nerfacc_cuda as nc, pack_and_align as pa
+    x = torch.rand(4, 3)
+    e = torch.rand(64, 2)
+    o = torch.tensor([0, 64], dtype=torch.int32)
+    r = torch.tensor([4], dtype=torch.int32)
+    out = torch.empty(1, 4, 2)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        be.grid_encode_forward(x, e, o, r, out, 4, 3, 2, 1, 0, 128, 0.0, None, None, None)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        pa.query_mask_3D(torch.zeros(4, 3, dtype=torch.int16), torch.ones(4, 4, 4, dtype=torch.bool),
+                         torch.zeros(4, dtype=torch.int16), torch.zeros(4, dtype=torch.int32), 18, 4)
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        nc.exclusive_sum(torch.zeros(1, dtype=torch.long), torch.ones(1, dtype=torch.long), torch.ones(1), False, False)

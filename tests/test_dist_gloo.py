@@ -1,0 +1,85 @@
+"""The N>1 path on CPU: two processes, gloo backend (no GPU): flat gradient bucket all-reduce,
+ray sharding, replica-state broadcast, max/sum-over-ranks timing helpers used by bench.py."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from cnc_amd import dist as cd
+    from cnc_amd.nerfacc import OccGridEstimator
+    r, lr, w = cd.init("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)                      # identical replicas
+    table = torch.nn.Parameter(torch.zeros(1000, 8))
+    mlp = torch.nn.Linear(16, 4)
+    bucket = cd.GradBucket([table] + list(mlp.parameters()))
+    bucket.bind()
+    # each rank's "rays" produce a different gradient
+    lo, hi = cd.shard_range(1001, rank, world)
+    x = torch.arange(lo, hi, dtype=torch.float32)
+    loss = (table[: hi - lo, 0] * x).sum() + mlp(torch.ones(1, 16) * (rank + 1)).sum()
+    loss.backward()
+    assert table.grad.data_ptr() == bucket.views[0].data_ptr()      # accumulated in the bucket
+    bucket.allreduce(average=True)
+    est = OccGridEstimator([-1.0] * 3 + [1.0] * 3, resolution=8)
+    if rank == 0:
+        est.occs.uniform_(0, 1)
+        est.binaries = est.occs.view(est.binaries.shape) > 0.5
+    cd.broadcast_module_buffers(est, ["occs", "binaries"])
+    q.put((rank, (lo, hi), table.grad[:, 0].clone(), mlp.weight.grad.clone(), est.binaries.sum().item(),
+           est.occs.sum().item(), cd.max_over_ranks(float(rank + 1), "cpu"), cd.sum_over_ranks(float(hi - lo), "cpu")))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_bucket_allreduce_and_sharding():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, g0, w0, b0, o0, m0, n0), (r1, s1, g1, w1, b1, o1, m1, n1) = res
+    assert s0 == (0, 501) and s1 == (501, 1001)                 # contiguous, exhaustive, balanced
+    assert torch.equal(g0, g1) and torch.equal(w0, w1)          # replicas hold the same reduced grads
+    expect = torch.zeros(1000)
+    expect[:501] += torch.arange(0, 501, dtype=torch.float32)
+    expect[:500] += torch.arange(501, 1001, dtype=torch.float32)
+    assert torch.allclose(g0, expect / 2)                       # mean over ranks
+    assert torch.allclose(w0, torch.full((4, 16), 1.5))         # (1 + 2) / 2
+    assert b0 == b1 and o0 == o1 and b0 > 0                     # occupancy replicated from rank 0
+    assert m0 == m1 == 2.0 and n0 == n1 == 1001.0
+
+
+def test_shard_range_properties():
+    from cnc_amd.dist import shard_range
+    for n in (0, 1, 7, 640000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,160 @@
+"""CPU-only tests of the host-side logic (no kernels): table construction, the nerfacc Python layer
+against the reference (golden vectors from tests/golden/make_golden.py), the range coder, and the
+context-model tables."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_gridencoder_tables_match_reference_class():
+    """Offsets / resolutions / parameter shape of GridEncoder == the reference class (ngp.py:197-223)."""
+    from cnc_amd.gridencoder import GridEncoder
+    g = np.load(os.path.join(GOLD, "gridencoder_glue.npz"))
+    cfgs = [dict(num_dim=3, n_features=4, resolutions_list=(6, 9, 14, 20, 31, 44), log2_hashmap_size=10),
+            dict(num_dim=2, n_features=8, resolutions_list=(10, 18, 34, 66), log2_hashmap_size=9),
+            dict(num_dim=3, n_features=2, resolutions_list=(6, 9, 14), log2_hashmap_size=12)]
+    for k, cfg in enumerate(cfgs):
+        enc = GridEncoder(**cfg)
+        assert enc.offsets_list.dtype == torch.int32
+        assert np.array_equal(enc.offsets_list.numpy(), g[f"g{k}_offsets"])
+        assert np.array_equal(enc.resolutions_list.numpy(), g[f"g{k}_res"])
+        assert tuple(enc.params.shape) == g[f"g{k}_params"].shape
+        assert enc.params.abs().max() <= 1e-4
+
+
+def test_reference_composition_table_sizes():
+    """SURVEY §8 header: 4,003,896 3-D rows, 345,616 rows per plane, 6,120,776 for the 16L bench grid."""
+    from cnc_amd import synthetic
+    assert synthetic.level_offsets(synthetic.RES_3D_REF, 19, 3).tolist() == [
+        0, 5832, 19656, 55600, 140784, 346168, 858168, 1382456, 1906744, 2431032, 2955320, 3479608, 4003896]
+    assert synthetic.level_offsets(synthetic.RES_2D_REF, 17, 2).tolist() == [0, 16904, 83472, 214544, 345616]
+    assert int(synthetic.level_offsets(synthetic.RES_16L, 19, 3)[-1]) == 6120776
+
+
+def test_ste_binary_known_answers():
+    from cnc_amd.gridencoder import STE_binary
+    g = np.load(os.path.join(GOLD, "gridencoder_glue.npz"))
+    v = torch.tensor(g["ste_in"], requires_grad=True)
+    s = STE_binary.apply(v)
+    s.backward(torch.arange(1.0, 10.0))
+    assert np.array_equal(s.detach().numpy(), g["ste_out"])
+    assert np.array_equal(v.grad.numpy(), g["ste_grad"])
+
+
+def test_occ_grid_update_matches_reference():
+    """OccGridEstimator._update on CPU with the reference's seed reproduces its occs / binaries."""
+    from cnc_amd.nerfacc import OccGridEstimator
+    g = np.load(os.path.join(GOLD, "occ_grid.npz"))
+    est = OccGridEstimator([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], resolution=16, levels=1)
+    est.train()
+    occ_fn = lambda x: torch.exp(-4.0 * (x ** 2).sum(-1, keepdim=True)) * 0.05
+    torch.manual_seed(123)
+    for step in (0, 16, 256, 272):
+        est._update(step=step, occ_eval_fn=occ_fn, occ_thre=0.01, ema_decay=0.95, warmup_steps=256)
+        assert np.array_equal(est.occs.numpy(), g[f"occs_{step}"])
+        assert np.array_equal(est.binaries.numpy(), g[f"bin_{step}"])
+    est.eval()
+    with pytest.raises(RuntimeError):
+        est.update_every_n_steps(0, occ_fn)
+
+
+def test_ray_aabb_torch_twin_and_enlarge():
+    from cnc_amd.nerfacc.grid import _enlarge_aabb, _ray_aabb_intersect
+    g = np.load(os.path.join(GOLD, "ray_aabb.npz"))
+    for k in range(3):
+        near, far, miss = (float(v) for v in g[f"nfm_{k}"])
+        t0, t1, h = _ray_aabb_intersect(torch.from_numpy(g["rays_o"]), torch.from_numpy(g["rays_d"]),
+                                        torch.from_numpy(g["aabbs"]), near, far, miss)
+        assert np.array_equal(h.numpy(), g[f"hit_{k}"])
+        assert np.array_equal(t0.numpy(), g[f"t0_{k}"]) and np.array_equal(t1.numpy(), g[f"t1_{k}"])
+    a = _enlarge_aabb(torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]), 2.0)
+    assert a.tolist() == [-3, -3, -3, 3, 3, 3]
+
+
+def test_batched_volrend_and_scans_cpu():
+    """Batched (non-packed) branches run on plain torch, like the reference."""
+    import cnc_amd.nerfacc as n
+    x = torch.tensor([[1., 2., 3.], [4., 5., 6.]])
+    assert n.inclusive_sum(x).tolist() == [[1, 3, 6], [4, 9, 15]]
+    assert n.exclusive_sum(x).tolist() == [[0, 1, 3], [0, 4, 9]]
+    assert n.exclusive_prod(x).tolist() == [[1, 1, 2], [1, 4, 20]]
+    alphas = torch.tensor([[0.4, 0.8, 0.1]])
+    w, tr = n.render_weight_from_alpha(alphas)
+    assert torch.allclose(tr, torch.tensor([[1.0, 0.6, 0.12]])) and torch.allclose(w, torch.tensor([[0.4, 0.48, 0.012]]))
+    vis = n.render_visibility_from_alpha(alphas, early_stop_eps=0.3, alpha_thre=0.2)
+    assert vis.tolist() == [[True, True, False]]
+    acc = n.accumulate_along_rays(w, torch.ones(1, 3, 2))
+    assert torch.allclose(acc, w.sum(-1, keepdim=True).expand(1, 2))
+    assert n.pack_info(torch.tensor([0, 0, 1, 1, 1, 2, 2, 2, 2]), 3).tolist() == [[0, 2], [2, 3], [5, 4]]
+    assert n.pack_info(torch.tensor([], dtype=torch.long), 2).tolist() == [[0, 0], [0, 0]]
+
+
+def test_product_range_coder_equals_oracle_bytes(oracle, tmp_path):
+    """libcnc_codec.so emits exactly the oracle's byte stream and decodes it back."""
+    from cnc_amd.context import decoder, encoder
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 4096, 200001):
+        p = rng.uniform(1e-6, 1 - 1e-6, size=n).astype(np.float32)
+        if n > 100:
+            p[:50] = 1e-6
+            p[50:100] = 1 - 1e-6
+        x = np.where(rng.uniform(size=n) < p, 1.0, -1.0).astype(np.float32)
+        f = str(tmp_path / f"s{n}.b")
+        bits = encoder(torch.from_numpy(x), torch.from_numpy(p), f)
+        stream = open(f, "rb").read()
+        assert bits == 8 * len(stream)
+        assert stream == oracle.rc_encode(p, ((x + 1) // 2).astype(np.int16))
+        back = decoder(torch.from_numpy(p), f)
+        assert back.dtype == torch.float32 and np.array_equal(back.numpy(), x)
+    with pytest.raises(AssertionError):
+        encoder(torch.ones(1), torch.full((1,), 0.5), "x.bin")
+
+
+def test_get_grid_index_twin(oracle):
+    from cnc_amd.context import get_grid_index
+    g = np.load(os.path.join(GOLD, "grid_index.npz"))
+    for k in range(int(g["n_cases"])):
+        D, R, hs = int(g[f"c{k}_D"]), int(g[f"c{k}_R"]), int(g[f"c{k}_hs"])
+        got = get_grid_index(hs, R, torch.from_numpy(g[f"c{k}_pos"].astype(np.int64)))
+        assert np.array_equal(got.numpy(), g[f"c{k}_rows"])
+
+
+def test_context_model_tables_toy():
+    """Vertex-by-slot tables: every vertex appears once, grouped by the slot the kernel hash sends it
+    to; counts/cumsums consistent; sample allocation sums to ~sample_num."""
+    from cnc_amd.context import CNC_context_models, get_grid_index
+    torch.manual_seed(0)
+    res = [6, 9, 14, 20, 31, 44]
+    m = CNC_context_models(resolutions_list=res, resolutions_list_2D=[10, 18, 34, 66], log2_hashmap_size=10,
+                           log2_hashmap_size_2D=9, n_features=4, sample_num=500, Pg_level=6, Pg_level_2D=4,
+                           Rb=8, skip_levels_3D=(0, 1, 2), skip_levels_2D=(0,), device="cpu",
+                           dimension_wise_resolution=34)
+    assert m.offsets_list.tolist() == [0, 216, 952, 1976, 3000, 4024, 5048]
+    assert m.n_levels_thresh == 2 and float(m.resolution_thresh) == 9.0
+    for n, R in enumerate(res):
+        pos = m.pos_grid_sorted_list[n]
+        assert pos.shape == (R ** 3, 3) and pos.dtype == torch.int16
+        hs = int(m.offsets_list[n + 1] - m.offsets_list[n])
+        slots = get_grid_index(hs, R, pos.long())
+        nslots = int(m.hashparams_num_levels[n])
+        cnt = m.unique_count_list[n, :nslots]
+        cum = m.unique_count_cumsum_list[n, :nslots + 1]
+        assert int(cnt.sum()) == R ** 3 and int(cum[-1]) == R ** 3
+        assert torch.equal(cum[1:] - cum[:-1], cnt)
+        # vertices of slot k occupy pos[cum[k]:cum[k+1]] and all hash to unique_value[k]
+        expect = torch.repeat_interleave(m.unique_value_list[n], cnt)
+        assert torch.equal(slots, expect)
+        assert torch.unique(pos.long() @ torch.tensor([R * R, R, 1])).numel() == R ** 3
+    assert abs(int(m.sample_num_levels.sum()) - 500) <= 3
+    assert m.ttl_sample_num_valid_levels == int(m.sample_num_levels[3:].sum())
+    # occupied-cell vertex lattice for the dimension-wise context
+    bv = torch.zeros(1, 8, 8, 8, dtype=torch.bool)
+    bv[0, 2, 3, 1] = True
+    c = m.get_idx_coords2(bv)
+    t = (34 - 2) // 8
+    assert c.shape == ((t + 2) ** 3, 3)
+    assert c.min(0).values.tolist() == [2 * t, 3 * t, 1 * t] and c.max(0).values.tolist() == [3 * t + 1, 4 * t + 1, 2 * t + 1]
