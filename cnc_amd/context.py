@@ -252,7 +252,9 @@ class CNC_context_models(nn.Module):
             R = int(resolutions_list[i].item())
             pos_grid = my_meshgrid3D(0, R, device=dev).view(-1, 3)
             indexes = get_grid_index(int(offsets_list[i + 1] - offsets_list[i]), R, pos_grid)
-            indexes_sorted, order = torch.sort(indexes, descending=False, dim=0)
+            # stable: vertices of one slot stay in lattice order on every device (the reference's
+            # unstable CUDA sort leaves that order unspecified; nothing downstream depends on it)
+            indexes_sorted, order = torch.sort(indexes, descending=False, dim=0, stable=True)
             pos_sorted = torch.index_select(pos_grid.to(torch.int16), dim=0, index=order)
             unique_value, unique_cnt = torch.unique(indexes_sorted, return_counts=True)
             if R <= self.resolution_thresh:
@@ -479,7 +481,7 @@ class CNC_context_models(nn.Module):
 
     def _sorted_slots_2D(self, binary_vxl_2D, n):
         indexes_2D, points_n = self.fetch_2D_batches(binary_vxl_2D, n)
-        indexes_sorted, order = torch.sort(indexes_2D, descending=False, dim=0)
+        indexes_sorted, order = torch.sort(indexes_2D, descending=False, dim=0, stable=True)
         unique_value, unique_cnt = torch.unique(indexes_sorted, return_counts=True)
         return points_n, order, unique_value.to(torch.long) + self.offsets_list_2D[n], unique_cnt
 

@@ -1,0 +1,229 @@
+"""Radiance field on 3-D + three 2-D binarised hash grids — host mirror of
+examples/radiance_fields/ngp.py:318-645 (`trunc_exp`, `contract_to_unisphere`,
+`NGPRadianceField_mygrid_2D3D`, `Embedder`/`get_embedder`, `compose_3D_2D_embed`).
+
+Same constructor arguments, sub-module names (`mlp_base.encoding_xyz/xy/xz/yz`, `mlp_base.network`,
+`mlp_head`, `direction_encoding`) and methods (`query_density`, `_query_rgb`, `forward`,
+`update_embedding_params`), so state dicts and the reference drivers line up.
+
+The one third-party piece, tiny-cuda-nn's `SphericalHarmonics degree 4` direction encoding
+(ngp.py:412-425), is restated in closed form (`SHEncoding`): tcnn is not part of the reference tree
+(unpinned git install, README.md:56) and not installable here, so its numerics — including the fp16
+output rounding tcnn applies on NVIDIA — are PARITY UNPINNED; `fp16_round=True` emulates the rounding.
+The dense layers are plain `nn.Linear` (hipBLASLt GEMMs); a fused MFMA field kernel is SURVEY §8f-3.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Union
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from .gridencoder import GridEncoder
+
+
+class _TruncExp(Function):
+    """exp with the gradient clamped at x<=15 (ngp.py:318-334)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(torch.clamp(x, max=15))
+
+
+trunc_exp = _TruncExp.apply
+
+
+def contract_to_unisphere(x, aabb, ord: Union[str, int] = 2, eps: float = 1e-6, derivative: bool = False):
+    """mip-NeRF-360 contraction of unbounded space into [0,1]^3 (ngp.py:337-361)."""
+    aabb_min, aabb_max = torch.split(aabb, 3, dim=-1)
+    x = (x - aabb_min) / (aabb_max - aabb_min)
+    x = x * 2 - 1
+    mag = torch.linalg.norm(x, ord=ord, dim=-1, keepdim=True)
+    mask = mag.squeeze(-1) > 1
+    if derivative:
+        dev = (2 * mag - 1) / mag ** 2 + 2 * x ** 2 * (1 / mag ** 3 - (2 * mag - 1) / mag ** 4)
+        dev[~mask] = 1.0
+        return torch.clamp(dev, min=eps)
+    x[mask] = (2 - 1 / mag[mask]) * (x[mask] / mag[mask])
+    return x / 4 + 0.5
+
+
+class SHEncoding(nn.Module):
+    """Real spherical harmonics up to degree 4 (16 values) of a direction given in [0,1]^3
+    (the reference feeds (dir+1)/2, ngp.py:540-541; tcnn maps back to [-1,1] internally)."""
+
+    n_output_dims = 16
+
+    def __init__(self, fp16_round: bool = False):
+        super().__init__()
+        self.fp16_round = fp16_round
+
+    def forward(self, d01):
+        d = d01 * 2.0 - 1.0
+        x, y, z = d[..., 0], d[..., 1], d[..., 2]
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        out = torch.stack([
+            torch.full_like(x, 0.28209479177387814),
+            -0.48860251190291987 * y,
+            0.48860251190291987 * z,
+            -0.48860251190291987 * x,
+            1.0925484305920792 * xy,
+            -1.0925484305920792 * yz,
+            0.94617469575755997 * zz - 0.31539156525251999,
+            -1.0925484305920792 * xz,
+            0.54627421529603959 * xx - 0.54627421529603959 * yy,
+            0.59004358992664352 * y * (-3.0 * xx + yy),
+            2.8906114426405538 * xy * z,
+            0.45704579946446572 * y * (1.0 - 5.0 * zz),
+            0.3731763325901154 * z * (5.0 * zz - 3.0),
+            0.45704579946446572 * x * (1.0 - 5.0 * zz),
+            1.4453057213202769 * z * (xx - yy),
+            0.59004358992664352 * x * (-xx + 3.0 * yy),
+        ], dim=-1)
+        if self.fp16_round:
+            out = out.to(torch.float16).to(d01.dtype)
+        return out
+
+
+class Embedder:
+    """Sinusoidal positional embedding: x, then sin/cos(2^k x) for k < num_freqs (ngp.py:569-599)."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        d = kwargs["input_dims"]
+        self.include_input = kwargs["include_input"]
+        n = kwargs["num_freqs"]
+        if kwargs["log_sampling"]:
+            self.freq_bands = 2.0 ** torch.linspace(0.0, kwargs["max_freq_log2"], steps=n)
+        else:
+            self.freq_bands = torch.linspace(2.0 ** 0.0, 2.0 ** kwargs["max_freq_log2"], steps=n)
+        self.periodic_fns = kwargs["periodic_fns"]
+        self.out_dim = d * (int(self.include_input) + n * len(self.periodic_fns))
+
+    def embed(self, inputs):
+        parts = [inputs] if self.include_input else []
+        for freq in self.freq_bands:
+            for fn in self.periodic_fns:
+                parts.append(fn(inputs * freq))
+        return torch.cat(parts, -1)
+
+
+def get_embedder(multires, i=0):
+    if i == -1:
+        return nn.Identity(), 3
+    e = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
+                 log_sampling=True, periodic_fns=[torch.sin, torch.cos])
+    return (lambda x, eo=e: eo.embed(x)), e.out_dim
+
+
+class compose_3D_2D_embed(nn.Module):
+    """[3-D grid | xy | xz | yz plane grids | 63 sinusoid features] -> base MLP (ngp.py:620-645)."""
+
+    def __init__(self, encoding_xyz, encoding_xy, encoding_xz, encoding_yz, embed_fn, network, sin_encode=False):
+        super().__init__()
+        self.encoding_xyz = encoding_xyz
+        self.encoding_xy = encoding_xy
+        self.encoding_xz = encoding_xz
+        self.encoding_yz = encoding_yz
+        self.embed_fn = embed_fn
+        self.network = network
+
+    def features(self, x):
+        xs, ys, zs = torch.chunk(x, 3, dim=-1)
+        parts = [self.encoding_xyz(x),
+                 self.encoding_xy(torch.cat([xs, ys], dim=-1)),
+                 self.encoding_xz(torch.cat([xs, zs], dim=-1)),
+                 self.encoding_yz(torch.cat([ys, zs], dim=-1))]
+        if self.embed_fn is not None:
+            parts.append(self.embed_fn(x))
+        return torch.cat(parts, dim=-1)
+
+    def forward(self, x):
+        return self.network(self.features(x))
+
+
+class NGPRadianceField_mygrid_2D3D(nn.Module):
+    def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
+                 density_activation: Callable = lambda x: trunc_exp(x - 1), unbounded: bool = False,
+                 geo_feat_dim: int = 15,
+                 resolutions_list=(16, 22, 31, 42, 57, 78, 106, 146, 199, 273, 374, 512),
+                 log2_hashmap_size: int = 19, resolutions_list_2D=(64, 128, 256, 512, 1024),
+                 log2_hashmap_size_2D=17, n_features_per_level=2, n_neurons=64, ste_binary=True,
+                 ste_multistep=False, add_noise=False, Q=10, sh_fp16_round=False, fused_ste=True) -> None:
+        super().__init__()
+        if not isinstance(aabb, torch.Tensor):
+            aabb = torch.tensor(aabb, dtype=torch.float32)
+        self.register_buffer("aabb", aabb)
+        self.num_dim = num_dim
+        self.use_viewdirs = use_viewdirs
+        self.density_activation = density_activation
+        self.unbounded = unbounded
+        self.geo_feat_dim = min(127, max(15, n_features_per_level * 10 - 1))     # ngp.py:398-401
+        self.resolutions_list, self.log2_hashmap_size = resolutions_list, log2_hashmap_size
+        self.resolutions_list_2D, self.log2_hashmap_size_2D = resolutions_list_2D, log2_hashmap_size_2D
+
+        if self.use_viewdirs:
+            self.direction_encoding = SHEncoding(fp16_round=sh_fp16_round)
+
+        def grid(D, res, T):
+            return GridEncoder(num_dim=D, n_features=n_features_per_level, resolutions_list=res,
+                               log2_hashmap_size=T, ste_binary=ste_binary, ste_multistep=ste_multistep,
+                               add_noise=add_noise, Q=Q, fused_ste=fused_ste)
+
+        encoding_xyz = grid(3, resolutions_list, log2_hashmap_size)
+        encoding_xy = grid(2, resolutions_list_2D, log2_hashmap_size_2D)
+        encoding_xz = grid(2, resolutions_list_2D, log2_hashmap_size_2D)
+        encoding_yz = grid(2, resolutions_list_2D, log2_hashmap_size_2D)
+        embed_fn, input_ch = get_embedder(10, 0)
+        in_chs = (encoding_xyz.n_output_dims + encoding_xy.n_output_dims + encoding_xz.n_output_dims
+                  + encoding_yz.n_output_dims + input_ch)
+        network = nn.Sequential(nn.Linear(in_chs, n_neurons), nn.ReLU(inplace=True),
+                                nn.Linear(n_neurons, 1 + self.geo_feat_dim))
+        self.mlp_base = compose_3D_2D_embed(encoding_xyz, encoding_xy, encoding_xz, encoding_yz, embed_fn, network)
+        if self.geo_feat_dim > 0:
+            head_in = (self.direction_encoding.n_output_dims if self.use_viewdirs else 0) + self.geo_feat_dim
+            self.mlp_head = nn.Sequential(nn.Linear(head_in, n_neurons), nn.ReLU(inplace=True),
+                                          nn.Linear(n_neurons, n_neurons), nn.ReLU(inplace=True),
+                                          nn.Linear(n_neurons, 3))
+
+    def update_embedding_params(self, params_q_xyz_rec, params_q_xy_rec, params_q_xz_rec, params_q_yz_rec):
+        self.mlp_base.encoding_xyz.params = nn.Parameter(params_q_xyz_rec)
+        self.mlp_base.encoding_xy.params = nn.Parameter(params_q_xy_rec)
+        self.mlp_base.encoding_xz.params = nn.Parameter(params_q_xz_rec)
+        self.mlp_base.encoding_yz.params = nn.Parameter(params_q_yz_rec)
+        print("embedding_params updated!")
+
+    def query_density(self, x, return_feat: bool = False):
+        if self.unbounded:
+            x = contract_to_unisphere(x, self.aabb)
+        else:
+            aabb_min, aabb_max = torch.split(self.aabb, self.num_dim, dim=-1)
+            x = (x - aabb_min) / (aabb_max - aabb_min)
+        selector = ((x > 0.0) & (x < 1.0)).all(dim=-1)
+        h = self.mlp_base(x.view(-1, self.num_dim)).view(list(x.shape[:-1]) + [1 + self.geo_feat_dim]).to(x)
+        density_before_activation, base_mlp_out = torch.split(h, [1, self.geo_feat_dim], dim=-1)
+        density = self.density_activation(density_before_activation) * selector[..., None]
+        return (density, base_mlp_out) if return_feat else density
+
+    def _query_rgb(self, dir, embedding, apply_act: bool = True):
+        if self.use_viewdirs:
+            d = self.direction_encoding(((dir + 1.0) / 2.0).reshape(-1, dir.shape[-1]))
+            h = torch.cat([d, embedding.reshape(-1, self.geo_feat_dim)], dim=-1)
+        else:
+            h = embedding.reshape(-1, self.geo_feat_dim)
+        rgb = self.mlp_head(h).reshape(list(embedding.shape[:-1]) + [3]).to(embedding)
+        return torch.sigmoid(rgb) if apply_act else rgb
+
+    def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):
+        if self.use_viewdirs and (directions is not None):
+            assert positions.shape == directions.shape, f"{positions.shape} v.s. {directions.shape}"
+        density, embedding = self.query_density(positions, return_feat=True)
+        rgb = self._query_rgb(directions, embedding=embedding)
+        return rgb, density

@@ -42,6 +42,8 @@ def lib() -> C.CDLL:
         _lib.orc_openmp_max_threads.restype = C.c_int
         _lib.orc_rc_encode.restype = C.c_int64
         _lib.orc_rc_decode.restype = C.c_int
+        _lib.orc_rc_encode2.restype = C.c_int64
+        _lib.orc_rc_decode2.restype = C.c_int
     return _lib
 
 
@@ -305,24 +307,27 @@ def prod_backward(inputs, outputs, grad_outputs, chunk_starts, chunk_cnts, exclu
 
 
 # ----------------------------------------------------------------------------- range coder
-def rc_encode(p_one: np.ndarray, symbols: np.ndarray) -> bytes:
+def rc_encode(p_one: np.ndarray, symbols: np.ndarray, prob_is_cdf1: bool = False) -> bytes:
     """Binary arithmetic coding of symbols in {0,1} with P(sym=1)=p_one, CDF [0, 1-p, 1]
-    (examples/utils_bpp_acc.py:77-93 -> torchac.encode_float_cdf)."""
+    (examples/utils_bpp_acc.py:77-93 -> torchac.encode_float_cdf).  prob_is_cdf1: the array holds
+    the CDF's middle column 1-p itself (what torchac receives) instead of p."""
     p = _c(p_one, np.float32).reshape(-1)
     s = _c(symbols, np.int16).reshape(-1)
     cap = p.shape[0] // 4 + 64
     while True:
         buf = np.empty(cap, dtype=np.uint8)
-        n = lib().orc_rc_encode(_p(p), _p(s), C.c_int64(p.shape[0]), _p(buf), C.c_int64(cap))
+        n = lib().orc_rc_encode2(_p(p), C.c_int(int(prob_is_cdf1)), _p(s), C.c_int64(p.shape[0]),
+                                 _p(buf), C.c_int64(cap))
         if n >= 0:
             return buf[:n].tobytes()
         cap *= 2
 
 
-def rc_decode(p_one: np.ndarray, stream: bytes) -> np.ndarray:
+def rc_decode(p_one: np.ndarray, stream: bytes, prob_is_cdf1: bool = False) -> np.ndarray:
     p = _c(p_one, np.float32).reshape(-1)
     buf = np.frombuffer(stream, dtype=np.uint8)
     out = np.empty(p.shape[0], dtype=np.int16)
-    rc = lib().orc_rc_decode(_p(p), C.c_int64(p.shape[0]), _p(buf), C.c_int64(buf.shape[0]), _p(out))
+    rc = lib().orc_rc_decode2(_p(p), C.c_int(int(prob_is_cdf1)), C.c_int64(p.shape[0]), _p(buf),
+                              C.c_int64(buf.shape[0]), _p(out))
     assert rc == 0
     return out

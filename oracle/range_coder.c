@@ -16,10 +16,12 @@
 #include <math.h>
 #include <stdint.h>
 
-static inline uint32_t orc_cdf1(float p_one)
+/* is_u != 0: the caller passes cdf[...,1] = 1 - p directly (what torchac itself receives) */
+static int g_unused;
+static inline uint32_t orc_cdf1_(float prob, int is_u)
 {
     /* torch: p_u = 1 - p (float32); cdf.mul(65534.0f).round() (half-to-even); +1 (arange) */
-    float u = 1.0f - p_one;
+    float u = is_u ? prob : 1.0f - prob;
     float s = u * 65534.0f;
     float r = nearbyintf(s);              /* default rounding mode = half-to-even == torch.round */
     return ((uint32_t)(int32_t)r + 1u) & 0xFFFFu;
@@ -45,14 +47,14 @@ static void bw_put_pending(orc_bw_t* w, int bit, uint64_t* pending)
 }
 
 /* returns number of bytes, or -1 if `cap` was too small */
-int64_t orc_rc_encode(const float* p_one, const int16_t* sym, int64_t n, uint8_t* out, int64_t cap)
+int64_t orc_rc_encode2(const float* p_one, int is_u, const int16_t* sym, int64_t n, uint8_t* out, int64_t cap)
 {
     orc_bw_t w = {out, cap, 0, 0, 0, 0};
     uint32_t low = 0, high = 0xFFFFFFFFu;
     uint64_t pending = 0;
     for (int64_t i = 0; i < n; i++) {
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
-        const uint32_t c1 = orc_cdf1(p_one[i]);
+        const uint32_t c1 = orc_cdf1_(p_one[i], is_u);
         const uint32_t c_low = sym[i] ? c1 : 0u;
         const uint32_t c_high = sym[i] ? 0x10000u : c1;
         high = (low - 1) + (uint32_t)((span * (uint64_t)c_high) >> 16);
@@ -91,7 +93,7 @@ static void br_get(orc_br_t* r, uint32_t* value)
     r->bits--;
 }
 
-int orc_rc_decode(const float* p_one, int64_t n, const uint8_t* in, int64_t len, int16_t* out)
+int orc_rc_decode2(const float* p_one, int is_u, int64_t n, const uint8_t* in, int64_t len, int16_t* out)
 {
     orc_br_t r = {in, len, 0, 0, 0};
     uint32_t low = 0, high = 0xFFFFFFFFu, value = 0;
@@ -99,7 +101,7 @@ int orc_rc_decode(const float* p_one, int64_t n, const uint8_t* in, int64_t len,
     for (int64_t i = 0; i < n; i++) {
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1;
         const uint16_t count = (uint16_t)((((uint64_t)value - (uint64_t)low + 1) * 0x10000u - 1) / span);
-        const uint32_t c1 = orc_cdf1(p_one[i]);
+        const uint32_t c1 = orc_cdf1_(p_one[i], is_u);
         /* binary search over {0, c1}: largest m with cdf[m] <= count */
         const int s = (c1 <= count) ? 1 : 0;
         out[i] = (int16_t)s;
@@ -121,4 +123,15 @@ int orc_rc_decode(const float* p_one, int64_t n, const uint8_t* in, int64_t len,
         }
     }
     return 0;
+}
+
+int64_t orc_rc_encode(const float* p_one, const int16_t* sym, int64_t n, uint8_t* out, int64_t cap)
+{
+    (void)g_unused;
+    return orc_rc_encode2(p_one, 0, sym, n, out, cap);
+}
+
+int orc_rc_decode(const float* p_one, int64_t n, const uint8_t* in, int64_t len, int16_t* out)
+{
+    return orc_rc_decode2(p_one, 0, n, in, len, out);
 }

@@ -1,0 +1,128 @@
+"""cnc_amd.context.CNC_context_models (HIP kernels) vs golden vectors produced by the REFERENCE's
+own class on CPU (tests/golden/make_golden_context.py): same tables, entropy estimate and gradients
+within fp32 tolerance, same set of coded rows, decode == the reference's decode bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "context_toy.npz")
+TOY = dict(res3=[6, 9, 14, 20, 26, 34], res2=[10, 18, 34, 66], T3=10, T2=9, F=4, Rb=8, fine=34,
+           sample_num=400, max_pts=20000)
+
+
+@pytest.fixture(scope="module")
+def setup(cuda):
+    from cnc_amd.context import CNC_context_models
+    from cnc_amd.gridencoder import GridEncoder
+    g = np.load(GOLD)
+    c = TOY
+    torch.manual_seed(11)     # same CPU draws (randperm of dense levels, utils_rand) as the golden run
+    m = CNC_context_models(num_dim=3, resolutions_list=c["res3"], resolutions_list_2D=c["res2"],
+                           log2_hashmap_size=c["T3"], log2_hashmap_size_2D=c["T2"], n_features=c["F"],
+                           sample_num=c["sample_num"], max_context_layer_num=3, ste_binary=True,
+                           Pg_level=6, Pg_level_2D=4, Rb=c["Rb"], step_update=16, skip_levels_3D=[0, 1, 2],
+                           skip_levels_2D=[0], device=cuda, dimension_wise_resolution=c["fine"])
+    m.MAX_POINTS_NUM_TO_OOM = c["max_pts"]
+    m.rand_like = lambda t: torch.rand(t.shape).to(t.device)     # replay the reference's CPU stream
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
+    m.load_state_dict(sd, strict=True)
+    encs = {}
+    for name, D, res, T in (("xyz", 3, c["res3"], c["T3"]), ("xy", 2, c["res2"], c["T2"]),
+                            ("xz", 2, c["res2"], c["T2"]), ("yz", 2, c["res2"], c["T2"])):
+        e = GridEncoder(num_dim=D, n_features=c["F"], resolutions_list=res, log2_hashmap_size=T, ste_binary=True).to(cuda)
+        with torch.no_grad():
+            e.params.copy_(torch.from_numpy(g[f"params_{name}"]))
+        encs[name] = e
+    binary = torch.from_numpy(g["binary_vxl"]).to(cuda)
+    return g, m, encs, binary
+
+
+def test_tables_equal_reference(setup):
+    g, m, encs, binary = setup
+    assert np.array_equal(m.utils_rand.cpu().numpy(), g["utils_rand"])
+    assert np.array_equal(m.unique_count_list.cpu().numpy(), g["unique_count_list"])
+    assert np.array_equal(m.sample_num_levels.cpu().numpy(), g["sample_num_levels"])
+    for n in range(6):
+        assert np.array_equal(m.unique_value_list[n].cpu().numpy(), g[f"uv_{n}"]), n
+        # the order of the vertices INSIDE one hash slot is whatever torch.sort leaves (unstable
+        # sort in the reference): compare slot by slot as sets
+        cnt = g["unique_count_list"][n][: len(g[f"uv_{n}"])]
+        slot = np.repeat(np.arange(len(cnt)), cnt)
+        def canon(pos):
+            key = (pos[:, 0].astype(np.int64) * 4096 + pos[:, 1]) * 4096 + pos[:, 2]
+            return pos[np.lexsort((key, slot))]
+        assert np.array_equal(canon(m.pos_grid_sorted_list[n].cpu().numpy()), canon(g[f"pos_{n}"])), n
+
+
+def test_training_pass_matches_reference(setup):
+    g, m, encs, binary = setup
+    for step, seed in ((0, 77), (1, 78)):
+        torch.manual_seed(seed)
+        for e in encs.values():
+            e.zero_grad()
+        m.zero_grad()
+        bpp, mb = m.forward_binary_vxl_mixPg_3D2D(encs["xyz"], encs["xy"], encs["xz"], encs["yz"], binary, step=step)
+        bpp.backward()
+        want = float(g[f"fwd{step}_bpp"])
+        assert abs(bpp.item() - want) <= 1e-4 * abs(want), (step, bpp.item(), want)
+        assert abs(mb - float(g[f"fwd{step}_mb"])) <= 1e-4 * float(g[f"fwd{step}_mb"])
+        for name, e in encs.items():
+            ref = g[f"fwd{step}_grad_{name}"]
+            got = e.params.grad.cpu().numpy()
+            scale = np.abs(ref).max()
+            assert np.abs(got - ref).max() <= 2e-4 * scale, (step, name, np.abs(got - ref).max(), scale)
+            assert np.array_equal(got == 0, ref == 0) or (np.abs(got[(got == 0) != (ref == 0)]).max() < 1e-9 * scale)
+        for key, w in (("ctx3d_w0", m.context_model_3D[0].weight), ("ctx2d_w0", m.context_model_2D[0][0].weight)):
+            ref = g[f"fwd{step}_grad_{key}"]
+            assert np.abs(w.grad.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+def test_encode_decode_matches_reference(setup, tmp_path):
+    g, m, encs, binary = setup
+    prefix = str(tmp_path / "b")
+    with torch.no_grad():
+        Pgs, est_mb, coded_mb = m.encode_binary_vxl_mixPg_3D2D(encs["xyz"], encs["xy"], encs["xz"], encs["yz"],
+                                                               binary, filename_prefix=prefix)
+    files = sorted(f for f in os.listdir(tmp_path) if f.endswith(".b"))
+    assert files == list(g["enc_files"])                                  # same levels / chunking
+    sizes = np.array([os.path.getsize(tmp_path / f) for f in files], np.int64)
+    ref_sizes = g["enc_sizes"]
+    assert abs(int(sizes.sum()) - int(ref_sizes.sum())) <= 0.005 * ref_sizes.sum()   # north-star: +-0.5 %
+    assert np.abs(sizes - ref_sizes).max() <= 2                              # per file: rounding of p only
+    assert abs(est_mb - float(g["enc_est_mb"])) <= 1e-4 * float(g["enc_est_mb"])
+    assert list(Pgs.keys()) == list(g["pg_keys"])
+    assert np.allclose([float(v) for v in Pgs.values()], g["pg_vals"], rtol=0, atol=1e-7)
+    recs = [torch.ones_like(encs[n].params.data) for n in ("xyz", "xy", "xz", "yz")]
+    out = m.decode_binary_vxl_mixPg_3D2D(encs["xyz"], encs["xy"], encs["xz"], encs["yz"], *recs, binary, Pgs,
+                                         filename_prefix=prefix)
+    for name, t in zip(("xyz", "xy", "xz", "yz"), out):
+        got = t.cpu().numpy().astype(np.int8)
+        assert np.array_equal(got, g[f"dec_{name}"]), name               # incl. which rows were never coded
+        q = np.where(g[f"params_{name}"] >= 0, 1, -1)
+        coded = ~(got == 1).all(axis=1) | (q == 1).all(axis=1)
+        assert np.array_equal(got[coded], q[coded])
+
+
+def test_fused_ste_equals_unfused(setup):
+    """GridEncoder(fused_ste=True) (sign inside the gather, mask inside the scatter) == the
+    reference's op-by-op STE_binary dataflow."""
+    from cnc_amd.gridencoder import GridEncoder
+    g, m, encs, binary = setup
+    c = TOY
+    a = GridEncoder(3, c["F"], c["res3"], c["T3"], ste_binary=True, fused_ste=True).to(binary.device)
+    b = GridEncoder(3, c["F"], c["res3"], c["T3"], ste_binary=True, fused_ste=False).to(binary.device)
+    with torch.no_grad():
+        a.params.copy_(torch.from_numpy(g["params_xyz"]))
+        b.params.copy_(a.params)
+    x = torch.rand(5000, 3, device=binary.device)
+    w = torch.randn(5000, c["F"] * 6, device=binary.device)
+    ya, yb = a(x), b(x)
+    assert torch.equal(ya, yb)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    # two atomic scatters of the same terms in different orders
+    assert (a.params.grad - b.params.grad).abs().max() <= 1e-5 * b.params.grad.abs().max()
+    assert torch.equal(a.params.grad == 0, b.params.grad == 0)
