@@ -1,0 +1,336 @@
+"""End-to-end driver for the CNC protocol: train -> evaluate -> encode -> decode -> evaluate.
+
+Follows the behaviour of examples/train_CNC_nerf_synthetic.py (hyper-parameters :135-186, optimisers
+and schedules :257-297, loop :302-366, evaluation / codec :384-506), not its text: the reference
+script cannot travel to the GPU box and its datasets are not available offline, so the scene here is
+a procedural one (`SyntheticBallDataset`, same `fetch`-style interface as
+examples/datasets/nerf_synthetic.py:132-239).  Flag names of the reference's argparse are kept in
+`TrainConfig`.
+
+Data parallelism (new): one process per GPU; each rank draws its own rays, gradients of
+ALL parameters live in one flat bucket that is all-reduced once per step (cnc_amd.dist.GradBucket);
+the occupancy grid and the context-window draw are broadcast from rank 0 so replicas stay identical.
+"""
+from __future__ import annotations
+
+import math
+import os
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import dist as cdist
+from .context import CNC_context_models
+from .field import NGPRadianceField_mygrid_2D3D
+from .nerfacc import OccGridEstimator
+from .render import Rays, render_image_with_occgrid, render_image_with_occgrid_test, set_random_seed
+
+
+@dataclass
+class TrainConfig:
+    # reference flags (train_CNC_nerf_synthetic.py:71-133)
+    scene: str = "ball"
+    lmbda: float = 2e-3
+    Pg_level: int = 12
+    Pg_level_2D: int = 4
+    log2_hashmap_size: int = 19
+    log2_hashmap_size_2D: int = 17
+    sample_num: int = 200000
+    max_context_layer_num: int = 3
+    n_features: int = 4
+    # hard-coded in the reference (:135-186)
+    n_neurons: int = 160
+    resolutions_list: Tuple[int, ...] = (18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514)
+    resolutions_list_2D: Tuple[int, ...] = (130, 258, 514, 1026)
+    step_update: int = 16
+    skip_levels_3D: Tuple[int, ...] = (0, 1, 2)
+    skip_levels_2D: Tuple[int, ...] = (0,)
+    max_steps: int = 20000
+    init_batch_size: int = 1024
+    target_sample_batch_size: int = 1 << 18
+    weight_decay: float = 2e-6
+    aabb: Tuple[float, ...] = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
+    near_plane: float = 0.0
+    far_plane: float = 1.0e10
+    grid_resolution: int = 128
+    grid_nlvl: int = 1
+    render_step_size: float = 5e-3
+    alpha_thre: float = 0.0
+    cone_angle: float = 0.0
+    lr: float = 6e-3
+    milestones: Tuple[int, ...] = (9000, 12000, 15000, 17000, 19000)
+    warmup_iters: int = 1000
+    seed: int = 42
+    # evaluation
+    test_views: int = 4
+    image_size: int = 200
+    dimension_wise_resolution: Optional[int] = None   # default: finest 3-D resolution
+    out_dir: str = "./bitstreams/ball"
+    log_every: int = 200
+
+
+class SyntheticBallDataset:
+    """Procedural scene: an opaque textured ball of radius 0.8 in front of a white background,
+    seen from cameras on a sphere of radius 4 (focal as nerf_synthetic, camera_angle_x=0.6911).
+    `fetch(num_rays)` returns random training pixels like SubjectLoader.fetch_data in training mode
+    (nerf_synthetic.py:164-239); `view(i)` returns a whole test image."""
+
+    RADIUS = 0.8
+
+    def __init__(self, image_size=200, n_train_views=100, device="cuda", seed=0):
+        self.H = self.W = image_size
+        self.focal = 0.5 * image_size / math.tan(0.5 * 0.6911)
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device).manual_seed(seed)
+        g = torch.Generator().manual_seed(1234)
+        self.train_c2w = self._poses(n_train_views, g).to(self.device)
+        self.test_c2w = self._poses(16, torch.Generator().manual_seed(4321)).to(self.device)
+        self.num_rays = 1024
+
+    @staticmethod
+    def _poses(n, g):
+        az = torch.rand(n, generator=g) * 2 * math.pi
+        el = (torch.rand(n, generator=g) - 0.3) * 1.2
+        eye = 4.0 * torch.stack([torch.cos(el) * torch.cos(az), torch.cos(el) * torch.sin(az), torch.sin(el)], -1)
+        fwd = -eye / eye.norm(dim=-1, keepdim=True)
+        up0 = torch.tensor([0.0, 0.0, 1.0]).expand_as(fwd)
+        right = torch.linalg.cross(fwd, up0)
+        right = right / right.norm(dim=-1, keepdim=True)
+        up = torch.linalg.cross(right, fwd)
+        return torch.cat([torch.stack([right, up, -fwd], dim=-1), eye[..., None]], dim=-1)   # [n,3,4]
+
+    def update_num_rays(self, n):
+        self.num_rays = int(n)
+
+    def _rays(self, c2w, x, y):
+        cam = torch.stack([(x - self.W / 2 + 0.5) / self.focal, -(y - self.H / 2 + 0.5) / self.focal,
+                           -torch.ones_like(x)], dim=-1)
+        d = (cam[:, None, :] * c2w[:, :3, :3]).sum(-1)
+        d = d / torch.linalg.norm(d, dim=-1, keepdim=True)
+        o = c2w[:, :3, 3].expand_as(d)
+        return o.contiguous(), d.contiguous()
+
+    def _shade(self, o, d):
+        """Ground-truth pixel colour and alpha: first hit of the ball."""
+        b = (o * d).sum(-1)
+        c = (o * o).sum(-1) - self.RADIUS ** 2
+        disc = b * b - c
+        hit = disc > 0
+        t = -b - torch.sqrt(disc.clamp_min(0))
+        p = o + d * t[:, None]
+        n = p / self.RADIUS
+        tex = 0.5 + 0.5 * torch.sin(p * 9.0 + torch.tensor([0.0, 2.0, 4.0], device=p.device))
+        lam = (0.35 + 0.65 * (n * torch.tensor([0.3, 0.5, 0.8], device=p.device)).sum(-1).clamp(0, 1))[:, None]
+        rgb = (tex * lam).clamp(0, 1)
+        return rgb, hit.float()[:, None]
+
+    def fetch(self, num_rays=None):
+        n = self.num_rays if num_rays is None else num_rays
+        img = torch.randint(0, self.train_c2w.shape[0], (n,), device=self.device, generator=self.gen)
+        x = torch.randint(0, self.W, (n,), device=self.device, generator=self.gen).float()
+        y = torch.randint(0, self.H, (n,), device=self.device, generator=self.gen).float()
+        o, d = self._rays(self.train_c2w[img], x, y)
+        rgb, alpha = self._shade(o, d)
+        bkgd = torch.rand(3, device=self.device, generator=self.gen)     # random bkgd in training
+        return {"rays": Rays(o, d), "pixels": rgb * alpha + bkgd * (1 - alpha), "color_bkgd": bkgd}
+
+    def view(self, i):
+        ys, xs = torch.meshgrid(torch.arange(self.H, device=self.device),
+                                torch.arange(self.W, device=self.device), indexing="ij")
+        x, y = xs.reshape(-1).float(), ys.reshape(-1).float()
+        c2w = self.test_c2w[i % self.test_c2w.shape[0]][None].expand(x.shape[0], 3, 4)
+        o, d = self._rays(c2w, x, y)
+        rgb, alpha = self._shade(o, d)
+        bkgd = torch.ones(3, device=self.device)
+        return {"rays": Rays(o.view(self.H, self.W, 3), d.view(self.H, self.W, 3)),
+                "pixels": (rgb * alpha + bkgd * (1 - alpha)).view(self.H, self.W, 3), "color_bkgd": bkgd}
+
+
+def quantize_params(state: Dict[str, torch.Tensor], digits=13):
+    """Uniform `digits`-bit quantisation of each MLP tensor (train_CNC_nerf_synthetic.py:30-50).
+    Returns (quantised MB, original MB, quantised state)."""
+    bits = bits_orig = 0
+    out = {}
+    for n, p in state.items():
+        lo, hi = torch.min(p), torch.max(p)
+        interval = (hi - lo) / (2 ** digits - 1) + 1e-6
+        q = (p - lo) // interval
+        out[n] = q * interval + lo
+        bits += digits * p.numel() + 64
+        bits_orig += 32 * p.numel()
+    return bits / 8.0 / 1024 / 1024, bits_orig / 8.0 / 1024 / 1024, out
+
+
+def get_binary_vxl_size(binary_vxl):
+    """Entropy bound of the occupancy grid in MB (train_CNC_nerf_synthetic.py:53-68)."""
+    with torch.no_grad():
+        n = binary_vxl.numel()
+        pos = torch.sum(binary_vxl)
+        Pg = pos / n
+        bits = pos * (-torch.log2(Pg)) + (n - pos) * (-torch.log2(1 - Pg)) + 32
+    return Pg, bits.item() / 8.0 / 1024 / 1024, n
+
+
+class Trainer:
+    def __init__(self, cfg: TrainConfig, device="cuda"):
+        self.cfg = cfg
+        self.rank, self.local_rank, self.world = cdist.env_world()
+        self.device = torch.device(device)
+        set_random_seed(cfg.seed)
+        c = cfg
+        aabb = torch.tensor(c.aabb, device=self.device)
+        self.estimator = OccGridEstimator(roi_aabb=aabb, resolution=c.grid_resolution, levels=c.grid_nlvl).to(self.device)
+        self.field = NGPRadianceField_mygrid_2D3D(
+            aabb=self.estimator.aabbs[-1], n_features_per_level=c.n_features, n_neurons=c.n_neurons,
+            resolutions_list=c.resolutions_list, log2_hashmap_size=c.log2_hashmap_size,
+            resolutions_list_2D=c.resolutions_list_2D, log2_hashmap_size_2D=c.log2_hashmap_size_2D,
+            ste_binary=True, Q=10).to(self.device)
+        self.context = CNC_context_models(
+            num_dim=3, resolutions_list=c.resolutions_list, resolutions_list_2D=c.resolutions_list_2D,
+            log2_hashmap_size=c.log2_hashmap_size, log2_hashmap_size_2D=c.log2_hashmap_size_2D,
+            n_features=c.n_features, sample_num=c.sample_num, max_context_layer_num=c.max_context_layer_num,
+            ste_binary=True, Q=10, Pg_level=c.Pg_level, Pg_level_2D=c.Pg_level_2D, Rb=c.grid_resolution,
+            step_update=c.step_update, skip_levels_3D=c.skip_levels_3D, skip_levels_2D=c.skip_levels_2D,
+            device=self.device,
+            dimension_wise_resolution=c.dimension_wise_resolution or c.resolutions_list[-1])
+        self.dataset = SyntheticBallDataset(c.image_size, device=self.device, seed=c.seed + 1000 * self.rank)
+        self.dataset.update_num_rays(c.init_batch_size)
+
+        self.opt = torch.optim.Adam(self.field.parameters(), lr=c.lr, eps=1e-15, weight_decay=c.weight_decay)
+        self.opt2 = torch.optim.Adam(self.context.parameters(), lr=c.lr, eps=1e-15)
+
+        def sched(o):
+            return torch.optim.lr_scheduler.ChainedScheduler([
+                torch.optim.lr_scheduler.LinearLR(o, start_factor=0.01, total_iters=c.warmup_iters),
+                torch.optim.lr_scheduler.MultiStepLR(o, milestones=list(c.milestones), gamma=0.33)])
+        self.sched, self.sched2 = sched(self.opt), sched(self.opt2)
+        self.loss_scale = 2.0 ** 10          # GradScaler(2**10), never unscaled (train:211,361-362)
+
+        self.bucket = None
+        if self.world > 1:
+            self.bucket = cdist.GradBucket(list(self.field.parameters()) + list(self.context.parameters()))
+            base = self.context.rand_like
+
+            def synced_rand_like(t):
+                r = base(t)
+                torch.distributed.broadcast(r, 0)
+                return r
+            self.context.rand_like = synced_rand_like
+
+    # -------------------------------------------------------------------------------- training
+    def train_step(self, step: int) -> Optional[Dict[str, float]]:
+        c = self.cfg
+        self.field.train(); self.estimator.train(); self.context.train()
+        data = self.dataset.fetch()
+        rays, pixels, bkgd = data["rays"], data["pixels"], data["color_bkgd"]
+        self.estimator.update_every_n_steps(
+            step=step, occ_eval_fn=lambda x: self.field.query_density(x) * c.render_step_size,
+            occ_thre=1e-2, n=c.step_update)
+        if self.world > 1 and step % c.step_update == 0:
+            cdist.broadcast_module_buffers(self.estimator, ["occs", "binaries"])
+        rgb, acc, depth, n_samples, extra = render_image_with_occgrid(
+            self.field, self.estimator, rays, near_plane=c.near_plane, render_step_size=c.render_step_size,
+            render_bkgd=bkgd, cone_angle=c.cone_angle, alpha_thre=c.alpha_thre, return_extra=True)
+        n_all = n_samples
+        if self.world > 1:   # every rank must take the same branch and keep the same ray budget
+            n_all = int(cdist.sum_over_ranks(float(n_samples), self.device) / self.world)
+        if n_all == 0:
+            return None
+        if c.target_sample_batch_size > 0:
+            self.dataset.update_num_rays(int(len(pixels) * (c.target_sample_batch_size / float(n_all))))
+        mse = F.mse_loss(rgb, pixels)
+        loss = mse
+        bpp, mb = 0.0, 0.0
+        if c.lmbda > 0:
+            e = self.field.mlp_base
+            bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(
+                e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
+                sample_num=None, step=step)
+            loss = loss + c.lmbda * bits_per_param
+            bpp = bits_per_param.item()
+        self.opt.zero_grad(set_to_none=self.bucket is None)
+        self.opt2.zero_grad(set_to_none=self.bucket is None)
+        if self.bucket is not None:
+            self.bucket.zero()
+            self.bucket.bind()
+        (loss * self.loss_scale).backward()
+        if self.bucket is not None:
+            self.bucket.bind()
+            self.bucket.allreduce(average=True)
+        self.opt.step()
+        if c.lmbda > 0:
+            self.opt2.step()
+        self.sched.step()
+        if c.lmbda > 0:
+            self.sched2.step()
+        return {"mse": mse.item(), "psnr": -10.0 * math.log10(max(mse.item(), 1e-12)), "bpp": bpp,
+                "embed_bits_MB": mb, "n_rendering_samples": n_samples, "num_rays": len(pixels)}
+
+    def train(self, steps: Optional[int] = None, log=print):
+        steps = self.cfg.max_steps if steps is None else steps
+        tic = time.time()
+        last = None
+        for step in range(steps + 1):
+            s = self.train_step(step)
+            if s is not None:
+                last = s
+            if log and s is not None and step % self.cfg.log_every == 0 and self.rank == 0:
+                log(f"elapsed_time={time.time() - tic:.2f}s | step={step} | psnr={s['psnr']:.2f} | "
+                    f"n_rendering_samples={s['n_rendering_samples']} | num_rays={s['num_rays']} | "
+                    f"bits_per_param={s['bpp']:.3f} | embed_bits_MB={s['embed_bits_MB']:.3f}")
+        return last
+
+    # ------------------------------------------------------------------------------ evaluation
+    @torch.no_grad()
+    def evaluate(self, n_views: Optional[int] = None) -> float:
+        """Mean PSNR over test views; views are sharded over ranks and the mean is all-reduced."""
+        c = self.cfg
+        self.field.eval(); self.estimator.eval()
+        n_views = c.test_views if n_views is None else n_views
+        lo, hi = cdist.shard_range(n_views, self.rank, self.world)
+        tot = 0.0
+        for i in range(lo, hi):
+            d = self.dataset.view(i)
+            rgb, acc, depth, _ = render_image_with_occgrid_test(
+                1024, self.field, self.estimator, d["rays"], near_plane=c.near_plane,
+                render_step_size=c.render_step_size, render_bkgd=d["color_bkgd"], cone_angle=c.cone_angle,
+                alpha_thre=c.alpha_thre)
+            mse = F.mse_loss(rgb, d["pixels"])
+            tot += -10.0 * math.log10(max(mse.item(), 1e-12))
+        tot = cdist.sum_over_ranks(tot, self.device)
+        return tot / max(n_views, 1)
+
+    # ------------------------------------------------------------------------------ codec
+    @torch.no_grad()
+    def encode(self, prefix: Optional[str] = None):
+        os.makedirs(self.cfg.out_dir, exist_ok=True)
+        prefix = prefix or os.path.join(self.cfg.out_dir, "b")
+        e = self.field.mlp_base
+        self.context.eval()
+        return self.context.encode_binary_vxl_mixPg_3D2D(e.encoding_xyz, e.encoding_xy, e.encoding_xz,
+                                                         e.encoding_yz, self.estimator.binaries,
+                                                         filename_prefix=prefix) + (prefix,)
+
+    @torch.no_grad()
+    def decode_into_field(self, Pgs, prefix):
+        """Wipe the four tables, decode them from the .b files, install them (train:445-470)."""
+        e = self.field.mlp_base
+        recs = [torch.ones_like(t.params.data) for t in (e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz)]
+        for t in (e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz):
+            t.params.data.zero_()
+        recs = self.context.decode_binary_vxl_mixPg_3D2D(e.encoding_xyz, e.encoding_xy, e.encoding_xz,
+                                                         e.encoding_yz, *recs, self.estimator.binaries, Pgs,
+                                                         filename_prefix=prefix)
+        self.field.update_embedding_params(*recs)
+
+    def sizes_MB(self, coded_MB: float) -> Dict[str, float]:
+        ctx_MB = sum(p.numel() * 32 for p in self.context.parameters()) / 8.0 / 1024 / 1024
+        _, occ_MB, _ = get_binary_vxl_size(self.estimator.binaries)
+        mlp = {k: v for k, v in self.field.state_dict().items() if "encoding" not in k and k != "aabb"}
+        mlp_MB, _, _ = quantize_params(mlp, digits=13)
+        return {"embeddings": coded_MB, "context_models": ctx_MB, "occupancy_grid": occ_MB, "mlp_13bit": mlp_MB,
+                "total": coded_MB + ctx_MB + occ_MB + mlp_MB}
