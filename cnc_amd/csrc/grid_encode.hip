@@ -291,12 +291,12 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
             const uint32_t R = (uint32_t)resolutions[level];
             Corners<D, VXL> c;
             c.setup(x, R, hs, Rb, vxl);
-            uint64_t cell = 0;
+            uint64_t cell = 0;   // integer cell coordinates, 16 bits per axis (R <= 65535)
 #pragma unroll
             for (uint32_t d = D; d-- > 0;) {
                 float p = x[d] * (float)(R - 2);
                 p = p + 0.5f;
-                cell = cell * R + (uint32_t)floorf(p);
+                cell = (cell << 16) | (uint32_t)floorf(p);
             }
             key = ((uint64_t)level << 52) | cell;
 #pragma unroll
@@ -320,36 +320,105 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
     __syncthreads();
 
     // ---- run detection: head = first point of a run of equal (level, cell) keys ----
-    const bool     head = (tid == 0) || (s_key[tid - 1] != key);
+    const uint64_t prev_key = tid == 0 ? ~0ull : s_key[tid - 1];
+    const bool     head = (tid == 0) || (prev_key != key);
+    // a head whose cell touches the previous point's cell (same level, every axis within +-1)
+    // shares corner rows with it: count those to decide whether write-combining pays
+    bool adjacent = false;
+    if (head && key != ~0ull && prev_key != ~0ull && (key >> 52) == (prev_key >> 52)) {
+        adjacent = true;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            const int a = (int)((key >> (16 * d)) & 0xFFFF), b2 = (int)((prev_key >> (16 * d)) & 0xFFFF);
+            adjacent &= (a - b2 <= 1) && (b2 - a <= 1);
+        }
+    }
     const uint64_t hb = __ballot(head);
+    const uint64_t ab = __ballot(adjacent);
     const uint32_t lane = tid & 63, wave = tid >> 6;
-    if (lane == 0) s_wave_heads[wave] = (uint32_t)__popcll(hb);
+    if (lane == 0) s_wave_heads[wave] = (uint32_t)__popcll(hb) | ((uint32_t)__popcll(ab) << 16);
     __syncthreads();
-    uint32_t before = 0, total = 0;
+    uint32_t before = 0, total = 0, n_adjacent = 0;
 #pragma unroll
     for (uint32_t w = 0; w < 4; w++) {
-        const uint32_t h = s_wave_heads[w];
+        const uint32_t h = s_wave_heads[w] & 0xFFFFu;
         before += (w < wave) ? h : 0u;
         total += h;
+        n_adjacent += s_wave_heads[w] >> 16;
     }
     if (head) s_run_start[before + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull))] = (uint16_t)tid;
     if (tid == 0) s_run_start[total] = 256;
     __syncthreads();
 
     // ---- phase B ----
+    // Each group of SLOTS lanes walks a CONTIGUOUS range of runs and keeps the previous run's
+    // (row, sum) pending in registers: a ray leaves a cell through a face, so the next run shares
+    // up to half of its corner rows with the pending one.  Rows of the pending run that reappear
+    // are absorbed by the new run instead of being written (write-combining across adjacent
+    // cells); only rows that do not reappear go out as atomics.
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
     const uint32_t grp = tid / SLOTS, l = tid % SLOTS;
     const uint32_t c = l / F, f = l % F;
-    for (uint32_t r = grp; r < total; r += GROUPS) {
-        const uint32_t p0 = s_run_start[r], p1 = s_run_start[r + 1];
-        if (!((s_valid[p0] >> c) & 1u)) continue;
-        float acc = 0;
-        for (uint32_t p = p0; p < p1; p++) acc += s_tw[p][c] * s_g[p][f];
-        const size_t at = (size_t)s_row[p0][c] * F + f;
+
+    auto flush = [&](uint32_t row, float v) {
+        const size_t at = (size_t)row * F + f;
         if constexpr (STE) {   // STE_binary.backward: pass gradient only where |param| <= 1
             const float e = emb[at];
-            if (!(e >= -1.0f && e <= 1.0f)) continue;
+            if (!(e >= -1.0f && e <= 1.0f)) return;
         }
-        unsafeAtomicAdd(grad_emb + at, acc);
+        unsafeAtomicAdd(grad_emb + at, v);
+    };
+
+    if (n_adjacent * 4 < total) {
+        // few neighbouring runs (random points, or levels finer than the sample spacing): nothing
+        // to combine, so every run goes straight out, runs interleaved over the groups
+        for (uint32_t r = grp; r < total; r += GROUPS) {
+            const uint32_t p0 = s_run_start[r], p1 = s_run_start[r + 1];
+            if (!((s_valid[p0] >> c) & 1u)) continue;
+            float acc = 0;
+            for (uint32_t p = p0; p < p1; p++) acc += s_tw[p][c] * s_g[p][f];
+            flush(s_row[p0][c], acc);
+        }
+        return;
+    }
+    const uint32_t gbase = lane - l;                       // first lane of my group inside the wave
+    uint64_t fmask = 0;                                    // lanes (c', f) of my group, all c'
+#pragma unroll
+    for (uint32_t cc = 0; cc < C; cc++) fmask |= 1ull << (gbase + cc * F + f);
+    const uint32_t rpg = (total + GROUPS - 1) / GROUPS;    // block-uniform trip count
+    const uint32_t r_begin = grp * rpg;
+    const uint32_t r_end = min(total, r_begin + rpg);
+
+    uint32_t carry_row = NONE;
+    float    carry_acc = 0;
+    for (uint32_t i = 0; i <= rpg; i++) {                  // one extra round drains the pending run
+        const uint32_t r = r_begin + i;
+        uint32_t my_row = NONE;
+        float    acc = 0;
+        if (i < rpg && r < r_end) {
+            const uint32_t p0 = s_run_start[r], p1 = s_run_start[r + 1];
+            if ((s_valid[p0] >> c) & 1u) {
+                my_row = s_row[p0][c];
+                for (uint32_t p = p0; p < p1; p++) acc += s_tw[p][c] * s_g[p][f];
+            }
+        }
+        bool claimed = false;
+#pragma unroll
+        for (uint32_t j = 0; j < C; j++) {
+            const uint32_t src = gbase + j * F + f;
+            const uint32_t cr = __shfl(carry_row, src);
+            const float    ca = __shfl(carry_acc, src);
+            const bool     hit = (my_row != NONE) && (cr == my_row);
+            const uint64_t cand = __ballot(hit) & fmask;
+            if (cand != 0) {
+                // pending lane (j, f) is taken over by exactly one new lane: the lowest one
+                if (c == j) claimed = true;
+                if ((uint32_t)__builtin_ctzll(cand) == lane) acc += ca;
+            }
+        }
+        if (carry_row != NONE && !claimed) flush(carry_row, carry_acc);
+        carry_row = my_row;
+        carry_acc = acc;
     }
 }
 
