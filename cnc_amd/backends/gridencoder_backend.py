@@ -65,7 +65,8 @@ def grid_encode_forward(inputs, embeddings, offsets_list, resolutions_list, outp
 
 def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_list, grad_embeddings,
                          N, num_dim, n_features, n_levels, max_level, Rb, dy_dx=None,
-                         grad_inputs=None, binary_vxl=None, min_level_id=None, *, ste_binary=False):
+                         grad_inputs=None, binary_vxl=None, min_level_id=None, *, ste_binary=False,
+                         ste_clip_count=None):
     _common_checks([("grad", grad), ("inputs", inputs), ("embeddings", embeddings),
                     ("offsets_list", offsets_list), ("resolutions_list", resolutions_list),
                     ("grad_embeddings", grad_embeddings)])
@@ -88,8 +89,50 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
         ptr(grad_embeddings), int(N), int(num_dim), int(n_features), int(n_levels), int(Rb),
         ptr(dy_dx), ptr(grad_inputs), ptr(binary_vxl), ptr(min_level_id),
-        _lib.CNC_FLAG_STE_BINARY if ste_binary else 0, stream())
+        _lib.CNC_FLAG_STE_BINARY if ste_binary else 0, ptr(ste_clip_count), stream())
     check(rc, "grid_encode_backward")
+
+
+def pack_sign_bits(embeddings, bits=None, clip_count=None):
+    """(extension) sign bit plane of a [rows, F] fp32 table: uint8 [ceil(rows*F/8)], bit = value >= 0.
+    clip_count: optional CUDA int32/uint32 tensor [1], set to the number of entries with |v| > 1."""
+    _common_checks([("embeddings", embeddings)])
+    _require_f32(embeddings, "embeddings")
+    rows, F = embeddings.shape
+    n_bytes = (rows * F + 7) // 8
+    if bits is None:
+        bits = torch.empty(n_bytes, dtype=torch.uint8, device=embeddings.device)
+    elif bits.numel() != n_bytes or bits.dtype != torch.uint8 or not bits.is_cuda:
+        raise RuntimeError("bits must be a CUDA uint8 tensor of ceil(rows*F/8) bytes")
+    rc = _lib.lib().cnc_pack_sign_bits(ptr(embeddings), ptr(bits), int(rows), int(F),
+                                       ptr(clip_count), stream())
+    check(rc, "pack_sign_bits")
+    return bits
+
+
+def grid_encode_forward_bits(inputs, bits, offsets_list, resolutions_list, outputs, N, num_dim,
+                             n_features, n_levels, Rb, binary_vxl=None, min_level_id=None):
+    """(extension) grid_encode_forward on the bit plane of a binarised table; same outputs as
+    grid_encode_forward(..., ste_binary=True) on the fp32 table."""
+    _common_checks([("inputs", inputs), ("bits", bits), ("offsets_list", offsets_list),
+                    ("resolutions_list", resolutions_list), ("outputs", outputs)])
+    _check_int(offsets_list, "offsets_list")
+    _check_int(resolutions_list, "resolutions_list")
+    _require_f32(inputs, "inputs")
+    _require_f32(outputs, "outputs")
+    if bits.dtype != torch.uint8:
+        raise RuntimeError("bits must be a uint8 tensor")
+    if n_features not in (1, 2, 4, 8, 16, 32):
+        raise RuntimeError("GridEncoding: n_fearures must be 1, 2, 4, 8, 16 or 32.")
+    if num_dim not in (1, 2, 3):
+        raise RuntimeError("GridEncoding: num_dim must be 1, 2, 3.")
+    if binary_vxl is not None:
+        binary_vxl = binary_vxl.contiguous()
+    rc = _lib.lib().cnc_grid_encode_forward_bits(
+        ptr(inputs), ptr(bits), ptr(offsets_list), ptr(resolutions_list), ptr(outputs), int(N),
+        int(num_dim), int(n_features), int(n_levels), int(Rb), ptr(binary_vxl), ptr(min_level_id),
+        stream())
+    check(rc, "grid_encode_forward_bits")
 
 
 def cnt_np_embed(inputs, embeddings_clip, outputs, N, resolution, n_features, hashmap_size, axis):

@@ -178,6 +178,107 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd(
 }
 
 // ---------------------------------------------------------------------------------------------
+// bit-plane forward: the binarised table as F bits per row.  One lane per point owns all F
+// output features; a corner costs one 1/2/4-byte load from a table that is 32x smaller than the
+// fp32 one (a whole level is <= 512 KiB at F=8: L2-resident), so the kernel is bound by its own
+// output stream (L*F*4 bytes per sample).  Same corner order and fmaf chain as the fp32 kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_sign_bits(const float* __restrict__ emb,
+                                                        uint8_t* __restrict__ bits,
+                                                        uint64_t n_bytes, uint64_t n_vals,
+                                                        uint32_t* __restrict__ clip_count)
+{
+    uint32_t clipped = 0;
+    // one lane builds one output byte from 8 consecutive floats (two dwordx4 loads, coalesced)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_bytes;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t b = 0;
+        const uint64_t base = i * 8;
+        if (base + 8 <= n_vals) {
+            const float4 lo = *reinterpret_cast<const float4*>(emb + base);
+            const float4 hi = *reinterpret_cast<const float4*>(emb + base + 4);
+            b = (lo.x >= 0 ? 1u : 0u) | (lo.y >= 0 ? 2u : 0u) | (lo.z >= 0 ? 4u : 0u) |
+                (lo.w >= 0 ? 8u : 0u) | (hi.x >= 0 ? 16u : 0u) | (hi.y >= 0 ? 32u : 0u) |
+                (hi.z >= 0 ? 64u : 0u) | (hi.w >= 0 ? 128u : 0u);
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++) clipped += !(v[k] >= -1.0f && v[k] <= 1.0f);
+        } else {
+            for (uint32_t k = 0; k < 8 && base + k < n_vals; k++) {
+                const float v = emb[base + k];
+                b |= (v >= 0 ? 1u : 0u) << k;
+                clipped += !(v >= -1.0f && v <= 1.0f);
+            }
+        }
+        bits[i] = (uint8_t)b;
+    }
+    if (clip_count != nullptr && __any(clipped != 0)) {
+        // rare: one integer atomic per lane that saw an out-of-range entry
+        if (clipped) atomicAdd(clip_count, clipped);
+    }
+}
+
+template <uint32_t F>
+__device__ __forceinline__ uint32_t load_row_bits(const uint8_t* __restrict__ bits, uint64_t row)
+{
+    if constexpr (F == 32) return *reinterpret_cast<const uint32_t*>(bits + row * 4);
+    else if constexpr (F == 16) return *reinterpret_cast<const uint16_t*>(bits + row * 2);
+    else if constexpr (F == 8) return bits[row];
+    else {
+        const uint64_t bit = row * F;
+        return (bits[bit >> 3] >> (bit & 7)) & ((1u << F) - 1u);
+    }
+}
+
+template <uint32_t D, uint32_t F, bool VXL>
+__global__ __launch_bounds__(256) void k_grid_encode_fwd_bits(
+    const float* __restrict__ inputs, const uint8_t* __restrict__ bits,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
+    float* __restrict__ out, uint32_t N, uint32_t Rb, const uint8_t* __restrict__ vxl,
+    const int32_t* __restrict__ min_level_id)
+{
+    constexpr uint32_t C = 1u << D;
+    constexpr uint32_t V = F < 4 ? F : 4;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= N) return;
+    const uint32_t slot = blockIdx.y;
+    const uint32_t level = slot + (min_level_id ? (uint32_t)min_level_id[b] : 0u);
+    float* o = out + ((size_t)slot * N + b) * F;
+    float  acc[F];
+#pragma unroll
+    for (uint32_t k = 0; k < F; k++) acc[k] = 0;
+
+    float x[D];
+    if (load_point<D>(inputs, b, x)) {
+        const uint32_t off = (uint32_t)offsets[level];
+        const uint32_t hs = (uint32_t)offsets[level + 1] - off;
+        const uint32_t R = (uint32_t)resolutions[level];
+        Corners<D, VXL> c;
+        c.setup(x, R, hs, Rb, vxl);
+        uint32_t rb[C];
+#pragma unroll
+        for (uint32_t i = 0; i < C; i++)
+            rb[i] = c.valid[i] ? load_row_bits<F>(bits, (uint64_t)off + c.row[i]) : 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < C; i++) {
+            const float tw = c.w[i] * c.wn_re;
+#pragma unroll
+            for (uint32_t k = 0; k < F; k++) {
+                const float e = ((rb[i] >> k) & 1u) ? 1.0f : -1.0f;
+                acc[k] = c.valid[i] ? __builtin_fmaf(tw, e, acc[k]) : acc[k];
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < F; k += V) {
+        float v[V];
+#pragma unroll
+        for (uint32_t j = 0; j < V; j++) v[j] = acc[k + j];
+        store_vec<V>(o + k, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward, generic fallback (row wider than a wave: C*F > 64): one lane per (point, 16-B chunk),
 // hardware fp32 atomics (global_atomic_add_f32, no CAS loop).
 // ---------------------------------------------------------------------------------------------
@@ -186,11 +287,13 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd_simple(
     const float* __restrict__ grad, const float* __restrict__ inputs,
     const float* __restrict__ emb, const int32_t* __restrict__ offsets,
     const int32_t* __restrict__ resolutions, float* __restrict__ grad_emb, uint32_t N,
-    uint32_t Rb, const uint8_t* __restrict__ vxl, const int32_t* __restrict__ min_level_id)
+    uint32_t Rb, const uint8_t* __restrict__ vxl, const int32_t* __restrict__ min_level_id,
+    const uint32_t* __restrict__ clip_count)
 {
     constexpr uint32_t V = F < 4 ? F : 4;
     constexpr uint32_t G = F / V;
     constexpr uint32_t C = 1u << D;
+    const bool mask_on = STE && (clip_count == nullptr || *clip_count != 0);
 
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = t / G;
@@ -219,7 +322,9 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd_simple(
         const float  tw = c.w[i] * c.wn_re;
         const size_t at = base + (size_t)c.row[i] * F;
         float keep[V];
-        if constexpr (STE) {   // STE_binary.backward: pass gradient only where |param| <= 1
+#pragma unroll
+        for (uint32_t k = 0; k < V; k++) keep[k] = 1.f;
+        if (mask_on) {   // STE_binary.backward: pass gradient only where |param| <= 1
             float e[V];
             load_vec<V>(emb + at, e);
 #pragma unroll
@@ -227,9 +332,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd_simple(
         }
 #pragma unroll
         for (uint32_t k = 0; k < V; k++) {
-            if constexpr (STE) {
-                if (keep[k] == 0.f) continue;
-            }
+            if (keep[k] == 0.f) continue;
             unsafeAtomicAdd(grad_emb + at + k, tw * g[k]);
         }
     }
@@ -257,10 +360,13 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
     const float* __restrict__ grad, const float* __restrict__ inputs,
     const float* __restrict__ emb, const int32_t* __restrict__ offsets,
     const int32_t* __restrict__ resolutions, float* __restrict__ grad_emb, uint32_t N,
-    uint32_t Rb, const uint8_t* __restrict__ vxl, const int32_t* __restrict__ min_level_id)
+    uint32_t Rb, const uint8_t* __restrict__ vxl, const int32_t* __restrict__ min_level_id,
+    const uint32_t* __restrict__ clip_count)
 {
     constexpr uint32_t C = 1u << D;
     constexpr uint32_t SLOTS = C * F;           // lanes per run in phase B (<= 64)
+    // STE mask needed only if some parameter left [-1, 1] (counted by cnc_pack_sign_bits)
+    const bool mask_on = STE && (clip_count == nullptr || *clip_count != 0);
     constexpr uint32_t GROUPS = 256 / SLOTS;    // runs processed concurrently by the block
     constexpr uint32_t V = F < 4 ? F : 4;
     static_assert(SLOTS <= 64, "use k_grid_encode_bwd_simple");
@@ -362,7 +468,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
 
     auto flush = [&](uint32_t row, float v) {
         const size_t at = (size_t)row * F + f;
-        if constexpr (STE) {   // STE_binary.backward: pass gradient only where |param| <= 1
+        if (mask_on) {   // STE_binary.backward: pass gradient only where |param| <= 1
             const float e = emb[at];
             if (!(e >= -1.0f && e <= 1.0f)) return;
         }
@@ -494,6 +600,7 @@ struct EncArgs {
     const uint8_t* vxl;
     const int32_t* mli;
     hipStream_t    stream;
+    const uint32_t* clip_count = nullptr;   // backward + STE only
 };
 
 template <uint32_t D, uint32_t F, bool VXL, bool STE>
@@ -512,13 +619,13 @@ static void launch_bwd(const EncArgs& a)
         const dim3 grid(div_up(a.N, 256), a.L, 1);
         hipLaunchKernelGGL((k_grid_encode_bwd<D, F, VXL, STE>), grid, dim3(256), 0, a.stream,
                            a.grad, a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N, a.Rb,
-                           a.vxl, a.mli);
+                           a.vxl, a.mli, a.clip_count);
     } else {
         constexpr uint32_t V = F < 4 ? F : 4, G = F / V;
         const dim3 grid(div_up(a.N * G, 256), a.L, 1);
         hipLaunchKernelGGL((k_grid_encode_bwd_simple<D, F, VXL, STE>), grid, dim3(256), 0,
                            a.stream, a.grad, a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N,
-                           a.Rb, a.vxl, a.mli);
+                           a.Rb, a.vxl, a.mli, a.clip_count);
     }
 }
 
@@ -591,14 +698,15 @@ extern "C" int cnc_grid_encode_backward(const float* grad, const float* inputs,
                                         uint32_t N, uint32_t D, uint32_t F, uint32_t L,
                                         uint32_t Rb, const float* dy_dx, float* grad_inputs,
                                         const uint8_t* binary_vxl, const int32_t* min_level_id,
-                                        uint32_t flags, void* stream)
+                                        uint32_t flags, const uint32_t* ste_clip_count,
+                                        void* stream)
 {
     if (dy_dx || grad_inputs) return CNC_ERR_UNSUPPORTED;
     if (N == 0 || L == 0) return CNC_OK;
     if (!grad || !inputs || !embeddings || !offsets || !resolutions || !grad_embeddings)
         return CNC_ERR_INVALID_VALUE;
     EncArgs a{inputs, embeddings, offsets, resolutions, grad_embeddings, grad, N, L, Rb,
-              binary_vxl, min_level_id, (hipStream_t)stream};
+              binary_vxl, min_level_id, (hipStream_t)stream, ste_clip_count};
     const int rc = dispatch_D<true>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
     return rc != CNC_OK ? rc : launch_status();
 }
@@ -641,6 +749,55 @@ extern "C" int cnc_cnt_np_embed_backward(const int16_t* inputs, const float* emb
     return launch_status();
 }
 
+
+extern "C" int cnc_pack_sign_bits(const float* embeddings, uint8_t* bits, uint64_t rows, uint32_t F,
+                                  uint32_t* clip_count, void* stream)
+{
+    if (clip_count && hipMemsetAsync(clip_count, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
+        return CNC_ERR_LAUNCH;
+    if (rows == 0) return CNC_OK;
+    if (!embeddings || !bits) return CNC_ERR_INVALID_VALUE;
+    if (!(F == 1 || F == 2 || F == 4 || F == 8 || F == 16 || F == 32)) return CNC_ERR_INVALID_VALUE;
+    const uint64_t n_vals = rows * F, n_bytes = (n_vals + 7) / 8;
+    const uint64_t want = (n_bytes + 255) / 256;
+    const uint32_t grid = (uint32_t)(want < 256ull * 32 ? want : 256ull * 32);
+    hipLaunchKernelGGL(k_pack_sign_bits, dim3(grid), dim3(256), 0, (hipStream_t)stream, embeddings,
+                       bits, n_bytes, n_vals, clip_count);
+    return launch_status();
+}
+
+template <uint32_t D, uint32_t F>
+static void launch_fwd_bits(const float* inputs, const uint8_t* bits, const int32_t* offsets,
+                            const int32_t* resolutions, float* outputs, uint32_t N, uint32_t L,
+                            uint32_t Rb, const uint8_t* vxl, const int32_t* mli, hipStream_t s)
+{
+    const dim3 grid(div_up(N, 256), L, 1);
+    if (vxl) hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, true>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, Rb, vxl, mli);
+    else hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, false>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, Rb, vxl, mli);
+}
+
+extern "C" int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* bits,
+                                            const int32_t* offsets, const int32_t* resolutions,
+                                            float* outputs, uint32_t N, uint32_t D, uint32_t F,
+                                            uint32_t L, uint32_t Rb, const uint8_t* binary_vxl,
+                                            const int32_t* min_level_id, void* stream)
+{
+    if (N == 0 || L == 0) return CNC_OK;
+    if (!inputs || !bits || !offsets || !resolutions || !outputs) return CNC_ERR_INVALID_VALUE;
+    hipStream_t s = (hipStream_t)stream;
+#define CNC_BITS_D(DD)                                                                              \
+    CNC_F_SWITCH(F, (launch_fwd_bits<DD, FF>(inputs, bits, offsets, resolutions, outputs, N, L, Rb, \
+                                             binary_vxl, min_level_id, s)))
+    switch (D) {
+    case 1: CNC_BITS_D(1); break;
+    case 2: CNC_BITS_D(2); break;
+    case 3: CNC_BITS_D(3); break;
+    default: return CNC_ERR_INVALID_VALUE;
+    }
+#undef CNC_BITS_D
+    return launch_status();
+}
+
 extern "C" const char* cnc_error_string(int code)
 {
     switch (code) {
@@ -654,4 +811,4 @@ extern "C" const char* cnc_error_string(int code)
     }
 }
 
-extern "C" int cnc_abi_version(void) { return 1; }
+extern "C" int cnc_abi_version(void) { return 3; }

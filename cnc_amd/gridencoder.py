@@ -62,7 +62,8 @@ class _grid_encode(Function):
 
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets_list, resolutions_list, calc_grad_inputs=False,
-                min_level_id=None, n_levels_calc=1, binary_vxl=None, PV=0, ste=False):
+                min_level_id=None, n_levels_calc=1, binary_vxl=None, PV=0, ste=False, bits=None,
+                clip_count=None):
         inputs = inputs.contiguous()
         if calc_grad_inputs:
             # dead in the reference too (ngp.py:58-60)
@@ -85,24 +86,30 @@ class _grid_encode(Function):
             mli = None
         else:
             offs, ress, mli = offsets_list, resolutions_list, min_level_id
-        _backend.grid_encode_forward(inputs, embeddings, offs, ress, outputs, N, num_dim, n_features,
-                                     n_levels_calc, 0, Rb, PV, None, binary_vxl, mli, ste_binary=ste)
+        if bits is not None and ste:
+            # binarised table gathered from its bit plane (same values, 32x less table traffic)
+            _backend.grid_encode_forward_bits(inputs, bits, offs, ress, outputs, N, num_dim,
+                                              n_features, n_levels_calc, Rb, binary_vxl, mli)
+        else:
+            _backend.grid_encode_forward(inputs, embeddings, offs, ress, outputs, N, num_dim,
+                                         n_features, n_levels_calc, 0, Rb, PV, None, binary_vxl, mli,
+                                         ste_binary=ste)
         # level-major [L, N, F] -> [N, L*F] (ngp.py:111)
         outputs = outputs.permute(1, 0, 2).reshape(N, n_levels_calc * n_features)
-        ctx.save_for_backward(inputs, embeddings, offs, ress, binary_vxl, mli)
+        ctx.save_for_backward(inputs, embeddings, offs, ress, binary_vxl, mli, clip_count)
         ctx.dims = (N, num_dim, n_features, n_levels_calc, Rb, ste)
         return outputs
 
     @staticmethod
     def backward(ctx, grad):
-        inputs, embeddings, offs, ress, binary_vxl, mli = ctx.saved_tensors
+        inputs, embeddings, offs, ress, binary_vxl, mli, clip_count = ctx.saved_tensors
         N, num_dim, n_features, n_levels_calc, Rb, ste = ctx.dims
         grad = grad.view(N, n_levels_calc, n_features).permute(1, 0, 2).contiguous()
         grad_embeddings = torch.zeros_like(embeddings)
         _backend.grid_encode_backward(grad, inputs, embeddings, offs, ress, grad_embeddings, N,
                                       num_dim, n_features, n_levels_calc, 0, Rb, None, None,
-                                      binary_vxl, mli, ste_binary=ste)
-        return None, grad_embeddings, None, None, None, None, None, None, None, None
+                                      binary_vxl, mli, ste_binary=ste, ste_clip_count=clip_count)
+        return None, grad_embeddings, None, None, None, None, None, None, None, None, None, None
 
 
 grid_encode = _grid_encode.apply
@@ -112,7 +119,7 @@ class GridEncoder(nn.Module):
     def __init__(self, num_dim=3, n_features=2,
                  resolutions_list=(16, 23, 32, 46, 64, 92, 128, 184, 256, 368, 512, 736),
                  log2_hashmap_size=19, ste_binary=False, ste_multistep=False, add_noise=False, Q=1,
-                 fused_ste=True):
+                 fused_ste=True, bitplane=True):
         super().__init__()
         resolutions_list = torch.as_tensor(np.asarray(resolutions_list)).to(torch.int)
         n_levels = resolutions_list.numel()
@@ -126,6 +133,12 @@ class GridEncoder(nn.Module):
         self.add_noise = add_noise
         self.Q = Q
         self.fused_ste = fused_ste
+        # bit-plane gather for binarised tables (needs the fused STE path); the packed plane is
+        # cached until the table is modified in place (optimizer step bumps Tensor._version)
+        self.bitplane = bitplane and fused_ste
+        self._bits = None
+        self._bits_key = None
+        self._clip_count = None
 
         # rows per level = min(2^log2T, R^D) rounded up to a multiple of 8 (ngp.py:197-210)
         self.max_params = 2 ** log2_hashmap_size
@@ -149,6 +162,18 @@ class GridEncoder(nn.Module):
                 f"log2_hashmap_size={self.log2_hashmap_size} params={tuple(self.params.shape)} "
                 f"ste_binary={self.ste_binary}")
 
+    def _bit_plane(self, params):
+        """(uint8 sign plane, clip counter) of `params`, repacked only when the tensor changed.
+        The counter (#entries with |p| > 1) lets backward skip the STE-mask gather when it is 0."""
+        key = (params.data_ptr(), params._version, tuple(params.shape))
+        if self._bits is None or self._bits_key != key:
+            with torch.no_grad():
+                cc = torch.empty(1, dtype=torch.int32, device=params.device)
+                self._bits = _backend.pack_sign_bits(params.detach().contiguous(), None, cc)
+                self._clip_count = cc
+            self._bits_key = key
+        return self._bits, self._clip_count
+
     # -- embeddings as the kernels should see them --------------------------------------------
     def _embeddings(self, params, test_phase):
         """Returns (table, ste_flag)."""
@@ -169,11 +194,12 @@ class GridEncoder(nn.Module):
         inputs = inputs.view(-1, self.num_dim)
         params = self.params if outspace_params is None else outspace_params
         embeddings, ste = self._embeddings(params, test_phase)
+        bits, clip = self._bit_plane(params) if (ste and self.bitplane) else (None, None)
         min_level_id = 0 if min_level_id is None else max(min_level_id, 0)
         max_level_id = self.n_levels if max_level_id is None else min(max_level_id, self.n_levels)
         n_levels_calc = max_level_id - min_level_id
         outputs = grid_encode(inputs, embeddings, self.offsets_list, self.resolutions_list, False,
-                              min_level_id, n_levels_calc, binary_vxl, PV, ste)
+                              min_level_id, n_levels_calc, binary_vxl, PV, ste, bits, clip)
         return outputs.view(prefix_shape + [n_levels_calc * self.n_features])
 
     def forward_diff_levels(self, inputs, min_level_id_list=None, n_levels_calc=1, test_phase=False,
@@ -183,8 +209,9 @@ class GridEncoder(nn.Module):
         inputs = inputs.view(-1, self.num_dim)
         params = self.params if outspace_params is None else outspace_params
         embeddings, ste = self._embeddings(params, test_phase)
+        bits, clip = self._bit_plane(params) if (ste and self.bitplane) else (None, None)
         outputs = grid_encode(inputs, embeddings, self.offsets_list, self.resolutions_list, False,
-                              min_level_id_list.contiguous(), n_levels_calc, binary_vxl, PV, ste)
+                              min_level_id_list.contiguous(), n_levels_calc, binary_vxl, PV, ste, bits, clip)
         return outputs.view(prefix_shape + [n_levels_calc * self.n_features])
 
     def forward_given_params(self, inputs, offsets_list, resolutions_list, outspace_params=None,

@@ -77,7 +77,27 @@ int cnc_grid_encode_backward(const float* grad, const float* inputs, const float
                              uint32_t N, uint32_t D, uint32_t F, uint32_t L, uint32_t Rb,
                              const float* dy_dx, float* grad_inputs,
                              const uint8_t* binary_vxl, const int32_t* min_level_id,
-                             uint32_t flags, void* stream);
+                             uint32_t flags, const uint32_t* ste_clip_count, void* stream);
+/*   ste_clip_count (device pointer, may be NULL): with CNC_FLAG_STE_BINARY, the number of table
+ *   entries with |v| > 1 as counted by cnc_pack_sign_bits.  When it reads 0 the STE mask is the
+ *   identity and the scatter skips the per-row parameter gather it otherwise needs.            */
+
+/* ---- MI355X-specific fast path for binarised tables (no counterpart in the reference) ----
+ * CNC always trains with ste_binary=True (train_CNC_nerf_synthetic.py:141): the encoder only ever
+ * sees sign(table).  cnc_pack_sign_bits writes that as a bit plane (bit = value >= 0; F bits per
+ * row, rows packed little-endian into bytes: 6.1 MB for the 16L x 2^19 x F8 table instead of 187 MiB)
+ * which stays resident in L2 / Infinity Cache; cnc_grid_encode_forward_bits gathers from it and
+ * returns exactly the bits cnc_grid_encode_forward(CNC_FLAG_STE_BINARY) returns.
+ *   bits: uint8 [ceil(rows * F / 8)], rows = offsets[last]; F in {1,2,4,8,16,32}.              */
+int cnc_pack_sign_bits(const float* embeddings, uint8_t* bits, uint64_t rows, uint32_t F,
+                       uint32_t* clip_count /* NULL or device u32: set to #entries with |v| > 1 */,
+                       void* stream);
+int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* bits,
+                                 const int32_t* offsets, const int32_t* resolutions,
+                                 float* outputs,
+                                 uint32_t N, uint32_t D, uint32_t F, uint32_t L, uint32_t Rb,
+                                 const uint8_t* binary_vxl, const int32_t* min_level_id,
+                                 void* stream);
 
 /* cnt_np_embed (gridencoder.h:39-44, gridencoder.cu:873-970): ±1 vote counts of the finest 3-D
  * level projected on a plane.  inputs i16 [N,3]; embeddings_clip [hashmap_size, F] f32;

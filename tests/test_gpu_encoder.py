@@ -235,3 +235,78 @@ def test_cnt_np_embed_forward_backward(cuda, oracle, axis, F):
     got_g = ge.cpu().numpy()
     bound = 64 * np.finfo(np.float32).eps * np.abs(absacc) + 1e-30
     assert np.all(np.abs(got_g.astype(np.float64) - acc) <= bound)
+
+
+@pytest.mark.parametrize("D", [2, 3])
+@pytest.mark.parametrize("F", [1, 2, 4, 8, 16, 32])
+def test_bit_plane_forward_equals_fp32_ste_forward(cuda, oracle, D, F):
+    """cnc_pack_sign_bits + cnc_grid_encode_forward_bits == fp32 gather with the STE flag == oracle."""
+    from cnc_amd.backends import gridencoder_backend as be
+    res = RES3 if D == 3 else RES2
+    offs, resl, emb = make_grid(res, 10, D, F, seed=40 + F)
+    emb[::5] = 0.0          # sign(0) = +1
+    emb[1::5] = -0.0
+    vxl = ball_occupancy(16 if D == 3 else 32, D)
+    x = _points(2111, D, seed=41)
+    rng = np.random.default_rng(42)
+    mli = rng.integers(0, len(res) - 2, size=x.shape[0]).astype(np.int32)
+    t = lambda a: None if a is None else torch.as_tensor(a, device=cuda)
+    bits = be.pack_sign_bits(t(emb))
+    want_bits = np.packbits((emb >= 0).reshape(-1), bitorder="little")
+    assert np.array_equal(bits.cpu().numpy(), want_bits)
+    for kw in (dict(), dict(vxl=vxl), dict(vxl=vxl, mli=mli, L=2)):
+        L = kw.get("L", len(res))
+        want = oracle.grid_encode_forward(x, emb, offs, resl, n_levels_calc=L, binary_vxl=kw.get("vxl"),
+                                          min_level_id=kw.get("mli"), ste_binary=True)
+        out = torch.empty((L, x.shape[0], F), device=cuda)
+        be.grid_encode_forward_bits(t(x), bits, t(offs), t(resl), out, x.shape[0], D, F, L,
+                                    128 if "vxl" not in kw else vxl.shape[-1], t(kw.get("vxl")), t(kw.get("mli")))
+        assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_gridencoder_bit_plane_cache_tracks_in_place_updates(cuda):
+    from cnc_amd.gridencoder import GridEncoder
+    a = GridEncoder(3, 8, RES3, 10, ste_binary=True, bitplane=True).to(cuda)
+    b = GridEncoder(3, 8, RES3, 10, ste_binary=True, bitplane=False).to(cuda)
+    with torch.no_grad():
+        a.params.uniform_(-1, 1)
+        b.params.copy_(a.params)
+    x = torch.rand(3000, 3, device=cuda)
+    assert torch.equal(a(x), b(x))
+    bits0 = a._bits
+    assert torch.equal(a(x), b(x)) and a._bits is bits0          # cached
+    with torch.no_grad():
+        a.params.mul_(-1.0)                                       # optimizer-style in-place update
+        b.params.mul_(-1.0)
+    assert torch.equal(a(x), b(x)) and a._bits is not bits0       # repacked
+    w = torch.randn(3000, 8 * len(RES3), device=cuda)
+    (a(x) * w).sum().backward()
+    (b(x) * w).sum().backward()
+    assert (a.params.grad - b.params.grad).abs().max() <= 1e-5 * b.params.grad.abs().max()
+
+
+@pytest.mark.parametrize("outliers", [False, True])
+def test_backward_ste_clip_count_hint(cuda, oracle, outliers):
+    """pack_sign_bits counts |v| > 1; backward skips the STE-mask gather iff the count is 0 and
+    gives the oracle's masked gradient either way."""
+    from cnc_amd.backends import gridencoder_backend as be
+    offs, resl, emb = make_grid(RES3, 10, 3, 8, seed=77)
+    emb = np.clip(emb, -1, 1)
+    if outliers:
+        emb[::11] *= 3.0
+    n_clip = int((np.abs(emb) > 1).sum())
+    assert (n_clip > 0) == outliers
+    x = _points(1500, 3, seed=78)
+    g = np.random.default_rng(79).normal(size=(len(RES3), x.shape[0], 8)).astype(np.float32)
+    t = lambda a: torch.as_tensor(a, device=cuda)
+    cc = torch.full((1,), 123, dtype=torch.int32, device=cuda)
+    be.pack_sign_bits(t(emb), None, cc)
+    assert int(cc.item()) == n_clip
+    ge = torch.zeros(emb.shape, device=cuda)
+    be.grid_encode_backward(t(g), t(x), t(emb), t(offs), t(resl), ge, x.shape[0], 3, 8, len(RES3), 0, 128,
+                            None, None, None, None, ste_binary=True, ste_clip_count=cc)
+    want32, acc64 = oracle.grid_encode_backward(g, x, emb, offs, resl, ste_binary=True, want_acc64=True)
+    _, abs64 = oracle.grid_encode_backward(np.abs(g), x, emb, offs, resl, ste_binary=True, want_acc64=True)
+    _check_bwd(ge.cpu().numpy(), want32, acc64, abs64, n_terms_max=x.shape[0] * 8)
+    if outliers:
+        assert np.all(ge.cpu().numpy()[np.abs(emb) > 1] == 0)

@@ -37,6 +37,22 @@ for name, N, gen in (("uniform 2^20", 1 << 20, None), ("uniform 2^22", 1 << 22, 
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
         print(f"fwd {name} ste={ste}: {ms:.3f} ms  {N/ms/1e6:.3f} Gsamples/s  alg {N*4620/ms/1e9:.2f} TB/s")
+    bits = be.pack_sign_bits(emb)
+    for _ in range(3):
+        be.grid_encode_forward_bits(x, bits, o_t, r_t, out, N, 3, F, L, 128)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        be.grid_encode_forward_bits(x, bits, o_t, r_t, out, N, 3, F, L, 128)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print(f"fwd-bits {name}: {ms:.3f} ms  {N/ms/1e6:.3f} Gsamples/s  out-write {N*512/ms/1e9:.2f} TB/s")
+    e0.record()
+    for _ in range(10):
+        be.pack_sign_bits(emb, bits)
+    e1.record(); torch.cuda.synchronize()
+    print(f"pack bits: {e0.elapsed_time(e1)/10:.3f} ms")
     for _ in range(2):
         be.grid_encode_backward(out, x, emb, o_t, r_t, ge, N, 3, F, L, 0, 128, None, None, None, None)
     torch.cuda.synchronize()
