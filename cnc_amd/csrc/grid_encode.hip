@@ -547,43 +547,66 @@ __device__ __forceinline__ bool cnt_loc(const int16_t* __restrict__ p, uint32_t 
     return inside;
 }
 
+// One request on the L2 atomic path is one (instruction, 64-byte segment) pair (see the backward
+// kernel).  A pixel's counters are F x {pos, neg} floats = 64 B at F=8, so a vertex is handled by
+// 2F adjacent lanes (one per counter) and costs ONE request instead of F; each lane group walks
+// KV consecutive vertices of the (sorted) list and keeps the running counters in registers while
+// the pixel does not change (vertices differing only along the projection axis are consecutive
+// for the xy plane), so a column of up to R-2 vertices collapses to R/KV requests.
 template <uint32_t F>
 __global__ __launch_bounds__(256) void k_cnt_np_embed(const int16_t* __restrict__ inputs,
                                                       const float* __restrict__ emb,
                                                       float* __restrict__ out, uint32_t N,
                                                       uint32_t R, uint32_t hs, uint32_t axis)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= N) return;
-    uint32_t q[3], loc;
-    if (!cnt_loc(inputs + (size_t)b * 3, R, F, axis, q, loc)) return;
-    const float* row = emb + (size_t)grid_row<3>(q, hs, R) * F;
-#pragma unroll
-    for (uint32_t ch = 0; ch < F; ch++) {
-        const bool pos = (double)row[ch] > 0.9;   // float vs double literal, gridencoder.cu:909
-        unsafeAtomicAdd(out + loc + ch * 2 + (pos ? 0 : 1), 1.0f);
+    constexpr uint32_t LPV = 2 * F;                  // lanes per vertex: (channel, pos|neg)
+    constexpr uint32_t KV = 8;                       // consecutive vertices per lane group
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t grp = t / LPV, sub = t % LPV;
+    const uint32_t ch = sub >> 1, neg = sub & 1u;
+    const uint32_t v0 = grp * KV;
+    if (v0 >= N) return;
+    uint32_t carry_loc = NONE;
+    float    carry = 0;
+    for (uint32_t i = 0; i < KV; i++) {
+        const uint32_t b = v0 + i;
+        if (b >= N) break;
+        uint32_t q[3], loc;
+        if (!cnt_loc(inputs + (size_t)b * 3, R, F, axis, q, loc)) continue;
+        const float e = emb[(size_t)grid_row<3>(q, hs, R) * F + ch];
+        const bool  pos = (double)e > 0.9;           // float vs double literal, gridencoder.cu:909
+        const float one = (pos != (neg != 0)) ? 1.0f : 0.0f;
+        if (loc == carry_loc) {
+            carry += one;
+        } else {
+            if (carry_loc != NONE) unsafeAtomicAdd(out + carry_loc + sub, carry);
+            carry_loc = loc;
+            carry = one;
+        }
     }
+    if (carry_loc != NONE) unsafeAtomicAdd(out + carry_loc + sub, carry);
 }
 
+// backward: one lane per (vertex, channel): the F lanes of a vertex update one 32-byte table row
+// with a single request (the reference: one thread per vertex, F separate atomics).
 template <uint32_t F>
 __global__ __launch_bounds__(256) void k_cnt_np_embed_bwd(
     const int16_t* __restrict__ inputs, const float* __restrict__ emb,
     const float* __restrict__ out_sum, const float* __restrict__ grad,
     float* __restrict__ grad_emb, uint32_t N, uint32_t R, uint32_t hs, uint32_t axis)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = t / F, ch = t % F;
     if (b >= N) return;
     uint32_t q[3], loc;
     if (!cnt_loc(inputs + (size_t)b * 3, R, F, axis, q, loc)) return;
     const size_t   at = (size_t)grid_row<3>(q, hs, R) * F;
     const uint32_t half = loc / 2;
-#pragma unroll
-    for (uint32_t ch = 0; ch < F; ch++) {
-        const float gv = 1 / out_sum[half + ch];
-        const bool  pos = (double)emb[at + ch] > 0.9;
-        const float contrib = pos ? gv * grad[loc + ch * 2 + 0] : -gv * grad[loc + ch * 2 + 1];
-        unsafeAtomicAdd(grad_emb + at + ch, contrib);
-    }
+    const float gv = 1 / out_sum[half + ch];
+    const bool  pos = (double)emb[at + ch] > 0.9;
+    const float contrib = pos ? gv * grad[loc + ch * 2 + 0] : -gv * grad[loc + ch * 2 + 1];
+    unsafeAtomicAdd(grad_emb + at + ch, contrib);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -728,9 +751,9 @@ extern "C" int cnc_cnt_np_embed(const int16_t* inputs, const float* embeddings_c
 {
     if (N == 0) return CNC_OK;
     if (!inputs || !embeddings_clip || !outputs || axis > 2) return CNC_ERR_INVALID_VALUE;
-    CNC_F_SWITCH(F, hipLaunchKernelGGL((k_cnt_np_embed<FF>), dim3(div_up(N, 256)), dim3(256), 0,
-                                       (hipStream_t)stream, inputs, embeddings_clip, outputs, N,
-                                       resolution, hashmap_size, axis));
+    CNC_F_SWITCH(F, hipLaunchKernelGGL((k_cnt_np_embed<FF>), dim3(div_up(div_up(N, 8) * 2 * FF, 256)),
+                                       dim3(256), 0, (hipStream_t)stream, inputs, embeddings_clip,
+                                       outputs, N, resolution, hashmap_size, axis));
     return launch_status();
 }
 
@@ -743,8 +766,8 @@ extern "C" int cnc_cnt_np_embed_backward(const int16_t* inputs, const float* emb
     if (N == 0) return CNC_OK;
     if (!inputs || !embeddings_clip || !outputs_sum || !grad || !grad_embeddings || axis > 2)
         return CNC_ERR_INVALID_VALUE;
-    CNC_F_SWITCH(F, hipLaunchKernelGGL((k_cnt_np_embed_bwd<FF>), dim3(div_up(N, 256)), dim3(256), 0,
-                                       (hipStream_t)stream, inputs, embeddings_clip, outputs_sum,
+    CNC_F_SWITCH(F, hipLaunchKernelGGL((k_cnt_np_embed_bwd<FF>), dim3(div_up(N * FF, 256)), dim3(256),
+                                       0, (hipStream_t)stream, inputs, embeddings_clip, outputs_sum,
                                        grad, grad_embeddings, N, resolution, hashmap_size, axis));
     return launch_status();
 }
