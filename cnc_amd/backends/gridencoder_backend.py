@@ -31,6 +31,28 @@ def _require_f32(t, name):
         raise RuntimeError(f"{name}: libcnc_hip builds the fp32 path only (got {t.dtype})")
 
 
+def occupancy_sat(binary_vxl):
+    """(extension) summed-volume table of a bool occupancy grid [Rb]^D -> int32 [(Rb+1)^D]:
+    sat[a,b,c] = number of set cells with indices < (a,b,c)."""
+    occ = binary_vxl.to(torch.int32)
+    D = occ.dim()
+    sat = torch.zeros([n + 1 for n in occ.shape], dtype=torch.int32, device=occ.device)
+    inner = occ
+    for d in range(D):
+        inner = torch.cumsum(inner, dim=d, dtype=torch.int32)
+    sat[tuple(slice(1, None) for _ in range(D))] = inner
+    return sat.contiguous()
+
+
+def _check_sat(occ_sat, binary_vxl):
+    if occ_sat is None or binary_vxl is None:
+        return None
+    if (occ_sat.dtype != torch.int32 or not occ_sat.is_cuda or not occ_sat.is_contiguous()
+            or tuple(occ_sat.shape) != tuple(n + 1 for n in binary_vxl.shape)):
+        raise RuntimeError("occ_sat must be a contiguous CUDA int32 tensor of shape (Rb+1)^D")
+    return occ_sat
+
+
 def _common_checks(named):
     for name, t in named:
         check_cuda(t, name)
@@ -40,7 +62,7 @@ def _common_checks(named):
 
 def grid_encode_forward(inputs, embeddings, offsets_list, resolutions_list, outputs, N, num_dim,
                         n_features, n_levels, max_level, Rb, PV, dy_dx=None, binary_vxl=None,
-                        min_level_id=None, *, ste_binary=False):
+                        min_level_id=None, *, ste_binary=False, occ_sat=None):
     _common_checks([("inputs", inputs), ("embeddings", embeddings), ("offsets_list", offsets_list),
                     ("resolutions_list", resolutions_list), ("outputs", outputs)])
     _check_floating(inputs, "inputs")
@@ -59,14 +81,15 @@ def grid_encode_forward(inputs, embeddings, offsets_list, resolutions_list, outp
     rc = _lib.lib().cnc_grid_encode_forward(
         ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list), ptr(outputs),
         int(N), int(num_dim), int(n_features), int(n_levels), int(Rb), float(PV), ptr(dy_dx),
-        ptr(binary_vxl), ptr(min_level_id), _lib.CNC_FLAG_STE_BINARY if ste_binary else 0, stream())
+        ptr(binary_vxl), ptr(min_level_id), _lib.CNC_FLAG_STE_BINARY if ste_binary else 0,
+        ptr(_check_sat(occ_sat, binary_vxl)), stream())
     check(rc, "grid_encode_forward")
 
 
 def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_list, grad_embeddings,
                          N, num_dim, n_features, n_levels, max_level, Rb, dy_dx=None,
                          grad_inputs=None, binary_vxl=None, min_level_id=None, *, ste_binary=False,
-                         ste_clip_count=None):
+                         ste_clip_count=None, occ_sat=None):
     _common_checks([("grad", grad), ("inputs", inputs), ("embeddings", embeddings),
                     ("offsets_list", offsets_list), ("resolutions_list", resolutions_list),
                     ("grad_embeddings", grad_embeddings)])
@@ -89,7 +112,8 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
         ptr(grad_embeddings), int(N), int(num_dim), int(n_features), int(n_levels), int(Rb),
         ptr(dy_dx), ptr(grad_inputs), ptr(binary_vxl), ptr(min_level_id),
-        _lib.CNC_FLAG_STE_BINARY if ste_binary else 0, ptr(ste_clip_count), stream())
+        _lib.CNC_FLAG_STE_BINARY if ste_binary else 0, ptr(ste_clip_count),
+        ptr(_check_sat(occ_sat, binary_vxl)), stream())
     check(rc, "grid_encode_backward")
 
 
@@ -111,7 +135,7 @@ def pack_sign_bits(embeddings, bits=None, clip_count=None):
 
 
 def grid_encode_forward_bits(inputs, bits, offsets_list, resolutions_list, outputs, N, num_dim,
-                             n_features, n_levels, Rb, binary_vxl=None, min_level_id=None):
+                             n_features, n_levels, Rb, binary_vxl=None, min_level_id=None, occ_sat=None):
     """(extension) grid_encode_forward on the bit plane of a binarised table; same outputs as
     grid_encode_forward(..., ste_binary=True) on the fp32 table."""
     _common_checks([("inputs", inputs), ("bits", bits), ("offsets_list", offsets_list),
@@ -131,7 +155,7 @@ def grid_encode_forward_bits(inputs, bits, offsets_list, resolutions_list, outpu
     rc = _lib.lib().cnc_grid_encode_forward_bits(
         ptr(inputs), ptr(bits), ptr(offsets_list), ptr(resolutions_list), ptr(outputs), int(N),
         int(num_dim), int(n_features), int(n_levels), int(Rb), ptr(binary_vxl), ptr(min_level_id),
-        stream())
+        ptr(_check_sat(occ_sat, binary_vxl)), stream())
     check(rc, "grid_encode_forward_bits")
 
 

@@ -95,4 +95,40 @@ __device__ __forceinline__ bool box_any(const uint32_t (&q)[D], uint32_t R, uint
     return false;
 }
 
+// Same predicate from a summed-volume table of the occupancy grid: sat[(a*P + b)*P + c], P = Rb+1,
+// = number of set cells with index < (a, b, c) per axis.  The box count is an integer
+// inclusion-exclusion of 2^D entries, so the result equals the scan's, at 2^D loads instead of up
+// to (2*Rb/(R-2)+1)^D byte reads (343 for a coarse context level against a 128^3 grid).
+template <uint32_t D>
+__device__ __forceinline__ bool box_any_sat(const uint32_t (&q)[D], uint32_t R, uint32_t Rb,
+                                            const int32_t* __restrict__ sat)
+{
+    const float scale_re = 1.0f / ((float)R - 2.0f);
+    uint32_t lo[D], hi[D];
+    bool     empty = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        float pn;
+        box_range((float)q[d], scale_re, Rb, lo[d], hi[d], pn);
+        hi[d] += 1;   // exclusive
+        empty |= hi[d] <= lo[d];
+    }
+    if (empty) return false;
+    const uint32_t P = Rb + 1;
+    int32_t cnt = 0;
+#pragma unroll
+    for (uint32_t m = 0; m < (1u << D); m++) {
+        uint32_t idx = 0;
+        int      sign = 1;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            const bool low = (m >> d) & 1u;
+            idx = idx * P + (low ? lo[d] : hi[d]);
+            if (low) sign = -sign;
+        }
+        cnt += sign * sat[idx];
+    }
+    return cnt > 0;
+}
+
 }  // namespace cnc

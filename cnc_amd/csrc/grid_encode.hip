@@ -57,7 +57,8 @@ struct Corners {
     float    wn_re;
 
     __device__ __forceinline__ void setup(const float (&x)[D], uint32_t R, uint32_t hs,
-                                          uint32_t Rb, const uint8_t* __restrict__ vxl)
+                                          uint32_t Rb, const uint8_t* __restrict__ vxl,
+                                          const int32_t* __restrict__ sat = nullptr)
     {
         float    pos[D];
         uint32_t g[D];
@@ -90,7 +91,7 @@ struct Corners {
             if constexpr (VXL) {
                 // the reference evaluates the box for every corner; its result only matters
                 // for non-border ones, so skip the (expensive) scan otherwise
-                if (ok) ok = box_any<D>(q, R, Rb, vxl);
+                if (ok) ok = sat ? box_any_sat<D>(q, R, Rb, sat) : box_any<D>(q, R, Rb, vxl);
             }
             w[i] = wi;
             valid[i] = ok;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd(
     const float* __restrict__ inputs, const float* __restrict__ emb,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
     float* __restrict__ out, uint32_t N, uint32_t Rb, const uint8_t* __restrict__ vxl,
-    const int32_t* __restrict__ min_level_id)
+    const int32_t* __restrict__ min_level_id, const int32_t* __restrict__ sat)
 {
     constexpr uint32_t V = F < 4 ? F : 4;
     constexpr uint32_t G = F / V;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd(
     const float* table = emb + (size_t)off * F + h * V;
 
     Corners<D, VXL> c;
-    c.setup(x, R, hs, Rb, vxl);
+    c.setup(x, R, hs, Rb, vxl, sat);
 
     float v[C][V];
 #pragma unroll
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd_bits(
     const float* __restrict__ inputs, const uint8_t* __restrict__ bits,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
     float* __restrict__ out, uint32_t N, uint32_t Rb, const uint8_t* __restrict__ vxl,
-    const int32_t* __restrict__ min_level_id)
+    const int32_t* __restrict__ min_level_id, const int32_t* __restrict__ sat)
 {
     constexpr uint32_t C = 1u << D;
     constexpr uint32_t V = F < 4 ? F : 4;
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd_bits(
         const uint32_t hs = (uint32_t)offsets[level + 1] - off;
         const uint32_t R = (uint32_t)resolutions[level];
         Corners<D, VXL> c;
-        c.setup(x, R, hs, Rb, vxl);
+        c.setup(x, R, hs, Rb, vxl, sat);
         uint32_t rb[C];
 #pragma unroll
         for (uint32_t i = 0; i < C; i++)
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd_simple(
     const float* __restrict__ emb, const int32_t* __restrict__ offsets,
     const int32_t* __restrict__ resolutions, float* __restrict__ grad_emb, uint32_t N,
     uint32_t Rb, const uint8_t* __restrict__ vxl, const int32_t* __restrict__ min_level_id,
-    const uint32_t* __restrict__ clip_count)
+    const uint32_t* __restrict__ clip_count, const int32_t* __restrict__ sat)
 {
     constexpr uint32_t V = F < 4 ? F : 4;
     constexpr uint32_t G = F / V;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd_simple(
     const size_t base = (size_t)off * F + h * V;
 
     Corners<D, VXL> c;
-    c.setup(x, R, hs, Rb, vxl);
+    c.setup(x, R, hs, Rb, vxl, sat);
 
 #pragma unroll
     for (uint32_t i = 0; i < C; i++) {
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
     const float* __restrict__ emb, const int32_t* __restrict__ offsets,
     const int32_t* __restrict__ resolutions, float* __restrict__ grad_emb, uint32_t N,
     uint32_t Rb, const uint8_t* __restrict__ vxl, const int32_t* __restrict__ min_level_id,
-    const uint32_t* __restrict__ clip_count)
+    const uint32_t* __restrict__ clip_count, const int32_t* __restrict__ sat)
 {
     constexpr uint32_t C = 1u << D;
     constexpr uint32_t SLOTS = C * F;           // lanes per run in phase B (<= 64)
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
             const uint32_t hs = (uint32_t)offsets[level + 1] - off;
             const uint32_t R = (uint32_t)resolutions[level];
             Corners<D, VXL> c;
-            c.setup(x, R, hs, Rb, vxl);
+            c.setup(x, R, hs, Rb, vxl, sat);
             uint64_t cell = 0;   // integer cell coordinates, 16 bits per axis (R <= 65535)
 #pragma unroll
             for (uint32_t d = D; d-- > 0;) {
@@ -624,6 +625,7 @@ struct EncArgs {
     const int32_t* mli;
     hipStream_t    stream;
     const uint32_t* clip_count = nullptr;   // backward + STE only
+    const int32_t*  sat = nullptr;          // optional summed-volume table of the occupancy grid
 };
 
 template <uint32_t D, uint32_t F, bool VXL, bool STE>
@@ -632,7 +634,7 @@ static void launch_fwd(const EncArgs& a)
     constexpr uint32_t V = F < 4 ? F : 4, G = F / V;
     const dim3 grid(div_up(a.N * G, 256), a.L, 1);
     hipLaunchKernelGGL((k_grid_encode_fwd<D, F, VXL, STE>), grid, dim3(256), 0, a.stream,
-                       a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N, a.Rb, a.vxl, a.mli);
+                       a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N, a.Rb, a.vxl, a.mli, a.sat);
 }
 
 template <uint32_t D, uint32_t F, bool VXL, bool STE>
@@ -642,13 +644,13 @@ static void launch_bwd(const EncArgs& a)
         const dim3 grid(div_up(a.N, 256), a.L, 1);
         hipLaunchKernelGGL((k_grid_encode_bwd<D, F, VXL, STE>), grid, dim3(256), 0, a.stream,
                            a.grad, a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N, a.Rb,
-                           a.vxl, a.mli, a.clip_count);
+                           a.vxl, a.mli, a.clip_count, a.sat);
     } else {
         constexpr uint32_t V = F < 4 ? F : 4, G = F / V;
         const dim3 grid(div_up(a.N * G, 256), a.L, 1);
         hipLaunchKernelGGL((k_grid_encode_bwd_simple<D, F, VXL, STE>), grid, dim3(256), 0,
                            a.stream, a.grad, a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N,
-                           a.Rb, a.vxl, a.mli, a.clip_count);
+                           a.Rb, a.vxl, a.mli, a.clip_count, a.sat);
     }
 }
 
@@ -703,14 +705,14 @@ extern "C" int cnc_grid_encode_forward(const float* inputs, const float* embeddi
                                        float* outputs, uint32_t N, uint32_t D, uint32_t F,
                                        uint32_t L, uint32_t Rb, float PV, float* dy_dx,
                                        const uint8_t* binary_vxl, const int32_t* min_level_id,
-                                       uint32_t flags, void* stream)
+                                       uint32_t flags, const int32_t* occ_sat, void* stream)
 {
     (void)PV;
     if (dy_dx) return CNC_ERR_UNSUPPORTED;
     if (N == 0 || L == 0) return CNC_OK;
     if (!inputs || !embeddings || !offsets || !resolutions || !outputs) return CNC_ERR_INVALID_VALUE;
     EncArgs a{inputs, embeddings, offsets, resolutions, outputs, nullptr, N, L, Rb,
-              binary_vxl, min_level_id, (hipStream_t)stream};
+              binary_vxl, min_level_id, (hipStream_t)stream, nullptr, binary_vxl ? occ_sat : nullptr};
     const int rc = dispatch_D<false>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
     return rc != CNC_OK ? rc : launch_status();
 }
@@ -722,14 +724,15 @@ extern "C" int cnc_grid_encode_backward(const float* grad, const float* inputs,
                                         uint32_t Rb, const float* dy_dx, float* grad_inputs,
                                         const uint8_t* binary_vxl, const int32_t* min_level_id,
                                         uint32_t flags, const uint32_t* ste_clip_count,
-                                        void* stream)
+                                        const int32_t* occ_sat, void* stream)
 {
     if (dy_dx || grad_inputs) return CNC_ERR_UNSUPPORTED;
     if (N == 0 || L == 0) return CNC_OK;
     if (!grad || !inputs || !embeddings || !offsets || !resolutions || !grad_embeddings)
         return CNC_ERR_INVALID_VALUE;
     EncArgs a{inputs, embeddings, offsets, resolutions, grad_embeddings, grad, N, L, Rb,
-              binary_vxl, min_level_id, (hipStream_t)stream, ste_clip_count};
+              binary_vxl, min_level_id, (hipStream_t)stream, ste_clip_count,
+              binary_vxl ? occ_sat : nullptr};
     const int rc = dispatch_D<true>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
     return rc != CNC_OK ? rc : launch_status();
 }
@@ -792,25 +795,27 @@ extern "C" int cnc_pack_sign_bits(const float* embeddings, uint8_t* bits, uint64
 template <uint32_t D, uint32_t F>
 static void launch_fwd_bits(const float* inputs, const uint8_t* bits, const int32_t* offsets,
                             const int32_t* resolutions, float* outputs, uint32_t N, uint32_t L,
-                            uint32_t Rb, const uint8_t* vxl, const int32_t* mli, hipStream_t s)
+                            uint32_t Rb, const uint8_t* vxl, const int32_t* mli, const int32_t* sat,
+                            hipStream_t s)
 {
     const dim3 grid(div_up(N, 256), L, 1);
-    if (vxl) hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, true>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, Rb, vxl, mli);
-    else hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, false>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, Rb, vxl, mli);
+    if (vxl) hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, true>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, Rb, vxl, mli, sat);
+    else hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, false>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, Rb, vxl, mli, nullptr);
 }
 
 extern "C" int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* bits,
                                             const int32_t* offsets, const int32_t* resolutions,
                                             float* outputs, uint32_t N, uint32_t D, uint32_t F,
                                             uint32_t L, uint32_t Rb, const uint8_t* binary_vxl,
-                                            const int32_t* min_level_id, void* stream)
+                                            const int32_t* min_level_id, const int32_t* occ_sat,
+                                            void* stream)
 {
     if (N == 0 || L == 0) return CNC_OK;
     if (!inputs || !bits || !offsets || !resolutions || !outputs) return CNC_ERR_INVALID_VALUE;
     hipStream_t s = (hipStream_t)stream;
 #define CNC_BITS_D(DD)                                                                              \
     CNC_F_SWITCH(F, (launch_fwd_bits<DD, FF>(inputs, bits, offsets, resolutions, outputs, N, L, Rb, \
-                                             binary_vxl, min_level_id, s)))
+                                             binary_vxl, min_level_id, occ_sat, s)))
     switch (D) {
     case 1: CNC_BITS_D(1); break;
     case 2: CNC_BITS_D(2); break;
@@ -834,4 +839,4 @@ extern "C" const char* cnc_error_string(int code)
     }
 }
 
-extern "C" int cnc_abi_version(void) { return 3; }
+extern "C" int cnc_abi_version(void) { return 4; }

@@ -63,7 +63,7 @@ class _grid_encode(Function):
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets_list, resolutions_list, calc_grad_inputs=False,
                 min_level_id=None, n_levels_calc=1, binary_vxl=None, PV=0, ste=False, bits=None,
-                clip_count=None):
+                clip_count=None, occ_sat=None):
         inputs = inputs.contiguous()
         if calc_grad_inputs:
             # dead in the reference too (ngp.py:58-60)
@@ -89,27 +89,28 @@ class _grid_encode(Function):
         if bits is not None and ste:
             # binarised table gathered from its bit plane (same values, 32x less table traffic)
             _backend.grid_encode_forward_bits(inputs, bits, offs, ress, outputs, N, num_dim,
-                                              n_features, n_levels_calc, Rb, binary_vxl, mli)
+                                              n_features, n_levels_calc, Rb, binary_vxl, mli, occ_sat)
         else:
             _backend.grid_encode_forward(inputs, embeddings, offs, ress, outputs, N, num_dim,
                                          n_features, n_levels_calc, 0, Rb, PV, None, binary_vxl, mli,
-                                         ste_binary=ste)
+                                         ste_binary=ste, occ_sat=occ_sat)
         # level-major [L, N, F] -> [N, L*F] (ngp.py:111)
         outputs = outputs.permute(1, 0, 2).reshape(N, n_levels_calc * n_features)
-        ctx.save_for_backward(inputs, embeddings, offs, ress, binary_vxl, mli, clip_count)
+        ctx.save_for_backward(inputs, embeddings, offs, ress, binary_vxl, mli, clip_count, occ_sat)
         ctx.dims = (N, num_dim, n_features, n_levels_calc, Rb, ste)
         return outputs
 
     @staticmethod
     def backward(ctx, grad):
-        inputs, embeddings, offs, ress, binary_vxl, mli, clip_count = ctx.saved_tensors
+        inputs, embeddings, offs, ress, binary_vxl, mli, clip_count, occ_sat = ctx.saved_tensors
         N, num_dim, n_features, n_levels_calc, Rb, ste = ctx.dims
         grad = grad.view(N, n_levels_calc, n_features).permute(1, 0, 2).contiguous()
         grad_embeddings = torch.zeros_like(embeddings)
         _backend.grid_encode_backward(grad, inputs, embeddings, offs, ress, grad_embeddings, N,
                                       num_dim, n_features, n_levels_calc, 0, Rb, None, None,
-                                      binary_vxl, mli, ste_binary=ste, ste_clip_count=clip_count)
-        return None, grad_embeddings, None, None, None, None, None, None, None, None, None, None
+                                      binary_vxl, mli, ste_binary=ste, ste_clip_count=clip_count,
+                                      occ_sat=occ_sat)
+        return None, grad_embeddings, None, None, None, None, None, None, None, None, None, None, None
 
 
 grid_encode = _grid_encode.apply
@@ -139,6 +140,8 @@ class GridEncoder(nn.Module):
         self._bits = None
         self._bits_key = None
         self._clip_count = None
+        self._sat = None
+        self._sat_key = None
 
         # rows per level = min(2^log2T, R^D) rounded up to a multiple of 8 (ngp.py:197-210)
         self.max_params = 2 ** log2_hashmap_size
@@ -174,6 +177,19 @@ class GridEncoder(nn.Module):
             self._bits_key = key
         return self._bits, self._clip_count
 
+    def _occ_sat(self, binary_vxl):
+        """Summed-volume table of the occupancy grid handed to a masked call, rebuilt only when the
+        grid tensor changes (the estimator replaces it every `step_update` steps)."""
+        if binary_vxl is None:
+            return None
+        key = (binary_vxl.data_ptr(), binary_vxl._version, tuple(binary_vxl.shape))
+        if self._sat is None or self._sat_key != key:
+            with torch.no_grad():
+                self._sat = _backend.occupancy_sat(binary_vxl)
+            self._sat_key = key
+            self._sat_src = binary_vxl      # keep the storage alive so data_ptr stays unique
+        return self._sat
+
     # -- embeddings as the kernels should see them --------------------------------------------
     def _embeddings(self, params, test_phase):
         """Returns (table, ste_flag)."""
@@ -199,7 +215,8 @@ class GridEncoder(nn.Module):
         max_level_id = self.n_levels if max_level_id is None else min(max_level_id, self.n_levels)
         n_levels_calc = max_level_id - min_level_id
         outputs = grid_encode(inputs, embeddings, self.offsets_list, self.resolutions_list, False,
-                              min_level_id, n_levels_calc, binary_vxl, PV, ste, bits, clip)
+                              min_level_id, n_levels_calc, binary_vxl, PV, ste, bits, clip,
+                              self._occ_sat(binary_vxl))
         return outputs.view(prefix_shape + [n_levels_calc * self.n_features])
 
     def forward_diff_levels(self, inputs, min_level_id_list=None, n_levels_calc=1, test_phase=False,
@@ -211,7 +228,8 @@ class GridEncoder(nn.Module):
         embeddings, ste = self._embeddings(params, test_phase)
         bits, clip = self._bit_plane(params) if (ste and self.bitplane) else (None, None)
         outputs = grid_encode(inputs, embeddings, self.offsets_list, self.resolutions_list, False,
-                              min_level_id_list.contiguous(), n_levels_calc, binary_vxl, PV, ste, bits, clip)
+                              min_level_id_list.contiguous(), n_levels_calc, binary_vxl, PV, ste, bits, clip,
+                              self._occ_sat(binary_vxl))
         return outputs.view(prefix_shape + [n_levels_calc * self.n_features])
 
     def forward_given_params(self, inputs, offsets_list, resolutions_list, outspace_params=None,
@@ -221,5 +239,5 @@ class GridEncoder(nn.Module):
         prefix_shape = list(inputs.shape[:-1])
         inputs = inputs.view(-1, 2)
         outputs = grid_encode(inputs, outspace_params, offsets_list, resolutions_list, False, 0, 1,
-                              binary_vxl, PV, False)
+                              binary_vxl, PV, False, None, None, self._occ_sat(binary_vxl))
         return outputs.view(prefix_shape + [self.n_features])

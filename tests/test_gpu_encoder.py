@@ -310,3 +310,37 @@ def test_backward_ste_clip_count_hint(cuda, oracle, outliers):
     _check_bwd(ge.cpu().numpy(), want32, acc64, abs64, n_terms_max=x.shape[0] * 8)
     if outliers:
         assert np.all(ge.cpu().numpy()[np.abs(emb) > 1] == 0)
+
+
+@pytest.mark.parametrize("D,Rb", [(3, 16), (3, 128), (2, 32), (2, 128)])
+def test_occupancy_sat_gives_the_scans_answer(cuda, oracle, D, Rb):
+    """Masked encode with the summed-volume table == masked encode with the box scan == oracle
+    (forward bit-exact for fp32 / STE / bit-plane kernels; backward within the bound)."""
+    from cnc_amd.backends import gridencoder_backend as be
+    res = RES3 if D == 3 else RES2
+    offs, resl, emb = make_grid(res, 10, D, 8, seed=90)
+    vxl = ball_occupancy(Rb, D, radius=0.3, seed=Rb)
+    x = _points(3000, D, seed=91)
+    t = lambda a: None if a is None else torch.as_tensor(a, device=cuda)
+    sat = be.occupancy_sat(t(vxl))
+    ref = np.zeros([n + 1 for n in vxl.shape], np.int64)
+    c = vxl.astype(np.int64)
+    for d in range(D):
+        c = np.cumsum(c, axis=d)
+    ref[tuple(slice(1, None) for _ in range(D))] = c
+    assert np.array_equal(sat.cpu().numpy(), ref)
+    L = len(res)
+    want = oracle.grid_encode_forward(x, emb, offs, resl, binary_vxl=vxl)
+    out = torch.empty((L, x.shape[0], 8), device=cuda)
+    be.grid_encode_forward(t(x), t(emb), t(offs), t(resl), out, x.shape[0], D, 8, L, 0, Rb, 0.0, None, t(vxl), None, occ_sat=sat)
+    assert np.array_equal(out.cpu().numpy(), want)
+    want_s = oracle.grid_encode_forward(x, emb, offs, resl, binary_vxl=vxl, ste_binary=True)
+    bits = be.pack_sign_bits(t(emb))
+    be.grid_encode_forward_bits(t(x), bits, t(offs), t(resl), out, x.shape[0], D, 8, L, Rb, t(vxl), None, sat)
+    assert np.array_equal(out.cpu().numpy(), want_s)
+    g = np.random.default_rng(92).normal(size=(L, x.shape[0], 8)).astype(np.float32)
+    want32, acc64 = oracle.grid_encode_backward(g, x, emb, offs, resl, binary_vxl=vxl, want_acc64=True)
+    _, abs64 = oracle.grid_encode_backward(np.abs(g), x, emb, offs, resl, binary_vxl=vxl, want_acc64=True)
+    ge = torch.zeros(emb.shape, device=cuda)
+    be.grid_encode_backward(t(g), t(x), t(emb), t(offs), t(resl), ge, x.shape[0], D, 8, L, 0, Rb, None, None, t(vxl), None, occ_sat=sat)
+    _check_bwd(ge.cpu().numpy(), want32, acc64, abs64, n_terms_max=x.shape[0] * 8)
