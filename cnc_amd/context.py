@@ -32,6 +32,7 @@ from torch.autograd import Function
 from .backends import gridencoder_backend as _backend
 from .backends import pack_and_align
 from .gridencoder import STE_binary, STE_multistep
+from .mlp import Linear
 
 _codec = None
 
@@ -295,15 +296,15 @@ class CNC_context_models(nn.Module):
         self.binary_vxl_2D_idx = torch.stack(torch.meshgrid(ar, ar, indexing="ij"), dim=-1)
 
         self.context_model_3D = nn.Sequential(
-            nn.Linear(n_features * max_context_layer_num + 1, 32), nn.LeakyReLU(),
-            nn.Linear(32, 32), nn.LeakyReLU(),
-            nn.Linear(32, n_features),
+            Linear(n_features * max_context_layer_num + 1, 32), nn.LeakyReLU(),
+            Linear(32, 32), nn.LeakyReLU(),
+            Linear(32, n_features),
         ).to(dev)
         heads = []
         for n in range(1, self.Pg_level_2D):
             ctx_layers = min(n, max_context_layer_num)
             heads.append(nn.Sequential(
-                nn.Linear(n_features * (ctx_layers + int(use_dimension_wise)) + 1, n_features)))
+                Linear(n_features * (ctx_layers + int(use_dimension_wise)) + 1, n_features)))
         self.context_model_2D = nn.Sequential(*heads).to(dev)
         self.entropy_model = Bernoulli_entropy()
 

@@ -21,6 +21,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from .gridencoder import GridEncoder
+from .mlp import Linear
 
 
 class _TruncExp(Function):
@@ -184,14 +185,14 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         embed_fn, input_ch = get_embedder(10, 0)
         in_chs = (encoding_xyz.n_output_dims + encoding_xy.n_output_dims + encoding_xz.n_output_dims
                   + encoding_yz.n_output_dims + input_ch)
-        network = nn.Sequential(nn.Linear(in_chs, n_neurons), nn.ReLU(inplace=True),
-                                nn.Linear(n_neurons, 1 + self.geo_feat_dim))
+        network = nn.Sequential(Linear(in_chs, n_neurons), nn.ReLU(inplace=True),
+                                Linear(n_neurons, 1 + self.geo_feat_dim))
         self.mlp_base = compose_3D_2D_embed(encoding_xyz, encoding_xy, encoding_xz, encoding_yz, embed_fn, network)
         if self.geo_feat_dim > 0:
             head_in = (self.direction_encoding.n_output_dims if self.use_viewdirs else 0) + self.geo_feat_dim
-            self.mlp_head = nn.Sequential(nn.Linear(head_in, n_neurons), nn.ReLU(inplace=True),
-                                          nn.Linear(n_neurons, n_neurons), nn.ReLU(inplace=True),
-                                          nn.Linear(n_neurons, 3))
+            self.mlp_head = nn.Sequential(Linear(head_in, n_neurons), nn.ReLU(inplace=True),
+                                          Linear(n_neurons, n_neurons), nn.ReLU(inplace=True),
+                                          Linear(n_neurons, 3))
 
     def update_embedding_params(self, params_q_xyz_rec, params_q_xy_rec, params_q_xz_rec, params_q_yz_rec):
         self.mlp_base.encoding_xyz.params = nn.Parameter(params_q_xyz_rec)

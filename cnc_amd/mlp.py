@@ -1,0 +1,67 @@
+"""Dense layers of the radiance field / context models.
+
+The layers are ordinary `nn.Linear` modules (same parameters, same state-dict keys as the
+reference's `nn.Sequential(nn.Linear, ...)`, ngp.py:475-504, utils_bpp_acc.py:378-393) whose GEMMs run
+on hipBLASLt's fp32 MFMA kernels.  One thing is done differently: the weight gradient.
+
+For these shapes — a reduction over N = 10^5..10^6 samples into a tiny [out, in] matrix — hipBLASLt's
+default kernel selection on MI355X runs at 0.4–39 TFLOP/s (tools/gemm_probe.py: 0.45 ms for a 160x3
+layer at N=2^18), while forward / input-gradient GEMMs of the same layers reach 60–100 TFLOP/s.
+`dW = dY^T X` is therefore computed as a batched GEMM over S row-slabs followed by a sum over slabs
+(split-K by hand): 4–17x faster on the same library, fp32 throughout.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _split(n_rows: int) -> int:
+    """Number of row slabs: ~1024+ rows per slab, power of two, at most 256."""
+    s = 1
+    while s < 256 and n_rows // (s * 2) >= 1024:
+        s *= 2
+    return s
+
+
+class _LinearSplitK(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        g = grad_out.reshape(-1, grad_out.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        grad_x = grad_w = grad_b = None
+        if ctx.needs_input_grad[0]:
+            grad_x = (g @ weight).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            n = x2.shape[0]
+            s = _split(n)
+            if s == 1:
+                grad_w = g.t() @ x2
+            else:
+                m = n // s
+                head = m * s
+                gs = g[:head].view(s, m, -1)
+                xs = x2[:head].view(s, m, -1)
+                grad_w = torch.bmm(gs.transpose(1, 2), xs).sum(0)
+                if head < n:
+                    grad_w = grad_w + g[head:].t() @ x2[head:]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_b = g.sum(0)
+        return grad_x, grad_w, grad_b
+
+
+class Linear(nn.Linear):
+    """nn.Linear with the split-K weight gradient (CUDA tensors only; CPU uses the stock path)."""
+
+    def forward(self, input):
+        if input.is_cuda and torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
+            return _LinearSplitK.apply(input, self.weight, self.bias)
+        return F.linear(input, self.weight, self.bias)
