@@ -65,3 +65,62 @@ class Linear(nn.Linear):
         if input.is_cuda and torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad):
             return _LinearSplitK.apply(input, self.weight, self.bias)
         return F.linear(input, self.weight, self.bias)
+
+
+def _round16(n: int) -> int:
+    return (n + 15) // 16 * 16
+
+
+class FusedMLPForward:
+    """Gradient-free forward of `nn.Sequential(Linear, ReLU, Linear[, ReLU, Linear])` through the
+    fused MFMA kernel (cnc_amd/csrc/mlp.hip).  Keeps zero-padded copies of the weights, refreshed
+    when a parameter is modified in place (optimizer step) or replaced."""
+
+    def __init__(self, seq: nn.Sequential):
+        self.linears = [m for m in seq if isinstance(m, nn.Linear)]
+        acts = [m for m in seq if not isinstance(m, nn.Linear)]
+        if len(self.linears) not in (2, 3) or len(acts) != len(self.linears) - 1 \
+                or not all(isinstance(a, nn.ReLU) for a in acts):
+            raise ValueError("FusedMLPForward supports Linear-ReLU-Linear[-ReLU-Linear]")
+        if any(l.out_features > 160 for l in self.linears) or any(l.bias is None for l in self.linears):
+            raise ValueError("FusedMLPForward: widths <= 160 and biases required")
+        self._key = None
+        self._packed = None
+
+    def _pack(self):
+        key = tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version)
+                    for l in self.linears)
+        if key != self._key:
+            packed = []
+            kp = _round16(self.linears[0].in_features)
+            for l in self.linears:
+                hp = _round16(l.out_features)
+                w = torch.zeros((hp, kp), dtype=torch.float32, device=l.weight.device)
+                w[: l.out_features, : l.in_features] = l.weight.detach()
+                b = torch.zeros(hp, dtype=torch.float32, device=l.weight.device)
+                b[: l.out_features] = l.bias.detach()
+                packed.append((w, b, hp))
+                kp = hp
+            self._packed, self._key = packed, key
+        return self._packed
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        from . import _lib
+        if not x.is_cuda:
+            raise RuntimeError("x must be a CUDA tensor")
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1]).to(torch.float32)
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        n, k0 = x2.shape
+        packed = self._pack()
+        n_out = self.linears[-1].out_features
+        y = torch.empty((n, n_out), dtype=torch.float32, device=x.device)
+        (w1, b1, h1), (w2, b2, h2) = packed[0], packed[1]
+        w3, b3, h3 = packed[2] if len(packed) == 3 else (None, None, 0)
+        rc = _lib.lib().cnc_mlp_forward(x2.data_ptr(), n, x2.stride(0), k0, w1.data_ptr(), b1.data_ptr(), h1,
+                                        w2.data_ptr(), b2.data_ptr(), h2, _lib.ptr(w3), _lib.ptr(b3), h3,
+                                        y.data_ptr(), n_out, n_out, _lib.stream())
+        _lib.check(rc, "mlp_forward")
+        return y.reshape(*lead, n_out)

@@ -120,6 +120,21 @@ int cnc_cnt_np_embed_backward(const int16_t* inputs, const float* embeddings_cli
                               uint32_t axis, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Radiance-field MLP (gradient-free evaluations) — stands in for the cuBLAS GEMM chain behind
+ * nn.Sequential(Linear, ReLU, Linear[, ReLU, Linear]) (examples/radiance_fields/ngp.py:475-504)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Y[N, n_out] = W3 relu(W2 relu(W1 x + b1) + b2) + b3 (W3 == NULL: two layers), fp32 on
+ * v_mfma_f32_16x16x4_f32, activations kept in LDS.  X [N, K0] with row stride ldx.  Weights are
+ * passed PADDED: W_l [Hp_l, Kp_l] row-major zero-filled, b_l [Hp_l], Kp_0 = roundup16(K0),
+ * Kp_l = Hp_{l-1}, Hp_l = roundup16(H_l) <= 160.                                                */
+int cnc_mlp_forward(const float* X, uint32_t N, uint32_t ldx, uint32_t K0,
+                    const float* W1, const float* b1, uint32_t H1p,
+                    const float* W2, const float* b2, uint32_t H2p,
+                    const float* W3, const float* b3, uint32_t H3p,
+                    float* Y, uint32_t ldy, uint32_t n_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Context-model aligner — replaces my_cuda_backen/aligner.cpp:4-79 (pack_and_align module)
  * ---------------------------------------------------------------------------------------- */
 

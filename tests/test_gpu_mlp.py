@@ -1,0 +1,44 @@
+"""Fused MFMA MLP forward vs torch fp32 (nn.Sequential on hipBLASLt): the MFMA result is a k-ordered
+fp32 fmaf chain, so agreement is at fp32 round-off."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dims", [(255, 160, 80), (95, 160, 160, 3), (25, 32, 32, 8), (64, 16, 16), (7, 48, 33)])
+@pytest.mark.parametrize("N", [1, 15, 16, 17, 4099, 1 << 16])
+def test_fused_mlp_forward_matches_torch(cuda, dims, N):
+    from cnc_amd.mlp import FusedMLPForward, Linear
+    torch.manual_seed(len(dims) * 1000 + N)
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2:
+            layers.append(nn.ReLU(inplace=True))
+    seq = nn.Sequential(*layers).to(cuda)
+    for l in seq:
+        if isinstance(l, nn.Linear):   # asymmetric, non-trivial weights
+            with torch.no_grad():
+                l.weight.copy_(torch.randn_like(l.weight) / dims[0] ** 0.5 + torch.arange(l.weight.shape[1], device=cuda) * 1e-3)
+                l.bias.copy_(torch.randn_like(l.bias))
+    fused = FusedMLPForward(seq)
+    x = torch.randn(N, dims[0], device=cuda)
+    with torch.no_grad():
+        want = seq(x)
+    got = fused(x)
+    assert got.shape == want.shape
+    scale = want.abs().max().clamp_min(1.0)
+    assert (got - want).abs().max() <= 2e-5 * scale
+    # a double-precision check pins both to the true value
+    ref = x.double()
+    for l in seq:
+        ref = torch.relu(ref) if isinstance(l, nn.ReLU) else ref @ l.weight.double().t() + l.bias.double()
+    assert (got.double() - ref).abs().max() <= 2e-5 * scale
+    # strided input view (columns of a wider matrix) and weight update tracking
+    wide = torch.randn(N, dims[0] + 9, device=cuda)
+    assert torch.allclose(fused(wide[:, 4:4 + dims[0]]), seq(wide[:, 4:4 + dims[0]]), rtol=0, atol=2e-5 * float(scale) + 1e-4)
+    with torch.no_grad():
+        seq[0].weight.mul_(0.5)
+    assert (fused(x) - seq(x)).abs().max() <= 2e-5 * scale
