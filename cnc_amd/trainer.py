@@ -334,3 +334,41 @@ class Trainer:
         mlp_MB, _, _ = quantize_params(mlp, digits=13)
         return {"embeddings": coded_MB, "context_models": ctx_MB, "occupancy_grid": occ_MB, "mlp_13bit": mlp_MB,
                 "total": coded_MB + ctx_MB + occ_MB + mlp_MB}
+
+    # ------------------------------------------------------------------------------ container
+    def _mlp_state(self):
+        return {k: v for k, v in self.field.state_dict().items() if "encoding" not in k and k != "aabb"}
+
+    @torch.no_grad()
+    def save_container(self, path: str) -> Dict[str, float]:
+        """Encode the tables and write everything a decoder needs into one file; returns sizes in KB."""
+        from .container import write_container
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            Pgs, est_MB, coded_MB, prefix = self.encode(os.path.join(td, "b"))
+            streams = {f[2:-2]: open(os.path.join(td, f), "rb").read()
+                       for f in sorted(os.listdir(td)) if f.endswith(".b")}
+        meta = {"Pgs": {k: float(v) for k, v in Pgs.items()}, "n_features": self.cfg.n_features,
+                "resolutions_list": list(self.cfg.resolutions_list),
+                "resolutions_list_2D": list(self.cfg.resolutions_list_2D),
+                "log2_hashmap_size": self.cfg.log2_hashmap_size,
+                "log2_hashmap_size_2D": self.cfg.log2_hashmap_size_2D}
+        size = write_container(path, meta=meta, table_streams=streams, binaries=self.estimator.binaries,
+                               field_mlp=self._mlp_state(), context_state=self.context.state_dict())
+        return {"file_KB": size / 1024.0, "embeddings_KB": coded_MB * 1024.0, "estimate_KB": est_MB * 1024.0}
+
+    @torch.no_grad()
+    def load_container(self, path: str) -> None:
+        """Inverse of save_container on a freshly constructed Trainer with the same config: restores
+        occupancy, context models and the (13-bit) MLP, then decodes the four tables."""
+        from .container import read_container
+        import tempfile
+        meta, streams, binaries, mlp, ctx = read_container(path, device=self.device)
+        self.estimator.binaries = binaries.to(self.device)
+        self.context.load_state_dict(ctx, strict=True)
+        self.field.load_state_dict(mlp, strict=False)
+        Pgs = {k: torch.tensor(v, device=self.device) for k, v in meta["Pgs"].items()}
+        with tempfile.TemporaryDirectory() as td:
+            for name, blob in streams.items():
+                open(os.path.join(td, f"b_{name}.b"), "wb").write(blob)
+            self.decode_into_field(Pgs, os.path.join(td, "b"))

@@ -54,6 +54,24 @@ def test_train_encode_decode_roundtrip(cuda, tmp_path):
     assert sizes["total"] > sizes["embeddings"] > 0
 
 
+def test_single_file_container_roundtrip(cuda, tmp_path):
+    """train a little -> one .cnc file -> a FRESH trainer decodes it -> same render quality as the
+    sender's field with a 13-bit MLP; the file size is the real size(KB)."""
+    from cnc_amd.trainer import Trainer
+    a = Trainer(_cfg(tmp_path), device=cuda)
+    a.train(steps=120, log=None)
+    psnr_a = a.evaluate()
+    info = a.save_container(str(tmp_path / "scene.cnc"))
+    assert os.path.getsize(tmp_path / "scene.cnc") == int(round(info["file_KB"] * 1024))
+    assert info["file_KB"] > info["embeddings_KB"] > 0
+    b = Trainer(_cfg(tmp_path, seed=7), device=cuda)          # different init: nothing shared but the config
+    assert abs(b.evaluate() - psnr_a) > 3.0
+    b.load_container(str(tmp_path / "scene.cnc"))
+    assert torch.equal(b.estimator.binaries, a.estimator.binaries)
+    psnr_b = b.evaluate()
+    assert abs(psnr_b - psnr_a) < 0.5, (psnr_a, psnr_b)
+
+
 def test_field_shapes_and_sh(cuda):
     from cnc_amd.field import NGPRadianceField_mygrid_2D3D, SHEncoding
     f = NGPRadianceField_mygrid_2D3D(aabb=[-1.5] * 3 + [1.5] * 3, n_features_per_level=8, n_neurons=160,

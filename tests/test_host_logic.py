@@ -158,3 +158,41 @@ def test_context_model_tables_toy():
     t = (34 - 2) // 8
     assert c.shape == ((t + 2) ** 3, 3)
     assert c.min(0).values.tolist() == [2 * t, 3 * t, 1 * t] and c.max(0).values.tolist() == [3 * t + 1, 4 * t + 1, 2 * t + 1]
+
+
+def test_nerf_synthetic_loader_on_a_fabricated_scene(tmp_path):
+    """PIL-based SubjectLoader: ray formula (OpenGL camera, nerf_synthetic.py:200-223), white
+    compositing at test time, random rays in training."""
+    import json
+    from PIL import Image
+    from cnc_amd.datasets import SubjectLoader
+    root = tmp_path / "nerf_synthetic" / "lego"
+    (root / "train").mkdir(parents=True)
+    H = W = 8
+    frames = []
+    rng = np.random.default_rng(0)
+    for i in range(3):
+        rgba = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+        Image.fromarray(rgba, "RGBA").save(root / "train" / f"r_{i}.png")
+        c2w = np.eye(4)
+        c2w[:3, 3] = [0.0, 0.0, 4.0 + i]
+        frames.append({"file_path": f"./train/r_{i}", "transform_matrix": c2w.tolist()})
+    for split in ("train", "test"):
+        json.dump({"camera_angle_x": 0.6911, "frames": frames}, open(root / f"transforms_{split}.json", "w"))
+    ds = SubjectLoader("lego", str(tmp_path / "nerf_synthetic"), "train", num_rays=64)
+    assert len(ds) == 3 and ds.training
+    d = ds[0]
+    assert d["pixels"].shape == (64, 3) and d["rays"].origins.shape == (64, 3)
+    assert torch.allclose(d["rays"].viewdirs.norm(dim=-1), torch.ones(64), atol=1e-6)
+    ds.update_num_rays(10)
+    assert ds[1]["pixels"].shape == (10, 3)
+    te = SubjectLoader("lego", str(tmp_path / "nerf_synthetic"), "test")
+    t0 = te[0]
+    assert t0["pixels"].shape == (H, W, 3) and t0["rays"].viewdirs.shape == (H, W, 3)
+    focal = 0.5 * W / np.tan(0.5 * 0.6911)
+    # centre-most pixel (x=4, y=4): camera dir ((4-4+.5)/f, -(4-4+.5)/f, -1), identity rotation
+    want = np.array([0.5 / focal, -0.5 / focal, -1.0]); want /= np.linalg.norm(want)
+    assert np.allclose(t0["rays"].viewdirs[4, 4].numpy(), want, atol=1e-6)
+    assert torch.equal(t0["rays"].origins[0, 0], torch.tensor([0.0, 0.0, 4.0]))
+    img = np.asarray(Image.open(root / "train" / "r_0.png"), np.float32) / 255.0
+    assert np.allclose(t0["pixels"].numpy(), img[..., :3] * img[..., 3:] + (1 - img[..., 3:]), atol=1e-6)
