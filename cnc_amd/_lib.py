@@ -35,6 +35,7 @@ SIGNATURES = {
     "cnc_query_mask_3D_qlist": [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u32, _vp],
     "cnc_align_and_pack_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp],
     "cnc_align_and_pack_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp],
+    "cnc_segment_weighted_sum": [_vp, _vp, _vp, _vp, _u32, _u32, _i32, _vp],
     "cnc_ray_aabb_intersect": [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "cnc_traverse_grids": [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                            _f32, _f32, _i32, _i32, C.POINTER(RaySegments), C.POINTER(RaySegments), _vp, _vp],

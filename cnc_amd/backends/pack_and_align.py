@@ -77,3 +77,21 @@ def query_mask_3D_qlist(points_n_orig_list, binary_vxl, mask, overlap_area_pool,
                                             ptr(overlap_area_pool), ptr(resolution_list),
                                             int(mask.shape[0]), stream())
     check(rc, "query_mask_3D_qlist")
+
+
+def segment_weighted_sum(values, weights, cumsum, mode=0):
+    """(extension) per-slot (weighted) sum / weighted mean / mean of ragged rows, see
+    cnc_segment_weighted_sum in include/cnc_hip.h.  values [T,F] f32, weights [T] f32 or None,
+    cumsum int64 [N+1] -> [N,F]."""
+    check_input(values, "values")
+    check_input(cumsum, "cumsum")
+    if weights is not None:
+        check_input(weights, "weights")
+    if values.dtype != torch.float32 or cumsum.dtype != torch.int64:
+        raise RuntimeError("segment_weighted_sum: values must be float32 and cumsum int64")
+    N, F = cumsum.shape[0] - 1, values.shape[1]
+    out = torch.empty((N, F), dtype=torch.float32, device=values.device)
+    rc = _lib.lib().cnc_segment_weighted_sum(ptr(values), ptr(weights), ptr(cumsum), ptr(out), N, F,
+                                             int(mode), stream())
+    check(rc, "segment_weighted_sum")
+    return out

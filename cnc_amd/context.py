@@ -162,6 +162,39 @@ class align_and_pack(Function):
         return d_feat, None, None, None
 
 
+class _segment_reduce(Function):
+    """Per-slot reduction of ragged rows without the padded tensor (extension, see
+    cnc_segment_weighted_sum): mode 0 sum(w*v), 1 sum(w*v)/sum(w), 2 mean.  Gradient w.r.t. values."""
+
+    @staticmethod
+    def forward(ctx, values, cumsum, weights, mode):
+        values = values.contiguous()
+        if weights is not None:
+            weights = weights.contiguous()
+        out = pack_and_align.segment_weighted_sum(values, weights, cumsum, mode)
+        ctx.save_for_backward(cumsum, weights)
+        ctx.mode, ctx.T = mode, values.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cumsum, weights = ctx.saved_tensors
+        N = cumsum.shape[0] - 1
+        cnt = cumsum[1:] - cumsum[:-1]
+        row2slot = torch.repeat_interleave(torch.arange(N, device=g.device), cnt, output_size=ctx.T)
+        scale = weights if weights is not None else torch.ones(ctx.T, dtype=g.dtype, device=g.device)
+        if ctx.mode == 1:
+            wsum = pack_and_align.segment_weighted_sum(scale.unsqueeze(-1).contiguous(), None, cumsum, 0)
+            scale = scale / wsum[row2slot, 0]
+        elif ctx.mode == 2:
+            scale = scale / cnt[row2slot].to(g.dtype)
+        return g.contiguous()[row2slot] * scale.unsqueeze(-1), None, None, None
+
+
+def _cum(cnt):
+    return torch.cat([torch.zeros(1, dtype=torch.long, device=cnt.device), torch.cumsum(cnt, dim=0)])
+
+
 def my_meshgrid3D(start=(0, 0, 0), end=(1000, 1000, 1000), dtype=torch.int32, device="cuda"):
     """[lx, ly, lz, 3] integer lattice (utils_bpp_acc.py:142-161)."""
     if isinstance(start, int):
@@ -190,10 +223,13 @@ class CNC_context_models(nn.Module):
                  ste_binary=False, ste_multistep=False, add_noise=False, Q=100, quantize_epoch=1000,
                  Pg_level=-1, Pg_level_2D=-1, Rb=128, step_update=16, skip_levels_3D=(0, 1, 2, 3),
                  skip_levels_2D=(0,), use_dimension_wise=True, use_overlap_area_pool=True,
-                 device="cuda", dimension_wise_resolution=514):
+                 device="cuda", dimension_wise_resolution=514, fused_segments=True):
         super().__init__()
         dev = torch.device(device)
         self.dev = dev
+        # hash fusion as one segmented-reduction kernel instead of pack -> multiply -> sum over a
+        # padded [slots, max collisions, F] tensor (False = the reference's dataflow)
+        self.fused_segments = fused_segments
         self.use_overlap_area_pool = use_overlap_area_pool
         self.use_dimension_wise = use_dimension_wise
         self.rand_like = torch.rand_like
@@ -432,11 +468,16 @@ class CNC_context_models(nn.Module):
             context = torch.cat([context, Pg_col], dim=-1)
         mean = self.context_model_2D[n - 1](context)
         mean = torch.index_select(mean, dim=0, index=order)
+        if self.fused_segments:
+            return _segment_reduce.apply(mean, _cum(unique_cnt), None, 2)
         mean = align_and_pack.apply(mean, unique_cnt, 0.0, 2)
         return torch.sum(mean, dim=1) / unique_cnt.unsqueeze(-1)
 
     def _fuse_3D(self, mean_pts, mask_cnt, overlap_w):
         """Hash fusion: combine the per-vertex predictions of one slot (overlap-weighted or plain mean)."""
+        if self.fused_segments:   # overlap_w holds the raw (clamped) overlaps, one per vertex
+            return _segment_reduce.apply(mean_pts, _cum(mask_cnt), overlap_w if self.use_overlap_area_pool else None,
+                                         1 if self.use_overlap_area_pool else 2)
         mean = align_and_pack.apply(mean_pts, mask_cnt, 0.0)
         if self.use_overlap_area_pool:
             return torch.sum(mean * overlap_w, dim=1)
@@ -445,6 +486,12 @@ class CNC_context_models(nn.Module):
     def _slot_masks(self, mask, overlap, unique_cnt):
         """Per slot: number of its vertices next to occupied space, whether any is, and the
         normalised overlap weights of those vertices (utils_bpp_acc.py:668-682)."""
+        if self.fused_segments:
+            per_slot = pack_and_align.segment_weighted_sum(mask.unsqueeze(-1).to(torch.float).contiguous(),
+                                                           None, _cum(unique_cnt.contiguous()), 0)[:, 0]
+            mask_exist = per_slot > 0
+            mask_cnt = per_slot.to(torch.long)[mask_exist]
+            return mask_cnt, mask_exist, torch.clamp(overlap[mask], min=1).to(torch.float)
         mask_packed = align_and_pack.apply(mask.unsqueeze(-1).to(torch.float), unique_cnt, 0)
         per_slot = torch.sum(mask_packed[:, :, 0], dim=1)
         mask_exist = per_slot > 0

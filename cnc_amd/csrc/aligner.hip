@@ -104,6 +104,34 @@ __global__ __launch_bounds__(256) void k_pack_bwd(const float* __restrict__ dpac
     }
 }
 
+// Hash fusion without the padded tensor: out[i][f] = sum_j w[s_i + j] * v[s_i + j][f]  (/ sum_j w)
+// over the rows s_i .. s_i + cnt_i - 1 of slot i.  The reference materialises [N, max(cnt), F]
+// (max(cnt) up to 288 at R=514), multiplies and reduces it (utils_bpp_acc.py:688-695); this reads
+// every value once.  One lane per (slot, feature): the F lanes of a slot read a row's F floats as
+// one contiguous segment.  mode: 0 = plain (weighted) sum, 1 = divide by the weight sum,
+// 2 = divide by the row count (mean; weights ignored if NULL).
+template <uint32_t F>
+__global__ __launch_bounds__(256) void k_segment_wsum(const float* __restrict__ v,
+                                                      const float* __restrict__ w,
+                                                      const int64_t* __restrict__ cumsum,
+                                                      float* __restrict__ out, uint32_t N,
+                                                      int mode)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = t / F, f = t % F;
+    if (i >= N) return;
+    const int64_t s = cumsum[i], e = cumsum[i + 1];
+    float acc = 0, wsum = 0;
+    for (int64_t r = s; r < e; r++) {
+        const float wr = w ? w[r] : 1.0f;
+        acc += wr * v[r * F + f];
+        wsum += wr;
+    }
+    if (mode == 1) acc = acc / wsum;
+    else if (mode == 2) acc = acc / (float)(e - s);
+    out[(size_t)i * F + f] = acc;
+}
+
 static uint32_t stream_grid(uint64_t total)
 {
     const uint64_t want = (total + 255) / 256;
@@ -172,5 +200,27 @@ extern "C" int cnc_align_and_pack_backward(const float* dL_packed, const int64_t
     if (!dL_packed || !cnt || !cumsum || !dL_feat) return CNC_ERR_INVALID_VALUE;
     hipLaunchKernelGGL(k_pack_bwd, dim3(stream_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        dL_packed, cnt, cumsum, dL_feat, N, M, F);
+    return launch_status();
+}
+
+extern "C" int cnc_segment_weighted_sum(const float* values, const float* weights,
+                                        const int64_t* cumsum, float* out, uint32_t N, uint32_t F,
+                                        int32_t mode, void* stream)
+{
+    if (N == 0) return CNC_OK;
+    if (!values || !cumsum || !out || mode < 0 || mode > 2) return CNC_ERR_INVALID_VALUE;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3  block(256);
+#define CNC_SEG(FF) hipLaunchKernelGGL((k_segment_wsum<FF>), dim3(div_up(N * FF, 256)), block, 0, s, values, weights, cumsum, out, N, mode)
+    switch (F) {
+    case 1: CNC_SEG(1); break;
+    case 2: CNC_SEG(2); break;
+    case 4: CNC_SEG(4); break;
+    case 8: CNC_SEG(8); break;
+    case 16: CNC_SEG(16); break;
+    case 32: CNC_SEG(32); break;
+    default: return CNC_ERR_INVALID_VALUE;
+    }
+#undef CNC_SEG
     return launch_status();
 }

@@ -163,6 +163,15 @@ int cnc_align_and_pack_backward(const float* dL_packed, const int64_t* cnt, cons
                                 float* dL_feat, uint32_t N, uint32_t M, uint32_t F,
                                 void* stream);
 
+/* (extension) the reduction the reference always applies to a packed tensor, without packing:
+ *   out[i][f] = sum_{r in [cumsum[i], cumsum[i+1])} w[r] * values[r][f]      mode 0
+ *             ... / sum_r w[r]                                                mode 1
+ *             ... / (cumsum[i+1]-cumsum[i])                                   mode 2
+ * replaces align_and_pack -> (* weights) -> sum(dim=1) [-> / cnt] (utils_bpp_acc.py:564-566,
+ * 668-669,681-682,688-695).  weights may be NULL (= 1).  values [T,F] f32, cumsum i64 [N+1].       */
+int cnc_segment_weighted_sum(const float* values, const float* weights, const int64_t* cumsum,
+                             float* out, uint32_t N, uint32_t F, int32_t mode, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Occupancy-grid marcher — replaces nerfacc/cuda/csrc/nerfacc.cpp:41-66 (grid.cu)
  * ---------------------------------------------------------------------------------------- */

@@ -126,3 +126,46 @@ def test_fused_ste_equals_unfused(setup):
     # two atomic scatters of the same terms in different orders
     assert (a.params.grad - b.params.grad).abs().max() <= 1e-5 * b.params.grad.abs().max()
     assert torch.equal(a.params.grad == 0, b.params.grad == 0)
+
+
+def test_fused_segment_reduction_equals_packed_dataflow(setup):
+    """fused_segments=True (one segmented-reduction kernel) vs the reference's pack -> multiply -> sum."""
+    g, m, encs, binary = setup
+    res = {}
+    for fused in (True, False):
+        m.fused_segments = fused
+        torch.manual_seed(5)
+        for e in encs.values():
+            e.zero_grad()
+        m.zero_grad()
+        bpp, _ = m.forward_binary_vxl_mixPg_3D2D(encs["xyz"], encs["xy"], encs["xz"], encs["yz"], binary, step=0)
+        bpp.backward()
+        res[fused] = (bpp.item(), encs["xyz"].params.grad.clone(), m.context_model_3D[0].weight.grad.clone())
+    m.fused_segments = True
+    assert abs(res[True][0] - res[False][0]) <= 1e-5 * abs(res[False][0])
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert (a - b).abs().max() <= 1e-4 * b.abs().max()
+
+
+def test_segment_weighted_sum_kernel(cuda):
+    from cnc_amd.backends import pack_and_align as pa
+    rng = np.random.default_rng(0)
+    cnt = rng.integers(0, 30, size=500).astype(np.int64)
+    cnt[3] = 288
+    T = int(cnt.sum())
+    cum = torch.as_tensor(np.concatenate([[0], np.cumsum(cnt)]), device=cuda)
+    for F in (1, 8):
+        v = torch.randn(T, F, device=cuda)
+        w = torch.rand(T, device=cuda) + 0.1
+        ref = torch.zeros(500, F, device=cuda, dtype=torch.float64)
+        slot = torch.repeat_interleave(torch.arange(500, device=cuda), torch.as_tensor(cnt, device=cuda))
+        ref.index_add_(0, slot, (v * w[:, None]).double())
+        wsum = torch.zeros(500, device=cuda, dtype=torch.float64).index_add_(0, slot, w.double())
+        got0 = pa.segment_weighted_sum(v, w, cum, 0)
+        assert torch.allclose(got0.double(), ref, atol=1e-4)
+        got1 = pa.segment_weighted_sum(v, w, cum, 1)
+        nz = torch.as_tensor(cnt, device=cuda) > 0
+        assert torch.allclose(got1[nz].double(), (ref / wsum[:, None])[nz], atol=1e-5)
+        got2 = pa.segment_weighted_sum(v, None, cum, 2)
+        plain = torch.zeros(500, F, device=cuda, dtype=torch.float64).index_add_(0, slot, v.double())
+        assert torch.allclose(got2[nz].double(), (plain / torch.as_tensor(cnt, device=cuda)[:, None])[nz], atol=1e-5)
