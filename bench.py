@@ -169,12 +169,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    # test hooks (not used by the driver): CNC_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # CNC_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N>1 control flow can be exercised on a
+    # single-GPU box
+    if os.environ.get("CNC_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("CNC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     w = build_workload(dev, rank)
     timed = Timed()

@@ -113,7 +113,10 @@ def traverse_grids(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
             samples.chunk_cnts = torch.full((n_rays,), traverse_steps_limit, dtype=torch.int64,
                                             device=dev) * rays_mask
             samples.memalloc_data_from_chunk(False, True, True)
-        launch(rays_mask, 0, terminate_planes)
+        n_out = (intervals.vals.numel() if compute_intervals else 0) + \
+                (samples.vals.numel() if compute_samples else 0)
+        if n_out > 0:   # every ray masked out: nothing to march
+            launch(rays_mask, 0, terminate_planes)
         intervals.compute_chunk_start()
         samples.compute_chunk_start()
     else:
@@ -127,7 +130,10 @@ def traverse_grids(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
             intervals.memalloc_data_from_chunk(True, True)
         if compute_samples:
             samples.memalloc_data_from_chunk(False, False, True)
-        launch(None, 0, terminate_planes)
+        n_out = (intervals.vals.numel() if compute_intervals else 0) + \
+                (samples.vals.numel() if compute_samples else 0)
+        if n_out > 0:   # with nothing to fill every ray is skipped (grid.cu:103-106): no launch needed
+            launch(None, 0, terminate_planes)
     return intervals, samples, terminate_planes
 
 

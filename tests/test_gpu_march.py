@@ -194,3 +194,59 @@ def test_scan_docstring_examples(cuda):
     assert inclusive_prod(x, pk).tolist() == [1., 2., 3., 12., 60., 6., 42., 336., 3024.]
     assert exclusive_prod(x, pk).tolist() == [1., 1., 1., 3., 12., 1., 6., 42., 336.]
     assert exclusive_sum(torch.empty(0, device=cuda), torch.zeros((3, 2), dtype=torch.long, device=cuda)).shape == (0,)
+
+
+def test_march_full_frame_properties(cuda):
+    """BASELINE size: 800x800 rays through the 128^3 ball occupancy (step 5e-3) — properties that
+    need no oracle: count pass == fill pass, samples ordered by (ray, t), every sample inside its
+    ray's box interval and inside an occupied cell, interval masks consistent."""
+    from cnc_amd import synthetic
+    from cnc_amd.nerfacc.grid import ray_aabb_intersect, traverse_grids
+    o, d = synthetic.pinhole_rays(800, 800, 0.6911, 4.0, 0.7, 0.5, device=cuda)
+    binaries = synthetic.ball_binaries(128, radius=1.0, device=cuda)
+    aabbs = torch.tensor([[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]], device=cuda)
+    iv, sm, term = traverse_grids(o, d, binaries, aabbs, step_size=5e-3, cone_angle=0.0)
+    cnt = sm.packed_info[:, 1]
+    S = int(cnt.sum())
+    assert S == sm.vals.shape[0] and 6.0e7 < S < 7.5e7
+    assert torch.equal(sm.packed_info[:, 0], torch.cumsum(cnt, 0) - cnt)
+    ri = sm.ray_indices
+    assert torch.all(ri[1:] >= ri[:-1])
+    same = ri[1:] == ri[:-1]
+    assert torch.all((sm.vals[1:] - sm.vals[:-1])[same] > 0)
+    assert torch.equal(torch.bincount(ri, minlength=o.shape[0]), cnt)
+    t0, t1, hit = ray_aabb_intersect(o, d, aabbs)
+    assert torch.all(sm.vals >= t0[ri, 0]) and torch.all(sm.vals <= t1[ri, 0])
+    assert not torch.any(cnt[~hit[:, 0]] > 0)
+    # interval edges: #left == #right == #samples, and mid-points are the samples
+    assert int(iv.is_left.sum()) == S and int(iv.is_right.sum()) == S
+    mids = (iv.vals[iv.is_left] + iv.vals[iv.is_right]) * 0.5
+    assert torch.equal(mids, sm.vals)
+    # sampled cells are occupied (up to float rounding at cell faces: allow a sliver)
+    pos = o[ri] + d[ri] * sm.vals[:, None]
+    cell = ((pos + 1.5) / 3.0 * 128).long().clamp(0, 127)
+    occ = binaries[0, cell[:, 0], cell[:, 1], cell[:, 2]]
+    assert occ.float().mean() > 0.999
+
+
+@pytest.mark.parametrize("n_rays", [0, 1, 7])
+def test_march_degenerate_inputs(cuda, oracle, n_rays):
+    """Empty ray sets, rays that all miss, and an all-False rays_mask."""
+    from cnc_amd.nerfacc.grid import traverse_grids
+    binaries = torch.ones((1, 8, 8, 8), dtype=torch.bool, device=cuda)
+    aabbs = torch.tensor([[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0]], device=cuda)
+    o = torch.full((n_rays, 3), 5.0, device=cuda)
+    d = torch.nn.functional.normalize(torch.ones((n_rays, 3), device=cuda), dim=-1) if n_rays else torch.zeros((0, 3), device=cuda)
+    iv, sm, term = traverse_grids(o, d, binaries, aabbs, step_size=1e-2)   # pointing away: all miss
+    assert sm.vals.shape == (0,) and iv.vals.shape == (0,)
+    assert sm.packed_info.shape == (n_rays, 2) and int(sm.packed_info.sum()) == 0
+    if n_rays:
+        d2 = -d
+        mask = torch.zeros(n_rays, dtype=torch.bool, device=cuda)
+        iv, sm, term = traverse_grids(o, d2, binaries, aabbs, step_size=1e-2, traverse_steps_limit=4,
+                                      over_allocate=True, rays_mask=mask)
+        assert int(sm.packed_info[:, 1].sum()) == 0 and sm.vals.shape == (0,)
+        iv, sm, term = traverse_grids(o, d2, binaries, aabbs, step_size=1e-2)
+        want = oracle.traverse_grids(o.cpu().numpy(), d2.cpu().numpy(), binaries.cpu().numpy(), aabbs.cpu().numpy(),
+                                     None, None, 1e-2, 0.0)
+        assert np.array_equal(sm.vals.cpu().numpy(), want[1]["vals"]) and sm.vals.shape[0] > 0
