@@ -265,7 +265,7 @@ def main():
                        "chunk": CHUNK, "table_rows": 6120776, "n_features": F, "levels": L},
             "roofline": roofline, "roofline_forward": other, "kernels": kernels,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))
     if world > 1:
