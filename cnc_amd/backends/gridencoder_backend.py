@@ -62,7 +62,7 @@ def _common_checks(named):
 
 def grid_encode_forward(inputs, embeddings, offsets_list, resolutions_list, outputs, N, num_dim,
                         n_features, n_levels, max_level, Rb, PV, dy_dx=None, binary_vxl=None,
-                        min_level_id=None, *, ste_binary=False, occ_sat=None):
+                        min_level_id=None, *, ste_binary=False, occ_sat=None, out_ld=0, out_col=0):
     _common_checks([("inputs", inputs), ("embeddings", embeddings), ("offsets_list", offsets_list),
                     ("resolutions_list", resolutions_list), ("outputs", outputs)])
     _check_floating(inputs, "inputs")
@@ -82,14 +82,14 @@ def grid_encode_forward(inputs, embeddings, offsets_list, resolutions_list, outp
         ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list), ptr(outputs),
         int(N), int(num_dim), int(n_features), int(n_levels), int(Rb), float(PV), ptr(dy_dx),
         ptr(binary_vxl), ptr(min_level_id), _lib.CNC_FLAG_STE_BINARY if ste_binary else 0,
-        ptr(_check_sat(occ_sat, binary_vxl)), stream())
+        ptr(_check_sat(occ_sat, binary_vxl)), int(out_ld), int(out_col), stream())
     check(rc, "grid_encode_forward")
 
 
 def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_list, grad_embeddings,
                          N, num_dim, n_features, n_levels, max_level, Rb, dy_dx=None,
                          grad_inputs=None, binary_vxl=None, min_level_id=None, *, ste_binary=False,
-                         ste_clip_count=None, occ_sat=None):
+                         ste_clip_count=None, occ_sat=None, grad_ld=0, grad_col=0):
     _common_checks([("grad", grad), ("inputs", inputs), ("embeddings", embeddings),
                     ("offsets_list", offsets_list), ("resolutions_list", resolutions_list),
                     ("grad_embeddings", grad_embeddings)])
@@ -113,7 +113,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         ptr(grad_embeddings), int(N), int(num_dim), int(n_features), int(n_levels), int(Rb),
         ptr(dy_dx), ptr(grad_inputs), ptr(binary_vxl), ptr(min_level_id),
         _lib.CNC_FLAG_STE_BINARY if ste_binary else 0, ptr(ste_clip_count),
-        ptr(_check_sat(occ_sat, binary_vxl)), stream())
+        ptr(_check_sat(occ_sat, binary_vxl)), int(grad_ld), int(grad_col), stream())
     check(rc, "grid_encode_backward")
 
 
@@ -135,7 +135,8 @@ def pack_sign_bits(embeddings, bits=None, clip_count=None):
 
 
 def grid_encode_forward_bits(inputs, bits, offsets_list, resolutions_list, outputs, N, num_dim,
-                             n_features, n_levels, Rb, binary_vxl=None, min_level_id=None, occ_sat=None):
+                             n_features, n_levels, Rb, binary_vxl=None, min_level_id=None, occ_sat=None,
+                             out_ld=0, out_col=0):
     """(extension) grid_encode_forward on the bit plane of a binarised table; same outputs as
     grid_encode_forward(..., ste_binary=True) on the fp32 table."""
     _common_checks([("inputs", inputs), ("bits", bits), ("offsets_list", offsets_list),
@@ -155,7 +156,7 @@ def grid_encode_forward_bits(inputs, bits, offsets_list, resolutions_list, outpu
     rc = _lib.lib().cnc_grid_encode_forward_bits(
         ptr(inputs), ptr(bits), ptr(offsets_list), ptr(resolutions_list), ptr(outputs), int(N),
         int(num_dim), int(n_features), int(n_levels), int(Rb), ptr(binary_vxl), ptr(min_level_id),
-        ptr(_check_sat(occ_sat, binary_vxl)), stream())
+        ptr(_check_sat(occ_sat, binary_vxl)), int(out_ld), int(out_col), stream())
     check(rc, "grid_encode_forward_bits")
 
 

@@ -21,6 +21,21 @@ constexpr int kWave = 64;
 
 __host__ __device__ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
+// Where the F features of (level slot, point b) live.  ld == 0: the reference's level-major
+// [L, N, F] tensor (gridencoder.cu:131).  ld != 0: point-major rows of a wider [N, ld] feature
+// matrix, this encoder's block starting at column `col` — lets several encoders write straight
+// into the MLP input (no permute / cat) and read its gradient in place.
+struct FeatLayout {
+    uint32_t ld;
+    uint32_t col;
+};
+
+__device__ __forceinline__ size_t feat_index(FeatLayout lay, uint32_t slot, uint32_t N, uint32_t b,
+                                             uint32_t F)
+{
+    return lay.ld ? (size_t)b * lay.ld + lay.col + slot * F : ((size_t)slot * N + b) * F;
+}
+
 inline int launch_status()
 {
     return hipGetLastError() == hipSuccess ? CNC_OK : CNC_ERR_LAUNCH;

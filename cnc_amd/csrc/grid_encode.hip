@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd(
     const float* __restrict__ inputs, const float* __restrict__ emb,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
     float* __restrict__ out, uint32_t N, uint32_t Rb, const uint8_t* __restrict__ vxl,
-    const int32_t* __restrict__ min_level_id, const int32_t* __restrict__ sat)
+    const int32_t* __restrict__ min_level_id, const int32_t* __restrict__ sat, FeatLayout lay)
 {
     constexpr uint32_t V = F < 4 ? F : 4;
     constexpr uint32_t G = F / V;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd(
     const uint32_t slot = blockIdx.y;
     const uint32_t level = slot + (min_level_id ? (uint32_t)min_level_id[b] : 0u);
 
-    float* o = out + ((size_t)slot * N + b) * F + h * V;
+    float* o = out + feat_index(lay, slot, N, b, F) + h * V;
     float  acc[V];
 #pragma unroll
     for (uint32_t k = 0; k < V; k++) acc[k] = 0;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd_bits(
     const float* __restrict__ inputs, const uint8_t* __restrict__ bits,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
     float* __restrict__ out, uint32_t N, uint32_t Rb, const uint8_t* __restrict__ vxl,
-    const int32_t* __restrict__ min_level_id, const int32_t* __restrict__ sat)
+    const int32_t* __restrict__ min_level_id, const int32_t* __restrict__ sat, FeatLayout lay)
 {
     constexpr uint32_t C = 1u << D;
     constexpr uint32_t V = F < 4 ? F : 4;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd_bits(
     if (b >= N) return;
     const uint32_t slot = blockIdx.y;
     const uint32_t level = slot + (min_level_id ? (uint32_t)min_level_id[b] : 0u);
-    float* o = out + ((size_t)slot * N + b) * F;
+    float* o = out + feat_index(lay, slot, N, b, F);
     float  acc[F];
 #pragma unroll
     for (uint32_t k = 0; k < F; k++) acc[k] = 0;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd_simple(
     const float* __restrict__ emb, const int32_t* __restrict__ offsets,
     const int32_t* __restrict__ resolutions, float* __restrict__ grad_emb, uint32_t N,
     uint32_t Rb, const uint8_t* __restrict__ vxl, const int32_t* __restrict__ min_level_id,
-    const uint32_t* __restrict__ clip_count, const int32_t* __restrict__ sat)
+    const uint32_t* __restrict__ clip_count, const int32_t* __restrict__ sat, FeatLayout lay)
 {
     constexpr uint32_t V = F < 4 ? F : 4;
     constexpr uint32_t G = F / V;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd_simple(
     if (!load_point<D>(inputs, b, x)) return;   // gridencoder.cu:435-440
 
     float g[V];
-    load_vec<V>(grad + ((size_t)slot * N + b) * F + h * V, g);
+    load_vec<V>(grad + feat_index(lay, slot, N, b, F) + h * V, g);
 
     const uint32_t off = (uint32_t)offsets[level];
     const uint32_t hs = (uint32_t)offsets[level + 1] - off;
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
     const float* __restrict__ emb, const int32_t* __restrict__ offsets,
     const int32_t* __restrict__ resolutions, float* __restrict__ grad_emb, uint32_t N,
     uint32_t Rb, const uint8_t* __restrict__ vxl, const int32_t* __restrict__ min_level_id,
-    const uint32_t* __restrict__ clip_count, const int32_t* __restrict__ sat)
+    const uint32_t* __restrict__ clip_count, const int32_t* __restrict__ sat, FeatLayout lay)
 {
     constexpr uint32_t C = 1u << D;
     constexpr uint32_t SLOTS = C * F;           // lanes per run in phase B (<= 64)
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
                 s_row[tid][i] = off + c.row[i];
                 validmask |= (c.valid[i] ? 1u : 0u) << i;
             }
-            const float* gp = grad + ((size_t)slot * N + b) * F;
+            const float* gp = grad + feat_index(lay, slot, N, b, F);
 #pragma unroll
             for (uint32_t k = 0; k < F; k += V) {
                 float gv[V];
@@ -626,6 +626,7 @@ struct EncArgs {
     hipStream_t    stream;
     const uint32_t* clip_count = nullptr;   // backward + STE only
     const int32_t*  sat = nullptr;          // optional summed-volume table of the occupancy grid
+    FeatLayout      lay{0, 0};              // where outputs (forward) / gradients (backward) live
 };
 
 template <uint32_t D, uint32_t F, bool VXL, bool STE>
@@ -634,7 +635,7 @@ static void launch_fwd(const EncArgs& a)
     constexpr uint32_t V = F < 4 ? F : 4, G = F / V;
     const dim3 grid(div_up(a.N * G, 256), a.L, 1);
     hipLaunchKernelGGL((k_grid_encode_fwd<D, F, VXL, STE>), grid, dim3(256), 0, a.stream,
-                       a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N, a.Rb, a.vxl, a.mli, a.sat);
+                       a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N, a.Rb, a.vxl, a.mli, a.sat, a.lay);
 }
 
 template <uint32_t D, uint32_t F, bool VXL, bool STE>
@@ -644,13 +645,13 @@ static void launch_bwd(const EncArgs& a)
         const dim3 grid(div_up(a.N, 256), a.L, 1);
         hipLaunchKernelGGL((k_grid_encode_bwd<D, F, VXL, STE>), grid, dim3(256), 0, a.stream,
                            a.grad, a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N, a.Rb,
-                           a.vxl, a.mli, a.clip_count, a.sat);
+                           a.vxl, a.mli, a.clip_count, a.sat, a.lay);
     } else {
         constexpr uint32_t V = F < 4 ? F : 4, G = F / V;
         const dim3 grid(div_up(a.N * G, 256), a.L, 1);
         hipLaunchKernelGGL((k_grid_encode_bwd_simple<D, F, VXL, STE>), grid, dim3(256), 0,
                            a.stream, a.grad, a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N,
-                           a.Rb, a.vxl, a.mli, a.clip_count, a.sat);
+                           a.Rb, a.vxl, a.mli, a.clip_count, a.sat, a.lay);
     }
 }
 
@@ -696,6 +697,14 @@ static int dispatch_D(const EncArgs& a, uint32_t D, uint32_t F, bool ste)
     }
 }
 
+// point-major layout: rows must hold the encoder's block and keep the vector accesses aligned
+static bool layout_ok(FeatLayout lay, uint32_t F, uint32_t L)
+{
+    if (lay.ld == 0) return lay.col == 0;
+    const uint32_t V = F < 4 ? F : 4;
+    return lay.col + L * F <= lay.ld && lay.ld % V == 0 && lay.col % V == 0;
+}
+
 }  // namespace cnc
 
 using namespace cnc;
@@ -705,14 +714,17 @@ extern "C" int cnc_grid_encode_forward(const float* inputs, const float* embeddi
                                        float* outputs, uint32_t N, uint32_t D, uint32_t F,
                                        uint32_t L, uint32_t Rb, float PV, float* dy_dx,
                                        const uint8_t* binary_vxl, const int32_t* min_level_id,
-                                       uint32_t flags, const int32_t* occ_sat, void* stream)
+                                       uint32_t flags, const int32_t* occ_sat, uint32_t out_ld,
+                                       uint32_t out_col, void* stream)
 {
     (void)PV;
     if (dy_dx) return CNC_ERR_UNSUPPORTED;
     if (N == 0 || L == 0) return CNC_OK;
     if (!inputs || !embeddings || !offsets || !resolutions || !outputs) return CNC_ERR_INVALID_VALUE;
     EncArgs a{inputs, embeddings, offsets, resolutions, outputs, nullptr, N, L, Rb,
-              binary_vxl, min_level_id, (hipStream_t)stream, nullptr, binary_vxl ? occ_sat : nullptr};
+              binary_vxl, min_level_id, (hipStream_t)stream, nullptr, binary_vxl ? occ_sat : nullptr,
+              FeatLayout{out_ld, out_col}};
+    if (!layout_ok(a.lay, F, L)) return CNC_ERR_INVALID_VALUE;
     const int rc = dispatch_D<false>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
     return rc != CNC_OK ? rc : launch_status();
 }
@@ -724,7 +736,8 @@ extern "C" int cnc_grid_encode_backward(const float* grad, const float* inputs,
                                         uint32_t Rb, const float* dy_dx, float* grad_inputs,
                                         const uint8_t* binary_vxl, const int32_t* min_level_id,
                                         uint32_t flags, const uint32_t* ste_clip_count,
-                                        const int32_t* occ_sat, void* stream)
+                                        const int32_t* occ_sat, uint32_t grad_ld,
+                                        uint32_t grad_col, void* stream)
 {
     if (dy_dx || grad_inputs) return CNC_ERR_UNSUPPORTED;
     if (N == 0 || L == 0) return CNC_OK;
@@ -732,7 +745,8 @@ extern "C" int cnc_grid_encode_backward(const float* grad, const float* inputs,
         return CNC_ERR_INVALID_VALUE;
     EncArgs a{inputs, embeddings, offsets, resolutions, grad_embeddings, grad, N, L, Rb,
               binary_vxl, min_level_id, (hipStream_t)stream, ste_clip_count,
-              binary_vxl ? occ_sat : nullptr};
+              binary_vxl ? occ_sat : nullptr, FeatLayout{grad_ld, grad_col}};
+    if (!layout_ok(a.lay, F, L)) return CNC_ERR_INVALID_VALUE;
     const int rc = dispatch_D<true>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
     return rc != CNC_OK ? rc : launch_status();
 }
@@ -796,11 +810,11 @@ template <uint32_t D, uint32_t F>
 static void launch_fwd_bits(const float* inputs, const uint8_t* bits, const int32_t* offsets,
                             const int32_t* resolutions, float* outputs, uint32_t N, uint32_t L,
                             uint32_t Rb, const uint8_t* vxl, const int32_t* mli, const int32_t* sat,
-                            hipStream_t s)
+                            FeatLayout lay, hipStream_t s)
 {
     const dim3 grid(div_up(N, 256), L, 1);
-    if (vxl) hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, true>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, Rb, vxl, mli, sat);
-    else hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, false>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, Rb, vxl, mli, nullptr);
+    if (vxl) hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, true>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, Rb, vxl, mli, sat, lay);
+    else hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, false>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, Rb, vxl, mli, nullptr, lay);
 }
 
 extern "C" int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* bits,
@@ -808,14 +822,16 @@ extern "C" int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* 
                                             float* outputs, uint32_t N, uint32_t D, uint32_t F,
                                             uint32_t L, uint32_t Rb, const uint8_t* binary_vxl,
                                             const int32_t* min_level_id, const int32_t* occ_sat,
-                                            void* stream)
+                                            uint32_t out_ld, uint32_t out_col, void* stream)
 {
     if (N == 0 || L == 0) return CNC_OK;
     if (!inputs || !bits || !offsets || !resolutions || !outputs) return CNC_ERR_INVALID_VALUE;
+    const FeatLayout lay{out_ld, out_col};
+    if (!layout_ok(lay, F, L)) return CNC_ERR_INVALID_VALUE;
     hipStream_t s = (hipStream_t)stream;
 #define CNC_BITS_D(DD)                                                                              \
     CNC_F_SWITCH(F, (launch_fwd_bits<DD, FF>(inputs, bits, offsets, resolutions, outputs, N, L, Rb, \
-                                             binary_vxl, min_level_id, occ_sat, s)))
+                                             binary_vxl, min_level_id, occ_sat, lay, s)))
     switch (D) {
     case 1: CNC_BITS_D(1); break;
     case 2: CNC_BITS_D(2); break;
@@ -839,4 +855,4 @@ extern "C" const char* cnc_error_string(int code)
     }
 }
 
-extern "C" int cnc_abi_version(void) { return 4; }
+extern "C" int cnc_abi_version(void) { return 5; }

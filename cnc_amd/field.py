@@ -18,10 +18,11 @@ from typing import Callable, List, Union
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.autograd import Function
 
 from .gridencoder import GridEncoder
-from .mlp import Linear
+from .mlp import Linear, linear_fn
 
 
 class _TruncExp(Function):
@@ -116,18 +117,84 @@ class Embedder:
         return torch.cat(parts, -1)
 
 
-def get_embedder(multires, i=0):
+def get_embedder(multires, i=0, with_freqs=False):
     if i == -1:
         return nn.Identity(), 3
     e = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
                  log_sampling=True, periodic_fns=[torch.sin, torch.cos])
-    return (lambda x, eo=e: eo.embed(x)), e.out_dim
+    fn = (lambda x, eo=e: eo.embed(x))
+    return (fn, e.out_dim, e.freq_bands) if with_freqs else (fn, e.out_dim)
+
+
+class _FusedFeatures(Function):
+    """The four grid encoders writing point-major into ONE [N, ld] feature matrix (the base MLP's
+    input), and their backward reading the MLP's input gradient in place.
+
+    Same values as `torch.cat([enc_xyz(x), enc_xy(xy), enc_xz(xz), enc_yz(yz), embed(x)], -1)`
+    (ngp.py:631-642) without the four [L,N,F]->[N,L*F] permutes, the cat, and the four
+    permute+contiguous copies of the gradient.  Only for the CNC configuration: every encoder
+    binarised with the fused STE and a bit plane."""
+
+    @staticmethod
+    def forward(ctx, x, owner, *params):
+        from .backends import gridencoder_backend as be
+        encs = owner._encoders()
+        N = x.shape[0]
+        ld, cols = owner._layout()
+        feat = torch.empty(N, ld, device=x.device, dtype=torch.float32)
+        xs = (x.contiguous(), x[:, [0, 1]].contiguous(), x[:, [0, 2]].contiguous(), x[:, [1, 2]].contiguous())
+        saved = []
+        for enc, p, xi, col in zip(encs, params, xs, cols):
+            bits, clip = enc._bit_plane(p)
+            be.grid_encode_forward_bits(xi, bits, enc.offsets_list, enc.resolutions_list, feat, N,
+                                        enc.num_dim, enc.n_features, enc.n_levels, 128, None, None,
+                                        None, out_ld=ld, out_col=col)
+            saved.append(clip)
+        c0 = cols[4]
+        if owner.embed_fn is not None:
+            # x | sin(2^k x) | cos(2^k x), k = 0..9 (ngp.py:583-599), written in place
+            n_f = owner._freqs.numel()
+            feat[:, c0:c0 + 3] = x
+            arg = x[:, None, :] * owner._freqs.to(x.device)[None, :, None]
+            v = feat[:, c0 + 3:c0 + 3 + 6 * n_f].view(N, n_f, 2, 3)
+            torch.sin(arg, out=v[:, :, 0, :])
+            torch.cos(arg, out=v[:, :, 1, :])
+            c0 += 3 + 6 * n_f
+        if c0 < ld:
+            feat[:, c0:].zero_()
+        ctx.save_for_backward(*xs, *params, *saved)
+        ctx.owner = owner
+        return feat
+
+    @staticmethod
+    def backward(ctx, grad):
+        from .backends import gridencoder_backend as be
+        owner = ctx.owner
+        encs = owner._encoders()
+        t = ctx.saved_tensors
+        xs, params, clips = t[0:4], t[4:8], t[8:12]
+        ld, cols = owner._layout()
+        grad = grad.contiguous()
+        N = grad.shape[0]
+        grads = []
+        for enc, p, xi, clip, col in zip(encs, params, xs, clips, cols):
+            g = torch.zeros_like(p)
+            be.grid_encode_backward(grad, xi, p, enc.offsets_list, enc.resolutions_list, g, N,
+                                    enc.num_dim, enc.n_features, enc.n_levels, 0, 128, None, None,
+                                    None, None, ste_binary=True, ste_clip_count=clip,
+                                    grad_ld=ld, grad_col=col)
+            grads.append(g)
+        return (None, None, *grads)
 
 
 class compose_3D_2D_embed(nn.Module):
-    """[3-D grid | xy | xz | yz plane grids | 63 sinusoid features] -> base MLP (ngp.py:620-645)."""
+    """[3-D grid | xy | xz | yz plane grids | 63 sinusoid features] -> base MLP (ngp.py:620-645).
 
-    def __init__(self, encoding_xyz, encoding_xy, encoding_xz, encoding_yz, embed_fn, network, sin_encode=False):
+    `fused=True` (extension): when all four encoders are binarised (the CNC configuration) they
+    write straight into the MLP's input matrix — see `_FusedFeatures`."""
+
+    def __init__(self, encoding_xyz, encoding_xy, encoding_xz, encoding_yz, embed_fn, network, sin_encode=False,
+                 fused=True, freq_bands=None):
         super().__init__()
         self.encoding_xyz = encoding_xyz
         self.encoding_xy = encoding_xy
@@ -135,6 +202,32 @@ class compose_3D_2D_embed(nn.Module):
         self.encoding_yz = encoding_yz
         self.embed_fn = embed_fn
         self.network = network
+        self.fused = fused
+        self._freqs = freq_bands
+
+    def _encoders(self):
+        return (self.encoding_xyz, self.encoding_xy, self.encoding_xz, self.encoding_yz)
+
+    def _layout(self):
+        """(row length padded to 4 floats, first column of [xyz, xy, xz, yz, sinusoid])."""
+        cols, c = [], 0
+        for e in self._encoders():
+            cols.append(c)
+            c += e.n_output_dims
+        cols.append(c)
+        if self.embed_fn is not None:
+            c += 3 + 6 * self._freqs.numel()
+        return (c + 3) // 4 * 4, cols
+
+    def _can_fuse(self, x):
+        return (self.fused and x.is_cuda and x.dtype == torch.float32
+                and (self.embed_fn is None or self._freqs is not None)
+                and isinstance(self.network[0], nn.Linear)
+                and all(e.ste_binary and e.fused_ste and e.bitplane for e in self._encoders()))
+
+    def features_fused(self, x):
+        """[N, ld] feature matrix; columns [width, ld) are zero."""
+        return _FusedFeatures.apply(x, self, *(e.params for e in self._encoders()))
 
     def features(self, x):
         xs, ys, zs = torch.chunk(x, 3, dim=-1)
@@ -147,6 +240,15 @@ class compose_3D_2D_embed(nn.Module):
         return torch.cat(parts, dim=-1)
 
     def forward(self, x):
+        if self._can_fuse(x):
+            feat = self.features_fused(x)
+            first = self.network[0]
+            pad = feat.shape[1] - first.in_features
+            w = F.pad(first.weight, (0, pad)) if pad else first.weight
+            h = linear_fn(feat, w, first.bias)
+            for layer in list(self.network)[1:]:
+                h = layer(h)
+            return h
         return self.network(self.features(x))
 
 
@@ -157,7 +259,8 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
                  resolutions_list=(16, 22, 31, 42, 57, 78, 106, 146, 199, 273, 374, 512),
                  log2_hashmap_size: int = 19, resolutions_list_2D=(64, 128, 256, 512, 1024),
                  log2_hashmap_size_2D=17, n_features_per_level=2, n_neurons=64, ste_binary=True,
-                 ste_multistep=False, add_noise=False, Q=10, sh_fp16_round=False, fused_ste=True) -> None:
+                 ste_multistep=False, add_noise=False, Q=10, sh_fp16_round=False, fused_ste=True,
+                 fused_features=True) -> None:
         super().__init__()
         if not isinstance(aabb, torch.Tensor):
             aabb = torch.tensor(aabb, dtype=torch.float32)
@@ -182,12 +285,13 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         encoding_xy = grid(2, resolutions_list_2D, log2_hashmap_size_2D)
         encoding_xz = grid(2, resolutions_list_2D, log2_hashmap_size_2D)
         encoding_yz = grid(2, resolutions_list_2D, log2_hashmap_size_2D)
-        embed_fn, input_ch = get_embedder(10, 0)
+        embed_fn, input_ch, freq_bands = get_embedder(10, 0, with_freqs=True)
         in_chs = (encoding_xyz.n_output_dims + encoding_xy.n_output_dims + encoding_xz.n_output_dims
                   + encoding_yz.n_output_dims + input_ch)
         network = nn.Sequential(Linear(in_chs, n_neurons), nn.ReLU(inplace=True),
                                 Linear(n_neurons, 1 + self.geo_feat_dim))
-        self.mlp_base = compose_3D_2D_embed(encoding_xyz, encoding_xy, encoding_xz, encoding_yz, embed_fn, network)
+        self.mlp_base = compose_3D_2D_embed(encoding_xyz, encoding_xy, encoding_xz, encoding_yz, embed_fn, network,
+                                            fused=fused_features, freq_bands=freq_bands)
         if self.geo_feat_dim > 0:
             head_in = (self.direction_encoding.n_output_dims if self.use_viewdirs else 0) + self.geo_feat_dim
             self.mlp_head = nn.Sequential(Linear(head_in, n_neurons), nn.ReLU(inplace=True),

@@ -67,6 +67,13 @@ class Linear(nn.Linear):
         return F.linear(input, self.weight, self.bias)
 
 
+def linear_fn(x, weight, bias):
+    """Functional form of `Linear.forward` (for callers that pad or slice the weight)."""
+    if x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        return _LinearSplitK.apply(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
 def _round16(n: int) -> int:
     return (n + 15) // 16 * 16
 

@@ -42,6 +42,7 @@ class TrainConfig:
     sample_num: int = 200000
     max_context_layer_num: int = 3
     n_features: int = 4
+    fused_features: bool = True      # encoders write straight into the base MLP's input matrix
     # hard-coded in the reference (:135-186)
     n_neurons: int = 160
     resolutions_list: Tuple[int, ...] = (18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514)
@@ -188,7 +189,7 @@ class Trainer:
             aabb=self.estimator.aabbs[-1], n_features_per_level=c.n_features, n_neurons=c.n_neurons,
             resolutions_list=c.resolutions_list, log2_hashmap_size=c.log2_hashmap_size,
             resolutions_list_2D=c.resolutions_list_2D, log2_hashmap_size_2D=c.log2_hashmap_size_2D,
-            ste_binary=True, Q=10).to(self.device)
+            ste_binary=True, Q=10, fused_features=c.fused_features).to(self.device)
         self.context = CNC_context_models(
             num_dim=3, resolutions_list=c.resolutions_list, resolutions_list_2D=c.resolutions_list_2D,
             log2_hashmap_size=c.log2_hashmap_size, log2_hashmap_size_2D=c.log2_hashmap_size_2D,

@@ -66,7 +66,12 @@ int cnc_grid_encode_forward(const float* inputs, const float* embeddings,
                             uint32_t N, uint32_t D, uint32_t F, uint32_t L,
                             uint32_t Rb, float PV,
                             float* dy_dx, const uint8_t* binary_vxl, const int32_t* min_level_id,
-                            uint32_t flags, const int32_t* occ_sat, void* stream);
+                            uint32_t flags, const int32_t* occ_sat,
+                            uint32_t out_ld, uint32_t out_col, void* stream);
+/*   out_ld / out_col: 0 / 0 = the reference's level-major outputs [L, N, F].  out_ld != 0: write
+ *   point-major into a wider feature matrix, outputs[b * out_ld + out_col + l * F + f], so several
+ *   encoders fill the MLP input directly (no permute, no cat; ngp.py:111,631-642).  Requires
+ *   out_col + L*F <= out_ld and both multiples of min(F, 4).                                       */
 /*   occ_sat (may be NULL; only read when binary_vxl != NULL): summed-volume table of binary_vxl,
  *   int32 [(Rb+1)^D], sat[a][b][c] = #set cells with indices < (a,b,c).  With it the per-corner
  *   occupancy test costs 2^D loads instead of a scan of the whole +-1 vertex box; the result is
@@ -82,7 +87,8 @@ int cnc_grid_encode_backward(const float* grad, const float* inputs, const float
                              const float* dy_dx, float* grad_inputs,
                              const uint8_t* binary_vxl, const int32_t* min_level_id,
                              uint32_t flags, const uint32_t* ste_clip_count,
-                             const int32_t* occ_sat, void* stream);
+                             const int32_t* occ_sat, uint32_t grad_ld, uint32_t grad_col,
+                             void* stream);   /* grad_ld/grad_col: layout of `grad`, as out_ld/out_col */
 /*   ste_clip_count (device pointer, may be NULL): with CNC_FLAG_STE_BINARY, the number of table
  *   entries with |v| > 1 as counted by cnc_pack_sign_bits.  When it reads 0 the STE mask is the
  *   identity and the scatter skips the per-row parameter gather it otherwise needs.            */
@@ -102,7 +108,8 @@ int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* bits,
                                  float* outputs,
                                  uint32_t N, uint32_t D, uint32_t F, uint32_t L, uint32_t Rb,
                                  const uint8_t* binary_vxl, const int32_t* min_level_id,
-                                 const int32_t* occ_sat, void* stream);
+                                 const int32_t* occ_sat, uint32_t grad_ld, uint32_t grad_col,
+                             void* stream);   /* grad_ld/grad_col: layout of `grad`, as out_ld/out_col */
 
 /* cnt_np_embed (gridencoder.h:39-44, gridencoder.cu:873-970): ±1 vote counts of the finest 3-D
  * level projected on a plane.  inputs i16 [N,3]; embeddings_clip [hashmap_size, F] f32;

@@ -91,3 +91,36 @@ def test_field_shapes_and_sh(cuda):
     Y = sh((v + 1) / 2)
     gram = (Y.T @ Y) / v.shape[0] * 4 * math.pi
     assert torch.allclose(gram, torch.eye(16, device=cuda), atol=0.03)
+
+
+@pytest.mark.parametrize("F", [1, 2, 4, 8])
+def test_fused_field_features_match_cat(cuda, F):
+    """Encoders writing point-major into the MLP input (cnc_grid_encode_*'s out_ld/out_col) give the
+    same feature matrix as permute + cat (ngp.py:111,631-642), and the same parameter gradients."""
+    from cnc_amd.field import NGPRadianceField_mygrid_2D3D
+    torch.manual_seed(3)
+    kw = dict(aabb=[-1.5] * 3 + [1.5] * 3, n_features_per_level=F, n_neurons=32,
+              resolutions_list=(10, 18, 33, 70), log2_hashmap_size=12,
+              resolutions_list_2D=(34, 130, 258), log2_hashmap_size_2D=10)
+    a = NGPRadianceField_mygrid_2D3D(fused_features=True, **kw).to(cuda)
+    b = NGPRadianceField_mygrid_2D3D(fused_features=False, **kw).to(cuda)
+    with torch.no_grad():
+        for p in a.parameters():
+            p.uniform_(-1.5, 1.5)       # some |p| > 1: STE mask in play
+    b.load_state_dict(a.state_dict())
+    x = torch.rand(5000, 3, device=cuda)
+    assert a.mlp_base._can_fuse(x) and not b.mlp_base._can_fuse(x)
+    fa, fb = a.mlp_base.features_fused(x), b.mlp_base.features(x)
+    w = fb.shape[1]
+    assert fa.shape[1] % 4 == 0 and torch.equal(fa[:, :w], fb) and (fa[:, w:] == 0).all()
+    ya, yb = a.mlp_base(x), b.mlp_base(x)
+    assert torch.allclose(ya, yb, rtol=1e-4, atol=1e-4)
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pa.grad is None:
+            assert pb.grad is None
+            continue
+        scale = pb.grad.abs().max().clamp_min(1e-6)
+        assert (pa.grad - pb.grad).abs().max() <= 2e-4 * scale, n

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cnc_amd.trainer import TrainConfig, Trainer
 
-cfg = TrainConfig(n_features=8, sample_num=150000, max_steps=400, image_size=400, out_dir="/tmp/bits")
+cfg = TrainConfig(n_features=8, sample_num=150000, max_steps=400, image_size=400, out_dir="/tmp/bits",
+                  fused_features="--unfused" not in sys.argv)
 t0 = time.time()
 tr = Trainer(cfg, device=torch.device("cuda:0"))
 torch.cuda.synchronize()
@@ -17,6 +18,8 @@ for step in range(300):
 torch.cuda.synchronize()
 dt = (time.time() - t0) / 200
 print(f"train step: {dt*1e3:.1f} ms  last: {s}")
+if "--no-profile" in sys.argv:
+    sys.exit(0)
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     for step in range(301, 305):
