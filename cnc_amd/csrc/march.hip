@@ -77,6 +77,54 @@ struct Seg {
     uint8_t* is_valid;
 };
 
+// Samples / interval edges a lane may hold in LDS before the wave writes them out together.
+constexpr int kStage = 16;
+constexpr int kStagePitch = kStage + 1;   // +1: the flush reads a lane's row with 16 lanes, conflict-free
+
+// LDS staging of one wave (FILL pass only): [64][17] sample mids, [64][17] interval edges,
+// [64][17] interval flag bytes (bit 0 = is_left, bit 1 = is_right).
+struct Stage {
+    float*   sm;
+    float*   iv;
+    uint8_t* ivf;
+};
+
+// The wave writes what its 64 rays staged: four source rays per step, 16 lanes each, so a ray's
+// entries leave as one contiguous 64-byte (vals), 128-byte (ray_indices) and 16-byte (flags) piece
+// instead of one transaction per lane and array.  `cnt` entries of lane `src` go to out[g .. g+cnt).
+template <bool IV>
+__device__ __forceinline__ void flush_stage(const Stage& st, const Seg& o, uint32_t cnt, int64_t g,
+                                            int32_t ray)
+{
+    const uint32_t lane = threadIdx.x, sub = lane >> 4, e = lane & 15;
+#pragma unroll 1
+    for (uint32_t it = 0; it < 16; it++) {
+        const uint32_t src = it * 4 + sub;
+        const uint32_t c = (uint32_t)__shfl((int)cnt, (int)src);
+        const int64_t  gs = __shfl(g, (int)src);
+        const int32_t  r = __shfl(ray, (int)src);
+        if (e < c) {
+            const int64_t k = gs + e;
+            if constexpr (IV) {
+                const uint8_t f = st.ivf[src * kStagePitch + e];
+                o.vals[k] = st.iv[src * kStagePitch + e];
+                o.ray_indices[k] = r;
+                o.is_left[k] = f & 1;
+                o.is_right[k] = (f >> 1) & 1;
+            } else {
+                o.vals[k] = st.sm[src * kStagePitch + e];
+                o.ray_indices[k] = r;
+                o.is_valid[k] = 1;
+            }
+        }
+    }
+}
+
+// One lane marches one ray (a serial DDA).  FILL = false: count only (first pass).  FILL = true:
+// the march is resumable — a lane stops when its LDS staging row is full, the wave flushes all 64
+// rows with coalesced stores (flush_stage), and the lane continues exactly where it stopped
+// (same registers, same cell), so values and order equal the one-sweep march of grid.cu:68-318.
+template <bool FILL>
 __global__ __launch_bounds__(64) void k_traverse(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const uint8_t* __restrict__ rays_mask, int32_t n_rays, const uint8_t* __restrict__ binaries,
@@ -84,145 +132,217 @@ __global__ __launch_bounds__(64) void k_traverse(
     const uint8_t* __restrict__ hits, const float* __restrict__ t_sorted,
     const int64_t* __restrict__ t_indices, const float* __restrict__ near_planes,
     const float* __restrict__ far_planes, float step_size, float cone_angle, int32_t limit,
-    int32_t first_pass, Seg iv, Seg sm, float* __restrict__ terminate_planes)
+    Seg iv, Seg sm, float* __restrict__ terminate_planes)
 {
+    extern __shared__ float s_dyn[];
     const float eps = 1e-6f;
     const int   res[3] = {resx, resy, resz};
     const bool  has_iv = iv.chunk_cnts != nullptr, has_sm = sm.chunk_cnts != nullptr;
+    const uint32_t lane = threadIdx.x;
+    const int32_t  tid = blockIdx.x * 64 + lane;
 
-    for (int32_t tid = blockIdx.x * blockDim.x + threadIdx.x; tid < n_rays;
-         tid += blockDim.x * gridDim.x) {
-        if (rays_mask != nullptr && !rays_mask[tid]) continue;
-        if (has_iv && !first_pass && iv.chunk_cnts[tid] == 0) continue;
-        if (has_sm && !first_pass && sm.chunk_cnts[tid] == 0) continue;
-        int64_t cs_iv = 0, cs_sm = 0;
-        if (!first_pass) {
-            if (has_iv) cs_iv = iv.chunk_starts[tid];
-            if (has_sm) cs_sm = sm.chunk_starts[tid];
-        }
-        const float near_plane = near_planes[tid], far_plane = far_planes[tid];
-        const float o[3] = {rays_o[(size_t)tid * 3], rays_o[(size_t)tid * 3 + 1], rays_o[(size_t)tid * 3 + 2]};
-        const float dir[3] = {rays_d[(size_t)tid * 3], rays_d[(size_t)tid * 3 + 1], rays_d[(size_t)tid * 3 + 2]};
-        const float inv[3] = {1.0f / dir[0], 1.0f / dir[1], 1.0f / dir[2]};
-        const int32_t base_hits = tid * n_grids, base_t = tid * n_grids * 2;
+    Stage st{};
+    if constexpr (FILL) {
+        st.sm = s_dyn;
+        st.iv = s_dyn + 64 * kStagePitch;
+        st.ivf = (uint8_t*)(s_dyn + 2 * 64 * kStagePitch);
+    }
 
-        int64_t n_iv = 0, n_sm = 0;
-        float   t_last = near_plane;
-        bool    continuous = false;
-
-        for (int32_t i = base_t; i < base_t + n_grids * 2 - 1; i++) {
-            const bool is_entering = t_indices[i] < n_grids;
-            int64_t    level = t_indices[i] % n_grids;
-            if (!hits[base_hits + level]) continue;
-            if (!is_entering) {
-                if (t_indices[i + 1] < n_grids) continue;
-                level = t_indices[i + 1] % n_grids;
-                if (!hits[base_hits + level]) continue;
-            }
-            const float this_tmin = fmaxf(t_sorted[i], near_plane);
-            const float this_tmax = fminf(t_sorted[i + 1], far_plane);
-            if (this_tmin >= this_tmax) continue;
-
-            if (!continuous) {
-                if (step_size <= 0.0f) {
-                    t_last = this_tmin;
-                } else {
-                    const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
-                    while (!(t_last + dt * 0.5f >= this_tmin)) t_last += dt;
-                }
-            }
-
-            const float* bb = aabbs + level * 6;
-            float tdist[3], delta[3];
-            int   step_i[3], cur[3], over[3];
+    bool live = tid < n_rays;
+    if (live && rays_mask != nullptr && !rays_mask[tid]) live = false;
+    if constexpr (FILL) {
+        if (live && has_iv && iv.chunk_cnts[tid] == 0) live = false;
+        if (live && has_sm && sm.chunk_cnts[tid] == 0) live = false;
+    }
+    int64_t cs_iv = 0, cs_sm = 0;
+    if (FILL && live) {
+        if (has_iv) cs_iv = iv.chunk_starts[tid];
+        if (has_sm) cs_sm = sm.chunk_starts[tid];
+    }
+    float near_plane = 0, far_plane = 0, o[3] = {0, 0, 0}, dir[3] = {1, 1, 1};
+    if (live) {
+        near_plane = near_planes[tid];
+        far_plane = far_planes[tid];
 #pragma unroll
-            for (int a = 0; a < 3; a++) {   // setup_traversal, utils_grid.cuh:59-118
-                const float resf = (float)res[a];
-                const float ext = bb[3 + a] - bb[a];
-                const float voxel = ext / resf;
-                const float rs = __builtin_fmaf(dir[a], this_tmin + eps, o[a]);
-                const float re = __builtin_fmaf(dir[a], this_tmax - eps, o[a]);
-                cur[a] = clampi((int)(((rs - bb[a]) / ext) * resf), 0, res[a] - 1);
-                const int fin = clampi((int)(((re - bb[a]) / ext) * resf), 0, res[a] - 1);
-                const int start_index = cur[a] + (dir[a] > 0 ? 1 : 0);
-                const float txyz = __builtin_fmaf(
-                    bb[a] + __builtin_fmaf((float)start_index, voxel, -rs), inv[a], this_tmin);
-                const bool  flat = dir[a] == 0.0f;
-                const float sf = flat ? 0.0f : (dir[a] > 0.0f ? 1.0f : -1.0f);
-                tdist[a] = flat ? this_tmax : txyz;
-                step_i[a] = (int)sf;
-                delta[a] = flat ? this_tmax : voxel * inv[a] * sf;
-                over[a] = fin + step_i[a];
-            }
+        for (int a = 0; a < 3; a++) {
+            o[a] = rays_o[(size_t)tid * 3 + a];
+            dir[a] = rays_d[(size_t)tid * 3 + a];
+        }
+    }
+    const float inv[3] = {1.0f / dir[0], 1.0f / dir[1], 1.0f / dir[2]};
+    const int32_t base_hits = tid * n_grids, base_t = tid * n_grids * 2;
+    const int32_t i_end = base_t + n_grids * 2 - 1;
 
-            while (limit <= 0 || n_sm < limit) {
-                float t_trav = fminf(tdist[0], fminf(tdist[1], tdist[2]));
-                t_trav = fminf(t_trav, this_tmax);
-                const int64_t cell = (int64_t)(cur[0] * res[1] * res[2] + cur[1] * res[2] + cur[2])
-                                     + level * res[0] * res[1] * res[2];
-                if (!binaries[cell]) {
-                    if (step_size <= 0.0f) {
-                        t_last = t_trav;
-                    } else {
-                        const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
-                        while (!(t_last + dt * 0.5f >= t_trav)) t_last += dt;
+    // march state, kept in registers across flushes
+    int64_t n_iv = 0, n_sm = 0;
+    float   t_last = near_plane;
+    bool    continuous = false;
+    int32_t i = base_t;
+    bool    resume = false, finished = !live;
+    int64_t level = 0;
+    float   this_tmax = 0;
+    float   tdist[3] = {0, 0, 0}, delta[3] = {0, 0, 0};
+    int     step_i[3] = {0, 0, 0}, cur[3] = {0, 0, 0}, over[3] = {0, 0, 0};
+    uint32_t st_sm = 0, st_iv = 0;     // entries staged in LDS
+    int64_t  fl_sm = 0, fl_iv = 0;     // entries already written out
+
+    for (;;) {
+        if (!finished) {
+            bool paused = false;
+            for (; i < i_end; i++) {
+                if (!resume) {
+                    const bool is_entering = t_indices[i] < n_grids;
+                    level = t_indices[i] % n_grids;
+                    if (!hits[base_hits + level]) continue;
+                    if (!is_entering) {
+                        if (t_indices[i + 1] < n_grids) continue;
+                        level = t_indices[i + 1] % n_grids;
+                        if (!hits[base_hits + level]) continue;
                     }
-                    continuous = false;
-                } else {
-                    while (limit <= 0 || n_sm < limit) {
-                        float t_next;
+                    const float this_tmin = fmaxf(t_sorted[i], near_plane);
+                    this_tmax = fminf(t_sorted[i + 1], far_plane);
+                    if (this_tmin >= this_tmax) continue;
+
+                    if (!continuous) {
                         if (step_size <= 0.0f) {
-                            t_next = t_trav;
+                            t_last = this_tmin;
                         } else {
                             const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
-                            if (t_last + dt * 0.5f >= t_trav) break;
-                            t_next = t_last + dt;
+                            while (!(t_last + dt * 0.5f >= this_tmin)) t_last += dt;
                         }
-                        if (has_iv) {
-                            if (!continuous) {
-                                if (!first_pass) {
-                                    const int64_t k = cs_iv + n_iv;
-                                    iv.vals[k] = t_last;
-                                    iv.ray_indices[k] = tid;
-                                    iv.is_left[k] = 1;
-                                    iv.vals[k + 1] = t_next;
-                                    iv.ray_indices[k + 1] = tid;
-                                    iv.is_right[k + 1] = 1;
-                                }
-                                n_iv += 2;
-                            } else {
-                                if (!first_pass) {
-                                    const int64_t k = cs_iv + n_iv;
-                                    iv.vals[k] = t_next;
-                                    iv.ray_indices[k] = tid;
-                                    iv.is_left[k - 1] = 1;
-                                    iv.is_right[k] = 1;
-                                }
-                                n_iv += 1;
-                            }
-                        }
-                        if (has_sm && !first_pass) {
-                            const int64_t k = cs_sm + n_sm;
-                            sm.vals[k] = (t_next + t_last) * 0.5f;
-                            sm.ray_indices[k] = tid;
-                            sm.is_valid[k] = 1;
-                        }
-                        n_sm++;
-                        continuous = true;
-                        t_last = t_next;
-                        if (t_next >= t_trav) break;
+                    }
+
+                    const float* bb = aabbs + level * 6;
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {   // setup_traversal, utils_grid.cuh:59-118
+                        const float resf = (float)res[a];
+                        const float ext = bb[3 + a] - bb[a];
+                        const float voxel = ext / resf;
+                        const float rs = __builtin_fmaf(dir[a], this_tmin + eps, o[a]);
+                        const float re = __builtin_fmaf(dir[a], this_tmax - eps, o[a]);
+                        cur[a] = clampi((int)(((rs - bb[a]) / ext) * resf), 0, res[a] - 1);
+                        const int fin = clampi((int)(((re - bb[a]) / ext) * resf), 0, res[a] - 1);
+                        const int start_index = cur[a] + (dir[a] > 0 ? 1 : 0);
+                        const float txyz = __builtin_fmaf(
+                            bb[a] + __builtin_fmaf((float)start_index, voxel, -rs), inv[a], this_tmin);
+                        const bool  flat = dir[a] == 0.0f;
+                        const float sf = flat ? 0.0f : (dir[a] > 0.0f ? 1.0f : -1.0f);
+                        tdist[a] = flat ? this_tmax : txyz;
+                        step_i[a] = (int)sf;
+                        delta[a] = flat ? this_tmax : voxel * inv[a] * sf;
+                        over[a] = fin + step_i[a];
                     }
                 }
-                // single_traversal, utils_grid.cuh:121-149 (strict '<' tie-break x, y, then z)
-                const int ax = (tdist[0] < tdist[1] && tdist[0] < tdist[2]) ? 0
-                               : (tdist[1] < tdist[2] ? 1 : 2);
-                bool done;
-                if (ax == 0)      { cur[0] += step_i[0]; tdist[0] += delta[0]; done = cur[0] == over[0]; }
-                else if (ax == 1) { cur[1] += step_i[1]; tdist[1] += delta[1]; done = cur[1] == over[1]; }
-                else              { cur[2] += step_i[2]; tdist[2] += delta[2]; done = cur[2] == over[2]; }
-                if (done) break;
+                resume = false;
+
+                while (limit <= 0 || n_sm < limit) {
+                    float t_trav = fminf(tdist[0], fminf(tdist[1], tdist[2]));
+                    t_trav = fminf(t_trav, this_tmax);
+                    const int64_t cell = (int64_t)(cur[0] * res[1] * res[2] + cur[1] * res[2] + cur[2])
+                                         + level * res[0] * res[1] * res[2];
+                    if (!binaries[cell]) {
+                        if (step_size <= 0.0f) {
+                            t_last = t_trav;
+                        } else {
+                            const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                            while (!(t_last + dt * 0.5f >= t_trav)) t_last += dt;
+                        }
+                        continuous = false;
+                    } else {
+                        while (limit <= 0 || n_sm < limit) {
+                            if constexpr (FILL) {
+                                // no room for this step's entries: stop here, flush, come back
+                                if (st_sm >= (uint32_t)kStage || st_iv + 2 > (uint32_t)kStage) {
+                                    paused = true;
+                                    break;
+                                }
+                            }
+                            float t_next;
+                            if (step_size <= 0.0f) {
+                                t_next = t_trav;
+                            } else {
+                                const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                                if (t_last + dt * 0.5f >= t_trav) break;
+                                t_next = t_last + dt;
+                            }
+                            if (has_iv) {
+                                if (!continuous) {
+                                    if constexpr (FILL) {
+                                        float*   v = st.iv + lane * kStagePitch + st_iv;
+                                        uint8_t* f = st.ivf + lane * kStagePitch + st_iv;
+                                        v[0] = t_last; f[0] = 1;
+                                        v[1] = t_next; f[1] = 2;
+                                        st_iv += 2;
+                                    }
+                                    n_iv += 2;
+                                } else {
+                                    if constexpr (FILL) {
+                                        // the previous edge is still staged (the flush keeps the
+                                        // last one back), so it can become a left edge here
+                                        st.iv[lane * kStagePitch + st_iv] = t_next;
+                                        st.ivf[lane * kStagePitch + st_iv - 1] |= 1;
+                                        st.ivf[lane * kStagePitch + st_iv] = 2;
+                                        st_iv += 1;
+                                    }
+                                    n_iv += 1;
+                                }
+                            }
+                            if constexpr (FILL) {
+                                if (has_sm) {
+                                    st.sm[lane * kStagePitch + st_sm] = (t_next + t_last) * 0.5f;
+                                    st_sm++;
+                                }
+                            }
+                            n_sm++;
+                            continuous = true;
+                            t_last = t_next;
+                            if (t_next >= t_trav) break;
+                        }
+                        if (paused) break;
+                    }
+                    // single_traversal, utils_grid.cuh:121-149 (strict '<' tie-break x, y, then z)
+                    const int ax = (tdist[0] < tdist[1] && tdist[0] < tdist[2]) ? 0
+                                   : (tdist[1] < tdist[2] ? 1 : 2);
+                    bool done;
+                    if (ax == 0)      { cur[0] += step_i[0]; tdist[0] += delta[0]; done = cur[0] == over[0]; }
+                    else if (ax == 1) { cur[1] += step_i[1]; tdist[1] += delta[1]; done = cur[1] == over[1]; }
+                    else              { cur[2] += step_i[2]; tdist[2] += delta[2]; done = cur[2] == over[2]; }
+                    if (done) break;
+                }
+                if (paused) {
+                    resume = true;
+                    break;
+                }
             }
+            if (!paused) finished = true;
         }
+        if constexpr (!FILL) break;
+        if constexpr (FILL) {
+            __syncthreads();   // one wave per workgroup: orders the LDS writes before the reads
+            if (has_sm) {
+                flush_stage<false>(st, sm, st_sm, cs_sm + fl_sm, tid);
+                fl_sm += st_sm;
+                st_sm = 0;
+            }
+            if (has_iv) {
+                // keep the newest edge back while the ray is still marching: the next sample may
+                // turn it into a left edge
+                const uint32_t keep = (!finished && st_iv > 0) ? 1u : 0u;
+                const uint32_t out = st_iv - keep;
+                flush_stage<true>(st, iv, out, cs_iv + fl_iv, tid);
+                __syncthreads();
+                if (keep && out > 0) {
+                    st.iv[lane * kStagePitch] = st.iv[lane * kStagePitch + out];
+                    st.ivf[lane * kStagePitch] = st.ivf[lane * kStagePitch + out];
+                }
+                fl_iv += out;
+                st_iv = keep;
+            }
+            __syncthreads();
+            if (__ballot(!finished) == 0) break;
+        }
+    }
+    if (live) {
         if (terminate_planes != nullptr) terminate_planes[tid] = t_last;
         if (has_iv) iv.chunk_cnts[tid] = n_iv;
         if (has_sm) sm.chunk_cnts[tid] = n_sm;
@@ -283,9 +403,17 @@ extern "C" int cnc_traverse_grids(const float* rays_o, const float* rays_d,
             return CNC_ERR_INVALID_VALUE;
     }
     const uint32_t blocks = div_up((uint32_t)n_rays, 64);
-    hipLaunchKernelGGL(k_traverse, dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d,
-                       rays_mask, n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits,
-                       t_sorted, t_indices, near_planes, far_planes, step_size, cone_angle,
-                       traverse_steps_limit, first_pass, iv, sm, terminate_planes);
+    if (first_pass) {
+        hipLaunchKernelGGL(k_traverse<false>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o,
+                           rays_d, rays_mask, n_rays, binaries, n_grids, resx, resy, resz, aabbs,
+                           hits, t_sorted, t_indices, near_planes, far_planes, step_size,
+                           cone_angle, traverse_steps_limit, iv, sm, terminate_planes);
+    } else {
+        const size_t lds = 64 * kStagePitch * (2 * sizeof(float) + 1);
+        hipLaunchKernelGGL(k_traverse<true>, dim3(blocks), dim3(64), lds, (hipStream_t)stream, rays_o,
+                           rays_d, rays_mask, n_rays, binaries, n_grids, resx, resy, resz, aabbs,
+                           hits, t_sorted, t_indices, near_planes, far_planes, step_size,
+                           cone_angle, traverse_steps_limit, iv, sm, terminate_planes);
+    }
     return launch_status();
 }
