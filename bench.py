@@ -73,6 +73,7 @@ def build_workload(dev, rank):
     table = (torch.rand((int(offs[-1]), F), generator=g) * 2 - 1) * 1e-4
     w = dict(
         offsets=torch.as_tensor(offs, device=dev),
+        offsets_host=[int(o) for o in offs],
         resolutions=torch.tensor(synthetic.RES_16L, dtype=torch.int32, device=dev),
         table=table.to(dev),
         binaries=synthetic.ball_binaries(128, AABB, 1.0, device=dev),
@@ -123,7 +124,8 @@ def step(w, timed, world):
         # the encoder output doubles as a resident, non-trivial upstream gradient [L, n, F]
         timed.launch("grid_encode_backward", n, lambda: enc.grid_encode_backward(
             o, xs, w["table"], w["offsets"], w["resolutions"], gt, n, D, F, L, 0, 128, None, None, None, None,
-            ste_binary=True, ste_clip_count=w["clip"]))
+            ste_binary=True, ste_clip_count=w["clip"],
+            binned=enc.plan_binned_levels(synthetic.RES_16L, w["offsets_host"], D, F, n)))
     if world > 1:
         # the only exchange of the path: one flat-bucket all-reduce of the table gradient
         timed.launch("allreduce(grad_table)", gt.numel() * 4, lambda: w["bucket"].allreduce(average=True))

@@ -26,6 +26,9 @@ class RaySegments(C.Structure):
 SIGNATURES = {
     "cnc_grid_encode_forward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _u32, _vp, _u32, _u32, _vp],
     "cnc_grid_encode_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp],
+    "cnc_grid_encode_backward_binned_workspace": [_u32, _u32, _u32],
+    "cnc_grid_encode_backward_binned": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32,
+                                        _u32, _u32, _vp, C.c_uint64, _vp],
     "cnc_pack_sign_bits": [_vp, _vp, C.c_uint64, _u32, _vp, _vp],
     "cnc_grid_encode_forward_bits": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_mlp_forward": [_vp, _u32, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _u32, _u32, _vp],
@@ -47,6 +50,9 @@ SIGNATURES = {
     "cnc_exclusive_prod_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _i64, _vp],
 }
 
+# entry points that return something other than a status code
+RESTYPES = {"cnc_grid_encode_backward_binned_workspace": C.c_uint64}
+
 CNC_FLAG_STE_BINARY = 1
 
 
@@ -62,7 +68,7 @@ def lib() -> C.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = argtypes
-            fn.restype = C.c_int
+            fn.restype = RESTYPES.get(name, C.c_int)
         L.cnc_error_string.argtypes = [C.c_int]
         L.cnc_error_string.restype = C.c_char_p
         L.cnc_abi_version.restype = C.c_int

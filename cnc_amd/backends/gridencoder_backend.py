@@ -89,7 +89,9 @@ def grid_encode_forward(inputs, embeddings, offsets_list, resolutions_list, outp
 def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_list, grad_embeddings,
                          N, num_dim, n_features, n_levels, max_level, Rb, dy_dx=None,
                          grad_inputs=None, binary_vxl=None, min_level_id=None, *, ste_binary=False,
-                         ste_clip_count=None, occ_sat=None, grad_ld=0, grad_col=0):
+                         ste_clip_count=None, occ_sat=None, grad_ld=0, grad_col=0, binned=None):
+    """gridencoder.h:24-36.  `binned` (extension) = (n_binned, level_rows) from `plan_binned_levels`:
+    take that many finest levels off the global-atomic path (cnc_grid_encode_backward_binned)."""
     _common_checks([("grad", grad), ("inputs", inputs), ("embeddings", embeddings),
                     ("offsets_list", offsets_list), ("resolutions_list", resolutions_list),
                     ("grad_embeddings", grad_embeddings)])
@@ -108,6 +110,19 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         raise RuntimeError("GridEncoding: num_dim must be 1, 2, 3.")
     if binary_vxl is not None:
         binary_vxl = binary_vxl.contiguous()
+    if binned is not None and binned[0] > 0 and binary_vxl is None and min_level_id is None \
+            and dy_dx is None and grad_inputs is None:
+        n_binned, level_rows = int(binned[0]), int(binned[1])
+        L = _lib.lib()
+        nbytes = int(L.cnc_grid_encode_backward_binned_workspace(int(N), n_binned, level_rows))
+        ws = _workspace(grad.device, nbytes)
+        rc = L.cnc_grid_encode_backward_binned(
+            ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
+            ptr(grad_embeddings), int(N), int(num_dim), int(n_features), int(n_levels),
+            _lib.CNC_FLAG_STE_BINARY if ste_binary else 0, ptr(ste_clip_count), int(grad_ld),
+            int(grad_col), n_binned, level_rows, ptr(ws), ws.numel(), stream())
+        check(rc, "grid_encode_backward_binned")
+        return
     rc = _lib.lib().cnc_grid_encode_backward(
         ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
         ptr(grad_embeddings), int(N), int(num_dim), int(n_features), int(n_levels), int(Rb),
@@ -115,6 +130,43 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         _lib.CNC_FLAG_STE_BINARY if ste_binary else 0, ptr(ste_clip_count),
         ptr(_check_sat(occ_sat, binary_vxl)), int(grad_ld), int(grad_col), stream())
     check(rc, "grid_encode_backward")
+
+
+_WORKSPACES = {}
+
+
+def _workspace(device, nbytes):
+    """Scratch for the binned backward, grown on demand and reused (stream-ordered reuse is safe:
+    every call clears what it reads)."""
+    key = (device.type, device.index)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def plan_binned_levels(resolutions, offsets, num_dim, n_features, n_points, min_resolution=384,
+                       min_points=1 << 16):
+    """Which finest levels the binned backward should take: (n_binned, level_rows) or None.
+
+    `resolutions` / `offsets` are HOST sequences (the library never reads device tables on the host).
+    A level qualifies when its cells are finer than typical sample spacing (resolution >=
+    min_resolution: below that, consecutive ray samples share cells and the run-merging atomic
+    kernel is the cheaper one) and its table has at least 2^16 rows; the qualifying levels must be
+    the last ones."""
+    if num_dim != 3 or n_features not in (2, 4, 8) or n_points < min_points or n_points >= 1 << 28:
+        return None
+    res = [int(r) for r in resolutions]
+    off = [int(o) for o in offsets]
+    n, rows = 0, 0
+    for l in range(len(res) - 1, -1, -1):
+        r = off[l + 1] - off[l]
+        if res[l] < min_resolution or r < (1 << 16) or r > (1 << 20):
+            break
+        n += 1
+        rows = max(rows, r)
+    return (n, rows) if n else None
 
 
 def pack_sign_bits(embeddings, bits=None, clip_count=None):

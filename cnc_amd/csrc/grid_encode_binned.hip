@@ -1,0 +1,382 @@
+// grid_encode_binned.hip — embedding-gradient scatter of the finest levels WITHOUT global atomics.
+//
+// Same result as kernel_grid_backward (gridencoder.cu:399-585) for the levels it is given; the
+// coarser levels of the same call stay on the run-aggregated atomic kernel of grid_encode.hip.
+//
+// Why: on MI355X global fp32 atomics retire ~21 G (instruction, 64-byte segment) requests/s
+// wherever the line lives (tools/atomic_probe.hip), and at the finest levels every sample sits in
+// its own cell: 4 (y, z) corner pairs -> ~6 requests per (sample, level) that no amount of run
+// merging removes.  tools/owner_probe.hip measured the alternative built here at 0.15 ms per
+// 2^20-sample level against 0.31 ms for the atomic scatter:
+//
+//   pass 1  k_bwd_bin    every (sample, level) emits one 4-byte item per (dy, dz) corner pair into
+//                        the bin of the 256-row table slab that owns the pair's rows (two items if
+//                        the x-neighbours straddle a slab edge).  Per workgroup the items are
+//                        counted in an LDS histogram, space is reserved with ONE global atomic per
+//                        (workgroup, non-empty bin), and the items are written at LDS-ranked slots.
+//   pass 2  k_bwd_owner  one wave owns one slab: 256 rows x F floats of accumulators in LDS.  It
+//                        streams its bin (items coalesced, point + gradient row gathered one batch
+//                        ahead), recomputes the corner weights exactly as the scatter kernel does
+//                        and adds into LDS with plain read-modify-writes.  Lanes of one instruction
+//                        that hit the same row are serialised by a tag vote (write lane id to
+//                        tag[row], read back, winners go, losers retry) — LDS fp32 atomics were
+//                        measured 5x slower than this.  The slab is then added to the gradient
+//                        table with coalesced 16-byte accesses (STE mask applied there).
+//
+// A bin that fills up sends the excess items down the atomic path inside pass 1, so skewed inputs
+// stay correct.  Summation order differs from the atomic kernel's (as it does between any two
+// runs of that kernel); values agree to fp32 rounding.
+#include "common.hpp"
+#include "encoder_common.hpp"
+
+namespace cnc {
+
+constexpr uint32_t kSlabLog2 = 8;                  // rows per owner wave
+constexpr uint32_t kSlab = 1u << kSlabLog2;
+constexpr uint32_t kBinSamplesPerThread = 4;       // pass 1: 4096 samples per 1024-thread block
+constexpr uint32_t kMaxBins = 4096;                // LDS histogram size (level_rows <= 2^20)
+
+struct BinnedArgs {
+    const float*    grad;
+    const float*    inputs;
+    const float*    emb;
+    const int32_t*  offsets;
+    const int32_t*  resolutions;
+    float*          grad_emb;
+    uint32_t        N;
+    uint32_t        first_level;     // binned levels are [first_level, first_level + gridDim.y)
+    uint32_t        bins;            // slabs per level = ceil(level_rows / 256)
+    uint32_t        cap;             // item slots per bin
+    uint32_t*       bin_count;       // [n_binned][bins]
+    uint32_t*       items;           // [n_binned][bins][cap]
+    const uint32_t* clip_count;
+    FeatLayout      lay;
+};
+
+// item = sample << 4 | rows << 2 | pair;  pair = dy + 2*dz, rows bit 0 = corner x, bit 1 = corner x+1
+__device__ __forceinline__ uint32_t make_item(uint32_t sample, uint32_t rows, uint32_t pair)
+{
+    return (sample << 4) | (rows << 2) | pair;
+}
+
+template <uint32_t F, bool STE>
+__device__ __forceinline__ void atomic_row(const BinnedArgs& a, bool mask_on, uint32_t abs_row,
+                                           float tw, const float* __restrict__ g)
+{
+#pragma unroll
+    for (uint32_t f = 0; f < F; f++) {
+        const size_t at = (size_t)abs_row * F + f;
+        if (mask_on) {
+            const float e = a.emb[at];
+            if (!(e >= -1.0f && e <= 1.0f)) continue;
+        }
+        unsafeAtomicAdd(a.grad_emb + at, tw * g[f]);
+    }
+}
+
+template <uint32_t F, bool STE>
+__global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
+{
+    __shared__ uint32_t s_cnt[kMaxBins];
+    const uint32_t slot = a.first_level + blockIdx.y;
+    const uint32_t off = (uint32_t)a.offsets[slot];
+    const uint32_t hs = (uint32_t)a.offsets[slot + 1] - off;
+    const uint32_t R = (uint32_t)a.resolutions[slot];
+    // a level with more rows than the caller sized the bins for cannot be binned: all atomics
+    const bool     binnable = div_up(hs, kSlab) <= a.bins;
+    const bool     mask_on = STE && (a.clip_count == nullptr || *a.clip_count != 0);
+    uint32_t*      bin_count = a.bin_count + (size_t)blockIdx.y * a.bins;
+    uint32_t*      items = a.items + (size_t)blockIdx.y * a.bins * a.cap;
+    const uint32_t base_i = blockIdx.x * 1024 * kBinSamplesPerThread;
+
+    for (uint32_t b = threadIdx.x; b < a.bins; b += 1024) s_cnt[b] = 0;
+    __syncthreads();
+
+    // ---- count ----
+    if (binnable) {
+        for (uint32_t k = 0; k < kBinSamplesPerThread; k++) {
+            const uint32_t i = base_i + k * 1024 + threadIdx.x;
+            float x[3];
+            if (i < a.N && load_point<3>(a.inputs, i, x)) {
+                Corners<3, false> c;
+                c.setup(x, R, hs, 0, nullptr);
+#pragma unroll
+                for (uint32_t p = 0; p < 4; p++) {
+                    const bool     v0 = c.valid[2 * p], v1 = c.valid[2 * p + 1];
+                    const uint32_t b0 = c.row[2 * p] >> kSlabLog2, b1 = c.row[2 * p + 1] >> kSlabLog2;
+                    if (v0) atomicAdd(&s_cnt[b0], 1u);
+                    if (v1 && !(v0 && b1 == b0)) atomicAdd(&s_cnt[b1], 1u);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- reserve: one global atomic per non-empty bin of this block ----
+    for (uint32_t b = threadIdx.x; b < a.bins; b += 1024) {
+        const uint32_t n = s_cnt[b];
+        s_cnt[b] = n ? atomicAdd(&bin_count[b], n) : 0u;
+    }
+    __syncthreads();
+    // ---- emit ----
+    for (uint32_t k = 0; k < kBinSamplesPerThread; k++) {
+        const uint32_t i = base_i + k * 1024 + threadIdx.x;
+        float x[3];
+        if (!(i < a.N && load_point<3>(a.inputs, i, x))) continue;
+        Corners<3, false> c;
+        c.setup(x, R, hs, 0, nullptr);
+        float g[F];
+        bool  have_g = false;
+        auto  spill = [&](uint32_t corner) {   // bin full (or level not binnable): atomic path
+            if (!have_g) {
+                constexpr uint32_t V = F < 4 ? F : 4;
+                const float* gp = a.grad + feat_index(a.lay, slot, a.N, i, F);
+#pragma unroll
+                for (uint32_t q = 0; q < F; q += V) {
+                    float gv[V];
+                    load_vec<V>(gp + q, gv);
+#pragma unroll
+                    for (uint32_t j = 0; j < V; j++) g[q + j] = gv[j];
+                }
+                have_g = true;
+            }
+            atomic_row<F, STE>(a, mask_on, off + c.row[corner], c.w[corner] * c.wn_re, g);
+        };
+#pragma unroll
+        for (uint32_t p = 0; p < 4; p++) {
+            const bool     v0 = c.valid[2 * p], v1 = c.valid[2 * p + 1];
+            const uint32_t b0 = c.row[2 * p] >> kSlabLog2, b1 = c.row[2 * p + 1] >> kSlabLog2;
+            if (!binnable) {
+                if (v0) spill(2 * p);
+                if (v1) spill(2 * p + 1);
+                continue;
+            }
+            const bool together = v0 && v1 && b1 == b0;
+            if (v0) {
+                const uint32_t at = atomicAdd(&s_cnt[b0], 1u);
+                if (at < a.cap) {
+                    items[(size_t)b0 * a.cap + at] = make_item(i, together ? 3u : 1u, p);
+                } else {
+                    spill(2 * p);
+                    if (together) spill(2 * p + 1);
+                }
+            }
+            if (v1 && !together) {
+                const uint32_t at = atomicAdd(&s_cnt[b1], 1u);
+                if (at < a.cap) items[(size_t)b1 * a.cap + at] = make_item(i, 2u, p);
+                else spill(2 * p + 1);
+            }
+        }
+    }
+}
+
+// read-modify-write of one accumulator row (F floats) in LDS
+template <uint32_t F>
+__device__ __forceinline__ void lds_row_add(float* __restrict__ row, const float (&v)[F])
+{
+    constexpr uint32_t V = F < 4 ? F : 4;
+    using T = typename vecf<V>::type;
+#pragma unroll
+    for (uint32_t q = 0; q < F; q += V) {
+        T      t = *reinterpret_cast<T*>(row + q);
+        float* f = reinterpret_cast<float*>(&t);
+#pragma unroll
+        for (uint32_t j = 0; j < V; j++) f[j] += v[q + j];
+        *reinterpret_cast<T*>(row + q) = t;
+    }
+}
+
+template <uint32_t F, bool STE>
+__global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
+{
+    constexpr uint32_t V = F < 4 ? F : 4;
+    __shared__ float   s_acc[kSlab * F];
+    __shared__ uint8_t s_tag[kSlab];
+    const uint32_t bin = blockIdx.x, lane = threadIdx.x;
+    const uint32_t slot = a.first_level + blockIdx.y;
+    const uint32_t off = (uint32_t)a.offsets[slot];
+    const uint32_t hs = (uint32_t)a.offsets[slot + 1] - off;
+    const uint32_t R = (uint32_t)a.resolutions[slot];
+    if (bin * kSlab >= hs) return;
+    uint32_t n = a.bin_count[(size_t)blockIdx.y * a.bins + bin];
+    if (n == 0) return;                 // nothing landed here: the table slab stays as it is
+    n = n < a.cap ? n : a.cap;
+    const uint32_t* my = a.items + ((size_t)blockIdx.y * a.bins + bin) * a.cap;
+
+    for (uint32_t k = lane; k < kSlab * F; k += 64) s_acc[k] = 0;
+
+    // next batch's raw data, in flight while the current batch is accumulated
+    uint32_t j = lane, nx_item = 0;
+    float    nx_x[3] = {0, 0, 0}, nx_g[F];
+    bool     nx_valid = false;
+    auto     prefetch = [&]() {
+        nx_valid = j < n;
+        if (nx_valid) {
+            nx_item = my[j];
+            const uint32_t i = nx_item >> 4;
+#pragma unroll
+            for (uint32_t d = 0; d < 3; d++) nx_x[d] = a.inputs[(size_t)i * 3 + d];
+            const float* gp = a.grad + feat_index(a.lay, slot, a.N, i, F);
+#pragma unroll
+            for (uint32_t q = 0; q < F; q += V) {
+                float gv[V];
+                load_vec<V>(gp + q, gv);
+#pragma unroll
+                for (uint32_t t = 0; t < V; t++) nx_g[q + t] = gv[t];
+            }
+        }
+        j += 64;
+    };
+    prefetch();
+    __syncthreads();   // single wave: orders the zero-fill before the first accumulate
+
+    while (__ballot(nx_valid) != 0) {
+        uint32_t pend = 0, r0 = 0, r1 = 0;
+        float    v0[F], v1[F];
+        if (nx_valid) {
+            const uint32_t pair = nx_item & 3u;
+            pend = (nx_item >> 2) & 3u;
+            Corners<3, false> c;
+            c.setup(nx_x, R, hs, 0, nullptr);
+            // corner index = dx + 2*dy + 4*dz, so the pair's corners are 2*pair and 2*pair + 1;
+            // a static select keeps the corner arrays in registers
+            float    w0 = 0, w1 = 0;
+            uint32_t q0 = 0, q1 = 0;
+#pragma unroll
+            for (uint32_t p = 0; p < 4; p++) {
+                if (p == pair) {
+                    w0 = c.w[2 * p];
+                    w1 = c.w[2 * p + 1];
+                    q0 = c.row[2 * p];
+                    q1 = c.row[2 * p + 1];
+                }
+            }
+            w0 *= c.wn_re;
+            w1 *= c.wn_re;
+            r0 = q0 & (kSlab - 1);
+            r1 = q1 & (kSlab - 1);
+#pragma unroll
+            for (uint32_t f = 0; f < F; f++) {
+                v0[f] = w0 * nx_g[f];
+                v1[f] = w1 * nx_g[f];
+            }
+        }
+        prefetch();
+        // tag vote: LDS instructions of a wave execute in order, so after every claimant wrote its
+        // id the read-back names exactly one winner per row; r0 != r1 within a lane
+        while (__ballot(pend != 0) != 0) {
+            if (pend & 1u) s_tag[r0] = (uint8_t)(2 * lane);
+            if (pend & 2u) s_tag[r1] = (uint8_t)(2 * lane + 1);
+            asm volatile("" ::: "memory");
+            const bool win0 = (pend & 1u) && s_tag[r0] == (uint8_t)(2 * lane);
+            const bool win1 = (pend & 2u) && s_tag[r1] == (uint8_t)(2 * lane + 1);
+            asm volatile("" ::: "memory");
+            if (win0) lds_row_add<F>(s_acc + r0 * F, v0);
+            asm volatile("" ::: "memory");
+            if (win1) lds_row_add<F>(s_acc + r1 * F, v1);
+            asm volatile("" ::: "memory");
+            pend &= ~((win0 ? 1u : 0u) | (win1 ? 2u : 0u));
+        }
+    }
+    __syncthreads();
+
+    // ---- slab -> gradient table (this wave is the only writer of these rows in this pass) ----
+    const bool     mask_on = STE && (a.clip_count == nullptr || *a.clip_count != 0);
+    const uint32_t rows = min(kSlab, hs - bin * kSlab);
+    const size_t   base = ((size_t)off + (size_t)bin * kSlab) * F;
+    for (uint32_t k = lane * V; k < rows * F; k += 64 * V) {
+        float t[V], e[V];
+        load_vec<V>(a.grad_emb + base + k, t);
+        if (mask_on) load_vec<V>(a.emb + base + k, e);
+#pragma unroll
+        for (uint32_t q = 0; q < V; q++) {
+            const bool pass = !mask_on || (e[q] >= -1.0f && e[q] <= 1.0f);
+            t[q] += pass ? s_acc[k + q] : 0.0f;
+        }
+        store_vec<V>(a.grad_emb + base + k, t);
+    }
+}
+
+template <uint32_t F>
+static void launch_binned(const BinnedArgs& a, uint32_t n_binned, bool ste, hipStream_t s)
+{
+    const dim3 g1(div_up(a.N, 1024 * kBinSamplesPerThread), n_binned), g2(a.bins, n_binned);
+    if (ste) {
+        hipLaunchKernelGGL((k_bwd_bin<F, true>), g1, dim3(1024), 0, s, a);
+        hipLaunchKernelGGL((k_bwd_owner<F, true>), g2, dim3(64), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((k_bwd_bin<F, false>), g1, dim3(1024), 0, s, a);
+        hipLaunchKernelGGL((k_bwd_owner<F, false>), g2, dim3(64), 0, s, a);
+    }
+}
+
+}  // namespace cnc
+
+using namespace cnc;
+
+// 2x the mean bin load (4 items per sample and level spread over the slabs), at least one batch
+static uint32_t default_cap(uint32_t N, uint32_t bins)
+{
+    const uint64_t mean = (4ull * N + bins - 1) / bins;
+    const uint64_t cap = 2 * mean + 64;
+    return (uint32_t)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap);
+}
+
+extern "C" uint64_t cnc_grid_encode_backward_binned_workspace(uint32_t N, uint32_t n_binned,
+                                                              uint32_t level_rows)
+{
+    if (n_binned == 0 || level_rows == 0) return 0;
+    const uint64_t bins = div_up(level_rows, kSlab);
+    return (uint64_t)n_binned * bins * (1 + (uint64_t)default_cap(N, (uint32_t)bins)) * 4;
+}
+
+extern "C" int cnc_grid_encode_backward_binned(const float* grad, const float* inputs,
+                                               const float* embeddings, const int32_t* offsets,
+                                               const int32_t* resolutions, float* grad_embeddings,
+                                               uint32_t N, uint32_t D, uint32_t F, uint32_t L,
+                                               uint32_t flags, const uint32_t* ste_clip_count,
+                                               uint32_t grad_ld, uint32_t grad_col,
+                                               uint32_t n_binned, uint32_t level_rows,
+                                               void* workspace, uint64_t workspace_bytes,
+                                               void* stream)
+{
+    if (N == 0 || L == 0) return CNC_OK;
+    if (!grad || !inputs || !embeddings || !offsets || !resolutions || !grad_embeddings)
+        return CNC_ERR_INVALID_VALUE;
+    if (n_binned > L) return CNC_ERR_INVALID_VALUE;
+    // what is not binned goes through the atomic kernel, with the same arguments
+    if (L - n_binned > 0) {
+        const int rc = cnc_grid_encode_backward(grad, inputs, embeddings, offsets, resolutions,
+                                                grad_embeddings, N, D, F, L - n_binned, 0, nullptr,
+                                                nullptr, nullptr, nullptr, flags, ste_clip_count,
+                                                nullptr, grad_ld, grad_col, stream);
+        if (rc != CNC_OK) return rc;
+    }
+    if (n_binned == 0) return CNC_OK;
+    if (D != 3 || !(F == 2 || F == 4 || F == 8)) return CNC_ERR_UNSUPPORTED;
+    if (N >= (1u << 28)) return CNC_ERR_UNSUPPORTED;              // 28-bit sample index in an item
+    if (grad_ld != 0) {
+        const uint32_t V = F < 4 ? F : 4;
+        if (grad_col + L * F > grad_ld || grad_ld % V || grad_col % V) return CNC_ERR_INVALID_VALUE;
+    } else if (grad_col != 0) {
+        return CNC_ERR_INVALID_VALUE;
+    }
+    const uint32_t bins = div_up(level_rows, kSlab);
+    if (bins == 0 || bins > kMaxBins || !workspace) return CNC_ERR_INVALID_VALUE;
+    const uint64_t words = workspace_bytes / 4, heads = (uint64_t)n_binned * bins;
+    if (words < heads * 65) return CNC_ERR_INVALID_VALUE;          // at least one batch per bin
+    uint64_t cap = (words - heads) / heads;
+    if (cap > 0x0FFFFFFFull) cap = 0x0FFFFFFFull;
+
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t*   ws = (uint32_t*)workspace;
+    if (hipMemsetAsync(ws, 0, heads * 4, s) != hipSuccess) return CNC_ERR_LAUNCH;
+    BinnedArgs a{grad, inputs, embeddings, offsets, resolutions, grad_embeddings, N, L - n_binned,
+                 bins, (uint32_t)cap, ws, ws + heads, ste_clip_count, FeatLayout{grad_ld, grad_col}};
+    const bool ste = (flags & CNC_FLAG_STE_BINARY) != 0;
+    switch (F) {
+    case 2: launch_binned<2>(a, n_binned, ste, s); break;
+    case 4: launch_binned<4>(a, n_binned, ste, s); break;
+    default: launch_binned<8>(a, n_binned, ste, s); break;
+    }
+    return launch_status();
+}

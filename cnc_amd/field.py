@@ -182,7 +182,7 @@ class _FusedFeatures(Function):
             be.grid_encode_backward(grad, xi, p, enc.offsets_list, enc.resolutions_list, g, N,
                                     enc.num_dim, enc.n_features, enc.n_levels, 0, 128, None, None,
                                     None, None, ste_binary=True, ste_clip_count=clip,
-                                    grad_ld=ld, grad_col=col)
+                                    grad_ld=ld, grad_col=col, binned=enc._binned_plan(N))
             grads.append(g)
         return (None, None, *grads)
 

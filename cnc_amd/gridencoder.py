@@ -63,7 +63,7 @@ class _grid_encode(Function):
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets_list, resolutions_list, calc_grad_inputs=False,
                 min_level_id=None, n_levels_calc=1, binary_vxl=None, PV=0, ste=False, bits=None,
-                clip_count=None, occ_sat=None):
+                clip_count=None, occ_sat=None, binned=None):
         inputs = inputs.contiguous()
         if calc_grad_inputs:
             # dead in the reference too (ngp.py:58-60)
@@ -98,6 +98,7 @@ class _grid_encode(Function):
         outputs = outputs.permute(1, 0, 2).reshape(N, n_levels_calc * n_features)
         ctx.save_for_backward(inputs, embeddings, offs, ress, binary_vxl, mli, clip_count, occ_sat)
         ctx.dims = (N, num_dim, n_features, n_levels_calc, Rb, ste)
+        ctx.binned = binned if (binary_vxl is None and mli is None) else None
         return outputs
 
     @staticmethod
@@ -109,8 +110,8 @@ class _grid_encode(Function):
         _backend.grid_encode_backward(grad, inputs, embeddings, offs, ress, grad_embeddings, N,
                                       num_dim, n_features, n_levels_calc, 0, Rb, None, None,
                                       binary_vxl, mli, ste_binary=ste, ste_clip_count=clip_count,
-                                      occ_sat=occ_sat)
-        return None, grad_embeddings, None, None, None, None, None, None, None, None, None, None, None
+                                      occ_sat=occ_sat, binned=ctx.binned)
+        return (None, grad_embeddings) + (None,) * 12
 
 
 grid_encode = _grid_encode.apply
@@ -149,6 +150,9 @@ class GridEncoder(nn.Module):
         for R in resolutions_list.tolist():
             rows = min(self.max_params, R ** num_dim)
             offsets.append(offsets[-1] + int(np.ceil(rows / 8) * 8))
+        # host copies: the binned-backward plan is made without reading device tables
+        self._off_host = list(offsets)
+        self._res_host = [int(r) for r in resolutions_list.tolist()]
         self.register_buffer("offsets_list", torch.from_numpy(np.array(offsets, dtype=np.int32)))
         self.register_buffer("resolutions_list", resolutions_list)
         self.n_params = self.offsets_list[-1] * n_features
@@ -176,6 +180,15 @@ class GridEncoder(nn.Module):
                 self._clip_count = cc
             self._bits_key = key
         return self._bits, self._clip_count
+
+    def _binned_plan(self, n_points, lo=0, hi=None, binary_vxl=None):
+        """(n_binned, level_rows) for the levels [lo, hi) of this call, or None (see
+        `gridencoder_backend.plan_binned_levels`)."""
+        if binary_vxl is not None:
+            return None
+        hi = self.n_levels if hi is None else hi
+        return _backend.plan_binned_levels(self._res_host[lo:hi], self._off_host[lo:hi + 1], self.num_dim,
+                                           self.n_features, n_points)
 
     def _occ_sat(self, binary_vxl):
         """Summed-volume table of the occupancy grid handed to a masked call, rebuilt only when the
@@ -216,7 +229,8 @@ class GridEncoder(nn.Module):
         n_levels_calc = max_level_id - min_level_id
         outputs = grid_encode(inputs, embeddings, self.offsets_list, self.resolutions_list, False,
                               min_level_id, n_levels_calc, binary_vxl, PV, ste, bits, clip,
-                              self._occ_sat(binary_vxl))
+                              self._occ_sat(binary_vxl),
+                              self._binned_plan(inputs.shape[0], min_level_id, max_level_id, binary_vxl))
         return outputs.view(prefix_shape + [n_levels_calc * self.n_features])
 
     def forward_diff_levels(self, inputs, min_level_id_list=None, n_levels_calc=1, test_phase=False,

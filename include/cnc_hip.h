@@ -108,8 +108,27 @@ int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* bits,
                                  float* outputs,
                                  uint32_t N, uint32_t D, uint32_t F, uint32_t L, uint32_t Rb,
                                  const uint8_t* binary_vxl, const int32_t* min_level_id,
-                                 const int32_t* occ_sat, uint32_t grad_ld, uint32_t grad_col,
-                             void* stream);   /* grad_ld/grad_col: layout of `grad`, as out_ld/out_col */
+                                 const int32_t* occ_sat, uint32_t out_ld, uint32_t out_col,
+                                 void* stream);   /* out_ld/out_col as cnc_grid_encode_forward */
+
+/* Same gradient as cnc_grid_encode_backward (no binary_vxl / min_level_id), with the n_binned FINEST
+ * levels taken off the global-atomic path (D = 3, F in {2,4,8}): their (sample, corner-pair)
+ * contributions are binned by 256-row table slab and summed in LDS by one wave per slab
+ * (cnc_amd/csrc/grid_encode_binned.hip).  Pays where every sample sits in its own cell, i.e. levels
+ * finer than the sample spacing; coarser levels stay on the run-merging atomic kernel.
+ *   level_rows: upper bound of rows per binned level (offsets[l+1]-offsets[l], <= 2^20); a level
+ *               with more rows than that is routed to atomics on the device, results unchanged.
+ *   workspace : device scratch of cnc_grid_encode_backward_binned_workspace(N, n_binned,
+ *               level_rows) bytes (more = deeper bins; a full bin spills to atomics).  The library
+ *               clears the part it needs; contents are dead after the call.                       */
+uint64_t cnc_grid_encode_backward_binned_workspace(uint32_t N, uint32_t n_binned, uint32_t level_rows);
+int cnc_grid_encode_backward_binned(const float* grad, const float* inputs, const float* embeddings,
+                                    const int32_t* offsets, const int32_t* resolutions,
+                                    float* grad_embeddings,
+                                    uint32_t N, uint32_t D, uint32_t F, uint32_t L, uint32_t flags,
+                                    const uint32_t* ste_clip_count, uint32_t grad_ld, uint32_t grad_col,
+                                    uint32_t n_binned, uint32_t level_rows,
+                                    void* workspace, uint64_t workspace_bytes, void* stream);
 
 /* cnt_np_embed (gridencoder.h:39-44, gridencoder.cu:873-970): ±1 vote counts of the finest 3-D
  * level projected on a plane.  inputs i16 [N,3]; embeddings_clip [hashmap_size, F] f32;

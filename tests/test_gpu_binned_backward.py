@@ -1,0 +1,125 @@
+"""Binned (atomic-free) embedding-gradient scatter for the finest levels
+(cnc_grid_encode_backward_binned) vs the CPU oracle's float64 shadow, and vs the atomic kernel."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_grid
+from test_gpu_encoder import _bwd_gpu, _check_bwd, _points
+
+pytestmark = pytest.mark.gpu
+
+RES = [6, 14, 31, 44]      # log2_T = 10: level 0 dense with 216 rows (a partial slab), 1-3 hashed, 1024 rows
+
+
+def _bwd_binned(dev, g, x, emb, offs, res, n_binned, level_rows, ste=False, ws_bytes=None, clip=None,
+                ld=0, col=0, g_dev=None):
+    from cnc_amd import _lib
+    t = lambda a: None if a is None else torch.as_tensor(a, device=dev)
+    L = len(res)
+    N, D = x.shape
+    F = emb.shape[1]
+    lib = _lib.lib()
+    if ws_bytes is None:
+        ws_bytes = int(lib.cnc_grid_encode_backward_binned_workspace(N, n_binned, level_rows))
+    ws = torch.full((max(ws_bytes, 4),), 0xAB, dtype=torch.uint8, device=dev)   # library must clear it
+    ge = torch.zeros(emb.shape, dtype=torch.float32, device=dev)
+    gd = t(g) if g_dev is None else g_dev
+    xd, ed, od, rd, cd = t(x), t(emb), t(offs), t(res), t(clip)
+    rc = lib.cnc_grid_encode_backward_binned(
+        gd.data_ptr(), xd.data_ptr(), ed.data_ptr(), od.data_ptr(), rd.data_ptr(), ge.data_ptr(),
+        N, D, F, L, _lib.CNC_FLAG_STE_BINARY if ste else 0, _lib.ptr(cd), ld, col,
+        n_binned, level_rows, ws.data_ptr(), ws_bytes, _lib.stream())
+    _lib.check(rc, "binned")
+    torch.cuda.synchronize()
+    return ge.cpu().numpy()
+
+
+@pytest.mark.parametrize("F", [2, 4, 8])
+@pytest.mark.parametrize("ste", [False, True])
+@pytest.mark.parametrize("n_binned", [1, 3, 4])
+def test_binned_backward_against_float64_shadow(cuda, oracle, F, ste, n_binned):
+    offs, resl, emb = make_grid(RES, 10, 3, F, seed=41)
+    x = _points(9001, 3, seed=42)
+    g = np.random.default_rng(43).normal(size=(len(RES), x.shape[0], F)).astype(np.float32)
+    want32, acc64 = oracle.grid_encode_backward(g, x, emb, offs, resl, ste_binary=ste, want_acc64=True)
+    _, abs64 = oracle.grid_encode_backward(np.abs(g), x, emb, offs, resl, ste_binary=ste, want_acc64=True)
+    got = _bwd_binned(cuda, g, x, emb, offs, resl, n_binned, 1024, ste=ste)
+    _check_bwd(got, want32, acc64, abs64, n_terms_max=x.shape[0] * 8)
+    if ste:
+        assert np.all(got[np.abs(emb) > 1] == 0)
+
+
+@pytest.mark.parametrize("case", ["tiny_workspace", "level_rows_too_small", "clip_count_zero"])
+def test_binned_backward_spill_and_fallback_paths(cuda, oracle, case):
+    """A full bin spills its excess items to atomics; a level with more rows than the bins were sized
+    for is scattered with atomics entirely; the clip-count hint skips the STE mask.  Same gradient."""
+    F = 8
+    offs, resl, emb = make_grid(RES, 10, 3, F, seed=51, binary=(case == "clip_count_zero"))
+    x = _points(6000, 3, seed=52)
+    g = np.random.default_rng(53).normal(size=(len(RES), x.shape[0], F)).astype(np.float32)
+    ste = case == "clip_count_zero"
+    want32, acc64 = oracle.grid_encode_backward(g, x, emb, offs, resl, ste_binary=ste, want_acc64=True)
+    _, abs64 = oracle.grid_encode_backward(np.abs(g), x, emb, offs, resl, ste_binary=ste, want_acc64=True)
+    kw = {}
+    if case == "tiny_workspace":
+        kw = dict(level_rows=1024, ws_bytes=3 * 4 * 65 * 4)          # 64 item slots per bin, ~6000 wanted
+    elif case == "level_rows_too_small":
+        kw = dict(level_rows=512)
+    else:
+        kw = dict(level_rows=1024, clip=np.zeros(1, np.int32))
+    got = _bwd_binned(cuda, g, x, emb, offs, resl, 3, ste=ste, **kw)
+    _check_bwd(got, want32, acc64, abs64, n_terms_max=x.shape[0] * 8)
+
+
+@pytest.mark.parametrize("N", [0, 1, 63, 4096, 4097])
+def test_binned_backward_ragged_sizes_match_atomic_kernel(cuda, N):
+    offs, resl, emb = make_grid(RES, 10, 3, 8, seed=61)
+    x = _points(N, 3, seed=62)
+    g = np.random.default_rng(63).normal(size=(len(RES), N, 8)).astype(np.float32)
+    a = _bwd_gpu(cuda, g, x, emb, offs, resl)
+    b = _bwd_binned(cuda, g, x, emb, offs, resl, 2, 1024)
+    scale = max(np.abs(a).max(), 1e-6) if N else 1.0
+    assert np.abs(a - b).max() <= 1e-5 * scale
+    assert np.array_equal(a == 0, b == 0)
+
+
+def test_binned_backward_point_major_gradient(cuda):
+    """grad_ld / grad_col: the gradient read in place from a wider [N, ld] matrix."""
+    F, N, ld, col = 4, 5000, 40, 8
+    offs, resl, emb = make_grid(RES, 10, 3, F, seed=71)
+    x = _points(N, 3, seed=72)
+    g = np.random.default_rng(73).normal(size=(len(RES), N, F)).astype(np.float32)
+    wide = torch.randn(N, ld, device=cuda)
+    wide[:, col:col + len(RES) * F] = torch.as_tensor(g, device=cuda).permute(1, 0, 2).reshape(N, -1)
+    a = _bwd_binned(cuda, g, x, emb, offs, resl, 3, 1024)
+    b = _bwd_binned(cuda, None, x, emb, offs, resl, 3, 1024, ld=ld, col=col, g_dev=wide.contiguous())
+    assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max()
+
+
+def test_plan_and_mirror_route(cuda):
+    """`plan_binned_levels` picks the finest big levels; the `_gridencoder` mirror routes to the
+    binned entry and gives the atomic kernel's gradient."""
+    from cnc_amd.backends import gridencoder_backend as be
+    from cnc_amd.synthetic import RES_16L, level_offsets
+    offs16 = level_offsets(RES_16L, 19, 3)
+    assert be.plan_binned_levels(RES_16L, offs16, 3, 8, 1 << 20) == (6, 1 << 19)
+    assert be.plan_binned_levels(RES_16L, offs16, 3, 8, 1000) is None
+    assert be.plan_binned_levels(RES_16L, offs16, 2, 8, 1 << 20) is None
+    res = [20, 40, 90, 200]
+    offs, resl, emb = make_grid(res, 16, 3, 8, seed=81)
+    N = 1 << 16
+    x = torch.rand(N, 3, device=cuda)
+    g = torch.randn(len(res), N, 8, device=cuda)
+    plan = be.plan_binned_levels(res, offs, 3, 8, N, min_resolution=64)
+    assert plan == (2, 1 << 16)
+    t = lambda a: torch.as_tensor(a, device=cuda)
+    outs = []
+    for binned in (None, plan):
+        ge = torch.zeros(emb.shape, device=cuda)
+        be.grid_encode_backward(g, x, t(emb), t(offs), t(resl), ge, N, 3, 8, len(res), 0, 128, None, None,
+                                None, None, ste_binary=True, binned=binned)
+        outs.append(ge)
+    torch.cuda.synchronize()
+    assert (outs[0] - outs[1]).abs().max() <= 2e-5 * outs[0].abs().max()
+    assert torch.equal(outs[0] == 0, outs[1] == 0)

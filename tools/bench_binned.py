@@ -1,0 +1,52 @@
+"""Scratch: binned vs atomic embedding-gradient scatter on the BASELINE 16Lx2^19xF8 grid, for the
+real marched-ray sample stream of bench.py (one 2^20 chunk) and for uniform-random points."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from cnc_amd.backends import gridencoder_backend as be
+from cnc_amd.synthetic import RES_16L, level_offsets, pinhole_rays, ball_binaries
+from cnc_amd.nerfacc.estimators.occ_grid import OccGridEstimator
+
+dev = torch.device("cuda:0")
+F, L = 8, 16
+offs = level_offsets(RES_16L, 19, 3)
+o_t = torch.as_tensor(offs, device=dev); r_t = torch.tensor(RES_16L, dtype=torch.int32, device=dev)
+torch.manual_seed(42)
+emb = torch.sign(torch.rand((int(offs[-1]), F), device=dev) * 2 - 1)
+clip = torch.zeros(1, dtype=torch.int32, device=dev)
+
+def marched(N):
+    aabb = torch.tensor([-1.5] * 3 + [1.5] * 3, device=dev)
+    est = OccGridEstimator(roi_aabb=aabb, resolution=128, levels=1).to(dev)
+    est.binaries = ball_binaries(128, device=dev)
+    ro, rd = pinhole_rays(device=dev)
+    ro, rd = ro.reshape(-1, 3)[:20000].contiguous(), rd.reshape(-1, 3)[200000:220000].contiguous()
+    ri, ts, te = est.sampling(ro, rd, render_step_size=5e-3, stratified=False)
+    p = ro[ri] + rd[ri] * ((ts + te) * 0.5)[:, None]
+    p = ((p - aabb[:3]) / (aabb[3:] - aabb[:3])).clamp(0, 1)
+    return p[:N].contiguous()
+
+def timeit(fn, n=5):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+for name, gen in (("marched rays", marched), ("uniform", lambda N: torch.rand((N, 3), device=dev))):
+    N = 1 << 20
+    x = gen(N); N = x.shape[0]
+    g = torch.randn((L, N, F), device=dev)
+    ge = torch.zeros_like(emb)
+    base = timeit(lambda: be.grid_encode_backward(g, x, emb, o_t, r_t, ge, N, 3, F, L, 0, 128, None, None, None, None, ste_binary=True, ste_clip_count=clip))
+    print(f"{name} N={N}: atomic {base:.3f} ms ({N*8716/base/1e9:.2f} TB/s alg)")
+    ref = torch.zeros_like(emb)
+    be.grid_encode_backward(g, x, emb, o_t, r_t, ref, N, 3, F, L, 0, 128, None, None, None, None, ste_binary=True, ste_clip_count=clip)
+    for nb in (3, 4, 5, 6, 7, 8, 10):
+        ms = timeit(lambda: be.grid_encode_backward(g, x, emb, o_t, r_t, ge, N, 3, F, L, 0, 128, None, None, None, None, ste_binary=True, ste_clip_count=clip, binned=(nb, 1 << 19)))
+        out = torch.zeros_like(emb)
+        be.grid_encode_backward(g, x, emb, o_t, r_t, out, N, 3, F, L, 0, 128, None, None, None, None, ste_binary=True, ste_clip_count=clip, binned=(nb, 1 << 19))
+        err = ((out - ref).abs().max() / ref.abs().max()).item()
+        print(f"   binned top {nb:2d}: {ms:.3f} ms ({N*8716/ms/1e9:.2f} TB/s alg)  rel err {err:.1e}")
