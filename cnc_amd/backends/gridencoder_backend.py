@@ -155,7 +155,7 @@ def plan_binned_levels(resolutions, offsets, num_dim, n_features, n_points, min_
     min_resolution: below that, consecutive ray samples share cells and the run-merging atomic
     kernel is the cheaper one) and its table has at least 2^16 rows; the qualifying levels must be
     the last ones."""
-    if num_dim != 3 or n_features not in (2, 4, 8) or n_points < min_points or n_points >= 1 << 28:
+    if num_dim != 3 or n_features not in (2, 4, 8) or n_points < min_points or n_points >= 1 << 24:
         return None
     res = [int(r) for r in resolutions]
     off = [int(o) for o in offsets]

@@ -9,9 +9,11 @@
 // merging removes.  tools/owner_probe.hip measured the alternative built here at 0.15 ms per
 // 2^20-sample level against 0.31 ms for the atomic scatter:
 //
-//   pass 1  k_bwd_bin    every (sample, level) emits one 4-byte item per (dy, dz) corner pair into
-//                        the bin of the 256-row table slab that owns the pair's rows (two items if
-//                        the x-neighbours straddle a slab edge).  Per workgroup the items are
+//   pass 1  k_bwd_bin    consecutive samples in the same cell of a level (ray-marched samples, at
+//                        all but the finest levels) form a run of up to 16; the run's first sample
+//                        emits one 4-byte item per (dy, dz) corner pair into the bin of the 256-row
+//                        table slab that owns the pair's rows (two items if the x-neighbours
+//                        straddle a slab edge).  Per workgroup the items are
 //                        counted in an LDS histogram, space is reserved with ONE global atomic per
 //                        (workgroup, non-empty bin), and the items are written at LDS-ranked slots.
 //   pass 2  k_bwd_owner  one wave owns one slab: 256 rows x F floats of accumulators in LDS.  It
@@ -53,10 +55,45 @@ struct BinnedArgs {
     FeatLayout      lay;
 };
 
-// item = sample << 4 | rows << 2 | pair;  pair = dy + 2*dz, rows bit 0 = corner x, bit 1 = corner x+1
-__device__ __forceinline__ uint32_t make_item(uint32_t sample, uint32_t rows, uint32_t pair)
+// item = sample << 8 | (run length - 1) << 4 | rows << 2 | pair
+//   sample: first sample of the run (24 bits); pair = dy + 2*dz; rows bit 0 = corner x, bit 1 = x+1
+constexpr uint32_t kMaxRun = 16;
+__device__ __forceinline__ uint32_t make_item(uint32_t sample, uint32_t len, uint32_t rows, uint32_t pair)
 {
-    return (sample << 4) | (rows << 2) | pair;
+    return (sample << 8) | ((len - 1) << 4) | (rows << 2) | pair;
+}
+
+// integer cell of a point at a level, packed; same arithmetic as Corners::setup
+__device__ __forceinline__ uint64_t cell_key(const float (&x)[3], uint32_t R)
+{
+    uint64_t key = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < 3; d++) {
+        float p = x[d] * (float)(R - 2);
+        p = p + 0.5f;
+        key = (key << 20) | (uint32_t)floorf(p);
+    }
+    return key;
+}
+
+// Run bookkeeping for sample i: 0 if i continues the run of sample i-1, else the length (1..16) of
+// the run it starts.  Runs never cross a multiple of 16 in the sample index, so whether a sample
+// starts a run is decided by looking at one neighbour only.
+__device__ __forceinline__ uint32_t run_length(const float* __restrict__ inputs, uint32_t i,
+                                               uint32_t N, uint32_t R, const float (&x)[3])
+{
+    const uint64_t key = cell_key(x, R);
+    if (i % kMaxRun != 0) {
+        float xp[3];
+        if (load_point<3>(inputs, i - 1, xp) && cell_key(xp, R) == key) return 0;
+    }
+    uint32_t len = 1;
+    for (uint32_t j = i + 1; j < N && j % kMaxRun != 0; j++) {
+        float xn[3];
+        if (!load_point<3>(inputs, j, xn) || cell_key(xn, R) != key) break;
+        len++;
+    }
+    return len;
 }
 
 template <uint32_t F, bool STE>
@@ -93,11 +130,17 @@ __global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
     __syncthreads();
 
     // ---- count ----
+    uint32_t run_len[kBinSamplesPerThread];   // 0: this sample continues its predecessor's run
+#pragma unroll
+    for (uint32_t k = 0; k < kBinSamplesPerThread; k++) run_len[k] = 0;
     if (binnable) {
+#pragma unroll
         for (uint32_t k = 0; k < kBinSamplesPerThread; k++) {
             const uint32_t i = base_i + k * 1024 + threadIdx.x;
             float x[3];
             if (i < a.N && load_point<3>(a.inputs, i, x)) {
+                run_len[k] = run_length(a.inputs, i, a.N, R, x);
+                if (run_len[k] == 0) continue;
                 Corners<3, false> c;
                 c.setup(x, R, hs, 0, nullptr);
 #pragma unroll
@@ -118,28 +161,37 @@ __global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
     }
     __syncthreads();
     // ---- emit ----
+#pragma unroll
     for (uint32_t k = 0; k < kBinSamplesPerThread; k++) {
         const uint32_t i = base_i + k * 1024 + threadIdx.x;
         float x[3];
         if (!(i < a.N && load_point<3>(a.inputs, i, x))) continue;
+        const uint32_t len = binnable ? run_len[k] : run_length(a.inputs, i, a.N, R, x);
+        if (len == 0) continue;
         Corners<3, false> c;
         c.setup(x, R, hs, 0, nullptr);
-        float g[F];
-        bool  have_g = false;
-        auto  spill = [&](uint32_t corner) {   // bin full (or level not binnable): atomic path
-            if (!have_g) {
-                constexpr uint32_t V = F < 4 ? F : 4;
-                const float* gp = a.grad + feat_index(a.lay, slot, a.N, i, F);
+        // bin full (or level not binnable): the run's contribution to this corner goes out as atomics
+        auto spill = [&](uint32_t corner) {
+            constexpr uint32_t V = F < 4 ? F : 4;
+            float sum[F];
+#pragma unroll
+            for (uint32_t f = 0; f < F; f++) sum[f] = 0;
+            for (uint32_t r = 0; r < len; r++) {
+                float xr[3];
+                (void)load_point<3>(a.inputs, i + r, xr);
+                Corners<3, false> cr;
+                cr.setup(xr, R, hs, 0, nullptr);
+                const float  w = cr.w[corner] * cr.wn_re;
+                const float* gp = a.grad + feat_index(a.lay, slot, a.N, i + r, F);
 #pragma unroll
                 for (uint32_t q = 0; q < F; q += V) {
                     float gv[V];
                     load_vec<V>(gp + q, gv);
 #pragma unroll
-                    for (uint32_t j = 0; j < V; j++) g[q + j] = gv[j];
+                    for (uint32_t j = 0; j < V; j++) sum[q + j] += w * gv[j];
                 }
-                have_g = true;
             }
-            atomic_row<F, STE>(a, mask_on, off + c.row[corner], c.w[corner] * c.wn_re, g);
+            atomic_row<F, STE>(a, mask_on, off + c.row[corner], 1.0f, sum);
         };
 #pragma unroll
         for (uint32_t p = 0; p < 4; p++) {
@@ -154,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
             if (v0) {
                 const uint32_t at = atomicAdd(&s_cnt[b0], 1u);
                 if (at < a.cap) {
-                    items[(size_t)b0 * a.cap + at] = make_item(i, together ? 3u : 1u, p);
+                    items[(size_t)b0 * a.cap + at] = make_item(i, len, together ? 3u : 1u, p);
                 } else {
                     spill(2 * p);
                     if (together) spill(2 * p + 1);
@@ -162,7 +214,7 @@ __global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
             }
             if (v1 && !together) {
                 const uint32_t at = atomicAdd(&s_cnt[b1], 1u);
-                if (at < a.cap) items[(size_t)b1 * a.cap + at] = make_item(i, 2u, p);
+                if (at < a.cap) items[(size_t)b1 * a.cap + at] = make_item(i, len, 2u, p);
                 else spill(2 * p + 1);
             }
         }
@@ -212,7 +264,7 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
         nx_valid = j < n;
         if (nx_valid) {
             nx_item = my[j];
-            const uint32_t i = nx_item >> 4;
+            const uint32_t i = nx_item >> 8;
 #pragma unroll
             for (uint32_t d = 0; d < 3; d++) nx_x[d] = a.inputs[(size_t)i * 3 + d];
             const float* gp = a.grad + feat_index(a.lay, slot, a.N, i, F);
@@ -233,31 +285,51 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
         uint32_t pend = 0, r0 = 0, r1 = 0;
         float    v0[F], v1[F];
         if (nx_valid) {
-            const uint32_t pair = nx_item & 3u;
+            const uint32_t pair = nx_item & 3u, len = ((nx_item >> 4) & 15u) + 1, first = nx_item >> 8;
             pend = (nx_item >> 2) & 3u;
-            Corners<3, false> c;
-            c.setup(nx_x, R, hs, 0, nullptr);
-            // corner index = dx + 2*dy + 4*dz, so the pair's corners are 2*pair and 2*pair + 1;
-            // a static select keeps the corner arrays in registers
-            float    w0 = 0, w1 = 0;
-            uint32_t q0 = 0, q1 = 0;
 #pragma unroll
-            for (uint32_t p = 0; p < 4; p++) {
-                if (p == pair) {
-                    w0 = c.w[2 * p];
-                    w1 = c.w[2 * p + 1];
-                    q0 = c.row[2 * p];
-                    q1 = c.row[2 * p + 1];
+            for (uint32_t f = 0; f < F; f++) v0[f] = v1[f] = 0;
+            float xs[3] = {nx_x[0], nx_x[1], nx_x[2]}, gs[F];
+#pragma unroll
+            for (uint32_t f = 0; f < F; f++) gs[f] = nx_g[f];
+            for (uint32_t r = 0;; r++) {
+                Corners<3, false> c;
+                c.setup(xs, R, hs, 0, nullptr);
+                // corner index = dx + 2*dy + 4*dz, so the pair's corners are 2*pair and 2*pair + 1;
+                // a static select keeps the corner arrays in registers
+                float    w0 = 0, w1 = 0;
+                uint32_t q0 = 0, q1 = 0;
+#pragma unroll
+                for (uint32_t p = 0; p < 4; p++) {
+                    if (p == pair) {
+                        w0 = c.w[2 * p];
+                        w1 = c.w[2 * p + 1];
+                        q0 = c.row[2 * p];
+                        q1 = c.row[2 * p + 1];
+                    }
                 }
-            }
-            w0 *= c.wn_re;
-            w1 *= c.wn_re;
-            r0 = q0 & (kSlab - 1);
-            r1 = q1 & (kSlab - 1);
+                w0 *= c.wn_re;
+                w1 *= c.wn_re;
+                r0 = q0 & (kSlab - 1);      // the same rows for every sample of the run
+                r1 = q1 & (kSlab - 1);
 #pragma unroll
-            for (uint32_t f = 0; f < F; f++) {
-                v0[f] = w0 * nx_g[f];
-                v1[f] = w1 * nx_g[f];
+                for (uint32_t f = 0; f < F; f++) {
+                    v0[f] += w0 * gs[f];
+                    v1[f] += w1 * gs[f];
+                }
+                if (r + 1 >= len) break;
+                // next sample of the run: adjacent in memory to the one just used
+                const uint32_t i = first + r + 1;
+#pragma unroll
+                for (uint32_t d = 0; d < 3; d++) xs[d] = a.inputs[(size_t)i * 3 + d];
+                const float* gp = a.grad + feat_index(a.lay, slot, a.N, i, F);
+#pragma unroll
+                for (uint32_t q = 0; q < F; q += V) {
+                    float gv[V];
+                    load_vec<V>(gp + q, gv);
+#pragma unroll
+                    for (uint32_t t = 0; t < V; t++) gs[q + t] = gv[t];
+                }
             }
         }
         prefetch();
@@ -353,7 +425,7 @@ extern "C" int cnc_grid_encode_backward_binned(const float* grad, const float* i
     }
     if (n_binned == 0) return CNC_OK;
     if (D != 3 || !(F == 2 || F == 4 || F == 8)) return CNC_ERR_UNSUPPORTED;
-    if (N >= (1u << 28)) return CNC_ERR_UNSUPPORTED;              // 28-bit sample index in an item
+    if (N >= (1u << 24)) return CNC_ERR_UNSUPPORTED;              // 24-bit sample index in an item
     if (grad_ld != 0) {
         const uint32_t V = F < 4 ? F : 4;
         if (grad_col + L * F > grad_ld || grad_ld % V || grad_col % V) return CNC_ERR_INVALID_VALUE;
