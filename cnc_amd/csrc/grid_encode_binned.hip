@@ -9,11 +9,9 @@
 // merging removes.  tools/owner_probe.hip measured the alternative built here at 0.15 ms per
 // 2^20-sample level against 0.31 ms for the atomic scatter:
 //
-//   pass 1  k_bwd_bin    consecutive samples in the same cell of a level (ray-marched samples, at
-//                        all but the finest levels) form a run of up to 16; the run's first sample
-//                        emits one 4-byte item per (dy, dz) corner pair into the bin of the 256-row
-//                        table slab that owns the pair's rows (two items if the x-neighbours
-//                        straddle a slab edge).  Per workgroup the items are
+//   pass 1  k_bwd_bin    every (sample, level) emits one 4-byte item per (dy, dz) corner pair into
+//                        the bin of the 256-row table slab that owns the pair's rows (two items if
+//                        the x-neighbours straddle a slab edge).  Per workgroup the items are
 //                        counted in an LDS histogram, space is reserved with ONE global atomic per
 //                        (workgroup, non-empty bin), and the items are written at LDS-ranked slots.
 //   pass 2  k_bwd_owner  one wave owns one slab: 256 rows x F floats of accumulators in LDS.  It
@@ -57,7 +55,11 @@ struct BinnedArgs {
 
 // item = sample << 8 | (run length - 1) << 4 | rows << 2 | pair
 //   sample: first sample of the run (24 bits); pair = dy + 2*dz; rows bit 0 = corner x, bit 1 = x+1
-constexpr uint32_t kMaxRun = 16;
+// Run merging is wired through both passes but switched off: with runs of up to 16 the mid levels
+// (where it matters) still cost more here than on the run-aggregating atomic kernel — every sample of
+// a run is re-read by each of its 4 pair owners — and the finest levels have no runs to merge
+// (measured on marched rays: 1.655 ms with runs vs 1.606 ms without, 6 binned levels).
+constexpr uint32_t kMaxRun = 1;
 __device__ __forceinline__ uint32_t make_item(uint32_t sample, uint32_t len, uint32_t rows, uint32_t pair)
 {
     return (sample << 8) | ((len - 1) << 4) | (rows << 2) | pair;
@@ -130,17 +132,13 @@ __global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
     __syncthreads();
 
     // ---- count ----
-    uint32_t run_len[kBinSamplesPerThread];   // 0: this sample continues its predecessor's run
-#pragma unroll
-    for (uint32_t k = 0; k < kBinSamplesPerThread; k++) run_len[k] = 0;
     if (binnable) {
 #pragma unroll
         for (uint32_t k = 0; k < kBinSamplesPerThread; k++) {
             const uint32_t i = base_i + k * 1024 + threadIdx.x;
             float x[3];
             if (i < a.N && load_point<3>(a.inputs, i, x)) {
-                run_len[k] = run_length(a.inputs, i, a.N, R, x);
-                if (run_len[k] == 0) continue;
+                if (run_length(a.inputs, i, a.N, R, x) == 0) continue;   // continues a run
                 Corners<3, false> c;
                 c.setup(x, R, hs, 0, nullptr);
 #pragma unroll
@@ -166,56 +164,52 @@ __global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
         const uint32_t i = base_i + k * 1024 + threadIdx.x;
         float x[3];
         if (!(i < a.N && load_point<3>(a.inputs, i, x))) continue;
-        const uint32_t len = binnable ? run_len[k] : run_length(a.inputs, i, a.N, R, x);
+        const uint32_t len = run_length(a.inputs, i, a.N, R, x);
         if (len == 0) continue;
         Corners<3, false> c;
         c.setup(x, R, hs, 0, nullptr);
-        // bin full (or level not binnable): the run's contribution to this corner goes out as atomics
-        auto spill = [&](uint32_t corner) {
-            constexpr uint32_t V = F < 4 ? F : 4;
-            float sum[F];
+        uint32_t spill = 0;   // corners whose item found no room (or level not binnable)
 #pragma unroll
-            for (uint32_t f = 0; f < F; f++) sum[f] = 0;
+        for (uint32_t p = 0; p < 4; p++) {
+            const bool     v0 = c.valid[2 * p], v1 = c.valid[2 * p + 1];
+            const uint32_t b0 = c.row[2 * p] >> kSlabLog2, b1 = c.row[2 * p + 1] >> kSlabLog2;
+            if (!binnable) {
+                spill |= (v0 ? 1u : 0u) << (2 * p) | (v1 ? 1u : 0u) << (2 * p + 1);
+                continue;
+            }
+            const bool together = v0 && v1 && b1 == b0;
+            if (v0) {
+                const uint32_t at = atomicAdd(&s_cnt[b0], 1u);
+                if (at < a.cap) items[(size_t)b0 * a.cap + at] = make_item(i, len, together ? 3u : 1u, p);
+                else spill |= (together ? 3u : 1u) << (2 * p);
+            }
+            if (v1 && !together) {
+                const uint32_t at = atomicAdd(&s_cnt[b1], 1u);
+                if (at < a.cap) items[(size_t)b1 * a.cap + at] = make_item(i, len, 2u, p);
+                else spill |= 2u << (2 * p);
+            }
+        }
+        // the slow path: every sample of the run adds its share of the spilled corners atomically
+        if (spill) {
+            constexpr uint32_t V = F < 4 ? F : 4;
             for (uint32_t r = 0; r < len; r++) {
                 float xr[3];
                 (void)load_point<3>(a.inputs, i + r, xr);
                 Corners<3, false> cr;
                 cr.setup(xr, R, hs, 0, nullptr);
-                const float  w = cr.w[corner] * cr.wn_re;
+                float        g[F];
                 const float* gp = a.grad + feat_index(a.lay, slot, a.N, i + r, F);
 #pragma unroll
                 for (uint32_t q = 0; q < F; q += V) {
                     float gv[V];
                     load_vec<V>(gp + q, gv);
 #pragma unroll
-                    for (uint32_t j = 0; j < V; j++) sum[q + j] += w * gv[j];
+                    for (uint32_t j = 0; j < V; j++) g[q + j] = gv[j];
                 }
-            }
-            atomic_row<F, STE>(a, mask_on, off + c.row[corner], 1.0f, sum);
-        };
 #pragma unroll
-        for (uint32_t p = 0; p < 4; p++) {
-            const bool     v0 = c.valid[2 * p], v1 = c.valid[2 * p + 1];
-            const uint32_t b0 = c.row[2 * p] >> kSlabLog2, b1 = c.row[2 * p + 1] >> kSlabLog2;
-            if (!binnable) {
-                if (v0) spill(2 * p);
-                if (v1) spill(2 * p + 1);
-                continue;
-            }
-            const bool together = v0 && v1 && b1 == b0;
-            if (v0) {
-                const uint32_t at = atomicAdd(&s_cnt[b0], 1u);
-                if (at < a.cap) {
-                    items[(size_t)b0 * a.cap + at] = make_item(i, len, together ? 3u : 1u, p);
-                } else {
-                    spill(2 * p);
-                    if (together) spill(2 * p + 1);
-                }
-            }
-            if (v1 && !together) {
-                const uint32_t at = atomicAdd(&s_cnt[b1], 1u);
-                if (at < a.cap) items[(size_t)b1 * a.cap + at] = make_item(i, len, 2u, p);
-                else spill(2 * p + 1);
+                for (uint32_t q = 0; q < 8; q++)
+                    if ((spill >> q) & 1u)
+                        atomic_row<F, STE>(a, mask_on, off + cr.row[q], cr.w[q] * cr.wn_re, g);
             }
         }
     }
