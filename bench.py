@@ -248,7 +248,11 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             traffic = json.load(open(tp)).get(dom_name)
-        roofline = {"kernel": dom_name, "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+        parts = {"grid_encode_backward": "one cnc_grid_encode_backward_binned call = k_grid_encode_bwd (10 coarse levels, "
+                                         "atomics) + k_bwd_bin + k_bwd_owner (6 finest levels, LDS accumulation); "
+                                         "avg_launch_ms is the whole call, = the sum of the three kernels' rocprof averages",
+                 "grid_encode_forward": "k_grid_encode_fwd_bits"}
+        roofline = {"kernel": dom_name, "kernel_parts": parts[dom_name], "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
                     "bytes_per_sample": bytes_per, "samples_per_launch": k[2] / k[1],
                     "avg_launch_ms": k[0] / k[1] * 1e3}
