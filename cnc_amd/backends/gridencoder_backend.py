@@ -146,7 +146,7 @@ def _workspace(device, nbytes):
     return ws
 
 
-def plan_binned_levels(resolutions, offsets, num_dim, n_features, n_points, min_resolution=384,
+def plan_binned_levels(resolutions, offsets, num_dim, n_features, n_points, min_resolution=288,
                        min_points=1 << 16):
     """Which finest levels the binned backward should take: (n_binned, level_rows) or None.
 

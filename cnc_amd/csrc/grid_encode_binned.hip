@@ -9,15 +9,17 @@
 // merging removes.  tools/owner_probe.hip measured the alternative built here at 0.15 ms per
 // 2^20-sample level against 0.31 ms for the atomic scatter:
 //
-//   pass 1  k_bwd_bin    every (sample, level) emits one 4-byte item per (dy, dz) corner pair into
-//                        the bin of the 256-row table slab that owns the pair's rows (two items if
-//                        the x-neighbours straddle a slab edge).  Per workgroup the items are
+//   pass 1  k_bwd_bin    every (sample, level) emits one 16-byte item per (dy, dz) corner pair —
+//                        sample index, the two corner weights w/sum(w), the two slab-local rows —
+//                        into the bin of the 256-row table slab that owns the pair's rows (two
+//                        items if the x-neighbours straddle a slab edge).  Per workgroup the items are
 //                        counted in an LDS histogram, space is reserved with ONE global atomic per
 //                        (workgroup, non-empty bin), and the items are written at LDS-ranked slots.
 //   pass 2  k_bwd_owner  one wave owns one slab: 256 rows x F floats of accumulators in LDS.  It
-//                        streams its bin (items coalesced, point + gradient row gathered one batch
-//                        ahead), recomputes the corner weights exactly as the scatter kernel does
-//                        and adds into LDS with plain read-modify-writes.  Lanes of one instruction
+//                        streams its bin (items coalesced, the sample's gradient row gathered one
+//                        batch ahead; the weights travel in the item, computed in pass 1 exactly as
+//                        the scatter kernel computes them) and adds into LDS with plain
+//                        read-modify-writes.  Lanes of one instruction
 //                        that hit the same row are serialised by a tag vote (write lane id to
 //                        tag[row], read back, winners go, losers retry) — LDS fp32 atomics were
 //                        measured 5x slower than this.  The slab is then added to the gradient
@@ -35,6 +37,18 @@ constexpr uint32_t kSlabLog2 = 8;                  // rows per owner wave
 constexpr uint32_t kSlab = 1u << kSlabLog2;
 constexpr uint32_t kBinSamplesPerThread = 4;       // pass 1: 4096 samples per 1024-thread block
 constexpr uint32_t kMaxBins = 4096;                // LDS histogram size (level_rows <= 2^20)
+constexpr uint32_t kHeadBytes = 16;                // workspace bytes per bin counter (4 used)
+
+// One corner pair of one sample at one level, as the owner wave needs it.  16 bytes, so a wave reads
+// 64 items as one contiguous KiB and only the gradient row is left to gather (carrying just the sample
+// index and recomputing the weights in pass 2 cost a second 64-byte sector per item for the point:
+// PMC showed that pass HBM-bound at 175 B fetched per item).
+struct Item {
+    uint32_t sample;
+    float    w0, w1;      // weight / sum of valid weights of corner x and corner x+1
+    uint32_t rows;        // r0 | r1 << 8 | mask << 16; mask bit 0: add row r0, bit 1: add row r1
+};
+static_assert(sizeof(Item) == 16, "Item is read as one dwordx4");
 
 struct BinnedArgs {
     const float*    grad;
@@ -48,55 +62,10 @@ struct BinnedArgs {
     uint32_t        bins;            // slabs per level = ceil(level_rows / 256)
     uint32_t        cap;             // item slots per bin
     uint32_t*       bin_count;       // [n_binned][bins]
-    uint32_t*       items;           // [n_binned][bins][cap]
+    Item*           items;           // [n_binned][bins][cap]
     const uint32_t* clip_count;
     FeatLayout      lay;
 };
-
-// item = sample << 8 | (run length - 1) << 4 | rows << 2 | pair
-//   sample: first sample of the run (24 bits); pair = dy + 2*dz; rows bit 0 = corner x, bit 1 = x+1
-// Run merging is wired through both passes but switched off: with runs of up to 16 the mid levels
-// (where it matters) still cost more here than on the run-aggregating atomic kernel — every sample of
-// a run is re-read by each of its 4 pair owners — and the finest levels have no runs to merge
-// (measured on marched rays: 1.655 ms with runs vs 1.606 ms without, 6 binned levels).
-constexpr uint32_t kMaxRun = 1;
-__device__ __forceinline__ uint32_t make_item(uint32_t sample, uint32_t len, uint32_t rows, uint32_t pair)
-{
-    return (sample << 8) | ((len - 1) << 4) | (rows << 2) | pair;
-}
-
-// integer cell of a point at a level, packed; same arithmetic as Corners::setup
-__device__ __forceinline__ uint64_t cell_key(const float (&x)[3], uint32_t R)
-{
-    uint64_t key = 0;
-#pragma unroll
-    for (uint32_t d = 0; d < 3; d++) {
-        float p = x[d] * (float)(R - 2);
-        p = p + 0.5f;
-        key = (key << 20) | (uint32_t)floorf(p);
-    }
-    return key;
-}
-
-// Run bookkeeping for sample i: 0 if i continues the run of sample i-1, else the length (1..16) of
-// the run it starts.  Runs never cross a multiple of 16 in the sample index, so whether a sample
-// starts a run is decided by looking at one neighbour only.
-__device__ __forceinline__ uint32_t run_length(const float* __restrict__ inputs, uint32_t i,
-                                               uint32_t N, uint32_t R, const float (&x)[3])
-{
-    const uint64_t key = cell_key(x, R);
-    if (i % kMaxRun != 0) {
-        float xp[3];
-        if (load_point<3>(inputs, i - 1, xp) && cell_key(xp, R) == key) return 0;
-    }
-    uint32_t len = 1;
-    for (uint32_t j = i + 1; j < N && j % kMaxRun != 0; j++) {
-        float xn[3];
-        if (!load_point<3>(inputs, j, xn) || cell_key(xn, R) != key) break;
-        len++;
-    }
-    return len;
-}
 
 template <uint32_t F, bool STE>
 __device__ __forceinline__ void atomic_row(const BinnedArgs& a, bool mask_on, uint32_t abs_row,
@@ -125,7 +94,7 @@ __global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
     const bool     binnable = div_up(hs, kSlab) <= a.bins;
     const bool     mask_on = STE && (a.clip_count == nullptr || *a.clip_count != 0);
     uint32_t*      bin_count = a.bin_count + (size_t)blockIdx.y * a.bins;
-    uint32_t*      items = a.items + (size_t)blockIdx.y * a.bins * a.cap;
+    Item*          items = a.items + (size_t)blockIdx.y * a.bins * a.cap;
     const uint32_t base_i = blockIdx.x * 1024 * kBinSamplesPerThread;
 
     for (uint32_t b = threadIdx.x; b < a.bins; b += 1024) s_cnt[b] = 0;
@@ -138,7 +107,6 @@ __global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
             const uint32_t i = base_i + k * 1024 + threadIdx.x;
             float x[3];
             if (i < a.N && load_point<3>(a.inputs, i, x)) {
-                if (run_length(a.inputs, i, a.N, R, x) == 0) continue;   // continues a run
                 Corners<3, false> c;
                 c.setup(x, R, hs, 0, nullptr);
 #pragma unroll
@@ -164,8 +132,6 @@ __global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
         const uint32_t i = base_i + k * 1024 + threadIdx.x;
         float x[3];
         if (!(i < a.N && load_point<3>(a.inputs, i, x))) continue;
-        const uint32_t len = run_length(a.inputs, i, a.N, R, x);
-        if (len == 0) continue;
         Corners<3, false> c;
         c.setup(x, R, hs, 0, nullptr);
         uint32_t spill = 0;   // corners whose item found no room (or level not binnable)
@@ -178,39 +144,40 @@ __global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
                 continue;
             }
             const bool together = v0 && v1 && b1 == b0;
+            Item it;
+            it.sample = i;
+            it.w0 = c.w[2 * p] * c.wn_re;
+            it.w1 = c.w[2 * p + 1] * c.wn_re;
+            const uint32_t lr = (c.row[2 * p] & (kSlab - 1)) | (c.row[2 * p + 1] & (kSlab - 1)) << 8;
             if (v0) {
                 const uint32_t at = atomicAdd(&s_cnt[b0], 1u);
-                if (at < a.cap) items[(size_t)b0 * a.cap + at] = make_item(i, len, together ? 3u : 1u, p);
+                it.rows = lr | (together ? 3u : 1u) << 16;
+                if (at < a.cap) items[(size_t)b0 * a.cap + at] = it;
                 else spill |= (together ? 3u : 1u) << (2 * p);
             }
             if (v1 && !together) {
                 const uint32_t at = atomicAdd(&s_cnt[b1], 1u);
-                if (at < a.cap) items[(size_t)b1 * a.cap + at] = make_item(i, len, 2u, p);
+                it.rows = lr | 2u << 16;
+                if (at < a.cap) items[(size_t)b1 * a.cap + at] = it;
                 else spill |= 2u << (2 * p);
             }
         }
-        // the slow path: every sample of the run adds its share of the spilled corners atomically
+        // the slow path: spilled corners are added atomically
         if (spill) {
             constexpr uint32_t V = F < 4 ? F : 4;
-            for (uint32_t r = 0; r < len; r++) {
-                float xr[3];
-                (void)load_point<3>(a.inputs, i + r, xr);
-                Corners<3, false> cr;
-                cr.setup(xr, R, hs, 0, nullptr);
-                float        g[F];
-                const float* gp = a.grad + feat_index(a.lay, slot, a.N, i + r, F);
+            float        g[F];
+            const float* gp = a.grad + feat_index(a.lay, slot, a.N, i, F);
 #pragma unroll
-                for (uint32_t q = 0; q < F; q += V) {
-                    float gv[V];
-                    load_vec<V>(gp + q, gv);
+            for (uint32_t q = 0; q < F; q += V) {
+                float gv[V];
+                load_vec<V>(gp + q, gv);
 #pragma unroll
-                    for (uint32_t j = 0; j < V; j++) g[q + j] = gv[j];
-                }
-#pragma unroll
-                for (uint32_t q = 0; q < 8; q++)
-                    if ((spill >> q) & 1u)
-                        atomic_row<F, STE>(a, mask_on, off + cr.row[q], cr.w[q] * cr.wn_re, g);
+                for (uint32_t j = 0; j < V; j++) g[q + j] = gv[j];
             }
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++)
+                if ((spill >> q) & 1u)
+                    atomic_row<F, STE>(a, mask_on, off + c.row[q], c.w[q] * c.wn_re, g);
         }
     }
 }
@@ -241,27 +208,28 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
     const uint32_t slot = a.first_level + blockIdx.y;
     const uint32_t off = (uint32_t)a.offsets[slot];
     const uint32_t hs = (uint32_t)a.offsets[slot + 1] - off;
-    const uint32_t R = (uint32_t)a.resolutions[slot];
     if (bin * kSlab >= hs) return;
     uint32_t n = a.bin_count[(size_t)blockIdx.y * a.bins + bin];
     if (n == 0) return;                 // nothing landed here: the table slab stays as it is
     n = n < a.cap ? n : a.cap;
-    const uint32_t* my = a.items + ((size_t)blockIdx.y * a.bins + bin) * a.cap;
+    const Item* my = a.items + ((size_t)blockIdx.y * a.bins + bin) * a.cap;
 
     for (uint32_t k = lane; k < kSlab * F; k += 64) s_acc[k] = 0;
 
-    // next batch's raw data, in flight while the current batch is accumulated
-    uint32_t j = lane, nx_item = 0;
-    float    nx_x[3] = {0, 0, 0}, nx_g[F];
+    // next batch's item and gradient row, in flight while the current batch is accumulated
+    uint32_t j = lane;
+    Item     nx_item{0, 0, 0, 0};
+    float    nx_g[F];
     bool     nx_valid = false;
     auto     prefetch = [&]() {
         nx_valid = j < n;
         if (nx_valid) {
-            nx_item = my[j];
-            const uint32_t i = nx_item >> 8;
-#pragma unroll
-            for (uint32_t d = 0; d < 3; d++) nx_x[d] = a.inputs[(size_t)i * 3 + d];
-            const float* gp = a.grad + feat_index(a.lay, slot, a.N, i, F);
+            const uint4 raw = *reinterpret_cast<const uint4*>(my + j);
+            nx_item.sample = raw.x;
+            nx_item.w0 = __uint_as_float(raw.y);
+            nx_item.w1 = __uint_as_float(raw.z);
+            nx_item.rows = raw.w;
+            const float* gp = a.grad + feat_index(a.lay, slot, a.N, nx_item.sample, F);
 #pragma unroll
             for (uint32_t q = 0; q < F; q += V) {
                 float gv[V];
@@ -279,51 +247,13 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
         uint32_t pend = 0, r0 = 0, r1 = 0;
         float    v0[F], v1[F];
         if (nx_valid) {
-            const uint32_t pair = nx_item & 3u, len = ((nx_item >> 4) & 15u) + 1, first = nx_item >> 8;
-            pend = (nx_item >> 2) & 3u;
+            pend = (nx_item.rows >> 16) & 3u;
+            r0 = nx_item.rows & 0xFFu;
+            r1 = (nx_item.rows >> 8) & 0xFFu;
 #pragma unroll
-            for (uint32_t f = 0; f < F; f++) v0[f] = v1[f] = 0;
-            float xs[3] = {nx_x[0], nx_x[1], nx_x[2]}, gs[F];
-#pragma unroll
-            for (uint32_t f = 0; f < F; f++) gs[f] = nx_g[f];
-            for (uint32_t r = 0;; r++) {
-                Corners<3, false> c;
-                c.setup(xs, R, hs, 0, nullptr);
-                // corner index = dx + 2*dy + 4*dz, so the pair's corners are 2*pair and 2*pair + 1;
-                // a static select keeps the corner arrays in registers
-                float    w0 = 0, w1 = 0;
-                uint32_t q0 = 0, q1 = 0;
-#pragma unroll
-                for (uint32_t p = 0; p < 4; p++) {
-                    if (p == pair) {
-                        w0 = c.w[2 * p];
-                        w1 = c.w[2 * p + 1];
-                        q0 = c.row[2 * p];
-                        q1 = c.row[2 * p + 1];
-                    }
-                }
-                w0 *= c.wn_re;
-                w1 *= c.wn_re;
-                r0 = q0 & (kSlab - 1);      // the same rows for every sample of the run
-                r1 = q1 & (kSlab - 1);
-#pragma unroll
-                for (uint32_t f = 0; f < F; f++) {
-                    v0[f] += w0 * gs[f];
-                    v1[f] += w1 * gs[f];
-                }
-                if (r + 1 >= len) break;
-                // next sample of the run: adjacent in memory to the one just used
-                const uint32_t i = first + r + 1;
-#pragma unroll
-                for (uint32_t d = 0; d < 3; d++) xs[d] = a.inputs[(size_t)i * 3 + d];
-                const float* gp = a.grad + feat_index(a.lay, slot, a.N, i, F);
-#pragma unroll
-                for (uint32_t q = 0; q < F; q += V) {
-                    float gv[V];
-                    load_vec<V>(gp + q, gv);
-#pragma unroll
-                    for (uint32_t t = 0; t < V; t++) gs[q + t] = gv[t];
-                }
+            for (uint32_t f = 0; f < F; f++) {
+                v0[f] = nx_item.w0 * nx_g[f];
+                v1[f] = nx_item.w1 * nx_g[f];
             }
         }
         prefetch();
@@ -392,7 +322,7 @@ extern "C" uint64_t cnc_grid_encode_backward_binned_workspace(uint32_t N, uint32
 {
     if (n_binned == 0 || level_rows == 0) return 0;
     const uint64_t bins = div_up(level_rows, kSlab);
-    return (uint64_t)n_binned * bins * (1 + (uint64_t)default_cap(N, (uint32_t)bins)) * 4;
+    return (uint64_t)n_binned * bins * (kHeadBytes + (uint64_t)default_cap(N, (uint32_t)bins) * sizeof(Item));
 }
 
 extern "C" int cnc_grid_encode_backward_binned(const float* grad, const float* inputs,
@@ -419,7 +349,6 @@ extern "C" int cnc_grid_encode_backward_binned(const float* grad, const float* i
     }
     if (n_binned == 0) return CNC_OK;
     if (D != 3 || !(F == 2 || F == 4 || F == 8)) return CNC_ERR_UNSUPPORTED;
-    if (N >= (1u << 24)) return CNC_ERR_UNSUPPORTED;              // 24-bit sample index in an item
     if (grad_ld != 0) {
         const uint32_t V = F < 4 ? F : 4;
         if (grad_col + L * F > grad_ld || grad_ld % V || grad_col % V) return CNC_ERR_INVALID_VALUE;
@@ -428,16 +357,19 @@ extern "C" int cnc_grid_encode_backward_binned(const float* grad, const float* i
     }
     const uint32_t bins = div_up(level_rows, kSlab);
     if (bins == 0 || bins > kMaxBins || !workspace) return CNC_ERR_INVALID_VALUE;
-    const uint64_t words = workspace_bytes / 4, heads = (uint64_t)n_binned * bins;
-    if (words < heads * 65) return CNC_ERR_INVALID_VALUE;          // at least one batch per bin
-    uint64_t cap = (words - heads) / heads;
+    // layout: [heads x 16 B: bin counters, padded so the items stay 16-byte aligned][heads x cap items]
+    const uint64_t heads = (uint64_t)n_binned * bins;
+    if ((uintptr_t)workspace % 16 != 0) return CNC_ERR_INVALID_VALUE;
+    if (workspace_bytes < heads * (kHeadBytes + 64 * sizeof(Item))) return CNC_ERR_INVALID_VALUE;   // one batch per bin
+    uint64_t cap = (workspace_bytes - heads * kHeadBytes) / (heads * sizeof(Item));
     if (cap > 0x0FFFFFFFull) cap = 0x0FFFFFFFull;
 
     hipStream_t s = (hipStream_t)stream;
     uint32_t*   ws = (uint32_t*)workspace;
     if (hipMemsetAsync(ws, 0, heads * 4, s) != hipSuccess) return CNC_ERR_LAUNCH;
     BinnedArgs a{grad, inputs, embeddings, offsets, resolutions, grad_embeddings, N, L - n_binned,
-                 bins, (uint32_t)cap, ws, ws + heads, ste_clip_count, FeatLayout{grad_ld, grad_col}};
+                 bins, (uint32_t)cap, ws, (Item*)((char*)workspace + heads * kHeadBytes), ste_clip_count,
+                 FeatLayout{grad_ld, grad_col}};
     const bool ste = (flags & CNC_FLAG_STE_BINARY) != 0;
     switch (F) {
     case 2: launch_binned<2>(a, n_binned, ste, s); break;

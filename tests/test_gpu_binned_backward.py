@@ -63,7 +63,7 @@ def test_binned_backward_spill_and_fallback_paths(cuda, oracle, case):
     _, abs64 = oracle.grid_encode_backward(np.abs(g), x, emb, offs, resl, ste_binary=ste, want_acc64=True)
     kw = {}
     if case == "tiny_workspace":
-        kw = dict(level_rows=1024, ws_bytes=3 * 4 * 65 * 4)          # 64 item slots per bin, ~6000 wanted
+        kw = dict(level_rows=1024, ws_bytes=3 * 4 * (16 + 64 * 16))   # 64 item slots per bin, ~6000 wanted
     elif case == "level_rows_too_small":
         kw = dict(level_rows=512)
     else:
@@ -103,7 +103,7 @@ def test_plan_and_mirror_route(cuda):
     from cnc_amd.backends import gridencoder_backend as be
     from cnc_amd.synthetic import RES_16L, level_offsets
     offs16 = level_offsets(RES_16L, 19, 3)
-    assert be.plan_binned_levels(RES_16L, offs16, 3, 8, 1 << 20) == (6, 1 << 19)
+    assert be.plan_binned_levels(RES_16L, offs16, 3, 8, 1 << 20) == (7, 1 << 19)
     assert be.plan_binned_levels(RES_16L, offs16, 3, 8, 1000) is None
     assert be.plan_binned_levels(RES_16L, offs16, 2, 8, 1 << 20) is None
     res = [20, 40, 90, 200]
@@ -137,6 +137,6 @@ def test_binned_backward_coherent_points_with_spills(cuda, N):
     x = x[np.lexsort((x[:, 0], x[:, 1], x[:, 2]))]
     g = rng.normal(size=(len(RES), N, F)).astype(np.float32)
     a = _bwd_gpu(cuda, g, x, emb, offs, resl)
-    for ws_bytes in (4 * 4 * 65 * 4, 4 * 4 * (1 + N // 8) * 4, None):
+    for ws_bytes in (4 * 4 * (16 + 64 * 16), 4 * 4 * (16 + (N // 8) * 16), None):
         b = _bwd_binned(cuda, g, x, emb, offs, resl, 4, 1024, ws_bytes=ws_bytes)
         assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max()

@@ -25,4 +25,4 @@ with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
     for step in range(301, 305):
         tr.train_step(step)
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=28, max_name_column_width=80))
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=80))
