@@ -34,6 +34,9 @@ SIGNATURES = {
     "cnc_mlp_forward": [_vp, _u32, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _u32, _u32, _vp],
     "cnc_cnt_np_embed": [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp],
     "cnc_cnt_np_embed_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp],
+    "cnc_cnt_np_plan": [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    "cnc_cnt_np_embed_planned": [_vp, _vp, _vp, _vp, _u32, _u32, _vp],
+    "cnc_cnt_np_embed_planned_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_query_mask_3D": [_vp, _u32, _vp, _u32, _vp, _vp, _i32, _u32, _vp],
     "cnc_query_mask_3D_qlist": [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u32, _vp],
     "cnc_align_and_pack_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp],

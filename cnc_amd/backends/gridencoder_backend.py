@@ -246,3 +246,74 @@ def cnt_np_embed_backward(inputs, embeddings_clip, outputs_sum, grad, grad_embed
                                               int(resolution), int(n_features), int(hashmap_size),
                                               int(axis), stream())
     check(rc, "cnt_np_embed_backward")
+
+
+class VotePlan:
+    """(extension) Static plan for `cnt_np_embed` on one vertex list: the list sorted by pixel of each
+    projection plane (forward) and by table row of the finest level (backward).  Built once per
+    occupancy refresh; see cnc_amd/csrc/cnt_votes.hip."""
+
+    def __init__(self, inputs_i16, resolution, hashmap_size):
+        _common_checks([("inputs", inputs_i16)])
+        if inputs_i16.dtype != torch.int16:
+            raise RuntimeError("expected scalar type Short for inputs")
+        N, dev = inputs_i16.shape[0], inputs_i16.device
+        self.resolution, self.hashmap_size = int(resolution), int(hashmap_size)
+        self.n_pixels = (self.resolution - 2) ** 2
+        L = _lib.lib()
+        rows = torch.empty(N, dtype=torch.int32, device=dev)
+        pix = [torch.empty(N, dtype=torch.int32, device=dev) for _ in range(3)]
+        for axis in range(3):
+            rc = L.cnc_cnt_np_plan(ptr(inputs_i16), N, self.resolution, self.hashmap_size, axis,
+                                   ptr(rows) if axis == 0 else None, ptr(pix[axis]), stream())
+            check(rc, "cnt_np_plan")
+        valid = rows >= 0                       # 0xFFFFFFFF reads as -1
+        rows, pix = rows[valid], [p[valid] for p in pix]
+        rows64 = rows.to(torch.int64)
+        # forward: rows ordered by pixel, per plane
+        self.rows_by_pixel, self.pixel_seg = [], []
+        for axis in range(3):
+            p64 = pix[axis].to(torch.int64)
+            order = torch.argsort(p64, stable=True)
+            self.rows_by_pixel.append(rows[order].contiguous())
+            self.pixel_seg.append(self._segments(p64, self.n_pixels))
+        # backward: pixels ordered by row (one order for the three planes)
+        order = torch.argsort(rows64, stable=True)
+        self.pixels_by_row = [p[order].contiguous() for p in pix]
+        self.row_seg = self._segments(rows64, self.hashmap_size)
+
+    @staticmethod
+    def _segments(keys64, n):
+        counts = torch.bincount(keys64, minlength=n)
+        seg = torch.zeros(n + 1, dtype=torch.int32, device=keys64.device)
+        seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        return seg
+
+
+def cnt_np_embed_planned(plan, embeddings_clip, outputs, n_features, axis):
+    """outputs [res-2, res-2, F, 2] written with cnt_np_embed's counts (no zero-fill needed)."""
+    _common_checks([("embeddings_clip", embeddings_clip), ("outputs", outputs)])
+    _require_f32(embeddings_clip, "embeddings_clip")
+    _require_f32(outputs, "outputs")
+    if outputs.numel() != plan.n_pixels * n_features * 2:
+        raise RuntimeError("cnt_np_embed_planned: tensor sizes do not match the plan")
+    rc = _lib.lib().cnc_cnt_np_embed_planned(ptr(plan.rows_by_pixel[axis]), ptr(plan.pixel_seg[axis]),
+                                             ptr(embeddings_clip), ptr(outputs), plan.n_pixels,
+                                             int(n_features), stream())
+    check(rc, "cnt_np_embed_planned")
+
+
+def cnt_np_embed_planned_backward(plan, embeddings_clip, grad_over_sum, grad_embeddings, n_features, axis):
+    _common_checks([("embeddings_clip", embeddings_clip), ("grad_over_sum", grad_over_sum),
+                    ("grad_embeddings", grad_embeddings)])
+    for name, t in (("embeddings_clip", embeddings_clip), ("grad_over_sum", grad_over_sum),
+                    ("grad_embeddings", grad_embeddings)):
+        _require_f32(t, name)
+    if grad_over_sum.numel() != plan.n_pixels * n_features * 2 or grad_embeddings.shape != embeddings_clip.shape:
+        raise RuntimeError("cnt_np_embed_planned_backward: tensor sizes do not match the plan")
+    rc = _lib.lib().cnc_cnt_np_embed_planned_backward(ptr(plan.pixels_by_row[axis]), ptr(plan.row_seg),
+                                                      ptr(embeddings_clip), ptr(grad_over_sum),
+                                                      ptr(grad_embeddings),
+                                                      min(plan.hashmap_size, embeddings_clip.shape[0]),
+                                                      int(n_features), stream())
+    check(rc, "cnt_np_embed_planned_backward")

@@ -25,6 +25,7 @@ from typing import Optional
 
 import numpy as np
 import torch
+from torch.profiler import record_function as _range
 import torch.nn as nn
 import torch.nn.functional as nnf
 from torch.autograd import Function
@@ -102,6 +103,33 @@ class _cnt_np_embed(Function):
         _backend.cnt_np_embed_backward(inputs, embeddings, pn_embed_sum, grad.contiguous(),
                                        grad_embeddings, N, resolution, n_features, hashmap_size, axis_id)
         return None, grad_embeddings, None, None, None
+
+
+class _cnt_np_embed_planned(Function):
+    """`_cnt_np_embed` from a `VotePlan` (vertex list pre-sorted by pixel / by table row): same counts
+    bit for bit, no atomics (cnc_amd/csrc/cnt_votes.hip)."""
+
+    @staticmethod
+    def forward(ctx, plan, embeddings, axis):
+        axis_id = ("xy", "xz", "yz").index(axis)
+        n_features = embeddings.shape[-1]
+        embeddings = embeddings.contiguous()
+        scale = plan.resolution - 2
+        pn_embed = torch.empty([scale, scale, n_features, 2], device=embeddings.device)
+        _backend.cnt_np_embed_planned(plan, embeddings, pn_embed, n_features, axis_id)
+        pn_embed_sum = torch.sum(pn_embed, dim=-1, keepdim=True) + 1e-6
+        ctx.save_for_backward(embeddings, pn_embed_sum)
+        ctx.plan, ctx.axis_id = plan, axis_id
+        return pn_embed / pn_embed_sum
+
+    @staticmethod
+    def backward(ctx, grad):
+        embeddings, pn_embed_sum = ctx.saved_tensors
+        grad_embeddings = torch.zeros_like(embeddings)
+        g_over_sum = (torch.reciprocal(pn_embed_sum) * grad).contiguous()   # gv * grad, gridencoder.cu:1035-1040
+        _backend.cnt_np_embed_planned_backward(ctx.plan, embeddings, g_over_sum, grad_embeddings,
+                                               embeddings.shape[-1], ctx.axis_id)
+        return None, grad_embeddings, None
 
 
 def encoder(x, p, file_name):
@@ -223,13 +251,15 @@ class CNC_context_models(nn.Module):
                  ste_binary=False, ste_multistep=False, add_noise=False, Q=100, quantize_epoch=1000,
                  Pg_level=-1, Pg_level_2D=-1, Rb=128, step_update=16, skip_levels_3D=(0, 1, 2, 3),
                  skip_levels_2D=(0,), use_dimension_wise=True, use_overlap_area_pool=True,
-                 device="cuda", dimension_wise_resolution=514, fused_segments=True):
+                 device="cuda", dimension_wise_resolution=514, fused_segments=True, planned_votes=True):
         super().__init__()
         dev = torch.device(device)
         self.dev = dev
         # hash fusion as one segmented-reduction kernel instead of pack -> multiply -> sum over a
         # padded [slots, max collisions, F] tensor (False = the reference's dataflow)
         self.fused_segments = fused_segments
+        # count the dimension-wise votes from a per-refresh sorted plan instead of with atomics
+        self.planned_votes = planned_votes
         self.use_overlap_area_pool = use_overlap_area_pool
         self.use_dimension_wise = use_dimension_wise
         self.rand_like = torch.rand_like
@@ -349,6 +379,7 @@ class CNC_context_models(nn.Module):
         self.init_binary_vxl_coords(scale=dimension_wise_resolution - 2)
         self.step_update = step_update
         self.idx_coords2_tmp = None
+        self.vote_plan = None
         self.batched_inputs_list = None
 
     # ------------------------------------------------------------------------------- helpers
@@ -437,9 +468,12 @@ class CNC_context_models(nn.Module):
         return torch.stack([lin // (resolution * resolution), (lin // resolution) % resolution,
                             lin % resolution], dim=-1)
 
-    def get_pn_embed_frac(self, embeddings_3D_q, idx_coords2, resolution=None, axis="xy"):
+    def get_pn_embed_frac(self, embeddings_3D_q, idx_coords2, resolution=None, axis="xy", plan=None):
         resolution = self.dimension_wise_resolution if resolution is None else resolution
-        frac = _cnt_np_embed.apply(idx_coords2, embeddings_3D_q, resolution, 2 ** self.log2_hashmap_size, axis)
+        if plan is not None:
+            frac = _cnt_np_embed_planned.apply(plan, embeddings_3D_q, axis)
+        else:
+            frac = _cnt_np_embed.apply(idx_coords2, embeddings_3D_q, resolution, 2 ** self.log2_hashmap_size, axis)
         frac = frac[..., 0].permute(2, 0, 1).unsqueeze(0).contiguous()      # [1, F, R-2, R-2]
         frac = nnf.pad(frac, pad=[1, 1, 1, 1])                              # ring of zeros
         return frac.squeeze(0).permute(1, 2, 0).contiguous().view(-1, self.n_features)
@@ -544,16 +578,21 @@ class CNC_context_models(nn.Module):
                                       binary_vxl=None, verbose=False, sample_num=None, step=0):
         """Entropy estimate (bits per parameter) of the four binarised tables under the context
         models; differentiable w.r.t. tables and context models (utils_bpp_acc.py:533-706)."""
-        params_q_xy = self.get_STE_params(Encoding_xy)
-        params_q_xz = self.get_STE_params(Encoding_xz)
-        params_q_yz = self.get_STE_params(Encoding_yz)
-        params_q_xyz = self.get_STE_params(Encoding_xyz)
+        with _range("ctx/ste_params"):
+            params_q_xy = self.get_STE_params(Encoding_xy)
+            params_q_xz = self.get_STE_params(Encoding_xz)
+            params_q_yz = self.get_STE_params(Encoding_yz)
+            params_q_xyz = self.get_STE_params(Encoding_xyz)
         ttl_bit_sum, ttl_num_sum = 0, 0
         axes = ("xy", "xz", "yz")
 
         refresh = step % self.step_update == 0
         if refresh and self.use_dimension_wise:
             self.idx_coords2_tmp = self.get_idx_coords2(binary_vxl)
+            # the vertex list is fixed until the next refresh: sort it once for the vote kernels
+            self.vote_plan = (_backend.VotePlan(self.idx_coords2_tmp.to(torch.int16).contiguous(),
+                                                self.dimension_wise_resolution, 2 ** self.log2_hashmap_size)
+                              if self.planned_votes else None)
         idx_coords2 = self.idx_coords2_tmp
         binary_2D = [self._project(binary_vxl, a) for a in axes]
         if refresh:
@@ -564,15 +603,19 @@ class CNC_context_models(nn.Module):
         finest_3D = params_q_xyz[self.offsets_list[-2]:self.offsets_list[-1]]
         for k, (Ec, p_q) in enumerate(zip((Encoding_xy, Encoding_xz, Encoding_yz),
                                           (params_q_xy, params_q_xz, params_q_yz))):
-            pn_frac = (self.get_pn_embed_frac(finest_3D, idx_coords2, axis=axes[k])
-                       if self.use_dimension_wise else None)
+            with _range("ctx/pn_frac"):
+                pn_frac = (self.get_pn_embed_frac(finest_3D, idx_coords2, axis=axes[k], plan=self.vote_plan)
+                           if self.use_dimension_wise else None)
             batches = iter(self.batched_inputs_list[k])
             for n in range(self.n_levels_2D):
-                Pg_n, bits_n, _ = self.get_BiRF_wentropy_leveln(p_q, n, self.offsets_list_2D)
+                with _range("ctx/level_Pg"):
+                    Pg_n, bits_n, _ = self.get_BiRF_wentropy_leveln(p_q, n, self.offsets_list_2D)
                 if self._coded_2D(n):
                     points_n, order, rows, unique_cnt = next(batches)
-                    mean = self._mean_2D(Ec, n, points_n, Pg_n, binary_2D[k], pn_frac, order, unique_cnt)
-                    bits_n = torch.sum(self.entropy_model(p_q[rows, :], mean))
+                    with _range("ctx/2D_mean"):
+                        mean = self._mean_2D(Ec, n, points_n, Pg_n, binary_2D[k], pn_frac, order, unique_cnt)
+                    with _range("ctx/2D_entropy"):
+                        bits_n = torch.sum(self.entropy_model(p_q[rows, :], mean))
                 ttl_bit_sum = ttl_bit_sum + bits_n
             ttl_num_sum += p_q.numel()
 
@@ -588,8 +631,11 @@ class CNC_context_models(nn.Module):
         p1s = self.unique_count_cumsum_list[self.utils_nlevel_idx, v1s]
 
         pts_orig, pts_n, Pg_cols, lvl_ids, cnts, values_q = [], [], [], [], [], []
+        _g = _range("ctx/3D_gather")
+        _g.__enter__()
         for n in range(self.n_levels):
-            Pg_n, bits_n, _ = self.get_BiRF_wentropy_leveln(params_q_xyz, n)
+            with _range("ctx/level_Pg"):
+                Pg_n, bits_n, _ = self.get_BiRF_wentropy_leveln(params_q_xyz, n)
             if not self._coded_3D(n):
                 ttl_bit_sum = ttl_bit_sum + bits_n
                 continue
@@ -600,18 +646,25 @@ class CNC_context_models(nn.Module):
             lvl_ids.append(torch.full((po.shape[0],), n, dtype=torch.long, device=self.dev))
             cnts.append(self.unique_count_list[n, v0s[n]:v1s[n]])
             values_q.append(params_q_xyz[self.unique_value_list[n][v0s[n]:v1s[n]] + self.offsets_list[n]])
+        _g.__exit__(None, None, None)
 
         if pts_orig:
-            pts_orig, pts_n, Pg_cols = torch.cat(pts_orig), torch.cat(pts_n), torch.cat(Pg_cols)
-            lvl_ids, cnts, values_q = torch.cat(lvl_ids), torch.cat(cnts), torch.cat(values_q)
-            mask, overlap = self.query_binary_vxl_qlist(pts_orig, binary_vxl, lvl_ids, return_overlap_area=True)
-            mask_cnt, mask_exist, overlap_w = self._slot_masks(mask, overlap, cnts)
+            with _range("ctx/3D_cat"):
+                pts_orig, pts_n, Pg_cols = torch.cat(pts_orig), torch.cat(pts_n), torch.cat(Pg_cols)
+                lvl_ids, cnts, values_q = torch.cat(lvl_ids), torch.cat(cnts), torch.cat(values_q)
+            with _range("ctx/3D_query"):
+                mask, overlap = self.query_binary_vxl_qlist(pts_orig, binary_vxl, lvl_ids, return_overlap_area=True)
+            with _range("ctx/3D_slot_masks"):
+                mask_cnt, mask_exist, overlap_w = self._slot_masks(mask, overlap, cnts)
             L = self.max_context_layer_num
-            context = Encoding_xyz.forward_diff_levels(pts_n[mask], lvl_ids[mask].to(torch.int) - L, L,
-                                                       binary_vxl=binary_vxl.squeeze(), PV=1001)
-            context = torch.cat([context, Pg_cols[mask]], dim=-1)
-            mean = self._fuse_3D(self.context_model_3D(context), mask_cnt, overlap_w)
-            bits = torch.sum(self.entropy_model(values_q[mask_exist], mean))
+            with _range("ctx/3D_encode"):
+                context = Encoding_xyz.forward_diff_levels(pts_n[mask], lvl_ids[mask].to(torch.int) - L, L,
+                                                           binary_vxl=binary_vxl.squeeze(), PV=1001)
+                context = torch.cat([context, Pg_cols[mask]], dim=-1)
+            with _range("ctx/3D_mlp_fuse"):
+                mean = self._fuse_3D(self.context_model_3D(context), mask_cnt, overlap_w)
+            with _range("ctx/3D_entropy"):
+                bits = torch.sum(self.entropy_model(values_q[mask_exist], mean))
             ttl_bit_sum = ttl_bit_sum + bits / ttl_sample_valid * self.ttl_hashparams_num_valid_levels
 
         ttl_num_sum += params_q_xyz.numel()

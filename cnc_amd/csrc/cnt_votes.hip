@@ -1,0 +1,166 @@
+// cnt_votes.hip — cnt_np_embed / cnt_np_embed_backward (gridencoder.cu:873-1087) from a static plan,
+// without atomics.
+//
+// The vertex list handed to cnt_np_embed (the occupied finest-level vertices, utils_bpp_acc.py:498-512)
+// only changes when the occupancy grid does (every 16 training steps), while the votes are recounted
+// three times per step (xy, xz, yz) and differentiated.  The atomic kernels of grid_encode.hip cost one
+// memory-side atomic request per vertex (2.1e7 vertices -> ~1.1-1.3 ms per call at full size, the
+// largest single item of the context pass).  With the list pre-sorted
+//   * by pixel of the projection plane  -> forward  = a segmented count per pixel,
+//   * by table row of the finest level  -> backward = a segmented sum per row,
+// both are plain gathers + one plain store per pixel / row.  The plan (row and pixel of every vertex)
+// comes from cnc_cnt_np_plan; the sorting itself is torch.sort in the host mirror, once per refresh.
+// Forward counts are integers, so the result is bit-identical to the atomic kernel's.
+#include "common.hpp"
+
+namespace cnc {
+
+// row / pixel of every vertex; 0xFFFFFFFF for vertices cnt_np_embed skips (not strictly inside)
+__global__ __launch_bounds__(256) void k_cnt_plan(const int16_t* __restrict__ inputs, uint32_t N,
+                                                  uint32_t R, uint32_t hs, uint32_t axis,
+                                                  uint32_t* __restrict__ rows,
+                                                  uint32_t* __restrict__ pixels)
+{
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= N) return;
+    uint32_t q[3];
+    bool     inside = true;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        q[d] = (uint32_t)(int32_t)inputs[(size_t)b * 3 + d];
+        inside &= !(q[d] <= 0 || q[d] >= R - 1);
+    }
+    const uint32_t u = axis == 2 ? q[1] : q[0];
+    const uint32_t w = axis == 0 ? q[1] : q[2];
+    if (rows) rows[b] = inside ? grid_row<3>(q, hs, R) : 0xFFFFFFFFu;
+    if (pixels) pixels[b] = inside ? (u - 1) * (R - 2) + (w - 1) : 0xFFFFFFFFu;
+}
+
+// forward: one wave per pixel; lane = (vertex slot, channel); out[p][ch][{pos, neg}]
+template <uint32_t F>
+__global__ __launch_bounds__(64) void k_cnt_votes(const uint32_t* __restrict__ rows_by_pixel,
+                                                  const int32_t* __restrict__ seg,
+                                                  const float* __restrict__ emb,
+                                                  float* __restrict__ out, uint32_t P)
+{
+    constexpr uint32_t VPI = 64 / F;                 // vertices per iteration
+    const uint32_t p = blockIdx.x;
+    if (p >= P) return;
+    const uint32_t lane = threadIdx.x, ch = lane % F, vs = lane / F;
+    const int32_t  s = seg[p], e = seg[p + 1];
+    float          pos = 0;
+    // four independent index -> row gathers in flight per lane (the loop is latency-bound otherwise)
+    for (int32_t k = s + (int32_t)vs; k < e; k += (int32_t)(4 * VPI)) {
+        uint32_t row[4];
+        float    v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int32_t kk = k + u * (int32_t)VPI;
+            row[u] = kk < e ? rows_by_pixel[kk] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = row[u] != 0xFFFFFFFFu ? emb[(size_t)row[u] * F + ch] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            pos += ((double)v[u] > 0.9) ? 1.0f : 0.0f;   // float vs double literal, gridencoder.cu:909
+    }
+#pragma unroll
+    for (uint32_t m = F; m < 64; m <<= 1) pos += __shfl_xor(pos, (int)m);
+    if (vs == 0) {
+        float2 r;
+        r.x = pos;
+        r.y = (float)(e - s) - pos;
+        *reinterpret_cast<float2*>(out + ((size_t)p * F + ch) * 2) = r;
+    }
+}
+
+// backward: one wave per table row; lane = (vertex slot, channel).  Every vertex of a row sees the
+// same embedding, hence the same vote: grad_emb[row][ch] = +sum G[pixel][ch][0] or -sum G[pixel][ch][1],
+// G = grad / outputs_sum (prepared by the caller).  Plain store: each row has one writer.
+template <uint32_t F>
+__global__ __launch_bounds__(64) void k_cnt_votes_bwd(const uint32_t* __restrict__ pixels_by_row,
+                                                      const int32_t* __restrict__ seg,
+                                                      const float* __restrict__ emb,
+                                                      const float* __restrict__ G,
+                                                      float* __restrict__ grad_emb, uint32_t rows)
+{
+    constexpr uint32_t VPI = 64 / F;
+    const uint32_t r = blockIdx.x;
+    if (r >= rows) return;
+    const uint32_t lane = threadIdx.x, ch = lane % F, vs = lane / F;
+    const int32_t  s = seg[r], e = seg[r + 1];
+    if (s == e) return;                              // no vertex maps here: gradient stays as it is
+    const bool     pos = (double)emb[(size_t)r * F + ch] > 0.9;
+    const uint32_t sel = pos ? 0u : 1u;
+    float          acc = 0;
+    for (int32_t k = s + (int32_t)vs; k < e; k += (int32_t)(4 * VPI)) {
+        uint32_t px[4];
+        float    v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int32_t kk = k + u * (int32_t)VPI;
+            px[u] = kk < e ? pixels_by_row[kk] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            v[u] = px[u] != 0xFFFFFFFFu ? G[((size_t)px[u] * F + ch) * 2 + sel] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc += v[u];
+    }
+#pragma unroll
+    for (uint32_t m = F; m < 64; m <<= 1) acc += __shfl_xor(acc, (int)m);
+    if (vs == 0) grad_emb[(size_t)r * F + ch] += pos ? acc : -acc;
+}
+
+}  // namespace cnc
+
+using namespace cnc;
+
+extern "C" int cnc_cnt_np_plan(const int16_t* inputs, uint32_t N, uint32_t resolution,
+                               uint32_t hashmap_size, uint32_t axis, uint32_t* rows,
+                               uint32_t* pixels, void* stream)
+{
+    if (N == 0) return CNC_OK;
+    if (!inputs || (!rows && !pixels) || axis > 2 || resolution < 3 || hashmap_size == 0)
+        return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_cnt_plan, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, inputs, N,
+                       resolution, hashmap_size, axis, rows, pixels);
+    return launch_status();
+}
+
+#define CNC_VOTE_SWITCH(F, CALL)                                  \
+    switch (F) {                                                  \
+    case 1: { constexpr uint32_t FF = 1; CALL; } break;           \
+    case 2: { constexpr uint32_t FF = 2; CALL; } break;           \
+    case 4: { constexpr uint32_t FF = 4; CALL; } break;           \
+    case 8: { constexpr uint32_t FF = 8; CALL; } break;           \
+    case 16: { constexpr uint32_t FF = 16; CALL; } break;         \
+    case 32: { constexpr uint32_t FF = 32; CALL; } break;         \
+    default: return CNC_ERR_INVALID_VALUE;                        \
+    }
+
+extern "C" int cnc_cnt_np_embed_planned(const uint32_t* rows_by_pixel, const int32_t* pixel_seg,
+                                        const float* embeddings_clip, float* outputs,
+                                        uint32_t n_pixels, uint32_t F, void* stream)
+{
+    if (n_pixels == 0) return CNC_OK;
+    if (!pixel_seg || !embeddings_clip || !outputs) return CNC_ERR_INVALID_VALUE;
+    hipStream_t s = (hipStream_t)stream;
+    CNC_VOTE_SWITCH(F, hipLaunchKernelGGL((k_cnt_votes<FF>), dim3(n_pixels), dim3(64), 0, s,
+                                          rows_by_pixel, pixel_seg, embeddings_clip, outputs, n_pixels));
+    return launch_status();
+}
+
+extern "C" int cnc_cnt_np_embed_planned_backward(const uint32_t* pixels_by_row, const int32_t* row_seg,
+                                                 const float* embeddings_clip, const float* grad_over_sum,
+                                                 float* grad_embeddings, uint32_t n_rows, uint32_t F,
+                                                 void* stream)
+{
+    if (n_rows == 0) return CNC_OK;
+    if (!row_seg || !embeddings_clip || !grad_over_sum || !grad_embeddings) return CNC_ERR_INVALID_VALUE;
+    hipStream_t s = (hipStream_t)stream;
+    CNC_VOTE_SWITCH(F, hipLaunchKernelGGL((k_cnt_votes_bwd<FF>), dim3(n_rows), dim3(64), 0, s,
+                                          pixels_by_row, row_seg, embeddings_clip, grad_over_sum,
+                                          grad_embeddings, n_rows));
+    return launch_status();
+}

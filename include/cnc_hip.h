@@ -145,6 +145,28 @@ int cnc_cnt_np_embed_backward(const int16_t* inputs, const float* embeddings_cli
                               uint32_t N, uint32_t resolution, uint32_t F, uint32_t hashmap_size,
                               uint32_t axis, void* stream);
 
+/* cnt_np_embed from a static plan, without atomics (MI355X extension; cnc_amd/csrc/cnt_votes.hip).
+ * The vertex list of cnt_np_embed changes only with the occupancy grid, so the host sorts it once per
+ * refresh — by pixel of the projection plane for the forward count, by table row for the backward sum
+ * — and each call is a segmented gather with one plain store per pixel / row.
+ *   cnc_cnt_np_plan: per vertex, rows[i] = table row (gridencoder.cu:45-87) and pixels[i] =
+ *     (u-1)*(res-2) + (w-1) of the plane `axis`; 0xFFFFFFFF for vertices cnt_np_embed skips.  Either
+ *     output may be NULL.
+ *   cnc_cnt_np_embed_planned: outputs [n_pixels, F, 2] is WRITTEN (not accumulated); rows_by_pixel
+ *     holds the rows of the valid vertices ordered by pixel, pixel_seg [n_pixels+1] their segment
+ *     starts.  Same counts as cnc_cnt_np_embed, bit for bit.
+ *   cnc_cnt_np_embed_planned_backward: grad_over_sum [n_pixels, F, 2] = grad * (1 / outputs_sum);
+ *     pixels_by_row / row_seg [n_rows+1] = the vertices' pixels ordered by table row;
+ *     grad_embeddings [n_rows, F] is accumulated into (rows without vertices untouched).           */
+int cnc_cnt_np_plan(const int16_t* inputs, uint32_t N, uint32_t resolution, uint32_t hashmap_size,
+                    uint32_t axis, uint32_t* rows, uint32_t* pixels, void* stream);
+int cnc_cnt_np_embed_planned(const uint32_t* rows_by_pixel, const int32_t* pixel_seg,
+                             const float* embeddings_clip, float* outputs, uint32_t n_pixels,
+                             uint32_t F, void* stream);
+int cnc_cnt_np_embed_planned_backward(const uint32_t* pixels_by_row, const int32_t* row_seg,
+                                      const float* embeddings_clip, const float* grad_over_sum,
+                                      float* grad_embeddings, uint32_t n_rows, uint32_t F, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Radiance-field MLP (gradient-free evaluations) — stands in for the cuBLAS GEMM chain behind
  * nn.Sequential(Linear, ReLU, Linear[, ReLU, Linear]) (examples/radiance_fields/ngp.py:475-504)

@@ -147,6 +147,28 @@ def test_fused_segment_reduction_equals_packed_dataflow(setup):
         assert (a - b).abs().max() <= 1e-4 * b.abs().max()
 
 
+def test_planned_votes_equal_atomic_votes(setup):
+    """planned_votes=True (vertex list sorted once per refresh, segmented gathers) vs the atomic
+    cnt_np_embed kernels: same entropy estimate, same gradients into the finest 3-D level and planes."""
+    g, m, encs, binary = setup
+    res = {}
+    for planned in (True, False):
+        m.planned_votes = planned
+        torch.manual_seed(5)
+        for e in encs.values():
+            e.zero_grad()
+        m.zero_grad()
+        bpp, _ = m.forward_binary_vxl_mixPg_3D2D(encs["xyz"], encs["xy"], encs["xz"], encs["yz"], binary, step=0)
+        bpp.backward()
+        assert (m.vote_plan is not None) == planned
+        res[planned] = (bpp.item(), encs["xyz"].params.grad.clone(), encs["xy"].params.grad.clone(),
+                        next(m.context_model_2D[1].parameters()).grad.clone())
+    m.planned_votes = True
+    assert res[True][0] == res[False][0]        # the votes are integer counts: the forward is identical
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert (a - b).abs().max() <= 1e-5 * b.abs().max()
+
+
 def test_segment_weighted_sum_kernel(cuda):
     from cnc_amd.backends import pack_and_align as pa
     rng = np.random.default_rng(0)

@@ -344,3 +344,34 @@ def test_occupancy_sat_gives_the_scans_answer(cuda, oracle, D, Rb):
     ge = torch.zeros(emb.shape, device=cuda)
     be.grid_encode_backward(t(g), t(x), t(emb), t(offs), t(resl), ge, x.shape[0], D, 8, L, 0, Rb, None, None, t(vxl), None, occ_sat=sat)
     _check_bwd(ge.cpu().numpy(), want32, acc64, abs64, n_terms_max=x.shape[0] * 8)
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+@pytest.mark.parametrize("F,R,log2T", [(8, 34, 12), (2, 34, 12), (4, 12, 12), (16, 20, 10)])
+def test_cnt_np_embed_planned_equals_oracle(cuda, oracle, axis, F, R, log2T):
+    """The sorted-plan vote kernels (no atomics): counts equal the oracle's exactly, gradients within
+    the float64-shadow bound; duplicates, border vertices and a dense finest level (R^3 < T) included."""
+    from cnc_amd.backends import gridencoder_backend as be
+    hs = 2 ** log2T
+    rng = np.random.default_rng(axis * 11 + F)
+    pts = rng.integers(0, R, size=(6000, 3)).astype(np.int16)
+    rows = min(hs, R ** 3)
+    emb = np.where(rng.uniform(size=(hs, F)) < 0.5, 1.0, -1.0).astype(np.float32)
+    emb[::5] *= 0.5
+    t = lambda a: torch.as_tensor(a, device=cuda)
+    plan = be.VotePlan(t(pts), R, hs)
+    want = oracle.cnt_np_embed(pts, emb, R, hs, axis)
+    out = torch.full((R - 2, R - 2, F, 2), -7.0, device=cuda)        # must be overwritten everywhere
+    be.cnt_np_embed_planned(plan, t(emb[:rows].copy()), out, F, axis)
+    assert np.array_equal(out.cpu().numpy(), want)
+    s = (want.sum(-1, keepdims=True) + 1e-6).astype(np.float32)
+    grad = rng.normal(size=want.shape).astype(np.float32)
+    _, acc = oracle.cnt_np_embed_backward(pts, emb, s, grad, R, hs, axis, want_acc64=True)
+    _, absacc = oracle.cnt_np_embed_backward(pts, emb, s, np.abs(grad), R, hs, axis, want_acc64=True)
+    ge = torch.zeros((rows, F), device=cuda)
+    g_over_sum = (torch.reciprocal(t(s)) * t(grad)).contiguous()
+    be.cnt_np_embed_planned_backward(plan, t(emb[:rows].copy()), g_over_sum, ge, F, axis)
+    got = ge.cpu().numpy().astype(np.float64)
+    bound = 64 * np.finfo(np.float32).eps * np.abs(absacc[:rows]) + 1e-30
+    assert np.all(np.abs(got - acc[:rows]) <= bound)
+    assert np.all(acc[rows:] == 0)

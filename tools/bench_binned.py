@@ -35,18 +35,20 @@ def timeit(fn, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 
-for name, gen in (("marched rays", marched), ("uniform", lambda N: torch.rand((N, 3), device=dev))):
-    N = 1 << 20
-    x = gen(N); N = x.shape[0]
-    g = torch.randn((L, N, F), device=dev)
-    ge = torch.zeros_like(emb)
-    base = timeit(lambda: be.grid_encode_backward(g, x, emb, o_t, r_t, ge, N, 3, F, L, 0, 128, None, None, None, None, ste_binary=True, ste_clip_count=clip))
-    print(f"{name} N={N}: atomic {base:.3f} ms ({N*8716/base/1e9:.2f} TB/s alg)")
-    ref = torch.zeros_like(emb)
-    be.grid_encode_backward(g, x, emb, o_t, r_t, ref, N, 3, F, L, 0, 128, None, None, None, None, ste_binary=True, ste_clip_count=clip)
-    for nb in (5, 6, 7, 8, 10):
-        ms = timeit(lambda: be.grid_encode_backward(g, x, emb, o_t, r_t, ge, N, 3, F, L, 0, 128, None, None, None, None, ste_binary=True, ste_clip_count=clip, binned=(nb, 1 << 19)))
-        out = torch.zeros_like(emb)
-        be.grid_encode_backward(g, x, emb, o_t, r_t, out, N, 3, F, L, 0, 128, None, None, None, None, ste_binary=True, ste_clip_count=clip, binned=(nb, 1 << 19))
-        err = ((out - ref).abs().max() / ref.abs().max()).item()
-        print(f"   binned top {nb:2d}: {ms:.3f} ms ({N*8716/ms/1e9:.2f} TB/s alg)  rel err {err:.1e}")
+if __name__ == "__main__":
+    for name, gen in (("marched rays", marched), ("uniform", lambda N: torch.rand((N, 3), device=dev))):
+        N = 1 << 20
+        x = gen(N); N = x.shape[0]
+        g = torch.randn((L, N, F), device=dev)
+        ge = torch.zeros_like(emb)
+        base = timeit(lambda: be.grid_encode_backward(g, x, emb, o_t, r_t, ge, N, 3, F, L, 0, 128, None, None, None, None, ste_binary=True, ste_clip_count=clip))
+        print(f"{name} N={N}: atomic {base:.3f} ms ({N*8716/base/1e9:.2f} TB/s alg)")
+        ref = torch.zeros_like(emb)
+        be.grid_encode_backward(g, x, emb, o_t, r_t, ref, N, 3, F, L, 0, 128, None, None, None, None, ste_binary=True, ste_clip_count=clip)
+        for nb in (5, 6, 7, 8, 10):
+            ms = timeit(lambda: be.grid_encode_backward(g, x, emb, o_t, r_t, ge, N, 3, F, L, 0, 128, None, None, None, None, ste_binary=True, ste_clip_count=clip, binned=(nb, 1 << 19)))
+            out = torch.zeros_like(emb)
+            be.grid_encode_backward(g, x, emb, o_t, r_t, out, N, 3, F, L, 0, 128, None, None, None, None, ste_binary=True, ste_clip_count=clip, binned=(nb, 1 << 19))
+            err = ((out - ref).abs().max() / ref.abs().max()).item()
+            print(f"   binned top {nb:2d}: {ms:.3f} ms ({N*8716/ms/1e9:.2f} TB/s alg)  rel err {err:.1e}")
+

@@ -38,4 +38,4 @@ with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
         bpp, mb = m.forward_binary_vxl_mixPg_3D2D(*encs, binaries, step=step)
         bpp.backward()
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=70))
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=60, max_name_column_width=70))
