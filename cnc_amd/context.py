@@ -105,6 +105,41 @@ class _cnt_np_embed(Function):
         return None, grad_embeddings, None, None, None
 
 
+_LEVEL_CONSTS = {}
+
+
+def _level_consts(off, n_features, device):
+    """(offsets, level lengths in rows, entries per level) as device tensors, made once per table layout."""
+    key = (off, n_features, str(device))
+    if key not in _LEVEL_CONSTS:
+        lengths = [off[i + 1] - off[i] for i in range(len(off) - 1)]
+        _LEVEL_CONSTS[key] = (torch.tensor(off, dtype=torch.long, device=device),
+                              torch.tensor(lengths, dtype=torch.long, device=device),
+                              torch.tensor([l * n_features for l in lengths], dtype=torch.float32, device=device))
+    return _LEVEL_CONSTS[key]
+
+
+class _LevelSums(Function):
+    """Sum of every level's entries of a [rows, F] table: out[l] = sum(table[off[l]:off[l+1]])."""
+
+    @staticmethod
+    def forward(ctx, table, off):
+        cs = torch.cumsum(table.sum(dim=1, dtype=torch.float64), 0)
+        idx = _level_consts(off, table.shape[1], table.device)[0]
+        cs0 = torch.cat([cs.new_zeros(1), cs])
+        ctx.off, ctx.shape = off, table.shape
+        return (cs0[idx[1:]] - cs0[idx[:-1]]).to(table.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        off = ctx.off
+        lengths = _level_consts(off, ctx.shape[1], g.device)[1]
+        rows = torch.repeat_interleave(g, lengths, output_size=off[-1] - off[0])
+        grad = rows.new_zeros(ctx.shape[0])
+        grad[off[0]:off[-1]] = rows
+        return grad[:, None].expand(ctx.shape), None
+
+
 class _cnt_np_embed_planned(Function):
     """`_cnt_np_embed` from a `VotePlan` (vertex list pre-sorted by pixel / by table row): same counts
     bit for bit, no atomics (cnc_amd/csrc/cnt_votes.hip)."""
@@ -303,6 +338,9 @@ class CNC_context_models(nn.Module):
         self.offsets_list = offsets(resolutions_list, max_params, num_dim)
         self.offsets_list_2D = offsets(resolutions_list_2D, 2 ** log2_hashmap_size_2D, 2)
         offsets_list = self.offsets_list
+        # host copies: slicing a table with device scalars costs a device->host sync per slice
+        self._off3_host = [int(v) for v in self.offsets_list.tolist()]
+        self._off2_host = [int(v) for v in self.offsets_list_2D.tolist()]
 
         # finest level that is still stored densely (utils_bpp_acc.py:288-293)
         self.n_levels_thresh = n_levels - 1
@@ -437,11 +475,23 @@ class CNC_context_models(nn.Module):
             return STE_multistep.apply(params, self.Q)
         return params + (self.rand_like(params) - 0.5) * (1 / self.Q)
 
+    def level_stats(self, params_q, off_host):
+        """`get_BiRF_wentropy_leveln` for every level of one table at once: (Pg [L], bits [L]).
+        One pass over the table instead of L sliced reductions and ~10 scalar kernels per level; the
+        level sums are differences of a float64 running sum of the row sums (exact for +-1 tables)."""
+        off = tuple(off_host)
+        sums = _LevelSums.apply(params_q, off)
+        ttl = _level_consts(off, params_q.shape[1], params_q.device)[2]
+        pos_num, neg_num = (ttl + sums) / 2.0, (ttl - sums) / 2.0
+        Pg = pos_num / ttl
+        bits = pos_num * (-torch.log2(Pg)) + neg_num * (-torch.log2(1 - Pg))
+        return Pg, bits
+
     def get_BiRF_wentropy_leveln(self, params_q, n, offsets_list=None):
         """Level frequency Pg_n = #(+1)/numel and the zero-order bit count (utils_bpp_acc.py:472-486)."""
-        if offsets_list is None:
-            offsets_list = self.offsets_list
-        level = params_q[offsets_list[n]:offsets_list[n + 1]]
+        off = self._off2_host if offsets_list is self.offsets_list_2D else \
+            (self._off3_host if offsets_list is None or offsets_list is self.offsets_list else offsets_list)
+        level = params_q[int(off[n]):int(off[n + 1])]
         ttl = level.numel()
         s = torch.sum(level)
         pos_num, neg_num = (ttl + s) / 2.0, (ttl - s) / 2.0
@@ -600,16 +650,17 @@ class CNC_context_models(nn.Module):
                 [self._sorted_slots_2D(binary_2D[k], n) for n in range(self.n_levels_2D) if self._coded_2D(n)]
                 for k in range(3)]
 
-        finest_3D = params_q_xyz[self.offsets_list[-2]:self.offsets_list[-1]]
+        finest_3D = params_q_xyz[self._off3_host[-2]:self._off3_host[-1]]
         for k, (Ec, p_q) in enumerate(zip((Encoding_xy, Encoding_xz, Encoding_yz),
                                           (params_q_xy, params_q_xz, params_q_yz))):
             with _range("ctx/pn_frac"):
                 pn_frac = (self.get_pn_embed_frac(finest_3D, idx_coords2, axis=axes[k], plan=self.vote_plan)
                            if self.use_dimension_wise else None)
             batches = iter(self.batched_inputs_list[k])
+            with _range("ctx/level_Pg"):
+                Pg_all, bits_all = self.level_stats(p_q, self._off2_host)
             for n in range(self.n_levels_2D):
-                with _range("ctx/level_Pg"):
-                    Pg_n, bits_n, _ = self.get_BiRF_wentropy_leveln(p_q, n, self.offsets_list_2D)
+                Pg_n, bits_n = Pg_all[n], bits_all[n]
                 if self._coded_2D(n):
                     points_n, order, rows, unique_cnt = next(batches)
                     with _range("ctx/2D_mean"):
@@ -631,11 +682,14 @@ class CNC_context_models(nn.Module):
         p1s = self.unique_count_cumsum_list[self.utils_nlevel_idx, v1s]
 
         pts_orig, pts_n, Pg_cols, lvl_ids, cnts, values_q = [], [], [], [], [], []
+        with _range("ctx/level_Pg"):
+            Pg_all, bits_all = self.level_stats(params_q_xyz, self._off3_host)
         _g = _range("ctx/3D_gather")
         _g.__enter__()
+        # the window bounds of every level in ONE device->host copy
+        v0s, v1s, p0s, p1s = torch.stack([v0s, v1s, p0s, p1s]).tolist()
         for n in range(self.n_levels):
-            with _range("ctx/level_Pg"):
-                Pg_n, bits_n, _ = self.get_BiRF_wentropy_leveln(params_q_xyz, n)
+            Pg_n, bits_n = Pg_all[n], bits_all[n]
             if not self._coded_3D(n):
                 ttl_bit_sum = ttl_bit_sum + bits_n
                 continue
@@ -645,7 +699,7 @@ class CNC_context_models(nn.Module):
             Pg_cols.append(Pg_n.reshape(1, 1).repeat(po.shape[0], 1))
             lvl_ids.append(torch.full((po.shape[0],), n, dtype=torch.long, device=self.dev))
             cnts.append(self.unique_count_list[n, v0s[n]:v1s[n]])
-            values_q.append(params_q_xyz[self.unique_value_list[n][v0s[n]:v1s[n]] + self.offsets_list[n]])
+            values_q.append(params_q_xyz[self.unique_value_list[n][v0s[n]:v1s[n]] + self._off3_host[n]])
         _g.__exit__(None, None, None)
 
         if pts_orig:
