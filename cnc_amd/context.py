@@ -699,13 +699,15 @@ class CNC_context_models(nn.Module):
             Pg_cols.append(Pg_n.reshape(1, 1).repeat(po.shape[0], 1))
             lvl_ids.append(torch.full((po.shape[0],), n, dtype=torch.long, device=self.dev))
             cnts.append(self.unique_count_list[n, v0s[n]:v1s[n]])
-            values_q.append(params_q_xyz[self.unique_value_list[n][v0s[n]:v1s[n]] + self._off3_host[n]])
+            values_q.append(self.unique_value_list[n][v0s[n]:v1s[n]] + self._off3_host[n])   # table rows
         _g.__exit__(None, None, None)
 
         if pts_orig:
             with _range("ctx/3D_cat"):
                 pts_orig, pts_n, Pg_cols = torch.cat(pts_orig), torch.cat(pts_n), torch.cat(Pg_cols)
-                lvl_ids, cnts, values_q = torch.cat(lvl_ids), torch.cat(cnts), torch.cat(values_q)
+                lvl_ids, cnts = torch.cat(lvl_ids), torch.cat(cnts)
+                # one gather for all levels: its backward is ONE scatter into a table-sized gradient
+                values_q = params_q_xyz[torch.cat(values_q)]
             with _range("ctx/3D_query"):
                 mask, overlap = self.query_binary_vxl_qlist(pts_orig, binary_vxl, lvl_ids, return_overlap_area=True)
             with _range("ctx/3D_slot_masks"):
