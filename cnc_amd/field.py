@@ -142,7 +142,8 @@ class _FusedFeatures(Function):
         N = x.shape[0]
         ld, cols = owner._layout()
         feat = torch.empty(N, ld, device=x.device, dtype=torch.float32)
-        xs = (x.contiguous(), x[:, [0, 1]].contiguous(), x[:, [0, 2]].contiguous(), x[:, [1, 2]].contiguous())
+        # plane coordinates by slicing (an index list would cost a host->device copy and a sync each)
+        xs = (x.contiguous(), x[:, :2].contiguous(), x[:, ::2].contiguous(), x[:, 1:].contiguous())
         saved = []
         for enc, p, xi, col in zip(encs, params, xs, cols):
             bits, clip = enc._bit_plane(p)
@@ -155,7 +156,9 @@ class _FusedFeatures(Function):
             # x | sin(2^k x) | cos(2^k x), k = 0..9 (ngp.py:583-599), written in place
             n_f = owner._freqs.numel()
             feat[:, c0:c0 + 3] = x
-            arg = x[:, None, :] * owner._freqs.to(x.device)[None, :, None]
+            if owner._freqs.device != x.device:
+                owner._freqs = owner._freqs.to(x.device)
+            arg = x[:, None, :] * owner._freqs[None, :, None]
             v = feat[:, c0 + 3:c0 + 3 + 6 * n_f].view(N, n_f, 2, 3)
             torch.sin(arg, out=v[:, :, 0, :])
             torch.cos(arg, out=v[:, :, 1, :])

@@ -124,8 +124,12 @@ class SyntheticBallDataset:
         t = -b - torch.sqrt(disc.clamp_min(0))
         p = o + d * t[:, None]
         n = p / self.RADIUS
-        tex = 0.5 + 0.5 * torch.sin(p * 9.0 + torch.tensor([0.0, 2.0, 4.0], device=p.device))
-        lam = (0.35 + 0.65 * (n * torch.tensor([0.3, 0.5, 0.8], device=p.device)).sum(-1).clamp(0, 1))[:, None]
+        if getattr(self, "_shade_consts", None) is None or self._shade_consts[0].device != p.device:
+            self._shade_consts = (torch.tensor([0.0, 2.0, 4.0], device=p.device),
+                                  torch.tensor([0.3, 0.5, 0.8], device=p.device))
+        phase, light = self._shade_consts
+        tex = 0.5 + 0.5 * torch.sin(p * 9.0 + phase)
+        lam = (0.35 + 0.65 * (n * light).sum(-1).clamp(0, 1))[:, None]
         rgb = (tex * lam).clamp(0, 1)
         return rgb, hit.float()[:, None]
 
@@ -252,7 +256,7 @@ class Trainer:
                 e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
                 sample_num=None, step=step)
             loss = loss + c.lmbda * bits_per_param
-            bpp = bits_per_param.item()
+            bpp = bits_per_param
         self.opt.zero_grad(set_to_none=self.bucket is None)
         self.opt2.zero_grad(set_to_none=self.bucket is None)
         if self.bucket is not None:
@@ -268,7 +272,9 @@ class Trainer:
         self.sched.step()
         if c.lmbda > 0:
             self.sched2.step()
-        return {"mse": mse.item(), "psnr": -10.0 * math.log10(max(mse.item(), 1e-12)), "bpp": bpp,
+        # the step's scalars in one device->host copy
+        mse_f, bpp_f = torch.stack([mse.detach(), torch.as_tensor(bpp, device=mse.device).detach().float()]).tolist()
+        return {"mse": mse_f, "psnr": -10.0 * math.log10(max(mse_f, 1e-12)), "bpp": bpp_f,
                 "embed_bits_MB": mb, "n_rendering_samples": n_samples, "num_rays": len(pixels)}
 
     def train(self, steps: Optional[int] = None, log=print):
