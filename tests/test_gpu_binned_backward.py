@@ -140,3 +140,38 @@ def test_binned_backward_coherent_points_with_spills(cuda, N):
     for ws_bytes in (4 * 4 * (16 + 64 * 16), 4 * 4 * (16 + (N // 8) * 16), None):
         b = _bwd_binned(cuda, g, x, emb, offs, resl, 4, 1024, ws_bytes=ws_bytes)
         assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max()
+
+
+def test_binned_backward_full_size_equals_atomic_kernel(cuda):
+    """BASELINE size (16L x 2^19 x F8, 2^20 ray-like samples, plan of the product path): the binned
+    call and the all-atomic call give the same table gradient; the sum of the gradient equals the
+    sum of the incoming gradient over in-range samples (the corner weights sum to 1: linearity)."""
+    from cnc_amd.backends import gridencoder_backend as be
+    from cnc_amd.synthetic import RES_16L, level_offsets
+    F, L, N = 8, 16, 1 << 20
+    offs = level_offsets(RES_16L, 19, 3)
+    o_t = torch.as_tensor(offs, device=cuda)
+    r_t = torch.tensor(RES_16L, dtype=torch.int32, device=cuda)
+    g = torch.Generator(device=cuda).manual_seed(7)
+    emb = torch.sign(torch.rand((int(offs[-1]), F), device=cuda, generator=g) * 2 - 1)
+    # 8192 rays of 128 samples, step 1/600 of the unit cube, inside the interior of every level
+    o = torch.rand((N // 128, 1, 3), device=cuda, generator=g) * 0.3 + 0.2
+    d = torch.nn.functional.normalize(torch.randn((N // 128, 1, 3), device=cuda, generator=g), dim=-1)
+    x = (o + d * (torch.arange(128, device=cuda).view(1, 128, 1) / 600.0)).clamp(0.02, 0.98).reshape(-1, 3).contiguous()
+    grad = torch.randn((L, N, F), device=cuda, generator=g)
+    plan = be.plan_binned_levels(RES_16L, offs, 3, F, N)
+    assert plan is not None and plan[0] >= 5
+    outs = []
+    for binned in (None, plan):
+        ge = torch.zeros_like(emb)
+        be.grid_encode_backward(grad, x, emb, o_t, r_t, ge, N, 3, F, L, 0, 128, None, None, None, None,
+                                ste_binary=True, binned=binned)
+        outs.append(ge)
+    a, b = outs
+    assert (a - b).abs().max() <= 2e-5 * a.abs().max()
+    # (no exact-zero comparison here: with ~16 terms per entry a sum can cancel to 0 in one order only)
+    # per level: sum over the table rows of the level == sum over samples of the incoming gradient
+    for l in range(L):
+        want = grad[l].double().sum(0)
+        got = b[int(offs[l]):int(offs[l + 1])].double().sum(0)
+        assert (got - want).abs().max() <= 1e-4 * grad[l].abs().double().sum(0).max()
