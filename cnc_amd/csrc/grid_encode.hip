@@ -167,11 +167,12 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd_bits(
             rb[i] = c.valid[i] ? load_row_bits<F>(bits, (uint64_t)off + c.row[i]) : 0u;
 #pragma unroll
         for (uint32_t i = 0; i < C; i++) {
-            const float tw = c.w[i] * c.wn_re;
+            // an invalid corner gets weight +0: fmaf(+0, +-1, acc) == acc, no per-feature select
+            const float tw = c.valid[i] ? c.w[i] * c.wn_re : 0.0f;
 #pragma unroll
             for (uint32_t k = 0; k < F; k++) {
                 const float e = ((rb[i] >> k) & 1u) ? 1.0f : -1.0f;
-                acc[k] = c.valid[i] ? __builtin_fmaf(tw, e, acc[k]) : acc[k];
+                acc[k] = __builtin_fmaf(tw, e, acc[k]);
             }
         }
     }
