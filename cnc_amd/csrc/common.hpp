@@ -62,7 +62,11 @@ __device__ __forceinline__ uint32_t grid_row(const uint32_t (&q)[D], uint32_t ha
 #pragma unroll
         for (uint32_t d = 0; d < D; d++) index ^= q[d] * primes[d];
     }
-    return index % hashmap_size;
+    // index % hashmap_size without the ~25-instruction u32 division in the common cases: hashed
+    // levels have a power-of-two table (mask), dense levels have index < R^D <= hashmap_size
+    // (identity).  Anything else (odd caller-made tables, uint32 wrap of R^D) takes the division.
+    if ((hashmap_size & (hashmap_size - 1)) == 0) return index & (hashmap_size - 1);
+    return index < hashmap_size ? index : index % hashmap_size;
 }
 
 // [lo, hi] range of occupancy cells covered by the +-1 vertex box of grid coordinate q along one
