@@ -248,9 +248,11 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             traffic = json.load(open(tp)).get(dom_name)
-        parts = {"grid_encode_backward": "one cnc_grid_encode_backward_binned call = k_grid_encode_bwd (10 coarse levels, "
-                                         "atomics) + k_bwd_bin + k_bwd_owner (6 finest levels, LDS accumulation); "
-                                         "avg_launch_ms is the whole call, = the sum of the three kernels' rocprof averages",
+        nb = (enc.plan_binned_levels(synthetic.RES_16L, w["offsets_host"], D, F, CHUNK) or (0, 0))[0]
+        parts = {"grid_encode_backward": f"one cnc_grid_encode_backward_binned call = k_grid_encode_bwd ({L - nb} coarse "
+                                         f"levels, atomics) + k_bwd_bin + k_bwd_owner ({nb} finest levels, LDS "
+                                         "accumulation); avg_launch_ms is the whole call, = the sum of the three "
+                                         "kernels' rocprof averages",
                  "grid_encode_forward": "k_grid_encode_fwd_bits"}
         roofline = {"kernel": dom_name, "kernel_parts": parts[dom_name], "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
