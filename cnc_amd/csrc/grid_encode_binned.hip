@@ -33,7 +33,7 @@
 
 namespace cnc {
 
-constexpr uint32_t kSlabLog2 = 8;                  // rows per owner wave
+constexpr uint32_t kSlabLog2 = 8;                  // rows per owner wave (<= 12: item row fields)
 constexpr uint32_t kSlab = 1u << kSlabLog2;
 constexpr uint32_t kBinSamplesPerThread = 4;       // pass 1: 4096 samples per 1024-thread block
 constexpr uint32_t kMaxBins = 4096;                // LDS histogram size (level_rows <= 2^20)
@@ -46,7 +46,7 @@ constexpr uint32_t kHeadBytes = 16;                // workspace bytes per bin co
 struct Item {
     uint32_t sample;
     float    w0, w1;      // weight / sum of valid weights of corner x and corner x+1
-    uint32_t rows;        // r0 | r1 << 8 | mask << 16; mask bit 0: add row r0, bit 1: add row r1
+    uint32_t rows;        // r0 | r1 << 12 | mask << 24; mask bit 0: add row r0, bit 1: add row r1
 };
 static_assert(sizeof(Item) == 16, "Item is read as one dwordx4");
 
@@ -148,16 +148,16 @@ __global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
             it.sample = i;
             it.w0 = c.w[2 * p] * c.wn_re;
             it.w1 = c.w[2 * p + 1] * c.wn_re;
-            const uint32_t lr = (c.row[2 * p] & (kSlab - 1)) | (c.row[2 * p + 1] & (kSlab - 1)) << 8;
+            const uint32_t lr = (c.row[2 * p] & (kSlab - 1)) | (c.row[2 * p + 1] & (kSlab - 1)) << 12;
             if (v0) {
                 const uint32_t at = atomicAdd(&s_cnt[b0], 1u);
-                it.rows = lr | (together ? 3u : 1u) << 16;
+                it.rows = lr | (together ? 3u : 1u) << 24;
                 if (at < a.cap) items[(size_t)b0 * a.cap + at] = it;
                 else spill |= (together ? 3u : 1u) << (2 * p);
             }
             if (v1 && !together) {
                 const uint32_t at = atomicAdd(&s_cnt[b1], 1u);
-                it.rows = lr | 2u << 16;
+                it.rows = lr | 2u << 24;
                 if (at < a.cap) items[(size_t)b1 * a.cap + at] = it;
                 else spill |= 2u << (2 * p);
             }
@@ -247,9 +247,9 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
         uint32_t pend = 0, r0 = 0, r1 = 0;
         float    v0[F], v1[F];
         if (nx_valid) {
-            pend = (nx_item.rows >> 16) & 3u;
-            r0 = nx_item.rows & 0xFFu;
-            r1 = (nx_item.rows >> 8) & 0xFFu;
+            pend = (nx_item.rows >> 24) & 3u;
+            r0 = nx_item.rows & 0xFFFu;
+            r1 = (nx_item.rows >> 12) & 0xFFFu;
 #pragma unroll
             for (uint32_t f = 0; f < F; f++) {
                 v0[f] = nx_item.w0 * nx_g[f];
