@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from torch.autograd import Function
 
 from .gridencoder import GridEncoder
-from .mlp import Linear, linear_fn
+from .mlp import Linear, linear_fn, run_layers
 
 
 class _TruncExp(Function):
@@ -248,11 +248,8 @@ class compose_3D_2D_embed(nn.Module):
             first = self.network[0]
             pad = feat.shape[1] - first.in_features
             w = F.pad(first.weight, (0, pad)) if pad else first.weight
-            h = linear_fn(feat, w, first.bias)
-            for layer in list(self.network)[1:]:
-                h = layer(h)
-            return h
-        return self.network(self.features(x))
+            return run_layers(self.network, feat, first_weight=w)
+        return run_layers(self.network, self.features(x))
 
 
 class NGPRadianceField_mygrid_2D3D(nn.Module):
@@ -326,7 +323,7 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
             h = torch.cat([d, embedding.reshape(-1, self.geo_feat_dim)], dim=-1)
         else:
             h = embedding.reshape(-1, self.geo_feat_dim)
-        rgb = self.mlp_head(h).reshape(list(embedding.shape[:-1]) + [3]).to(embedding)
+        rgb = run_layers(self.mlp_head, h).reshape(list(embedding.shape[:-1]) + [3]).to(embedding)
         return torch.sigmoid(rgb) if apply_act else rgb
 
     def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):

@@ -74,6 +74,29 @@ def linear_fn(x, weight, bias):
     return F.linear(x, weight, bias)
 
 
+def run_layers(layers, h, first_weight=None):
+    """`nn.Sequential(*layers)(h)`.  Without autograd (evaluation renders, occupancy updates) a Linear
+    followed by a ReLU runs as ONE hipBLASLt GEMM with bias + ReLU in the epilogue
+    (`torch._addmm_activation`) instead of a GEMM and a separate pass over the activations.
+    `first_weight` replaces the first Linear's weight (zero-padded input columns)."""
+    layers = list(layers)
+    fuse = h.is_cuda and not torch.is_grad_enabled() and h.dim() == 2
+    i = 0
+    while i < len(layers):
+        m = layers[i]
+        if isinstance(m, nn.Linear):
+            w = first_weight if (i == 0 and first_weight is not None) else m.weight
+            if fuse and m.bias is not None and i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU):
+                h = torch._addmm_activation(m.bias, h, w.t())
+                i += 2
+                continue
+            h = linear_fn(h, w, m.bias)
+        else:
+            h = m(h)
+        i += 1
+    return h
+
+
 def _round16(n: int) -> int:
     return (n + 15) // 16 * 16
 

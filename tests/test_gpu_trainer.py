@@ -124,3 +124,24 @@ def test_fused_field_features_match_cat(cuda, F):
             continue
         scale = pb.grad.abs().max().clamp_min(1e-6)
         assert (pa.grad - pb.grad).abs().max() <= 2e-4 * scale, n
+
+
+def test_no_grad_field_uses_fused_epilogue_and_matches(cuda):
+    """Evaluation path (bias + ReLU in the GEMM epilogue) vs the training path (separate ReLU):
+    same rgb / density within the north-star's 1e-4."""
+    from cnc_amd.field import NGPRadianceField_mygrid_2D3D
+    torch.manual_seed(9)
+    f = NGPRadianceField_mygrid_2D3D(aabb=[-1.5] * 3 + [1.5] * 3, n_features_per_level=8, n_neurons=160,
+                                     resolutions_list=(18, 24, 33, 70), log2_hashmap_size=14,
+                                     resolutions_list_2D=(130, 258), log2_hashmap_size_2D=12).to(cuda)
+    with torch.no_grad():
+        for p in f.parameters():
+            if p.dim() == 2 and p.shape[1] <= 8:
+                p.uniform_(-1, 1)
+    x = torch.rand(20000, 3, device=cuda) * 2.6 - 1.3
+    d = torch.nn.functional.normalize(torch.randn(20000, 3, device=cuda), dim=-1)
+    rgb_a, sig_a = f(x, d)
+    with torch.no_grad():
+        rgb_b, sig_b = f(x, d)
+    assert (rgb_a - rgb_b).abs().max() <= 1e-4
+    assert ((sig_a - sig_b).abs() <= 1e-4 * (1 + sig_a.abs())).all()
