@@ -58,6 +58,39 @@ class _LinearSplitK(torch.autograd.Function):
         return grad_x, grad_w, grad_b
 
 
+class _LinearReLUSplitK(torch.autograd.Function):
+    """relu(x W^T + b) with the bias + ReLU in the GEMM epilogue; backward masks the incoming gradient
+    with (y > 0) and continues as `_LinearSplitK`."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = torch._addmm_activation(bias, x, weight.t())
+        ctx.save_for_backward(x, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, y = ctx.saved_tensors
+        g = torch.where(y > 0, grad_out, torch.zeros((), dtype=grad_out.dtype, device=grad_out.device))
+        grad_x = grad_w = grad_b = None
+        if ctx.needs_input_grad[0]:
+            grad_x = g @ weight
+        if ctx.needs_input_grad[1]:
+            n = x.shape[0]
+            s = _split(n)
+            if s == 1:
+                grad_w = g.t() @ x
+            else:
+                m = n // s
+                head = m * s
+                grad_w = torch.bmm(g[:head].view(s, m, -1).transpose(1, 2), x[:head].view(s, m, -1)).sum(0)
+                if head < n:
+                    grad_w = grad_w + g[head:].t() @ x[head:]
+        if ctx.needs_input_grad[2]:
+            grad_b = g.sum(0)
+        return grad_x, grad_w, grad_b
+
+
 class Linear(nn.Linear):
     """nn.Linear with the split-K weight gradient (CUDA tensors only; CPU uses the stock path)."""
 
@@ -75,19 +108,22 @@ def linear_fn(x, weight, bias):
 
 
 def run_layers(layers, h, first_weight=None):
-    """`nn.Sequential(*layers)(h)`.  Without autograd (evaluation renders, occupancy updates) a Linear
-    followed by a ReLU runs as ONE hipBLASLt GEMM with bias + ReLU in the epilogue
-    (`torch._addmm_activation`) instead of a GEMM and a separate pass over the activations.
+    """`nn.Sequential(*layers)(h)`, with every Linear -> ReLU pair as ONE hipBLASLt GEMM with bias +
+    ReLU in the epilogue (`torch._addmm_activation`) instead of a GEMM and a separate pass over the
+    activations; under autograd through `_LinearReLUSplitK`.
     `first_weight` replaces the first Linear's weight (zero-padded input columns)."""
     layers = list(layers)
-    fuse = h.is_cuda and not torch.is_grad_enabled() and h.dim() == 2
+    fuse = h.is_cuda and h.dim() == 2
     i = 0
     while i < len(layers):
         m = layers[i]
         if isinstance(m, nn.Linear):
             w = first_weight if (i == 0 and first_weight is not None) else m.weight
             if fuse and m.bias is not None and i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU):
-                h = torch._addmm_activation(m.bias, h, w.t())
+                if torch.is_grad_enabled() and (h.requires_grad or w.requires_grad):
+                    h = _LinearReLUSplitK.apply(h, w, m.bias)
+                else:
+                    h = torch._addmm_activation(m.bias, h, w.t())
                 i += 2
                 continue
             h = linear_fn(h, w, m.bias)

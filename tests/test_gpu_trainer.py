@@ -145,3 +145,15 @@ def test_no_grad_field_uses_fused_epilogue_and_matches(cuda):
         rgb_b, sig_b = f(x, d)
     assert (rgb_a - rgb_b).abs().max() <= 1e-4
     assert ((sig_a - sig_b).abs() <= 1e-4 * (1 + sig_a.abs())).all()
+    # and against plain nn.Sequential modules (separate ReLU), forward and parameter gradients
+    import copy
+    ref_base, ref_head = copy.deepcopy(f.mlp_base.network), copy.deepcopy(f.mlp_head)
+    feat = f.mlp_base.features(((x + 1.5) / 3.0).clamp(0, 1)).detach()
+    from cnc_amd.mlp import run_layers
+    ya = run_layers(f.mlp_base.network, feat)
+    yb = ref_base(feat)
+    assert (ya - yb).abs().max() <= 1e-4 * (1 + yb.abs().max())
+    g = torch.randn_like(ya)
+    ya.backward(g); yb.backward(g)
+    for pa, pb in zip(f.mlp_base.network.parameters(), ref_base.parameters()):
+        assert (pa.grad - pb.grad).abs().max() <= 1e-4 * (1 + pb.grad.abs().max())
