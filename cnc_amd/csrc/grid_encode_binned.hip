@@ -19,10 +19,9 @@
 //                        streams its bin (items coalesced, the sample's gradient row gathered one
 //                        batch ahead; the weights travel in the item, computed in pass 1 exactly as
 //                        the scatter kernel computes them) and adds into LDS with plain
-//                        read-modify-writes.  Lanes of one instruction
-//                        that hit the same row are serialised by a tag vote (write lane id to
-//                        tag[row], read back, winners go, losers retry) — LDS fp32 atomics were
-//                        measured 5x slower than this.  The slab is then added to the gradient
+//                        read-modify-writes.  Claims of one batch on the same row are serialised
+//                        with tickets from a per-row LDS counter (integer atomic), one round per
+//                        ticket — LDS fp32 atomics were measured 5x slower than this.  The slab is then added to the gradient
 //                        table with coalesced 16-byte accesses (STE mask applied there).
 //
 // A bin that fills up sends the excess items down the atomic path inside pass 1, so skewed inputs
@@ -182,19 +181,30 @@ __global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
     }
 }
 
+// LDS accumulators are stored by 16-byte chunk: acc[chunk][row][4 floats].  With row-major
+// [row][F] a 16-byte access of random rows only ever touches every other 16-byte bank group (the
+// first halves of 32-byte rows), doubling the conflicts of the read-modify-write that bounds pass 2.
+template <uint32_t F>
+__device__ __forceinline__ uint32_t acc_index(uint32_t row, uint32_t q)
+{
+    constexpr uint32_t V = F < 4 ? F : 4;
+    return ((q / V) * kSlab + row) * V + (q % V);
+}
+
 // read-modify-write of one accumulator row (F floats) in LDS
 template <uint32_t F>
-__device__ __forceinline__ void lds_row_add(float* __restrict__ row, const float (&v)[F])
+__device__ __forceinline__ void lds_row_add(float* __restrict__ acc, uint32_t row, const float (&v)[F])
 {
     constexpr uint32_t V = F < 4 ? F : 4;
     using T = typename vecf<V>::type;
 #pragma unroll
     for (uint32_t q = 0; q < F; q += V) {
-        T      t = *reinterpret_cast<T*>(row + q);
+        T*     p = reinterpret_cast<T*>(acc + acc_index<F>(row, q));
+        T      t = *p;
         float* f = reinterpret_cast<float*>(&t);
 #pragma unroll
         for (uint32_t j = 0; j < V; j++) f[j] += v[q + j];
-        *reinterpret_cast<T*>(row + q) = t;
+        *p = t;
     }
 }
 
@@ -202,8 +212,9 @@ template <uint32_t F, bool STE>
 __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
 {
     constexpr uint32_t V = F < 4 ? F : 4;
-    __shared__ float   s_acc[kSlab * F];
-    __shared__ uint8_t s_tag[kSlab];
+    __shared__ __attribute__((aligned(16))) float s_acc[kSlab * F];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kSlab];
+    static_assert(kSlab * sizeof(uint32_t) == 64 * sizeof(uint4), "one uint4 per lane clears the tickets");
     const uint32_t bin = blockIdx.x, lane = threadIdx.x;
     const uint32_t slot = a.first_level + blockIdx.y;
     const uint32_t off = (uint32_t)a.offsets[slot];
@@ -257,20 +268,20 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
             }
         }
         prefetch();
-        // tag vote: LDS instructions of a wave execute in order, so after every claimant wrote its
-        // id the read-back names exactly one winner per row; r0 != r1 within a lane
-        while (__ballot(pend != 0) != 0) {
-            if (pend & 1u) s_tag[r0] = (uint8_t)(2 * lane);
-            if (pend & 2u) s_tag[r1] = (uint8_t)(2 * lane + 1);
+        // Claims on the same row must not share an LDS instruction.  Every claim takes a ticket from
+        // a per-row counter (one integer LDS atomic); round k serves the claims holding ticket k, so
+        // all rows touched in a round are distinct and its reads and writes need no ordering among
+        // themselves.  Rounds = the largest number of claims on one row in the batch (image-ordered
+        // rays put ~5 samples of neighbouring rays into the same fine cell).  LDS instructions of a
+        // wave execute in order, which orders the counter reset, the tickets and the rounds.
+        reinterpret_cast<uint4*>(s_cnt)[lane] = make_uint4(0, 0, 0, 0);
+        asm volatile("" ::: "memory");
+        int32_t t0 = (pend & 1u) ? (int32_t)atomicAdd(&s_cnt[r0], 1u) : -1;
+        int32_t t1 = (pend & 2u) ? (int32_t)atomicAdd(&s_cnt[r1], 1u) : -1;
+        for (int32_t k = 0; __ballot(t0 >= k || t1 >= k) != 0; k++) {
+            if (t0 == k) lds_row_add<F>(s_acc, r0, v0);
+            if (t1 == k) lds_row_add<F>(s_acc, r1, v1);
             asm volatile("" ::: "memory");
-            const bool win0 = (pend & 1u) && s_tag[r0] == (uint8_t)(2 * lane);
-            const bool win1 = (pend & 2u) && s_tag[r1] == (uint8_t)(2 * lane + 1);
-            asm volatile("" ::: "memory");
-            if (win0) lds_row_add<F>(s_acc + r0 * F, v0);
-            asm volatile("" ::: "memory");
-            if (win1) lds_row_add<F>(s_acc + r1 * F, v1);
-            asm volatile("" ::: "memory");
-            pend &= ~((win0 ? 1u : 0u) | (win1 ? 2u : 0u));
         }
     }
     __syncthreads();
@@ -279,16 +290,27 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
     const bool     mask_on = STE && (a.clip_count == nullptr || *a.clip_count != 0);
     const uint32_t rows = min(kSlab, hs - bin * kSlab);
     const size_t   base = ((size_t)off + (size_t)bin * kSlab) * F;
-    for (uint32_t k = lane * V; k < rows * F; k += 64 * V) {
-        float t[V], e[V];
-        load_vec<V>(a.grad_emb + base + k, t);
-        if (mask_on) load_vec<V>(a.emb + base + k, e);
+    constexpr uint32_t NI = kSlab * F / (64 * V);     // 8 at F = 8: all loads issued before the first use
+    float t[NI][V], e[NI][V];
 #pragma unroll
-        for (uint32_t q = 0; q < V; q++) {
-            const bool pass = !mask_on || (e[q] >= -1.0f && e[q] <= 1.0f);
-            t[q] += pass ? s_acc[k + q] : 0.0f;
+    for (uint32_t i = 0; i < NI; i++) {
+        const uint32_t k = (i * 64 + lane) * V;
+        if (k < rows * F) {
+            load_vec<V>(a.grad_emb + base + k, t[i]);
+            if (mask_on) load_vec<V>(a.emb + base + k, e[i]);
         }
-        store_vec<V>(a.grad_emb + base + k, t);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < NI; i++) {
+        const uint32_t k = (i * 64 + lane) * V;
+        if (k < rows * F) {
+#pragma unroll
+            for (uint32_t q = 0; q < V; q++) {
+                const bool pass = !mask_on || (e[i][q] >= -1.0f && e[i][q] <= 1.0f);
+                t[i][q] += pass ? s_acc[acc_index<F>(k / F, k % F + q)] : 0.0f;
+            }
+            store_vec<V>(a.grad_emb + base + k, t[i]);
+        }
     }
 }
 
