@@ -228,12 +228,19 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
     for (uint32_t k = lane; k < kSlab * F; k += 64) s_acc[k] = 0;
 
     // next batch's item and gradient row, in flight while the current batch is accumulated
-    uint32_t j = lane;
-    Item     nx_item{0, 0, 0, 0};
+    // A batch takes kRun consecutive items from each of 64 / kRun regions of the bin rather
+    // than 64 consecutive ones: items of one cell arrive clustered (neighbouring rays of one pass-1
+    // block), and every extra claim on a row costs the batch another round.
+    constexpr uint32_t kRun = 8, kRegions = 64 / kRun;         // consecutive items per region and batch
+    const uint32_t region = (div_up(n, kRegions) + kRun - 1) & ~(kRun - 1);   // items per region
+    uint32_t       step = 0;                                   // batches taken so far
+    Item           nx_item{0, 0, 0, 0};
     float    nx_g[F];
     bool     nx_valid = false;
     auto     prefetch = [&]() {
-        nx_valid = j < n;
+        const uint32_t in_region = step * kRun + (lane % kRun);
+        const uint32_t j = (lane / kRun) * region + in_region;
+        nx_valid = in_region < region && j < n;
         if (nx_valid) {
             const uint4 raw = *reinterpret_cast<const uint4*>(my + j);
             nx_item.sample = raw.x;
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
                 for (uint32_t t = 0; t < V; t++) nx_g[q + t] = gv[t];
             }
         }
-        j += 64;
+        step++;
     };
     prefetch();
     __syncthreads();   // single wave: orders the zero-fill before the first accumulate
