@@ -4,6 +4,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/r01
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
