@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 from cnc_amd import synthetic  # noqa: E402
 from cnc_amd.backends import gridencoder_backend as enc  # noqa: E402
 from cnc_amd.nerfacc import grid as ngrid  # noqa: E402
+from cnc_amd.backends import nerfacc_cuda as ngrid_cuda  # noqa: E402
 
 F, L, D = 8, 16, 3
 LOG2_T = 19
@@ -106,9 +107,7 @@ def step(w, timed, world):
     sm = box["sm"]
     S = sm.vals.shape[0]
     # sample positions, normalised to the unit cube (radiance field's aabb mapping, ngp.py:518-519)
-    ri = sm.ray_indices
-    pos = rays_o[ri] + rays_d[ri] * sm.vals[:, None]
-    x = ((pos - w["aabbs"][0, :3]) / (w["aabbs"][0, 3:] - w["aabbs"][0, :3])).contiguous()
+    x = ngrid_cuda.sample_positions(rays_o, rays_d, sm.ray_indices, sm.vals, None, w["aabbs"][0])
 
     gt = w["grad_table"]
     gt.zero_()                                         # zeros_like(embeddings), ngp.py:129

@@ -45,6 +45,7 @@ SIGNATURES = {
     "cnc_ray_aabb_intersect": [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "cnc_traverse_grids": [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                            _f32, _f32, _i32, _i32, C.POINTER(RaySegments), C.POINTER(RaySegments), _vp, _vp],
+    "cnc_sample_positions": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "cnc_inclusive_sum": [_vp, _vp, _vp, _vp, _u32, _i64, _i32, _i32, _vp],
     "cnc_exclusive_sum": [_vp, _vp, _vp, _vp, _u32, _i64, _i32, _i32, _vp],
     "cnc_inclusive_prod_forward": [_vp, _vp, _vp, _vp, _u32, _i64, _vp],

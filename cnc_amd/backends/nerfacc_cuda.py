@@ -137,6 +137,28 @@ def traverse_grids(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
     return intervals, samples, terminate_planes
 
 
+def sample_positions(rays_o, rays_d, ray_indices, t_a, t_b=None, aabb=None, want_dirs=False):
+    """(extension) positions [S,3] (and directions) of ray samples in one kernel; see
+    cnc_sample_positions in include/cnc_hip.h."""
+    for name, t in (("rays_o", rays_o), ("rays_d", rays_d), ("ray_indices", ray_indices), ("t_a", t_a)):
+        check_input(t, name)
+    if ray_indices.dtype != torch.int64 or rays_o.dtype != torch.float32 or t_a.dtype != torch.float32:
+        raise RuntimeError("sample_positions: ray_indices must be int64, rays and t float32")
+    S = ray_indices.shape[0]
+    pos = torch.empty((S, 3), dtype=torch.float32, device=rays_o.device)
+    dirs = torch.empty((S, 3), dtype=torch.float32, device=rays_o.device) if want_dirs else None
+    if t_b is not None:
+        check_input(t_b, "t_b")
+    if aabb is not None:
+        aabb = aabb.reshape(-1).to(torch.float32).contiguous()
+        if aabb.numel() != 6:
+            raise RuntimeError("sample_positions: aabb must hold 6 values")
+    rc = _lib.lib().cnc_sample_positions(ptr(rays_o), ptr(rays_d), ptr(ray_indices), ptr(t_a), ptr(t_b),
+                                         ptr(aabb), S, ptr(pos), ptr(dirs), stream())
+    check(rc, "sample_positions")
+    return (pos, dirs) if want_dirs else pos
+
+
 def _scan_checks(chunk_starts, chunk_cnts, inputs):
     check_input(chunk_starts, "chunk_starts")
     check_input(chunk_cnts, "chunk_cnts")

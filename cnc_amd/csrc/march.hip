@@ -349,6 +349,33 @@ __global__ __launch_bounds__(64) void k_traverse(
     }
 }
 
+// Sample positions (and directions) for the field: positions[s] = o[ray] + d[ray] * t with
+// t = t_a[s], or (d * (t_a[s] + t_b[s])) / 2 when t_b is given (the expression of the reference's
+// rgb_sigma_fn, examples/utils.py:251-262, evaluated in the same order); optionally mapped to the
+// unit cube of an aabb as the field does first thing (ngp.py:518-519).  One pass instead of the
+// gather / mul / add / div chain of elementwise kernels.
+__global__ __launch_bounds__(256) void k_sample_positions(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const int64_t* __restrict__ ray_indices, const float* __restrict__ t_a,
+    const float* __restrict__ t_b, const float* __restrict__ aabb, int64_t S,
+    float* __restrict__ positions, float* __restrict__ dirs)
+{
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    const int64_t r = ray_indices[s];
+    const float   ta = t_a[s];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float o = rays_o[r * 3 + a], d = rays_d[r * 3 + a];
+        float p;
+        if (t_b) p = o + (d * (ta + t_b[s])) / 2.0f;
+        else p = o + d * ta;
+        if (aabb) p = (p - aabb[a]) / (aabb[3 + a] - aabb[a]);
+        positions[s * 3 + a] = p;
+        if (dirs) dirs[s * 3 + a] = d;
+    }
+}
+
 static Seg to_seg(const cnc_ray_segments_t* s)
 {
     Seg r{};
@@ -415,5 +442,19 @@ extern "C" int cnc_traverse_grids(const float* rays_o, const float* rays_d,
                            hits, t_sorted, t_indices, near_planes, far_planes, step_size,
                            cone_angle, traverse_steps_limit, iv, sm, terminate_planes);
     }
+    return launch_status();
+}
+
+extern "C" int cnc_sample_positions(const float* rays_o, const float* rays_d,
+                                    const int64_t* ray_indices, const float* t_a, const float* t_b,
+                                    const float* aabb, int64_t n_samples, float* positions,
+                                    float* dirs, void* stream)
+{
+    if (n_samples <= 0) return CNC_OK;
+    if (!rays_o || !rays_d || !ray_indices || !t_a || !positions) return CNC_ERR_INVALID_VALUE;
+    const int64_t blocks = (n_samples + 255) / 256;
+    if (blocks > 0x7FFFFFFF) return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_sample_positions, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream,
+                       rays_o, rays_d, ray_indices, t_a, t_b, aabb, n_samples, positions, dirs);
     return launch_status();
 }

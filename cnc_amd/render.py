@@ -15,6 +15,17 @@ from .nerfacc import OccGridEstimator
 from .nerfacc.grid import ray_aabb_intersect, traverse_grids
 from .nerfacc.volrend import accumulate_along_rays_, render_weight_from_density, rendering
 
+
+def _sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends):
+    """(positions, directions) of the samples; the fused kernel on the GPU, the reference's
+    expression elsewhere (rays are never differentiated)."""
+    if rays_o.is_cuda and ray_indices.dtype == torch.int64:
+        from .backends import nerfacc_cuda as _C
+        return _C.sample_positions(rays_o.contiguous(), rays_d.contiguous(), ray_indices.contiguous(),
+                                   t_starts.contiguous(), t_ends.contiguous(), want_dirs=True)
+    o, d = rays_o[ray_indices], rays_d[ray_indices]
+    return o + d * (t_starts + t_ends)[:, None] / 2.0, d
+
 Rays = collections.namedtuple("Rays", ("origins", "viewdirs"))
 
 NERF_SYNTHETIC_SCENES = ["chair", "drums", "ficus", "hotdog", "lego", "materials", "mic", "ship"]
@@ -52,9 +63,8 @@ def render_image_with_occgrid(radiance_field: torch.nn.Module, estimator: OccGri
     rays, rays_shape, num_rays = _flatten(rays)
 
     def positions_of(t_starts, t_ends, ray_indices):
-        o = chunk_rays.origins[ray_indices]
-        d = chunk_rays.viewdirs[ray_indices]
-        return o + d * (t_starts + t_ends)[:, None] / 2.0, d
+        # o + d * (t_starts + t_ends) / 2 and d, one kernel (examples/utils.py:251-262)
+        return _sample_positions(chunk_rays.origins, chunk_rays.viewdirs, ray_indices, t_starts, t_ends)
 
     def sigma_fn(t_starts, t_ends, ray_indices):
         positions, _ = positions_of(t_starts, t_ends, ray_indices)
@@ -102,8 +112,7 @@ def render_image_with_occgrid_test(max_samples: int, radiance_field: torch.nn.Mo
     device = rays_o.device
 
     def rgb_sigma_fn(t_starts, t_ends, ray_indices):
-        o, d = rays_o[ray_indices], rays_d[ray_indices]
-        positions = o + d * (t_starts[:, None] + t_ends[:, None]) / 2.0
+        positions, d = _sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends)
         rgbs, sigmas = radiance_field(positions, d)
         return rgbs, sigmas.squeeze(-1)
 

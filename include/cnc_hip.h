@@ -258,6 +258,15 @@ int cnc_traverse_grids(const float* rays_o, const float* rays_d, const uint8_t* 
                        const cnc_ray_segments_t* intervals, const cnc_ray_segments_t* samples,
                        float* terminate_planes, void* stream);
 
+/* (extension) Sample positions for the field in one pass: positions[s] = o[ray] + d[ray] * t_a[s], or
+ * o + (d * (t_a[s] + t_b[s])) / 2 when t_b != NULL (rgb_sigma_fn, examples/utils.py:251-262, same
+ * evaluation order); aabb != NULL (6 floats on the device) maps them to the unit cube,
+ * (p - min) / (max - min), as ngp.py:518-519.  dirs (may be NULL) receives d[ray].
+ * rays_o, rays_d [n_rays,3]; ray_indices i64 [n_samples]; positions, dirs [n_samples,3].         */
+int cnc_sample_positions(const float* rays_o, const float* rays_d, const int64_t* ray_indices,
+                         const float* t_a, const float* t_b, const float* aabb, int64_t n_samples,
+                         float* positions, float* dirs, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Per-ray segmented scans — replaces nerfacc/cuda/csrc/nerfacc.cpp:8-39 (scan.cu)
  * ---------------------------------------------------------------------------------------- */

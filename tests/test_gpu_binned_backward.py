@@ -81,7 +81,9 @@ def test_binned_backward_ragged_sizes_match_atomic_kernel(cuda, N):
     b = _bwd_binned(cuda, g, x, emb, offs, resl, 2, 1024)
     scale = max(np.abs(a).max(), 1e-6) if N else 1.0
     assert np.abs(a - b).max() <= 1e-5 * scale
-    assert np.array_equal(a == 0, b == 0)
+    # entries no sample touches stay exactly 0 (touched ones may cancel to 0 in one summation order only)
+    touched = _bwd_gpu(cuda, np.abs(g), x, emb, offs, resl) != 0
+    assert np.all(b[~touched] == 0) and np.all(a[~touched] == 0)
 
 
 def test_binned_backward_point_major_gradient(cuda):
@@ -122,7 +124,10 @@ def test_plan_and_mirror_route(cuda):
         outs.append(ge)
     torch.cuda.synchronize()
     assert (outs[0] - outs[1]).abs().max() <= 2e-5 * outs[0].abs().max()
-    assert torch.equal(outs[0] == 0, outs[1] == 0)
+    ge = torch.zeros(emb.shape, device=cuda)
+    be.grid_encode_backward(g.abs(), x, t(emb), t(offs), t(resl), ge, N, 3, 8, len(res), 0, 128, None, None,
+                            None, None, ste_binary=False)
+    assert (outs[1][ge == 0] == 0).all()          # rows no sample touches stay exactly 0
 
 
 @pytest.mark.parametrize("N", [4096, 9001])

@@ -125,7 +125,10 @@ def test_fused_ste_equals_unfused(setup):
     (yb * w).sum().backward()
     # two atomic scatters of the same terms in different orders
     assert (a.params.grad - b.params.grad).abs().max() <= 1e-5 * b.params.grad.abs().max()
-    assert torch.equal(a.params.grad == 0, b.params.grad == 0)
+    # same untouched entries; a touched entry may cancel to exactly 0 in one summation order only
+    differ = (a.params.grad == 0) != (b.params.grad == 0)
+    assert (a.params.grad[differ].abs().max() if differ.any() else 0) <= 1e-9 * b.params.grad.abs().max()
+    assert (b.params.grad[differ].abs().max() if differ.any() else 0) <= 1e-9 * b.params.grad.abs().max()
 
 
 def test_fused_segment_reduction_equals_packed_dataflow(setup):

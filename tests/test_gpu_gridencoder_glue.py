@@ -31,7 +31,8 @@ def test_forward_backward_and_variants(cuda, k, fused):
     ref = g[f"g{k}_grad"]
     got = enc.params.grad.cpu().numpy()
     assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
-    assert np.array_equal(got == 0, ref == 0)
+    differ = (got == 0) != (ref == 0)          # a touched entry may cancel to exactly 0 in one order only
+    assert not differ.any() or max(np.abs(got[differ]).max(), np.abs(ref[differ]).max()) <= 1e-9 * np.abs(ref).max()
     # level window + mask + outspace params
     y2 = enc(x, 1, enc.n_levels, outspace_params=t("osp"), binary_vxl=t("vxl"))
     assert np.array_equal(y2.detach().cpu().numpy(), g[f"g{k}_y_win"])

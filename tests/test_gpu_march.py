@@ -250,3 +250,24 @@ def test_march_degenerate_inputs(cuda, oracle, n_rays):
         want = oracle.traverse_grids(o.cpu().numpy(), d2.cpu().numpy(), binaries.cpu().numpy(), aabbs.cpu().numpy(),
                                      None, None, 1e-2, 0.0)
         assert np.array_equal(sm.vals.cpu().numpy(), want[1]["vals"]) and sm.vals.shape[0] > 0
+
+
+def test_sample_positions_equals_torch_expression(cuda):
+    """cnc_sample_positions vs the reference's rgb_sigma_fn expression (examples/utils.py:251-262) and
+    the field's aabb mapping (ngp.py:518-519): bit-exact, both modes."""
+    from cnc_amd.backends import nerfacc_cuda as C
+    g = torch.Generator(device=cuda).manual_seed(3)
+    n, S = 1000, 50001
+    o = torch.randn(n, 3, device=cuda, generator=g)
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device=cuda, generator=g), dim=-1)
+    ri = torch.randint(0, n, (S,), device=cuda, generator=g)
+    ts = torch.rand(S, device=cuda, generator=g) * 5
+    te = ts + torch.rand(S, device=cuda, generator=g) * 0.01
+    pos, dirs = C.sample_positions(o, d, ri, ts, te, want_dirs=True)
+    assert torch.equal(pos, o[ri] + d[ri] * (ts + te)[:, None] / 2.0)
+    assert torch.equal(dirs, d[ri])
+    aabb = torch.tensor([-1.5, -1.4, -1.3, 1.5, 1.6, 1.7], device=cuda)
+    x = C.sample_positions(o, d, ri, ts, None, aabb)
+    p = o[ri] + d[ri] * ts[:, None]
+    assert torch.equal(x, (p - aabb[:3]) / (aabb[3:] - aabb[:3]))
+    assert C.sample_positions(o, d, ri[:0], ts[:0]).shape == (0, 3)
