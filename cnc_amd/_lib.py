@@ -58,6 +58,7 @@ SIGNATURES = {
 RESTYPES = {"cnc_grid_encode_backward_binned_workspace": C.c_uint64}
 
 CNC_FLAG_STE_BINARY = 1
+ABI_VERSION = 7          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:
@@ -76,6 +77,9 @@ def lib() -> C.CDLL:
         L.cnc_error_string.argtypes = [C.c_int]
         L.cnc_error_string.restype = C.c_char_p
         L.cnc_abi_version.restype = C.c_int
+        if L.cnc_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI v{L.cnc_abi_version()}, this package expects v{ABI_VERSION}: "
+                               "rebuild it with `python -m cnc_amd.build`")
         _lib = L
     return _lib
 
