@@ -120,7 +120,10 @@ int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* bits,
  *               with more rows than that is routed to atomics on the device, results unchanged.
  *   workspace : device scratch of cnc_grid_encode_backward_binned_workspace(N, n_binned,
  *               level_rows) bytes (more = deeper bins; a full bin spills to atomics).  The library
- *               clears the part it needs; contents are dead after the call.                       */
+ *               clears the part it needs; contents are dead after the call.
+ *   The slab owners add into grad_embeddings with plain read-modify-writes: calls that target the
+ *   same grad_embeddings must be stream-ordered, not concurrent (the atomic entry point has no such
+ *   restriction).                                                                                */
 uint64_t cnc_grid_encode_backward_binned_workspace(uint32_t N, uint32_t n_binned, uint32_t level_rows);
 int cnc_grid_encode_backward_binned(const float* grad, const float* inputs, const float* embeddings,
                                     const int32_t* offsets, const int32_t* resolutions,
