@@ -56,6 +56,16 @@ out = torch.zeros((512, 512, 8, 2), device=dev)
 for ax, nm in ((0, "xy"), (1, "xz")):
     ms = timeit(lambda: ge.cnt_np_embed(verts, emb, out, verts.shape[0], 514, 8, 2 ** 19, ax))
     rec(f"cnt_np_embed axis={nm} ({verts.shape[0]/1e6:.1f} M vertices)", verts.shape[0], "vertices", 6 + 32, ms)
+# --- the same votes from the per-refresh sorted plan (no atomics)
+plan = ge.VotePlan(verts, 514, 2 ** 19)
+outp = torch.empty((512, 512, 8, 2), device=dev)
+gos = torch.randn((512, 512, 8, 2), device=dev)
+gemb = torch.zeros_like(emb)
+for ax, nm in ((0, "xy"), (1, "xz")):
+    ms = timeit(lambda: ge.cnt_np_embed_planned(plan, emb, outp, 8, ax))
+    rec(f"cnt_np_embed_planned axis={nm} (sorted plan, no atomics)", verts.shape[0], "vertices", 4 + 32, ms)
+    ms = timeit(lambda: ge.cnt_np_embed_planned_backward(plan, emb, gos, gemb, 8, ax))
+    rec(f"cnt_np_embed_planned_backward axis={nm}", verts.shape[0], "vertices", 4 + 64, ms)
 # --- eval march: 800x800, over-allocated 64-step rounds
 o, d = synthetic.pinhole_rays(800, 800, 0.6911, 4.0, 0.7, 0.5, device=dev)
 aabbs = torch.tensor([[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]], device=dev)
@@ -74,8 +84,11 @@ def tr():
 ms = timeit(tr, n=5)
 S = box["t"][1].vals.shape[0]
 rec("traverse_grids training form (two passes + cumsum + host sync)", 640_000, "rays", 24 + 27 * S / 640_000, ms)
-# --- segmented scans over the frame's samples
+# --- sample positions for the field
 sm = box["t"][1]
+ms = timeit(lambda: nc.sample_positions(o, d, sm.ray_indices, sm.vals, None, aabbs[0]))
+rec(f"sample_positions ({S/1e6:.0f} M samples)", S, "samples", 8 + 4 + 12, ms)
+# --- segmented scans over the frame's samples
 starts, cnts = sm.packed_info[:, 0].contiguous(), sm.packed_info[:, 1].contiguous()
 x = torch.rand(S, device=dev)
 ms = timeit(lambda: nc.exclusive_sum(starts, cnts, x, False, False))
