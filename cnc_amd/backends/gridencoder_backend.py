@@ -269,23 +269,25 @@ class VotePlan:
             check(rc, "cnt_np_plan")
         valid = rows >= 0                       # 0xFFFFFFFF reads as -1
         rows, pix = rows[valid], [p[valid] for p in pix]
-        rows64 = rows.to(torch.int64)
-        # forward: rows ordered by pixel, per plane
+        # forward: rows ordered by pixel, per plane (32-bit keys: half the radix passes of int64)
         self.rows_by_pixel, self.pixel_seg = [], []
         for axis in range(3):
-            p64 = pix[axis].to(torch.int64)
-            order = torch.argsort(p64, stable=True)
-            self.rows_by_pixel.append(rows[order].contiguous())
-            self.pixel_seg.append(self._segments(p64, self.n_pixels))
+            p = pix[axis]
+            if bool((p[1:] >= p[:-1]).all()) if p.numel() > 1 else True:
+                rows_sorted = rows                      # the xy plane of an (x, y, z)-sorted list
+            else:
+                rows_sorted = rows[torch.sort(p, stable=True)[1]]
+            self.rows_by_pixel.append(rows_sorted.contiguous())
+            self.pixel_seg.append(self._segments(p, self.n_pixels))
         # backward: pixels ordered by row (one order for the three planes)
-        order = torch.argsort(rows64, stable=True)
+        order = torch.sort(rows, stable=True)[1]
         self.pixels_by_row = [p[order].contiguous() for p in pix]
-        self.row_seg = self._segments(rows64, self.hashmap_size)
+        self.row_seg = self._segments(rows, self.hashmap_size)
 
     @staticmethod
-    def _segments(keys64, n):
-        counts = torch.bincount(keys64, minlength=n)
-        seg = torch.zeros(n + 1, dtype=torch.int32, device=keys64.device)
+    def _segments(keys, n):
+        counts = torch.bincount(keys, minlength=n)
+        seg = torch.zeros(n + 1, dtype=torch.int32, device=keys.device)
         seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
         return seg
 
