@@ -9,7 +9,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
+# kernel stats of the SAME command as the bench line above (default flags)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py > $OUT/stats.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1
 find $OUT -name "*kernel_trace.csv" -delete      # large; the stats csv is what is kept
