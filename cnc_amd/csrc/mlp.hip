@@ -31,59 +31,108 @@ struct MlpArgs {
     uint32_t     Hp[3];                              // padded widths (multiples of 16); Hp[2] = 0 for 2 layers
     uint32_t     n_layers;
     float*       Y;   uint32_t ldy, n_out;           // output [N, n_out]
+    uint32_t     a_vec;                              // X rows 16-byte aligned and >= K0p floats long
 };
 
-// One layer for this wave's 16 rows: acc[t] = A(16 x Kp) * W^T tile t, A read from LDS.
-template <bool RELU>
-__device__ __forceinline__ void layer(const float* __restrict__ a_lds, uint32_t lda, uint32_t Kp,
-                                      const float* __restrict__ W, const float* __restrict__ bias,
-                                      uint32_t Hp, f32x4 (&acc)[kMaxTiles], uint32_t lane)
+// One layer for this wave's 16 rows: acc[t] = A(16 x Kp) * W^T tile t.
+// NT = number of 16-column output tiles, a compile-time constant: the accumulators, the weight
+// fragments and their prefetch copies are then exactly NT registers-quads each (with a runtime tile
+// count the compiler kept all ten alive in every layer: 300 VGPRs + 40 AGPRs, one wave per SIMD).
+// Weight addresses are a wave-uniform tile base plus one 32-bit lane offset.
+// A_GLOBAL: the A operand (first layer: the input rows) is read straight from global memory in MFMA
+// A layout — lane (r, g) needs x[row r][kb + 4g .. 4g+3] — and prefetched one K block ahead like the
+// weights, so the input never occupies LDS.  k_valid guards the tail; a_row == nullptr = row >= N.
+template <bool RELU, bool A_GLOBAL, int NT>
+__device__ __forceinline__ void layer_nt(const float* __restrict__ a_lds, uint32_t lda, uint32_t Kp,
+                                         const float* __restrict__ W, const float* __restrict__ bias,
+                                         f32x4 (&acc)[kMaxTiles], uint32_t lane,
+                                         const float* __restrict__ a_row, uint32_t k_valid)
 {
     const uint32_t r = lane & 15, g = lane >> 4;
-    const uint32_t n_tiles = Hp / 16;
+    const uint32_t lane_off = r * Kp + g * 4;            // floats, inside one 16-row weight tile
 #pragma unroll
-    for (int t = 0; t < kMaxTiles; t++) acc[t] = f32x4{0, 0, 0, 0};
-    // software pipeline: the B fragments (weights, from L2) of K-block kb+16 are requested before the
-    // 4 * n_tiles MFMAs of block kb issue, so their latency hides under ~1280 cycles of matrix work
-    float4 wn[kMaxTiles];
+    for (int t = 0; t < NT; t++) acc[t] = f32x4{0, 0, 0, 0};
+    auto load_w = [&](uint32_t kb, float4 (&dst)[NT]) {
 #pragma unroll
-    for (int t = 0; t < kMaxTiles; t++)
-        if ((uint32_t)t < n_tiles) wn[t] = *reinterpret_cast<const float4*>(W + (size_t)(t * 16 + r) * Kp + g * 4);
-    for (uint32_t kb = 0; kb < Kp; kb += 16) {
-        // A fragment for 4 MFMA steps: row r, k = kb + g*4 + {0,1,2,3}
-        const float4 a = *reinterpret_cast<const float4*>(a_lds + r * lda + kb + g * 4);
-        float4 w[kMaxTiles];
-#pragma unroll
-        for (int t = 0; t < kMaxTiles; t++) w[t] = wn[t];
-        if (kb + 16 < Kp) {
-#pragma unroll
-            for (int t = 0; t < kMaxTiles; t++)
-                if ((uint32_t)t < n_tiles)
-                    wn[t] = *reinterpret_cast<const float4*>(W + (size_t)(t * 16 + r) * Kp + kb + 16 + g * 4);
-        }
-#pragma unroll
-        for (int t = 0; t < kMaxTiles; t++) {
-            if ((uint32_t)t < n_tiles) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[t].x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[t].y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[t].z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[t].w, acc[t], 0, 0, 0);
+        for (int t = 0; t < NT; t++)
+            dst[t] = *reinterpret_cast<const float4*>(W + (size_t)t * 16 * Kp + kb + lane_off);
+    };
+    // k_valid bit 31 set: rows are 16-byte aligned and at least Kp floats long (the caller checked
+    // ldx), so a fragment is one float4 load and only the columns >= K0 are zeroed afterwards
+    const bool     a_vec = (k_valid >> 31) != 0;
+    const uint32_t k_real = k_valid & 0x7FFFFFFFu;
+    auto load_a = [&](uint32_t kb) -> float4 {
+        float4 v{0, 0, 0, 0};
+        const uint32_t k = kb + g * 4;
+        if (a_row) {
+            if (a_vec) {
+                v = *reinterpret_cast<const float4*>(a_row + k);
+                if (k + 4 > k_real) {
+                    if (k >= k_real) v.x = 0;
+                    if (k + 1 >= k_real) v.y = 0;
+                    if (k + 2 >= k_real) v.z = 0;
+                    v.w = 0;
+                }
+            } else if (k + 4 <= k_real) {
+                v.x = a_row[k]; v.y = a_row[k + 1]; v.z = a_row[k + 2]; v.w = a_row[k + 3];
+            } else {
+                if (k < k_real) v.x = a_row[k];
+                if (k + 1 < k_real) v.y = a_row[k + 1];
+                if (k + 2 < k_real) v.z = a_row[k + 2];
             }
         }
+        return v;
+    };
+    // software pipeline: the fragments of K block kb+16 are requested before the 4*NT MFMAs of block kb
+    float4 wn[NT], an{0, 0, 0, 0};
+    load_w(0, wn);
+    if constexpr (A_GLOBAL) an = load_a(0);
+    for (uint32_t kb = 0; kb < Kp; kb += 16) {
+        float4 a, w[NT];
+        if constexpr (A_GLOBAL) a = an;
+        else a = *reinterpret_cast<const float4*>(a_lds + r * lda + kb + g * 4);
+#pragma unroll
+        for (int t = 0; t < NT; t++) w[t] = wn[t];
+        if (kb + 16 < Kp) {
+            load_w(kb + 16, wn);
+            if constexpr (A_GLOBAL) an = load_a(kb + 16);
+        }
+        // k-step outermost: consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[t].w, acc[t], 0, 0, 0);
     }
     // bias (+ ReLU): C layout is col = lane & 15, row = (lane >> 4) * 4 + i
 #pragma unroll
-    for (int t = 0; t < kMaxTiles; t++) {
-        if ((uint32_t)t < n_tiles) {
-            const float b = bias[t * 16 + r];
+    for (int t = 0; t < NT; t++) {
+        const float b = bias[t * 16 + r];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float v = acc[t][i] + b;
-                if (RELU) v = v > 0 ? v : 0;
-                acc[t][i] = v;
-            }
+        for (int i = 0; i < 4; i++) {
+            float v = acc[t][i] + b;
+            if (RELU) v = v > 0 ? v : 0;
+            acc[t][i] = v;
         }
     }
+}
+
+template <bool RELU, bool A_GLOBAL = false>
+__device__ __forceinline__ void layer(const float* __restrict__ a_lds, uint32_t lda, uint32_t Kp,
+                                      const float* __restrict__ W, const float* __restrict__ bias,
+                                      uint32_t Hp, f32x4 (&acc)[kMaxTiles], uint32_t lane,
+                                      const float* __restrict__ a_row = nullptr, uint32_t k_valid = 0)
+{
+#define CNC_LAYER_NT(NTV) case NTV: layer_nt<RELU, A_GLOBAL, NTV>(a_lds, lda, Kp, W, bias, acc, lane, a_row, k_valid); break;
+    switch (Hp / 16) {      // wave-uniform
+        CNC_LAYER_NT(1) CNC_LAYER_NT(2) CNC_LAYER_NT(3) CNC_LAYER_NT(4) CNC_LAYER_NT(5)
+        CNC_LAYER_NT(6) CNC_LAYER_NT(7) CNC_LAYER_NT(8) CNC_LAYER_NT(9) CNC_LAYER_NT(10)
+    default: break;
+    }
+#undef CNC_LAYER_NT
 }
 
 __device__ __forceinline__ void acc_to_lds(float* __restrict__ dst, uint32_t ld, uint32_t Hp,
@@ -99,54 +148,45 @@ __device__ __forceinline__ void acc_to_lds(float* __restrict__ dst, uint32_t ld,
     }
 }
 
+// NT0/NT1/NT2 > 0: the layer widths in 16-column tiles are compile-time (one lean kernel per network
+// shape the field uses); 0 = decided at run time by the switch in layer().
+template <int NT0, int NT1, int NT2>
 __global__ __launch_bounds__(64) void k_mlp_forward(MlpArgs p)
 {
     extern __shared__ float lds[];
     const uint32_t lane = threadIdx.x;
-    const uint32_t ld0 = p.K0p + kPad, ld1 = p.Hp[0] + kPad, ld2 = (p.n_layers == 3 ? p.Hp[1] : 0) + kPad;
-    float* x_lds = lds;
-    float* h1_lds = x_lds + 16 * ld0;
+    const uint32_t ld1 = p.Hp[0] + kPad, ld2 = (p.n_layers == 3 ? p.Hp[1] : 0) + kPad;
+    float* h1_lds = lds;
     float* h2_lds = h1_lds + 16 * ld1;
 
     const uint32_t tiles = (p.N + 15) / 16;
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const uint32_t row0 = tile * 16;
-        // stage 16 input rows (zero padded to K0p): lanes sweep each row contiguously; all loads
-        // of a 64-column chunk are issued before any LDS store so they overlap
-        for (uint32_t k0 = 0; k0 < p.K0p; k0 += 64) {
-            const uint32_t k = k0 + lane;
-            float v[16];
-#pragma unroll
-            for (uint32_t r = 0; r < 16; r++) {
-                const uint32_t row = row0 + r;
-                v[r] = (row < p.N && k < p.K0) ? p.X[(size_t)row * p.ldx + k] : 0.0f;
-            }
-            if (k < p.K0p) {
-#pragma unroll
-                for (uint32_t r = 0; r < 16; r++) x_lds[r * ld0 + k] = v[r];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t my_row = row0 + (lane & 15);
+        const float*   a_row = my_row < p.N ? p.X + (size_t)my_row * p.ldx : nullptr;
 
         f32x4 acc[kMaxTiles];
-        layer<true>(x_lds, ld0, p.K0p, p.W[0], p.B[0], p.Hp[0], acc, lane);
+        const uint32_t kv = p.K0 | (p.a_vec ? 0x80000000u : 0u);
+        if constexpr (NT0 > 0) layer_nt<true, true, NT0>(nullptr, 0, p.K0p, p.W[0], p.B[0], acc, lane, a_row, kv);
+        else layer<true, true>(nullptr, 0, p.K0p, p.W[0], p.B[0], p.Hp[0], acc, lane, a_row, kv);
         acc_to_lds(h1_lds, ld1, p.Hp[0], acc, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         uint32_t Hlast;
         if (p.n_layers == 3) {
-            layer<true>(h1_lds, ld1, p.Hp[0], p.W[1], p.B[1], p.Hp[1], acc, lane);
+            if constexpr (NT1 > 0) layer_nt<true, false, NT1>(h1_lds, ld1, p.Hp[0], p.W[1], p.B[1], acc, lane, nullptr, 0);
+            else layer<true>(h1_lds, ld1, p.Hp[0], p.W[1], p.B[1], p.Hp[1], acc, lane);
             acc_to_lds(h2_lds, ld2, p.Hp[1], acc, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            layer<false>(h2_lds, ld2, p.Hp[1], p.W[2], p.B[2], p.Hp[2], acc, lane);
+            if constexpr (NT2 > 0) layer_nt<false, false, NT2>(h2_lds, ld2, p.Hp[1], p.W[2], p.B[2], acc, lane, nullptr, 0);
+            else layer<false>(h2_lds, ld2, p.Hp[1], p.W[2], p.B[2], p.Hp[2], acc, lane);
             Hlast = p.Hp[2];
         } else {
-            layer<false>(h1_lds, ld1, p.Hp[0], p.W[1], p.B[1], p.Hp[1], acc, lane);
+            if constexpr (NT1 > 0) layer_nt<false, false, NT1>(h1_lds, ld1, p.Hp[0], p.W[1], p.B[1], acc, lane, nullptr, 0);
+            else layer<false>(h1_lds, ld1, p.Hp[0], p.W[1], p.B[1], p.Hp[1], acc, lane);
             Hlast = p.Hp[1];
         }
         // store: lanes with the same i write 16 consecutive columns of one row
@@ -165,9 +205,149 @@ __global__ __launch_bounds__(64) void k_mlp_forward(MlpArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Variant with the weights shared through LDS: a workgroup of 4 waves (64 rows).  The one-wave kernel
+// above re-fetches every 16-wide K block of the weights from L2 per wave (10 KB per 640 MFMA cycles
+// and wave: ~50 TB/s over the chip) and stalls on it at 33 % MFMA utilisation.  Here the 256 threads
+// bring each K block in once (double-buffered, one barrier per block) and all four waves read their
+// B fragments from LDS ([Hp][16 + 4] floats: 80-byte rows keep the 16-byte fragment reads of a wave
+// on distinct banks).
+// ---------------------------------------------------------------------------------------------
+constexpr int kWPitch = 20;
+
+template <bool RELU>
+__device__ __forceinline__ void layer_shared(const float* __restrict__ a_lds, uint32_t lda, uint32_t Kp,
+                                             const float* __restrict__ W, const float* __restrict__ bias,
+                                             uint32_t Hp, f32x4 (&acc)[kMaxTiles], uint32_t lane,
+                                             float* __restrict__ wbuf /* 2 x [160][kWPitch] */)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t r = lane & 15, g = lane >> 4;
+    const uint32_t n_tiles = Hp / 16;
+    const uint32_t n_vec = Hp * 4;                       // float4 per K block
+#pragma unroll
+    for (int t = 0; t < kMaxTiles; t++) acc[t] = f32x4{0, 0, 0, 0};
+    // block 0 straight into buffer 0
+    for (uint32_t idx = tid; idx < n_vec; idx += 256) {
+        const uint32_t row = idx >> 2, q = idx & 3u;
+        *reinterpret_cast<float4*>(wbuf + row * kWPitch + q * 4) =
+            *reinterpret_cast<const float4*>(W + (size_t)row * Kp + q * 4);
+    }
+    __syncthreads();
+    uint32_t cur = 0;
+    for (uint32_t kb = 0; kb < Kp; kb += 16) {
+        // next block: global -> registers now, registers -> LDS after this block's MFMAs
+        float4 nx[3];
+        const bool more = kb + 16 < Kp;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const uint32_t idx = tid + j * 256;
+                if (idx < n_vec) nx[j] = *reinterpret_cast<const float4*>(W + (size_t)(idx >> 2) * Kp + kb + 16 + (idx & 3u) * 4);
+            }
+        }
+        const float4 a = *reinterpret_cast<const float4*>(a_lds + r * lda + kb + g * 4);
+        const float* wb = wbuf + cur * (160 * kWPitch);
+#pragma unroll
+        for (int t = 0; t < kMaxTiles; t++) {
+            if ((uint32_t)t < n_tiles) {
+                const float4 w = *reinterpret_cast<const float4*>(wb + (t * 16 + r) * kWPitch + g * 4);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc[t], 0, 0, 0);
+            }
+        }
+        if (more) {
+            float* wn = wbuf + (cur ^ 1u) * (160 * kWPitch);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const uint32_t idx = tid + j * 256;
+                if (idx < n_vec) *reinterpret_cast<float4*>(wn + (idx >> 2) * kWPitch + (idx & 3u) * 4) = nx[j];
+            }
+        }
+        __syncthreads();
+        cur ^= 1u;
+    }
+#pragma unroll
+    for (int t = 0; t < kMaxTiles; t++) {
+        if ((uint32_t)t < n_tiles) {
+            const float b = bias[t * 16 + r];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float v = acc[t][i] + b;
+                if (RELU) v = v > 0 ? v : 0;
+                acc[t][i] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mlp_forward4(MlpArgs p)
+{
+    extern __shared__ float lds[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t ld0 = p.K0p + kPad, ld1 = p.Hp[0] + kPad, ld2 = (p.n_layers == 3 ? p.Hp[1] : 0) + kPad;
+    // per wave: [x | h2 (aliases x, dead after layer 1)] [h1]; then the two weight buffers
+    const uint32_t reg0 = 16 * (ld0 > ld2 ? ld0 : ld2), per_wave = reg0 + 16 * ld1;
+    float* x_lds = lds + wave * per_wave;
+    float* h2_lds = x_lds;
+    float* h1_lds = x_lds + reg0;
+    float* wbuf = lds + 4 * per_wave;
+
+    const uint32_t groups = (p.N + 63) / 64;
+    for (uint32_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const uint32_t row0 = grp * 64 + wave * 16;
+        for (uint32_t k0 = 0; k0 < p.K0p; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            float v[16];
+#pragma unroll
+            for (uint32_t r = 0; r < 16; r++) {
+                const uint32_t row = row0 + r;
+                v[r] = (row < p.N && k < p.K0) ? p.X[(size_t)row * p.ldx + k] : 0.0f;
+            }
+            if (k < p.K0p) {
+#pragma unroll
+                for (uint32_t r = 0; r < 16; r++) x_lds[r * ld0 + k] = v[r];
+            }
+        }
+        __syncthreads();
+        f32x4 acc[kMaxTiles];
+        layer_shared<true>(x_lds, ld0, p.K0p, p.W[0], p.B[0], p.Hp[0], acc, lane, wbuf);
+        acc_to_lds(h1_lds, ld1, p.Hp[0], acc, lane);
+        __syncthreads();
+        uint32_t Hlast;
+        if (p.n_layers == 3) {
+            layer_shared<true>(h1_lds, ld1, p.Hp[0], p.W[1], p.B[1], p.Hp[1], acc, lane, wbuf);
+            acc_to_lds(h2_lds, ld2, p.Hp[1], acc, lane);
+            __syncthreads();
+            layer_shared<false>(h2_lds, ld2, p.Hp[1], p.W[2], p.B[2], p.Hp[2], acc, lane, wbuf);
+            Hlast = p.Hp[2];
+        } else {
+            layer_shared<false>(h1_lds, ld1, p.Hp[0], p.W[1], p.B[1], p.Hp[1], acc, lane, wbuf);
+            Hlast = p.Hp[1];
+        }
+        const uint32_t c = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int t = 0; t < kMaxTiles; t++) {
+            if ((uint32_t)t < Hlast / 16) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t row = row0 + g * 4 + i, col = t * 16 + c;
+                    if (row < p.N && col < p.n_out) p.Y[(size_t)row * p.ldy + col] = acc[t][i];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace cnc
 
 using namespace cnc;
+
+static int g_mlp_variant = 0;    // 0: one wave per workgroup (default); 1: four waves share the weights through LDS (measured slower)
+extern "C" int cnc_mlp_set_variant(int v) { g_mlp_variant = v; return CNC_OK; }
 
 // Fused 2- or 3-layer fp32 MLP forward.  Weights must be pre-padded by the caller:
 //   W_l : [Hp_l, Kp_l] row-major, zero filled outside [H_l, K_l];  b_l : [Hp_l];
@@ -196,16 +376,39 @@ extern "C" int cnc_mlp_forward(const float* X, uint32_t N, uint32_t ldx, uint32_
     p.n_layers = n_layers;
     p.Y = Y; p.ldy = ldy; p.n_out = n_out;
 
-    const uint32_t per_wave = 16 * ((K0p + kPad) + (H1p + kPad) + ((n_layers == 3 ? H2p : 0) + kPad));
+    if (g_mlp_variant == 1) {
+        const uint32_t ld0 = K0p + kPad, ld1 = H1p + kPad, ld2 = (n_layers == 3 ? H2p : 0) + kPad;
+        const uint32_t pw = 16 * (ld0 > ld2 ? ld0 : ld2) + 16 * ld1;
+        const size_t   bytes = ((size_t)4 * pw + 2 * 160 * kWPitch) * sizeof(float);
+        if (bytes > 160 * 1024) return CNC_ERR_INVALID_VALUE;
+        if (hipFuncSetAttribute((const void*)k_mlp_forward4, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return CNC_ERR_LAUNCH;
+        uint32_t blocks4 = (N + 63) / 64;
+        if (blocks4 > 256u * 8) blocks4 = 256u * 8;
+        hipLaunchKernelGGL(k_mlp_forward4, dim3(blocks4), dim3(256), bytes, (hipStream_t)stream, p);
+        return launch_status();
+    }
+    const uint32_t per_wave = 16 * ((H1p + kPad) + ((n_layers == 3 ? H2p : 0) + kPad));
     const size_t   lds_bytes = (size_t)per_wave * sizeof(float);
     if (lds_bytes > 160 * 1024) return CNC_ERR_INVALID_VALUE;
     // > 64 KiB of dynamic LDS needs the opt-in (per device; cheap, so done on every call)
-    if (hipFuncSetAttribute((const void*)k_mlp_forward, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-        return CNC_ERR_LAUNCH;
+    p.a_vec = (ldx % 4 == 0 && ldx >= K0p && ((uintptr_t)X % 16) == 0) ? 1u : 0u;
     const uint32_t tiles = (N + 15) / 16;
     uint32_t       blocks = tiles;
     if (blocks > 256u * 32) blocks = 256u * 32;   // waves loop over tiles beyond that
-    hipLaunchKernelGGL(k_mlp_forward, dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, p);
+#define CNC_MLP_LAUNCH(A, B, C)                                                                        \
+    do {                                                                                               \
+        if (hipFuncSetAttribute((const void*)k_mlp_forward<A, B, C>,                                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) \
+            return CNC_ERR_LAUNCH;                                                                     \
+        hipLaunchKernelGGL((k_mlp_forward<A, B, C>), dim3(blocks), dim3(64), lds_bytes,                \
+                           (hipStream_t)stream, p);                                                    \
+    } while (0)
+    // the two networks of the radiance field get kernels with compile-time layer widths
+    if (n_layers == 2 && H1p == 160 && H2p == 80) CNC_MLP_LAUNCH(10, 5, 0);
+    else if (n_layers == 3 && H1p == 160 && H2p == 160 && H3p == 16) CNC_MLP_LAUNCH(10, 10, 1);
+    else CNC_MLP_LAUNCH(0, 0, 0);
+#undef CNC_MLP_LAUNCH
     return launch_status();
 }

@@ -17,7 +17,11 @@ for dims in ((255,160,80),(95,160,160,3)):
     seq=nn.Sequential(*layers).to(dev); fused=FusedMLPForward(seq)
     fl = 2*sum(dims[i]*dims[i+1] for i in range(len(dims)-1))
     for N in (1<<16, 1<<18, 1<<20, 1<<22):
-        x=torch.randn(N,dims[0],device=dev)
+        xb=torch.randn(N,(dims[0]+3)//4*4,device=dev); x=xb[:,:dims[0]]
+        from cnc_amd import _lib
         with torch.no_grad():
-            a=t(lambda: seq(x)); b=t(lambda: fused(x))
-        print(f"{dims} N=2^{N.bit_length()-1}: torch {a:.3f} ms ({fl*N/a/1e9:.1f} TF, {N/a/1e6:.3f} Grows/s)   fused-mfma {b:.3f} ms ({fl*N/b/1e9:.1f} TF, {N/b/1e6:.3f} Grows/s)  x{a/b:.2f}")
+            a=t(lambda: seq(x))
+            _lib.lib().cnc_mlp_set_variant(0); b=t(lambda: fused(x))
+            _lib.lib().cnc_mlp_set_variant(1); c=t(lambda: fused(x))
+            err=(fused(x)-seq(x)).abs().max().item()
+        print(f"{dims} N=2^{N.bit_length()-1}: torch {a:.3f} ms ({fl*N/a/1e9:.1f} TF)   1-wave {b:.3f} ms ({fl*N/b/1e9:.1f} TF)   4-wave shared {c:.3f} ms ({fl*N/c/1e9:.1f} TF)  max err {err:.1e}")
