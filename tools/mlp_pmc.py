@@ -6,7 +6,7 @@ dev = torch.device("cuda:0")
 dims = (255, 160, 80)
 seq = nn.Sequential(Linear(255, 160), nn.ReLU(inplace=True), Linear(160, 80)).to(dev)
 fused = FusedMLPForward(seq)
-x = torch.randn(1 << 20, 255, device=dev)
+x = torch.randn(1 << 20, 256, device=dev)[:, :255]      # row stride 256, as the field feeds it
 with torch.no_grad():
     for _ in range(3):
         seq(x); fused(x)
