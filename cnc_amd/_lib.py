@@ -31,6 +31,7 @@ SIGNATURES = {
                                         _u32, _u32, _vp, C.c_uint64, _vp],
     "cnc_pack_sign_bits": [_vp, _vp, C.c_uint64, _u32, _vp, _vp],
     "cnc_grid_encode_forward_bits": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp],
+    "cnc_mlp_forward32": [_vp, _u32, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _u32, _u32, _vp],
     "cnc_mlp_set_variant": [_i32],
     "cnc_mlp_forward": [_vp, _u32, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _u32, _u32, _vp],
     "cnc_cnt_np_embed": [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp],

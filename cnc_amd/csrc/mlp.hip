@@ -342,6 +342,150 @@ __global__ __launch_bounds__(256) void k_mlp_forward4(MlpArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 32-row variant on v_mfma_f32_32x32x2_f32: one wave owns 32 rows, so every weight fragment fetched
+// from L2 serves twice the rows, and a fragment is one float per (tile, k) instead of per 16 columns:
+// 5 tiles x 4 k = 20 weight registers per K block of 8 for a 160-wide layer (40 in the 16-row kernel).
+// Operand layouts (lane l, i = l & 31, h = l >> 5):  A[i][k = h], B[k = h][j = i],
+// D[row = 8*(v >> 2) + 4*h + (v & 3)][col = i] for v = 0..15.  Inside a K block of 8 the lane's four
+// k-values are kb + 4h .. 4h+3 (a float4), MFMA m taking the m-th of them from both half-waves.
+// Widths are padded to multiples of 32 by the caller, K to multiples of 8.
+// ---------------------------------------------------------------------------------------------
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int kMaxTiles32 = 5;
+
+template <bool RELU, bool A_GLOBAL, int NT>
+__device__ __forceinline__ void layer32(const float* __restrict__ a_lds, uint32_t lda, uint32_t Kp,
+                                        const float* __restrict__ W, const float* __restrict__ bias,
+                                        f32x16 (&acc)[kMaxTiles32], uint32_t lane,
+                                        const float* __restrict__ a_row, uint32_t k_valid)
+{
+    const uint32_t i = lane & 31, h = lane >> 5;
+    const uint32_t lane_off = i * Kp + h * 4;
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) acc[t][v] = 0;
+    auto load_w = [&](uint32_t kb, float4 (&dst)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            dst[t] = *reinterpret_cast<const float4*>(W + (size_t)t * 32 * Kp + kb + lane_off);
+    };
+    const bool     a_vec = (k_valid >> 31) != 0;
+    const uint32_t k_real = k_valid & 0x7FFFFFFFu;
+    auto load_a = [&](uint32_t kb) -> float4 {
+        float4 v{0, 0, 0, 0};
+        const uint32_t k = kb + h * 4;
+        if (a_row) {
+            if (a_vec) {
+                v = *reinterpret_cast<const float4*>(a_row + k);
+                if (k + 4 > k_real) {
+                    if (k >= k_real) v.x = 0;
+                    if (k + 1 >= k_real) v.y = 0;
+                    if (k + 2 >= k_real) v.z = 0;
+                    v.w = 0;
+                }
+            } else {
+                if (k < k_real) v.x = a_row[k];
+                if (k + 1 < k_real) v.y = a_row[k + 1];
+                if (k + 2 < k_real) v.z = a_row[k + 2];
+                if (k + 3 < k_real) v.w = a_row[k + 3];
+            }
+        }
+        return v;
+    };
+    float4 wn[NT], an{0, 0, 0, 0};
+    load_w(0, wn);
+    if constexpr (A_GLOBAL) an = load_a(0);
+    for (uint32_t kb = 0; kb < Kp; kb += 8) {
+        float4 a, w[NT];
+        if constexpr (A_GLOBAL) a = an;
+        else a = *reinterpret_cast<const float4*>(a_lds + i * lda + kb + h * 4);
+#pragma unroll
+        for (int t = 0; t < NT; t++) w[t] = wn[t];
+        if (kb + 8 < Kp) {
+            load_w(kb + 8, wn);
+            if constexpr (A_GLOBAL) an = load_a(kb + 8);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t].w, acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const float b = bias[t * 32 + i];
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            float x = acc[t][v] + b;
+            if (RELU) x = x > 0 ? x : 0;
+            acc[t][v] = x;
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void acc_to_lds32(float* __restrict__ dst, uint32_t ld,
+                                             const f32x16 (&acc)[kMaxTiles32], uint32_t lane)
+{
+    const uint32_t i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) dst[(8 * (v >> 2) + 4 * h + (v & 3)) * ld + t * 32 + i] = acc[t][v];
+}
+
+template <int NT0, int NT1, int NT2>
+__global__ __launch_bounds__(64) void k_mlp_forward32(MlpArgs p)
+{
+    extern __shared__ float lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t ld1 = NT0 * 32 + kPad, ld2 = NT1 * 32 + kPad;
+    float* h_lds = lds;                       // h1, then h2 in the same place (h1 is dead by then)
+
+    const uint32_t tiles = (p.N + 31) / 32;
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint32_t row0 = tile * 32;
+        const uint32_t my_row = row0 + (lane & 31);
+        const float*   a_row = my_row < p.N ? p.X + (size_t)my_row * p.ldx : nullptr;
+        const uint32_t kv = p.K0 | (p.a_vec ? 0x80000000u : 0u);
+
+        f32x16 acc[kMaxTiles32];
+        layer32<true, true, NT0>(nullptr, 0, p.K0p, p.W[0], p.B[0], acc, lane, a_row, kv);
+        acc_to_lds32<NT0>(h_lds, ld1, acc, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if constexpr (NT2 > 0) {
+            layer32<true, false, NT1>(h_lds, ld1, NT0 * 32, p.W[1], p.B[1], acc, lane, nullptr, 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            acc_to_lds32<NT1>(h_lds, ld2, acc, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            layer32<false, false, NT2>(h_lds, ld2, NT1 * 32, p.W[2], p.B[2], acc, lane, nullptr, 0);
+        } else {
+            layer32<false, false, NT1>(h_lds, ld1, NT0 * 32, p.W[1], p.B[1], acc, lane, nullptr, 0);
+        }
+        constexpr int NTL = NT2 > 0 ? NT2 : NT1;
+        const uint32_t i = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int t = 0; t < NTL; t++) {
+#pragma unroll
+            for (int v = 0; v < 16; v++) {
+                const uint32_t row = row0 + 8 * (v >> 2) + 4 * h + (v & 3), col = t * 32 + i;
+                if (row < p.N && col < p.n_out) p.Y[(size_t)row * p.ldy + col] = acc[t][v];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace cnc
 
 using namespace cnc;
@@ -410,5 +554,41 @@ extern "C" int cnc_mlp_forward(const float* X, uint32_t N, uint32_t ldx, uint32_
     else if (n_layers == 3 && H1p == 160 && H2p == 160 && H3p == 16) CNC_MLP_LAUNCH(10, 10, 1);
     else CNC_MLP_LAUNCH(0, 0, 0);
 #undef CNC_MLP_LAUNCH
+    return launch_status();
+}
+
+// The same network on the 32-row kernel.  Padding convention differs: W_l [Hp_l, Kp_l] with Hp_l a
+// multiple of 32 (<= 160), Kp_0 = roundup8(K0), Kp_l = Hp_{l-1}.  Only the two shapes of the radiance
+// field are instantiated: (160, 96[, -]) two layers and (160, 160, 32) three layers.
+extern "C" int cnc_mlp_forward32(const float* X, uint32_t N, uint32_t ldx, uint32_t K0,
+                                 const float* W1, const float* b1, uint32_t H1p,
+                                 const float* W2, const float* b2, uint32_t H2p,
+                                 const float* W3, const float* b3, uint32_t H3p,
+                                 float* Y, uint32_t ldy, uint32_t n_out, void* stream)
+{
+    if (N == 0) return CNC_OK;
+    if (!X || !W1 || !b1 || !W2 || !b2 || !Y) return CNC_ERR_INVALID_VALUE;
+    const uint32_t n_layers = (W3 != nullptr) ? 3 : 2;
+    if (n_layers == 3 && !b3) return CNC_ERR_INVALID_VALUE;
+    const uint32_t K0p = (K0 + 7) / 8 * 8;
+    MlpArgs p{};
+    p.X = X; p.N = N; p.ldx = ldx; p.K0 = K0; p.K0p = K0p;
+    p.W[0] = W1; p.B[0] = b1; p.Hp[0] = H1p;
+    p.W[1] = W2; p.B[1] = b2; p.Hp[1] = H2p;
+    p.W[2] = W3; p.B[2] = b3; p.Hp[2] = n_layers == 3 ? H3p : 0;
+    p.n_layers = n_layers;
+    p.Y = Y; p.ldy = ldy; p.n_out = n_out;
+    p.a_vec = (ldx % 4 == 0 && ldx >= K0p && ((uintptr_t)X % 16) == 0) ? 1u : 0u;
+    const uint32_t tiles = (N + 31) / 32;
+    uint32_t       blocks = tiles;
+    if (blocks > 256u * 32) blocks = 256u * 32;
+    const size_t lds_bytes = (size_t)32 * (160 + kPad) * sizeof(float);
+    if (n_layers == 2 && H1p == 160 && H2p == 96 && n_out <= 96) {
+        hipLaunchKernelGGL((k_mlp_forward32<5, 3, 0>), dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, p);
+    } else if (n_layers == 3 && H1p == 160 && H2p == 160 && H3p == 32 && n_out <= 32) {
+        hipLaunchKernelGGL((k_mlp_forward32<5, 5, 1>), dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, p);
+    } else {
+        return CNC_ERR_UNSUPPORTED;
+    }
     return launch_status();
 }

@@ -14,6 +14,7 @@ The dense layers are plain `nn.Linear` (hipBLASLt GEMMs); a fused MFMA field ker
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Union
 
 import torch
@@ -271,6 +272,9 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         self.unbounded = unbounded
         self.geo_feat_dim = min(127, max(15, n_features_per_level * 10 - 1))     # ngp.py:398-401
         self.resolutions_list, self.log2_hashmap_size = resolutions_list, log2_hashmap_size
+        self.fused_head = os.environ.get("CNC_FUSED_HEAD", "1") == "1"
+        self._head_fused = None
+        self._head_shape_ok = n_neurons == 160       # the 32-row kernel is instantiated for 160-wide layers
         self.resolutions_list_2D, self.log2_hashmap_size_2D = resolutions_list_2D, log2_hashmap_size_2D
 
         if self.use_viewdirs:
@@ -323,7 +327,18 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
             h = torch.cat([d, embedding.reshape(-1, self.geo_feat_dim)], dim=-1)
         else:
             h = embedding.reshape(-1, self.geo_feat_dim)
-        rgb = run_layers(self.mlp_head, h).reshape(list(embedding.shape[:-1]) + [3]).to(embedding)
+        if self.fused_head and h.is_cuda and not torch.is_grad_enabled() and self._head_shape_ok:
+            # gradient-free evaluation: the three layers in one MFMA kernel (32 rows per wave), hidden
+            # activations stay in LDS; the input gets a 16-byte aligned row stride
+            if self._head_fused is None:
+                from .mlp import FusedMLPForward
+                self._head_fused = FusedMLPForward(self.mlp_head, rows_per_wave=32)
+            pad = (-h.shape[1]) % 4
+            hp = F.pad(h, (0, pad)) if pad else h
+            rgb = self._head_fused(hp[:, :h.shape[1]])
+        else:
+            rgb = run_layers(self.mlp_head, h)
+        rgb = rgb.reshape(list(embedding.shape[:-1]) + [3]).to(embedding)
         return torch.sigmoid(rgb) if apply_act else rgb
 
     def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):

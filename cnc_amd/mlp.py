@@ -142,7 +142,10 @@ class FusedMLPForward:
     fused MFMA kernel (cnc_amd/csrc/mlp.hip).  Keeps zero-padded copies of the weights, refreshed
     when a parameter is modified in place (optimizer step) or replaced."""
 
-    def __init__(self, seq: nn.Sequential):
+    def __init__(self, seq: nn.Sequential, rows_per_wave: int = 16):
+        # 16: v_mfma_f32_16x16x4 kernel, any widths <= 160; 32: v_mfma_f32_32x32x2 kernel, only the
+        # radiance field's two shapes (hidden 160, second width <= 96 or 160, output <= 32)
+        self.rows_per_wave = rows_per_wave
         self.linears = [m for m in seq if isinstance(m, nn.Linear)]
         acts = [m for m in seq if not isinstance(m, nn.Linear)]
         if len(self.linears) not in (2, 3) or len(acts) != len(self.linears) - 1 \
@@ -158,9 +161,10 @@ class FusedMLPForward:
                     for l in self.linears)
         if key != self._key:
             packed = []
-            kp = _round16(self.linears[0].in_features)
+            wide = self.rows_per_wave == 32
+            kp = (self.linears[0].in_features + 7) // 8 * 8 if wide else _round16(self.linears[0].in_features)
             for l in self.linears:
-                hp = _round16(l.out_features)
+                hp = (l.out_features + 31) // 32 * 32 if wide else _round16(l.out_features)
                 w = torch.zeros((hp, kp), dtype=torch.float32, device=l.weight.device)
                 w[: l.out_features, : l.in_features] = l.weight.detach()
                 b = torch.zeros(hp, dtype=torch.float32, device=l.weight.device)
@@ -185,7 +189,8 @@ class FusedMLPForward:
         y = torch.empty((n, n_out), dtype=torch.float32, device=x.device)
         (w1, b1, h1), (w2, b2, h2) = packed[0], packed[1]
         w3, b3, h3 = packed[2] if len(packed) == 3 else (None, None, 0)
-        rc = _lib.lib().cnc_mlp_forward(x2.data_ptr(), n, x2.stride(0), k0, w1.data_ptr(), b1.data_ptr(), h1,
+        fn = _lib.lib().cnc_mlp_forward32 if self.rows_per_wave == 32 else _lib.lib().cnc_mlp_forward
+        rc = fn(x2.data_ptr(), n, x2.stride(0), k0, w1.data_ptr(), b1.data_ptr(), h1,
                                         w2.data_ptr(), b2.data_ptr(), h2, _lib.ptr(w3), _lib.ptr(b3), h3,
                                         y.data_ptr(), n_out, n_out, _lib.stream())
         _lib.check(rc, "mlp_forward")

@@ -42,3 +42,31 @@ def test_fused_mlp_forward_matches_torch(cuda, dims, N):
     with torch.no_grad():
         seq[0].weight.mul_(0.5)
     assert (fused(x) - seq(x)).abs().max() <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("dims", [(255, 160, 80), (95, 160, 160, 3), (64, 160, 96)])
+@pytest.mark.parametrize("N", [1, 31, 33, 5000])
+@pytest.mark.parametrize("aligned", [True, False])
+def test_fused_mlp_32_row_kernel(cuda, dims, N, aligned):
+    """v_mfma_f32_32x32x2 kernel (32 rows per wave, cnc_mlp_forward32) vs torch: fp32 round-off only;
+    ragged row counts, 16-byte aligned and unaligned input rows."""
+    import torch.nn as nn
+    from cnc_amd.mlp import FusedMLPForward
+    torch.manual_seed(N + len(dims))
+    layers = []
+    for i in range(len(dims) - 1):
+        layers.append(nn.Linear(dims[i], dims[i + 1]))
+        if i < len(dims) - 2:
+            layers.append(nn.ReLU())
+    seq = nn.Sequential(*layers).to(cuda)
+    fused = FusedMLPForward(seq, rows_per_wave=32)
+    if aligned:
+        x = torch.randn(N, (dims[0] + 3) // 4 * 4, device=cuda)[:, :dims[0]]
+    else:
+        x = torch.randn(N, dims[0] + 1, device=cuda)[:, 1:].contiguous() if dims[0] % 4 else \
+            torch.randn(N, dims[0] + 1, device=cuda)[:, :dims[0]]
+    with torch.no_grad():
+        want = seq(x)
+        got = fused(x)
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= 2e-5 * (1 + want.abs().max())

@@ -14,7 +14,7 @@ for dims in ((255,160,80),(95,160,160,3)):
     for i in range(len(dims)-1):
         layers.append(Linear(dims[i],dims[i+1]))
         if i < len(dims)-2: layers.append(nn.ReLU(inplace=True))
-    seq=nn.Sequential(*layers).to(dev); fused=FusedMLPForward(seq)
+    seq=nn.Sequential(*layers).to(dev); fused=FusedMLPForward(seq); fused32=FusedMLPForward(seq, rows_per_wave=32)
     fl = 2*sum(dims[i]*dims[i+1] for i in range(len(dims)-1))
     for N in (1<<16, 1<<18, 1<<20, 1<<22):
         xb=torch.randn(N,(dims[0]+3)//4*4,device=dev); x=xb[:,:dims[0]]
@@ -22,6 +22,6 @@ for dims in ((255,160,80),(95,160,160,3)):
         with torch.no_grad():
             a=t(lambda: seq(x))
             _lib.lib().cnc_mlp_set_variant(0); b=t(lambda: fused(x))
-            _lib.lib().cnc_mlp_set_variant(1); c=t(lambda: fused(x))
-            err=(fused(x)-seq(x)).abs().max().item()
-        print(f"{dims} N=2^{N.bit_length()-1}: torch {a:.3f} ms ({fl*N/a/1e9:.1f} TF)   1-wave {b:.3f} ms ({fl*N/b/1e9:.1f} TF)   4-wave shared {c:.3f} ms ({fl*N/c/1e9:.1f} TF)  max err {err:.1e}")
+            _lib.lib().cnc_mlp_set_variant(0); c=t(lambda: fused32(x))
+            err=(fused32(x)-seq(x)).abs().max().item()
+        print(f"{dims} N=2^{N.bit_length()-1}: torch {a:.3f} ms ({fl*N/a/1e9:.1f} TF)   1-wave {b:.3f} ms ({fl*N/b/1e9:.1f} TF)   32-row {c:.3f} ms ({fl*N/c/1e9:.1f} TF)  max err {err:.1e}")
