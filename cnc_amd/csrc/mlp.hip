@@ -416,6 +416,17 @@ __device__ __forceinline__ void layer32(const float* __restrict__ a_lds, uint32_
 #pragma unroll
         for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t].w, acc[t], 0, 0, 0);
     }
+    (void)bias;
+}
+
+// bias (+ ReLU) and the C-layout -> row-major store to LDS, one tile at a time: the accumulators are
+// read once and never rewritten (modifying them in place first kept a second copy of all 80 alive)
+template <bool RELU, int NT>
+__device__ __forceinline__ void acc_to_lds32(float* __restrict__ dst, uint32_t ld,
+                                             const float* __restrict__ bias,
+                                             const f32x16 (&acc)[kMaxTiles32], uint32_t lane)
+{
+    const uint32_t i = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         const float b = bias[t * 32 + i];
@@ -423,20 +434,9 @@ __device__ __forceinline__ void layer32(const float* __restrict__ a_lds, uint32_
         for (int v = 0; v < 16; v++) {
             float x = acc[t][v] + b;
             if (RELU) x = x > 0 ? x : 0;
-            acc[t][v] = x;
+            dst[(8 * (v >> 2) + 4 * h + (v & 3)) * ld + t * 32 + i] = x;
         }
     }
-}
-
-template <int NT>
-__device__ __forceinline__ void acc_to_lds32(float* __restrict__ dst, uint32_t ld,
-                                             const f32x16 (&acc)[kMaxTiles32], uint32_t lane)
-{
-    const uint32_t i = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int t = 0; t < NT; t++)
-#pragma unroll
-        for (int v = 0; v < 16; v++) dst[(8 * (v >> 2) + 4 * h + (v & 3)) * ld + t * 32 + i] = acc[t][v];
 }
 
 template <int NT0, int NT1, int NT2>
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64) void k_mlp_forward32(MlpArgs p)
 
         f32x16 acc[kMaxTiles32];
         layer32<true, true, NT0>(nullptr, 0, p.K0p, p.W[0], p.B[0], acc, lane, a_row, kv);
-        acc_to_lds32<NT0>(h_lds, ld1, acc, lane);
+        acc_to_lds32<true, NT0>(h_lds, ld1, p.B[0], acc, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(64) void k_mlp_forward32(MlpArgs p)
             layer32<true, false, NT1>(h_lds, ld1, NT0 * 32, p.W[1], p.B[1], acc, lane, nullptr, 0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            acc_to_lds32<NT1>(h_lds, ld2, acc, lane);
+            acc_to_lds32<true, NT1>(h_lds, ld2, p.B[1], acc, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -473,13 +473,16 @@ __global__ __launch_bounds__(64) void k_mlp_forward32(MlpArgs p)
             layer32<false, false, NT1>(h_lds, ld1, NT0 * 32, p.W[1], p.B[1], acc, lane, nullptr, 0);
         }
         constexpr int NTL = NT2 > 0 ? NT2 : NT1;
+        const float*   b_last = NT2 > 0 ? p.B[2] : p.B[1];
         const uint32_t i = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int t = 0; t < NTL; t++) {
+            const uint32_t col = t * 32 + i;
+            const float    b = b_last[col];
 #pragma unroll
             for (int v = 0; v < 16; v++) {
-                const uint32_t row = row0 + 8 * (v >> 2) + 4 * h + (v & 3), col = t * 32 + i;
-                if (row < p.N && col < p.n_out) p.Y[(size_t)row * p.ldy + col] = acc[t][v];
+                const uint32_t row = row0 + 8 * (v >> 2) + 4 * h + (v & 3);
+                if (row < p.N && col < p.n_out) p.Y[(size_t)row * p.ldy + col] = acc[t][v] + b;
             }
         }
         __builtin_amdgcn_wave_barrier();
