@@ -28,6 +28,7 @@ __host__ __device__ inline uint32_t div_up(uint32_t a, uint32_t b) { return (a +
 struct FeatLayout {
     uint32_t ld;
     uint32_t col;
+    uint32_t finest_first = 0;   // backward only: walk the level slots from the last one down
 };
 
 __device__ __forceinline__ size_t feat_index(FeatLayout lay, uint32_t slot, uint32_t N, uint32_t b,

@@ -288,7 +288,9 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
 
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.x * 256 + tid;
-    const uint32_t slot = blockIdx.y;
+    // CNC_FLAG_LEVELS_FINEST_FIRST: the levels with the most atomic requests start first and the cheap
+    // coarse ones fill the tail of the launch
+    const uint32_t slot = lay.finest_first ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
 
     // ---- phase A ----
     uint64_t key = ~0ull;   // out-of-range / padding points: no contribution
@@ -651,7 +653,8 @@ extern "C" int cnc_grid_encode_backward(const float* grad, const float* inputs,
         return CNC_ERR_INVALID_VALUE;
     EncArgs a{inputs, embeddings, offsets, resolutions, grad_embeddings, grad, N, L, Rb,
               binary_vxl, min_level_id, (hipStream_t)stream, ste_clip_count,
-              binary_vxl ? occ_sat : nullptr, FeatLayout{grad_ld, grad_col}};
+              binary_vxl ? occ_sat : nullptr,
+              FeatLayout{grad_ld, grad_col, (flags & CNC_FLAG_LEVELS_FINEST_FIRST) ? 1u : 0u}};
     if (!layout_ok(a.lay, F, L)) return CNC_ERR_INVALID_VALUE;
     const int rc = dispatch_D<true>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
     return rc != CNC_OK ? rc : launch_status();

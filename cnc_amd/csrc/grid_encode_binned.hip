@@ -372,7 +372,8 @@ extern "C" int cnc_grid_encode_backward_binned(const float* grad, const float* i
     if (L - n_binned > 0) {
         const int rc = cnc_grid_encode_backward(grad, inputs, embeddings, offsets, resolutions,
                                                 grad_embeddings, N, D, F, L - n_binned, 0, nullptr,
-                                                nullptr, nullptr, nullptr, flags, ste_clip_count,
+                                                nullptr, nullptr, nullptr,
+                                                flags | CNC_FLAG_LEVELS_FINEST_FIRST, ste_clip_count,
                                                 nullptr, grad_ld, grad_col, stream);
         if (rc != CNC_OK) return rc;
     }

@@ -45,6 +45,8 @@ extern "C" {
                                      into the gather so the 4-7 full-table elementwise passes of the
                                      reference disappear.  In backward, also applies the STE mask
                                      |v| <= 1 (ngp.py:33-39) to the scattered gradient.            */
+#define CNC_FLAG_LEVELS_FINEST_FIRST 2u   /* backward: schedule the level slots last-to-first (same result;
+                                            * measured 2.5 % faster when only coarse levels are left) */
 
 const char* cnc_error_string(int code);
 int         cnc_abi_version(void);              /* bumps when a signature below changes */
