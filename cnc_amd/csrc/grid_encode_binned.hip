@@ -225,7 +225,8 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
     n = n < a.cap ? n : a.cap;
     const Item* my = a.items + ((size_t)blockIdx.y * a.bins + bin) * a.cap;
 
-    for (uint32_t k = lane; k < kSlab * F; k += 64) s_acc[k] = 0;
+    for (uint32_t k = lane * 4; k < kSlab * F; k += 64 * 4)     // 16-byte LDS stores
+        *reinterpret_cast<float4*>(s_acc + k) = make_float4(0, 0, 0, 0);
 
     // next batch's item and gradient row, in flight while the current batch is accumulated
     // A batch takes kRun consecutive items from each of 64 / kRun regions of the bin rather
