@@ -489,11 +489,140 @@ __global__ __launch_bounds__(64) void k_mlp_forward32(MlpArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 64 rows per wave for the FIRST layer: two 32-row tiles share every weight fragment of the widest
+// layer (the L2 weight stream, not the MFMA pipe, is what the 32-row kernel waits for), 160 accumulator
+// registers in AGPRs.  The tiles then go through the remaining layers one after the other, so LDS
+// still holds one 32-row activation block per wave.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void layer32_first_x2(uint32_t Kp, const float* __restrict__ W,
+                                                 f32x16 (&accA)[kMaxTiles32], f32x16 (&accB)[kMaxTiles32],
+                                                 uint32_t lane, const float* __restrict__ rowA,
+                                                 const float* __restrict__ rowB, uint32_t k_valid)
+{
+    const uint32_t i = lane & 31, h = lane >> 5;
+    const uint32_t lane_off = i * Kp + h * 4;
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            accA[t][v] = 0;
+            accB[t][v] = 0;
+        }
+    auto load_w = [&](uint32_t kb, float4 (&dst)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            dst[t] = *reinterpret_cast<const float4*>(W + (size_t)t * 32 * Kp + kb + lane_off);
+    };
+    const bool     a_vec = (k_valid >> 31) != 0;
+    const uint32_t k_real = k_valid & 0x7FFFFFFFu;
+    auto load_a = [&](const float* __restrict__ a_row, uint32_t kb) -> float4 {
+        float4 v{0, 0, 0, 0};
+        const uint32_t k = kb + h * 4;
+        if (a_row) {
+            if (a_vec) {
+                v = *reinterpret_cast<const float4*>(a_row + k);
+                if (k + 4 > k_real) {
+                    if (k >= k_real) v.x = 0;
+                    if (k + 1 >= k_real) v.y = 0;
+                    if (k + 2 >= k_real) v.z = 0;
+                    v.w = 0;
+                }
+            } else {
+                if (k < k_real) v.x = a_row[k];
+                if (k + 1 < k_real) v.y = a_row[k + 1];
+                if (k + 2 < k_real) v.z = a_row[k + 2];
+                if (k + 3 < k_real) v.w = a_row[k + 3];
+            }
+        }
+        return v;
+    };
+    float4 wn[NT], anA = load_a(rowA, 0), anB = load_a(rowB, 0);
+    load_w(0, wn);
+    for (uint32_t kb = 0; kb < Kp; kb += 8) {
+        float4 w[NT];
+        const float4 aA = anA, aB = anB;
+#pragma unroll
+        for (int t = 0; t < NT; t++) w[t] = wn[t];
+        if (kb + 8 < Kp) {
+            load_w(kb + 8, wn);
+            anA = load_a(rowA, kb + 8);
+            anB = load_a(rowB, kb + 8);
+        }
+#define CNC_STEP(C)                                                                                             \
+    _Pragma("unroll") for (int t = 0; t < NT; t++) {                                                            \
+        accA[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA.C, w[t].C, accA[t], 0, 0, 0);                         \
+        accB[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aB.C, w[t].C, accB[t], 0, 0, 0);                         \
+    }
+        CNC_STEP(x) CNC_STEP(y) CNC_STEP(z) CNC_STEP(w)
+#undef CNC_STEP
+    }
+}
+
+template <int NT0, int NT1, int NT2>
+__global__ __launch_bounds__(64) void k_mlp_forward64(MlpArgs p)
+{
+    extern __shared__ float lds[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t ld1 = NT0 * 32 + kPad, ld2 = NT1 * 32 + kPad;
+    float* h_lds = lds;
+
+    const uint32_t tiles = (p.N + 63) / 64;
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint32_t row0 = tile * 64;
+        const uint32_t rA = row0 + (lane & 31), rB = rA + 32;
+        const float*   rowA = rA < p.N ? p.X + (size_t)rA * p.ldx : nullptr;
+        const float*   rowB = rB < p.N ? p.X + (size_t)rB * p.ldx : nullptr;
+        const uint32_t kv = p.K0 | (p.a_vec ? 0x80000000u : 0u);
+
+        f32x16 accA[kMaxTiles32], accB[kMaxTiles32], acc[kMaxTiles32];
+        layer32_first_x2<NT0>(p.K0p, p.W[0], accA, accB, lane, rowA, rowB, kv);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const uint32_t base_row = row0 + half * 32;
+            acc_to_lds32<true, NT0>(h_lds, ld1, p.B[0], half == 0 ? accA : accB, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if constexpr (NT2 > 0) {
+                layer32<true, false, NT1>(h_lds, ld1, NT0 * 32, p.W[1], p.B[1], acc, lane, nullptr, 0);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                acc_to_lds32<true, NT1>(h_lds, ld2, p.B[1], acc, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                layer32<false, false, NT2>(h_lds, ld2, NT1 * 32, p.W[2], p.B[2], acc, lane, nullptr, 0);
+            } else {
+                layer32<false, false, NT1>(h_lds, ld1, NT0 * 32, p.W[1], p.B[1], acc, lane, nullptr, 0);
+            }
+            constexpr int NTL = NT2 > 0 ? NT2 : NT1;
+            const float*   b_last = NT2 > 0 ? p.B[2] : p.B[1];
+            const uint32_t i = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int t = 0; t < NTL; t++) {
+                const uint32_t col = t * 32 + i;
+                const float    b = b_last[col];
+#pragma unroll
+                for (int v = 0; v < 16; v++) {
+                    const uint32_t row = base_row + 8 * (v >> 2) + 4 * h + (v & 3);
+                    if (row < p.N && col < p.n_out) p.Y[(size_t)row * p.ldy + col] = acc[t][v] + b;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();   // the LDS block is rewritten by the second half / next tile
+        }
+    }
+}
+
 }  // namespace cnc
 
 using namespace cnc;
 
-static int g_mlp_variant = 0;    // 0: one wave per workgroup (default); 1: four waves share the weights through LDS (measured slower)
+// cnc_mlp_forward: 0 = one wave per 16 rows (default), 1 = four waves sharing the weights through LDS
+// (measured slower).  cnc_mlp_forward32: 3 = one 32-row tile per wave, anything else = two tiles sharing
+// the first layer's weights (default).
+static int g_mlp_variant = 0;
 extern "C" int cnc_mlp_set_variant(int v) { g_mlp_variant = v; return CNC_OK; }
 
 // Fused 2- or 3-layer fp32 MLP forward.  Weights must be pre-padded by the caller:
@@ -586,6 +715,17 @@ extern "C" int cnc_mlp_forward32(const float* X, uint32_t N, uint32_t ldx, uint3
     uint32_t       blocks = tiles;
     if (blocks > 256u * 32) blocks = 256u * 32;
     const size_t lds_bytes = (size_t)32 * (160 + kPad) * sizeof(float);
+    if (g_mlp_variant != 3) {   // default: two 32-row tiles share the first layer's weight fragments
+        uint32_t b64 = (N + 63) / 64;
+        if (b64 > 256u * 32) b64 = 256u * 32;
+        if (n_layers == 2 && H1p == 160 && H2p == 96 && n_out <= 96)
+            hipLaunchKernelGGL((k_mlp_forward64<5, 3, 0>), dim3(b64), dim3(64), lds_bytes, (hipStream_t)stream, p);
+        else if (n_layers == 3 && H1p == 160 && H2p == 160 && H3p == 32 && n_out <= 32)
+            hipLaunchKernelGGL((k_mlp_forward64<5, 5, 1>), dim3(b64), dim3(64), lds_bytes, (hipStream_t)stream, p);
+        else
+            return CNC_ERR_UNSUPPORTED;
+        return launch_status();
+    }
     if (n_layers == 2 && H1p == 160 && H2p == 96 && n_out <= 96) {
         hipLaunchKernelGGL((k_mlp_forward32<5, 3, 0>), dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, p);
     } else if (n_layers == 3 && H1p == 160 && H2p == 160 && H3p == 32 && n_out <= 32) {

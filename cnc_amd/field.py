@@ -327,7 +327,8 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
             h = torch.cat([d, embedding.reshape(-1, self.geo_feat_dim)], dim=-1)
         else:
             h = embedding.reshape(-1, self.geo_feat_dim)
-        if self.fused_head and h.is_cuda and not torch.is_grad_enabled() and self._head_shape_ok:
+        if (self.fused_head and h.is_cuda and not torch.is_grad_enabled() and self._head_shape_ok
+                and h.shape[0] >= (1 << 17)):      # below that the 64-row tiles do not fill the 1024 SIMDs
             # gradient-free evaluation: the three layers in one MFMA kernel (32 rows per wave), hidden
             # activations stay in LDS; the input gets a 16-byte aligned row stride
             if self._head_fused is None:

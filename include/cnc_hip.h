@@ -181,7 +181,8 @@ int cnc_cnt_np_embed_planned_backward(const uint32_t* pixels_by_row, const int32
  * v_mfma_f32_16x16x4_f32, activations kept in LDS.  X [N, K0] with row stride ldx.  Weights are
  * passed PADDED: W_l [Hp_l, Kp_l] row-major zero-filled, b_l [Hp_l], Kp_0 = roundup16(K0),
  * Kp_l = Hp_{l-1}, Hp_l = roundup16(H_l) <= 160.                                                */
-/* The same network on a 32-row-per-wave kernel (v_mfma_f32_32x32x2_f32).  Padding: Hp_l multiples of
+/* The same network on v_mfma_f32_32x32x2_f32: 32-row tiles, two of them per wave through the first
+ * layer so that its weight fragments are fetched once per 64 rows.  Padding: Hp_l multiples of
  * 32, Kp_0 = roundup8(K0), Kp_l = Hp_{l-1}.  Only (160, 96) and (160, 160, 32) are instantiated (the
  * radiance field's base and head networks); anything else returns CNC_ERR_UNSUPPORTED.            */
 int cnc_mlp_forward32(const float* X, uint32_t N, uint32_t ldx, uint32_t K0,
@@ -189,8 +190,10 @@ int cnc_mlp_forward32(const float* X, uint32_t N, uint32_t ldx, uint32_t K0,
                       const float* W2, const float* b2, uint32_t H2p,
                       const float* W3, const float* b3, uint32_t H3p,
                       float* Y, uint32_t ldy, uint32_t n_out, void* stream);
-int cnc_mlp_set_variant(int variant);   /* 0 (default): one wave per 16 rows; 1: 4-wave workgroups sharing
-                                          * the weight K blocks through LDS — kept for the record, slower */
+int cnc_mlp_set_variant(int variant);   /* measurement switch.  cnc_mlp_forward: 0 (default) one wave per 16
+                                          * rows, 1 = 4-wave workgroups sharing the weight K blocks through LDS
+                                          * (slower).  cnc_mlp_forward32: 3 = one 32-row tile per wave, else
+                                          * (default) two tiles per wave sharing the first layer's weights */
 int cnc_mlp_forward(const float* X, uint32_t N, uint32_t ldx, uint32_t K0,
                     const float* W1, const float* b1, uint32_t H1p,
                     const float* W2, const float* b2, uint32_t H2p,
