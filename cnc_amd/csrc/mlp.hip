@@ -495,21 +495,19 @@ __global__ __launch_bounds__(64) void k_mlp_forward32(MlpArgs p)
 // registers in AGPRs.  The tiles then go through the remaining layers one after the other, so LDS
 // still holds one 32-row activation block per wave.
 // ---------------------------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ void layer32_first_x2(uint32_t Kp, const float* __restrict__ W,
-                                                 f32x16 (&accA)[kMaxTiles32], f32x16 (&accB)[kMaxTiles32],
-                                                 uint32_t lane, const float* __restrict__ rowA,
-                                                 const float* __restrict__ rowB, uint32_t k_valid)
+template <int NT, int T>
+__device__ __forceinline__ void layer32_first_xT(uint32_t Kp, const float* __restrict__ W,
+                                                 f32x16 (&acc)[T][kMaxTiles32], uint32_t lane,
+                                                 const float* const (&rows)[T], uint32_t k_valid)
 {
     const uint32_t i = lane & 31, h = lane >> 5;
     const uint32_t lane_off = i * Kp + h * 4;
 #pragma unroll
-    for (int t = 0; t < NT; t++)
+    for (int m = 0; m < T; m++)
 #pragma unroll
-        for (int v = 0; v < 16; v++) {
-            accA[t][v] = 0;
-            accB[t][v] = 0;
-        }
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int v = 0; v < 16; v++) acc[m][t][v] = 0;
     auto load_w = [&](uint32_t kb, float4 (&dst)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; t++)
@@ -538,29 +536,34 @@ __device__ __forceinline__ void layer32_first_x2(uint32_t Kp, const float* __res
         }
         return v;
     };
-    float4 wn[NT], anA = load_a(rowA, 0), anB = load_a(rowB, 0);
+    float4 wn[NT], an[T];
+#pragma unroll
+    for (int m = 0; m < T; m++) an[m] = load_a(rows[m], 0);
     load_w(0, wn);
     for (uint32_t kb = 0; kb < Kp; kb += 8) {
-        float4 w[NT];
-        const float4 aA = anA, aB = anB;
+        float4 w[NT], a[T];
+#pragma unroll
+        for (int m = 0; m < T; m++) a[m] = an[m];
 #pragma unroll
         for (int t = 0; t < NT; t++) w[t] = wn[t];
         if (kb + 8 < Kp) {
             load_w(kb + 8, wn);
-            anA = load_a(rowA, kb + 8);
-            anB = load_a(rowB, kb + 8);
+#pragma unroll
+            for (int m = 0; m < T; m++) an[m] = load_a(rows[m], kb + 8);
         }
-#define CNC_STEP(C)                                                                                             \
-    _Pragma("unroll") for (int t = 0; t < NT; t++) {                                                            \
-        accA[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA.C, w[t].C, accA[t], 0, 0, 0);                         \
-        accB[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aB.C, w[t].C, accB[t], 0, 0, 0);                         \
+#define CNC_STEP(C)                                                                                     \
+    _Pragma("unroll") for (int t = 0; t < NT; t++) {                                                    \
+        _Pragma("unroll") for (int m = 0; m < T; m++)                                                   \
+            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].C, w[t].C, acc[m][t], 0, 0, 0);       \
     }
         CNC_STEP(x) CNC_STEP(y) CNC_STEP(z) CNC_STEP(w)
 #undef CNC_STEP
     }
 }
 
-template <int NT0, int NT1, int NT2>
+// T 32-row tiles per wave through the first layer (weights fetched once per 32*T rows), then one tile
+// at a time through the rest, so LDS holds one 32-row activation block per wave.
+template <int NT0, int NT1, int NT2, int T>
 __global__ __launch_bounds__(64) void k_mlp_forward64(MlpArgs p)
 {
     extern __shared__ float lds[];
@@ -568,20 +571,23 @@ __global__ __launch_bounds__(64) void k_mlp_forward64(MlpArgs p)
     const uint32_t ld1 = NT0 * 32 + kPad, ld2 = NT1 * 32 + kPad;
     float* h_lds = lds;
 
-    const uint32_t tiles = (p.N + 63) / 64;
+    const uint32_t tiles = (p.N + 32 * T - 1) / (32 * T);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const uint32_t row0 = tile * 64;
-        const uint32_t rA = row0 + (lane & 31), rB = rA + 32;
-        const float*   rowA = rA < p.N ? p.X + (size_t)rA * p.ldx : nullptr;
-        const float*   rowB = rB < p.N ? p.X + (size_t)rB * p.ldx : nullptr;
+        const uint32_t row0 = tile * 32 * T;
+        const float* rows[T];
+#pragma unroll
+        for (int m = 0; m < T; m++) {
+            const uint32_t r = row0 + m * 32 + (lane & 31);
+            rows[m] = r < p.N ? p.X + (size_t)r * p.ldx : nullptr;
+        }
         const uint32_t kv = p.K0 | (p.a_vec ? 0x80000000u : 0u);
 
-        f32x16 accA[kMaxTiles32], accB[kMaxTiles32], acc[kMaxTiles32];
-        layer32_first_x2<NT0>(p.K0p, p.W[0], accA, accB, lane, rowA, rowB, kv);
+        f32x16 accT[T][kMaxTiles32], acc[kMaxTiles32];
+        layer32_first_xT<NT0, T>(p.K0p, p.W[0], accT, lane, rows, kv);
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
+        for (int half = 0; half < T; half++) {
             const uint32_t base_row = row0 + half * 32;
-            acc_to_lds32<true, NT0>(h_lds, ld1, p.B[0], half == 0 ? accA : accB, lane);
+            acc_to_lds32<true, NT0>(h_lds, ld1, p.B[0], accT[half], lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(64) void k_mlp_forward64(MlpArgs p)
                     if (row < p.N && col < p.n_out) p.Y[(size_t)row * p.ldy + col] = acc[t][v] + b;
                 }
             }
-            __builtin_amdgcn_wave_barrier();   // the LDS block is rewritten by the second half / next tile
+            __builtin_amdgcn_wave_barrier();   // the LDS block is rewritten by the next tile
         }
     }
 }
@@ -715,15 +721,18 @@ extern "C" int cnc_mlp_forward32(const float* X, uint32_t N, uint32_t ldx, uint3
     uint32_t       blocks = tiles;
     if (blocks > 256u * 32) blocks = 256u * 32;
     const size_t lds_bytes = (size_t)32 * (160 + kPad) * sizeof(float);
-    if (g_mlp_variant != 3) {   // default: two 32-row tiles share the first layer's weight fragments
-        uint32_t b64 = (N + 63) / 64;
-        if (b64 > 256u * 32) b64 = 256u * 32;
-        if (n_layers == 2 && H1p == 160 && H2p == 96 && n_out <= 96)
-            hipLaunchKernelGGL((k_mlp_forward64<5, 3, 0>), dim3(b64), dim3(64), lds_bytes, (hipStream_t)stream, p);
-        else if (n_layers == 3 && H1p == 160 && H2p == 160 && H3p == 32 && n_out <= 32)
-            hipLaunchKernelGGL((k_mlp_forward64<5, 5, 1>), dim3(b64), dim3(64), lds_bytes, (hipStream_t)stream, p);
-        else
-            return CNC_ERR_UNSUPPORTED;
+    if (g_mlp_variant != 3) {   // default: several 32-row tiles share the first layer's weight fragments
+        const bool     three = g_mlp_variant == 5;                 // measurement: 96 rows per wave
+        const uint32_t rows_per_wave = three ? 96 : 64;
+        uint32_t       bw = (N + rows_per_wave - 1) / rows_per_wave;
+        if (bw > 256u * 32) bw = 256u * 32;
+        const bool base = n_layers == 2 && H1p == 160 && H2p == 96 && n_out <= 96;
+        const bool head = n_layers == 3 && H1p == 160 && H2p == 160 && H3p == 32 && n_out <= 32;
+        if (!base && !head) return CNC_ERR_UNSUPPORTED;
+        if (base && !three) hipLaunchKernelGGL((k_mlp_forward64<5, 3, 0, 2>), dim3(bw), dim3(64), lds_bytes, (hipStream_t)stream, p);
+        if (base && three) hipLaunchKernelGGL((k_mlp_forward64<5, 3, 0, 3>), dim3(bw), dim3(64), lds_bytes, (hipStream_t)stream, p);
+        if (head && !three) hipLaunchKernelGGL((k_mlp_forward64<5, 5, 1, 2>), dim3(bw), dim3(64), lds_bytes, (hipStream_t)stream, p);
+        if (head && three) hipLaunchKernelGGL((k_mlp_forward64<5, 5, 1, 3>), dim3(bw), dim3(64), lds_bytes, (hipStream_t)stream, p);
         return launch_status();
     }
     if (n_layers == 2 && H1p == 160 && H2p == 96 && n_out <= 96) {
