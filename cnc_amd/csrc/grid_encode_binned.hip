@@ -228,66 +228,82 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
     for (uint32_t k = lane * 4; k < kSlab * F; k += 64 * 4)     // 16-byte LDS stores
         *reinterpret_cast<float4*>(s_acc + k) = make_float4(0, 0, 0, 0);
 
-    // next batch's item and gradient row, in flight while the current batch is accumulated
+    // Two loads deep: while batch i is accumulated, the gradient rows of batch i+1 and the items of
+    // batch i+2 are in flight (the gradient address needs the item, so a one-deep prefetch waits for
+    // the two latencies back to back in every iteration — the pass was bound by exactly that).
     // A batch takes kRun consecutive items from each of 64 / kRun regions of the bin rather
     // than 64 consecutive ones: items of one cell arrive clustered (neighbouring rays of one pass-1
     // block), and every extra claim on a row costs the batch another round.
     constexpr uint32_t kRun = 8, kRegions = 64 / kRun;         // consecutive items per region and batch
     const uint32_t region = (div_up(n, kRegions) + kRun - 1) & ~(kRun - 1);   // items per region
-    uint32_t       step = 0;                                   // batches taken so far
-    Item           nx_item{0, 0, 0, 0};
-    float    nx_g[F];
-    bool     nx_valid = false;
-    auto     prefetch = [&]() {
+    uint32_t       step = 0;                                   // item batches requested so far
+    uint4          it2 = make_uint4(0, 0, 0, 0), it1 = make_uint4(0, 0, 0, 0);
+    bool           valid2 = false, valid1 = false;
+    float          g1[F];
+    auto           fetch_items = [&]() {
         const uint32_t in_region = step * kRun + (lane % kRun);
         const uint32_t j = (lane / kRun) * region + in_region;
-        nx_valid = in_region < region && j < n;
-        if (nx_valid) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(my + j);
-            nx_item.sample = raw.x;
-            nx_item.w0 = __uint_as_float(raw.y);
-            nx_item.w1 = __uint_as_float(raw.z);
-            nx_item.rows = raw.w;
-            const float* gp = a.grad + feat_index(a.lay, slot, a.N, nx_item.sample, F);
+        valid2 = in_region < region && j < n;
+        if (valid2) it2 = *reinterpret_cast<const uint4*>(my + j);
+        step++;
+    };
+    auto fetch_grad = [&]() {
+        if (valid1) {
+            const float* gp = a.grad + feat_index(a.lay, slot, a.N, it1.x, F);
 #pragma unroll
             for (uint32_t q = 0; q < F; q += V) {
                 float gv[V];
                 load_vec<V>(gp + q, gv);
 #pragma unroll
-                for (uint32_t t = 0; t < V; t++) nx_g[q + t] = gv[t];
+                for (uint32_t t = 0; t < V; t++) g1[q + t] = gv[t];
             }
         }
-        step++;
     };
-    prefetch();
+    fetch_items();
+    it1 = it2;
+    valid1 = valid2;
+    fetch_items();
+    fetch_grad();
     __syncthreads();   // single wave: orders the zero-fill before the first accumulate
 
-    while (__ballot(nx_valid) != 0) {
+    while (__ballot(valid1) != 0) {
         uint32_t pend = 0, r0 = 0, r1 = 0;
         float    v0[F], v1[F];
-        if (nx_valid) {
-            pend = (nx_item.rows >> 24) & 3u;
-            r0 = nx_item.rows & 0xFFFu;
-            r1 = (nx_item.rows >> 12) & 0xFFFu;
+        if (valid1) {
+            pend = (it1.w >> 24) & 3u;
+            r0 = it1.w & 0xFFFu;
+            r1 = (it1.w >> 12) & 0xFFFu;
+            const float w0 = __uint_as_float(it1.y), w1 = __uint_as_float(it1.z);
 #pragma unroll
             for (uint32_t f = 0; f < F; f++) {
-                v0[f] = nx_item.w0 * nx_g[f];
-                v1[f] = nx_item.w1 * nx_g[f];
+                v0[f] = w0 * g1[f];
+                v1[f] = w1 * g1[f];
             }
         }
-        prefetch();
+        it1 = it2;
+        valid1 = valid2;
+        fetch_items();
+        fetch_grad();
         // Claims on the same row must not share an LDS instruction.  Every claim takes a ticket from
         // a per-row counter (one integer LDS atomic); round k serves the claims holding ticket k, so
         // all rows touched in a round are distinct and its reads and writes need no ordering among
-        // themselves.  Rounds = the largest number of claims on one row in the batch (image-ordered
-        // rays put ~5 samples of neighbouring rays into the same fine cell).  LDS instructions of a
-        // wave execute in order, which orders the counter reset, the tickets and the rounds.
+        // themselves.  Rounds = the largest number of claims on one row.  The x and the x+1 rows of
+        // the items are served in two phases with their own tickets: 64 instead of 128 claims on the
+        // 256 rows per phase (64 random claims already put 2-3 on one row), and a round is 4 instead
+        // of 8 16-byte LDS operations — 8.1 half-rounds per batch where the joint scheme needed 6.5
+        // full ones (marched rays, 7 levels).  LDS instructions of a wave execute in order, which
+        // orders the counter reset, the tickets and the rounds.
         reinterpret_cast<uint4*>(s_cnt)[lane] = make_uint4(0, 0, 0, 0);
         asm volatile("" ::: "memory");
-        int32_t t0 = (pend & 1u) ? (int32_t)atomicAdd(&s_cnt[r0], 1u) : -1;
-        int32_t t1 = (pend & 2u) ? (int32_t)atomicAdd(&s_cnt[r1], 1u) : -1;
-        for (int32_t k = 0; __ballot(t0 >= k || t1 >= k) != 0; k++) {
+        const int32_t t0 = (pend & 1u) ? (int32_t)atomicAdd(&s_cnt[r0], 1u) : -1;
+        for (int32_t k = 0; __ballot(t0 >= k) != 0; k++) {
             if (t0 == k) lds_row_add<F>(s_acc, r0, v0);
+            asm volatile("" ::: "memory");
+        }
+        reinterpret_cast<uint4*>(s_cnt)[lane] = make_uint4(0, 0, 0, 0);
+        asm volatile("" ::: "memory");
+        const int32_t t1 = (pend & 2u) ? (int32_t)atomicAdd(&s_cnt[r1], 1u) : -1;
+        for (int32_t k = 0; __ballot(t1 >= k) != 0; k++) {
             if (t1 == k) lds_row_add<F>(s_acc, r1, v1);
             asm volatile("" ::: "memory");
         }
