@@ -153,8 +153,23 @@ def cpu_baseline(w):
     y = oracle.grid_encode_forward(x, table, offs, res, threads=threads)
     oracle.grid_encode_backward(y, x, table, offs, res, threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": S / dt, "unit": "ray-samples/s", "cores": threads, "kind": "port",
+    port = {"value": S / dt, "unit": "ray-samples/s", "cores": threads, "kind": "port",
             "sample": f"{n_rays_sub} rays of the same frame -> {S} samples, march(1 thread)+encode fwd+bwd (OpenMP x{threads}), {dt:.1f}s"}
+    # the "PyTorch-CPU gridencoder fallback" BASELINE.json names: index math + index_select +
+    # autograd's index_add_ (oracle/torch_cpu_encoder.py), on 2^16 samples from the middle of the same
+    # sample stream, same table; the encoder only (the march above is not repeated)
+    from oracle import torch_cpu_encoder as tce
+    n_t = min(1 << 16, S)
+    xt = torch.from_numpy(np.ascontiguousarray(x[S // 2 - n_t // 2: S // 2 - n_t // 2 + n_t]))
+    tt = torch.from_numpy(table)
+    gt = torch.from_numpy(np.ascontiguousarray(y[:, :n_t]))
+    t0 = time.perf_counter()
+    tce.forward_backward(xt, tt, offs, res, gt, ste_binary=True)
+    dtt = time.perf_counter() - t0
+    torch_fallback = {"value": n_t / dtt, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                      "sample": f"{n_t} samples of the same stream, pure-torch CPU GridEncoder fwd+bwd "
+                                f"({torch.get_num_threads()} torch threads), {dtt:.1f}s"}
+    return port, torch_fallback
 
 
 def main():
@@ -273,7 +288,7 @@ def main():
             "roofline": roofline, "roofline_forward": other, "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(w)
+            out["cpu_baseline"], out["cpu_baseline_torch"] = cpu_baseline(w)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -184,3 +184,36 @@ def test_range_coder_roundtrip_and_size(oracle):
     p = np.array([1e-6, 1 - 1e-6, 1e-6, 1 - 1e-6, 0.5] * 50, np.float32)
     s = np.array([1, 0, 0, 1, 1] * 50, np.int16)
     assert np.array_equal(oracle.rc_decode(p, oracle.rc_encode(p, s)), s)
+
+
+@pytest.mark.parametrize("F,ste", [(2, True), (2, False), (8, True)])
+def test_torch_cpu_encoder_matches_c_restatement(oracle, F, ste):
+    """The pure-PyTorch-CPU encoder (oracle/torch_cpu_encoder.py — the "PyTorch-CPU gridencoder
+    fallback" of BASELINE config 1: 16 levels, log2T=19, F=2) against the C restatement on the same
+    inputs.  Binarised table: every product is by +-1, so the forward is bit-exact; raw table:
+    the C path uses fmaf where torch rounds the product first (<= 1 ulp of the running sum per corner)."""
+    import torch
+    from cnc_amd.synthetic import RES_16L, level_offsets
+    from oracle import torch_cpu_encoder as tce
+    rng = np.random.default_rng(7)
+    offs = level_offsets(RES_16L, 19, 3)
+    N = 3000
+    x = rng.random((N, 3), dtype=np.float32)
+    x[:8] = [[0, 0, 0], [1, 1, 1], [0.5, 0.5, 0.5], [1, 0, 0.25], [1e-7, 0.9999999, 0.5],
+             [0.03, 0.97, 0.5], [0.999, 0.001, 0.5], [0.25, 0.75, 1.0]]
+    emb = (rng.random((int(offs[-1]), F), dtype=np.float32) * 2 - 1) * (1.5 if ste else 1e-4)
+    grad = rng.standard_normal((len(RES_16L), N, F)).astype(np.float32)
+    want = oracle.grid_encode_forward(x, emb, offs, RES_16L, ste_binary=ste)
+    want_g, acc64 = oracle.grid_encode_backward(grad, x, emb, offs, RES_16L, ste_binary=ste, want_acc64=True)
+    torch.set_num_threads(4)
+    out, g = tce.forward_backward(torch.from_numpy(x), torch.from_numpy(emb), offs, RES_16L,
+                                  torch.from_numpy(grad), ste_binary=ste)
+    if ste:
+        assert np.array_equal(out.numpy(), want)
+    else:
+        np.testing.assert_allclose(out.numpy(), want, rtol=0, atol=2e-11)     # |emb| <= 1e-4
+    # the gradient differs by summation order only: compare with the float64 shadow
+    scale = np.abs(acc64).max()
+    assert np.abs(g.numpy() - acc64).max() <= 2e-6 * scale
+    assert np.abs(want_g - acc64).max() <= 2e-6 * scale
+    assert np.array_equal(g.numpy() == 0, acc64 == 0)
