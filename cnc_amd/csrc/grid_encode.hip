@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
     __shared__ uint64_t s_key[256];
     __shared__ uint16_t s_run_start[257];
     __shared__ uint8_t  s_valid[256];
+    __shared__ uint8_t  s_dup[256];             // two valid corners of the cell share a table row
     __shared__ uint32_t s_wave_heads[4];
 
     const uint32_t tid = threadIdx.x;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
     // ---- phase A ----
     uint64_t key = ~0ull;   // out-of-range / padding points: no contribution
     uint32_t validmask = 0;
+    bool     dup = false;
     {
         float x[D];
         bool  in_range = false;
@@ -320,6 +322,13 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
                 s_row[tid][i] = off + c.row[i];
                 validmask |= (c.valid[i] ? 1u : 0u) << i;
             }
+            if constexpr (SLOTS == 64) {   // hash collisions inside one cell (about 28 / rows of the level)
+#pragma unroll
+                for (uint32_t i = 0; i < C; i++)
+#pragma unroll
+                    for (uint32_t j = i + 1; j < C; j++)
+                        dup |= c.valid[i] && c.valid[j] && c.row[i] == c.row[j];
+            }
             const float* gp = grad + feat_index(lay, slot, N, b, F);
 #pragma unroll
             for (uint32_t k = 0; k < F; k += V) {
@@ -331,6 +340,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
         }
         s_key[tid] = key;
         s_valid[tid] = (uint8_t)validmask;
+        s_dup[tid] = dup ? 1 : 0;
     }
     __syncthreads();
 
@@ -403,6 +413,53 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
     const uint32_t rpg = (total + GROUPS - 1) / GROUPS;    // block-uniform trip count
     const uint32_t r_begin = grp * rpg;
     const uint32_t r_end = min(total, r_begin + rpg);
+
+    if constexpr (SLOTS == 64) {
+        // One run per wave at a time, so the pending run's C rows are wave-uniform: they are read
+        // into scalars and every lane compares its own row against them — C compares whose
+        // results are the ballots, instead of 2C cross-lane reads, C ballots and a 64-bit
+        // find-first per pending corner (PMC: the kernel was VALU-bound on exactly that, ~100 vector
+        // instructions per run at every level).  The one-to-one matching this relies on needs the
+        // rows of a cell to be distinct; a cell with a hash collision among its own corners (s_dup)
+        // neither absorbs nor is absorbed.
+        uint32_t carry_row = NONE;
+        float    carry_acc = 0;
+        for (uint32_t i = 0; i <= rpg; i++) {              // one extra round drains the pending run
+            const uint32_t r = r_begin + i;
+            uint32_t my_row = NONE;
+            float    acc = 0;
+            bool     lone = false;
+            if (i < rpg && r < r_end) {
+                const uint32_t p0 = s_run_start[r], p1 = s_run_start[r + 1];
+                lone = s_dup[p0] != 0;
+                if ((s_valid[p0] >> c) & 1u) {
+                    my_row = s_row[p0][c];
+                    for (uint32_t p = p0; p < p1; p++) acc += s_tw[p][c] * s_g[p][f];
+                }
+            }
+            uint32_t jm = C;                               // pending corner with my row, if any
+            uint64_t claimed = 0;                          // lanes of the pending run taken over
+            if (!lone) {
+#pragma unroll
+                for (uint32_t j = 0; j < C; j++) {
+                    const uint32_t pr = __builtin_amdgcn_readlane(carry_row, j * F);
+                    const bool     hit = my_row == pr && my_row != NONE;
+                    if (__ballot(hit) != 0) claimed |= ((1ull << F) - 1ull) << (j * F);
+                    jm = hit ? j : jm;
+                }
+            }
+            const float ca = __shfl(carry_acc, (int)((jm & (C - 1)) * F + f));
+            if (jm < C) acc += ca;
+            if (carry_row != NONE && !((claimed >> lane) & 1ull)) flush(carry_row, carry_acc);
+            if (lone) {                                    // goes straight out, nothing stays pending
+                if (my_row != NONE) flush(my_row, acc);
+                my_row = NONE;
+            }
+            carry_row = my_row;
+            carry_acc = acc;
+        }
+        return;
+    }
 
     uint32_t carry_row = NONE;
     float    carry_acc = 0;
