@@ -280,7 +280,11 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
 
     __shared__ float    s_tw[256][C];
     __shared__ float    s_g[256][F];
-    __shared__ uint32_t s_row[256][C];
+    // with one run per wave (SLOTS == 64) the table rows are recomputed in phase B from the cell in
+    // s_key: without the 8 KB of rows the block needs 19.5 KB of LDS and 8 instead of 5 blocks fit a
+    // CU — the kernel is latency-bound (2 resident blocks: 1.6x slower), not issue-bound
+    constexpr bool kRowsFromKey = SLOTS == 64;
+    __shared__ uint32_t s_row[kRowsFromKey ? 1 : 256][C];
     __shared__ uint64_t s_key[256];
     __shared__ uint16_t s_run_start[257];
     __shared__ uint8_t  s_valid[256];
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
 #pragma unroll
             for (uint32_t i = 0; i < C; i++) {
                 s_tw[tid][i] = c.valid[i] ? c.w[i] * c.wn_re : 0.0f;
-                s_row[tid][i] = off + c.row[i];
+                if constexpr (!kRowsFromKey) s_row[tid][i] = off + c.row[i];
                 validmask |= (c.valid[i] ? 1u : 0u) << i;
             }
             if constexpr (SLOTS == 64) {   // hash collisions inside one cell (about 28 / rows of the level)
@@ -394,6 +398,30 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
         unsafeAtomicAdd(grad_emb + at, v);
     };
 
+    // absolute table row of corner c of the cell in `k` (the same arithmetic as Corners::setup)
+    uint32_t u_off = 0, u_hs = 1, u_R = 2;
+    if (!min_level_id) {
+        u_off = (uint32_t)offsets[slot];
+        u_hs = (uint32_t)offsets[slot + 1] - u_off;
+        u_R = (uint32_t)resolutions[slot];
+    }
+    auto row_of = [&](uint64_t k) -> uint32_t {
+        uint32_t off = u_off, hs = u_hs, R = u_R;
+        if (min_level_id) {                                // per-point level windows: level is in the key
+            const uint32_t level = (uint32_t)(k >> 52);
+            off = (uint32_t)offsets[level];
+            hs = (uint32_t)offsets[level + 1] - off;
+            R = (uint32_t)resolutions[level];
+        }
+        uint32_t q[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            const uint32_t gd = (uint32_t)(k >> (16 * d)) & 0xFFFFu;
+            q[d] = ((c >> d) & 1u) ? min(gd + 1, R - 1) : gd;
+        }
+        return off + grid_row<D>(q, hs, R);
+    };
+
     if (n_adjacent * 4 < total) {
         // few neighbouring runs (random points, or levels finer than the sample spacing): nothing
         // to combine, so every run goes straight out, runs interleaved over the groups
@@ -402,7 +430,8 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
             if (!((s_valid[p0] >> c) & 1u)) continue;
             float acc = 0;
             for (uint32_t p = p0; p < p1; p++) acc += s_tw[p][c] * s_g[p][f];
-            flush(s_row[p0][c], acc);
+            if constexpr (kRowsFromKey) flush(row_of(s_key[p0]), acc);
+            else flush(s_row[p0][c], acc);
         }
         return;
     }
@@ -424,18 +453,35 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
         // neither absorbs nor is absorbed.
         uint32_t carry_row = NONE;
         float    carry_acc = 0;
+        // The run's head record (bounds, validity, row, first sample's weight and gradient) is read
+        // one run ahead: a wave walks its runs serially, and the dependent LDS round trips
+        // (bounds -> head -> samples) otherwise add up to most of a run's latency.
+        auto head_of = [&](uint32_t r, uint32_t& p0, uint32_t& p1, bool& lone, uint32_t& row, float& tw0,
+                           float& g0) {
+            const bool     live = r < r_end;
+            const uint32_t rr = live ? r : 0u;
+            p0 = s_run_start[rr];
+            p1 = live ? (uint32_t)s_run_start[rr + 1] : p0;
+            const uint32_t q = p0 < 256u ? p0 : 255u;
+            lone = live && s_dup[q] != 0;
+            row = (live && ((s_valid[q] >> c) & 1u)) ? row_of(s_key[q]) : NONE;
+            tw0 = s_tw[q][c];
+            g0 = s_g[q][f];
+        };
+        uint32_t n_p0, n_p1, n_row;
+        bool     n_lone;
+        float    n_tw0, n_g0;
+        head_of(r_begin, n_p0, n_p1, n_lone, n_row, n_tw0, n_g0);
         for (uint32_t i = 0; i <= rpg; i++) {              // one extra round drains the pending run
-            const uint32_t r = r_begin + i;
-            uint32_t my_row = NONE;
-            float    acc = 0;
-            bool     lone = false;
-            if (i < rpg && r < r_end) {
-                const uint32_t p0 = s_run_start[r], p1 = s_run_start[r + 1];
-                lone = s_dup[p0] != 0;
-                if ((s_valid[p0] >> c) & 1u) {
-                    my_row = s_row[p0][c];
-                    for (uint32_t p = p0; p < p1; p++) acc += s_tw[p][c] * s_g[p][f];
-                }
+            const uint32_t p0 = n_p0, p1 = n_p1;
+            uint32_t       my_row = n_row;
+            const bool     lone = n_lone;
+            float          acc = 0;
+            const float    tw0 = n_tw0, g0 = n_g0;
+            head_of(i < rpg ? r_begin + i + 1 : r_end, n_p0, n_p1, n_lone, n_row, n_tw0, n_g0);
+            if (my_row != NONE) {
+                acc = tw0 * g0;
+                for (uint32_t p = p0 + 1; p < p1; p++) acc += s_tw[p][c] * s_g[p][f];
             }
             uint32_t jm = C;                               // pending corner with my row, if any
             uint64_t claimed = 0;                          // lanes of the pending run taken over
