@@ -405,21 +405,52 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
         u_hs = (uint32_t)offsets[slot + 1] - u_off;
         u_R = (uint32_t)resolutions[slot];
     }
+    // Level geometry as wave-uniform scalars when the whole block works on one level (no per-point
+    // level window): the dense / hashed decision and the modulo form of grid_row are then scalar
+    // branches, and the row costs ~10 vector instructions instead of ~70 (it is evaluated once per
+    // run by all 64 lanes, not once per 64 samples as in phase A).
+    u_off = __builtin_amdgcn_readfirstlane(u_off);
+    u_hs = __builtin_amdgcn_readfirstlane(u_hs);
+    u_R = __builtin_amdgcn_readfirstlane(u_R);
+    uint32_t u_stride[D];
+    bool     u_dense;
+    {
+        uint32_t stride = 1;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {                 // the stride walk of grid_row, scalar
+            u_stride[d] = stride <= u_hs ? stride : 0u;
+            if (stride <= u_hs) stride *= u_R;
+        }
+        u_dense = !(stride > u_hs);
+    }
+    const bool u_pow2 = (u_hs & (u_hs - 1)) == 0;
     auto row_of = [&](uint64_t k) -> uint32_t {
-        uint32_t off = u_off, hs = u_hs, R = u_R;
         if (min_level_id) {                                // per-point level windows: level is in the key
             const uint32_t level = (uint32_t)(k >> 52);
-            off = (uint32_t)offsets[level];
-            hs = (uint32_t)offsets[level + 1] - off;
-            R = (uint32_t)resolutions[level];
+            const uint32_t off = (uint32_t)offsets[level];
+            const uint32_t hs = (uint32_t)offsets[level + 1] - off;
+            const uint32_t R = (uint32_t)resolutions[level];
+            uint32_t q[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                const uint32_t gd = (uint32_t)(k >> (16 * d)) & 0xFFFFu;
+                q[d] = ((c >> d) & 1u) ? min(gd + 1, R - 1) : gd;
+            }
+            return off + grid_row<D>(q, hs, R);
         }
-        uint32_t q[D];
+        constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u,
+                                        2097192037u, 1434869437u, 2165219737u};
+        uint32_t index = 0;
 #pragma unroll
         for (uint32_t d = 0; d < D; d++) {
             const uint32_t gd = (uint32_t)(k >> (16 * d)) & 0xFFFFu;
-            q[d] = ((c >> d) & 1u) ? min(gd + 1, R - 1) : gd;
+            const uint32_t qd = ((c >> d) & 1u) ? min(gd + 1, u_R - 1) : gd;
+            if (u_dense) index += qd * u_stride[d];
+            else index ^= qd * primes[d];
         }
-        return off + grid_row<D>(q, hs, R);
+        if (u_pow2) index &= u_hs - 1;
+        else if (index >= u_hs) index %= u_hs;
+        return u_off + index;
     };
 
     if (n_adjacent * 4 < total) {
