@@ -288,7 +288,6 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
     __shared__ uint64_t s_key[256];
     __shared__ uint16_t s_run_start[257];
     __shared__ uint8_t  s_valid[256];
-    __shared__ uint8_t  s_dup[256];             // two valid corners of the cell share a table row
     __shared__ uint32_t s_wave_heads[4];
 
     const uint32_t tid = threadIdx.x;
@@ -300,7 +299,6 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
     // ---- phase A ----
     uint64_t key = ~0ull;   // out-of-range / padding points: no contribution
     uint32_t validmask = 0;
-    bool     dup = false;
     {
         float x[D];
         bool  in_range = false;
@@ -326,13 +324,6 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
                 if constexpr (!kRowsFromKey) s_row[tid][i] = off + c.row[i];
                 validmask |= (c.valid[i] ? 1u : 0u) << i;
             }
-            if constexpr (SLOTS == 64) {   // hash collisions inside one cell (about 28 / rows of the level)
-#pragma unroll
-                for (uint32_t i = 0; i < C; i++)
-#pragma unroll
-                    for (uint32_t j = i + 1; j < C; j++)
-                        dup |= c.valid[i] && c.valid[j] && c.row[i] == c.row[j];
-            }
             const float* gp = grad + feat_index(lay, slot, N, b, F);
 #pragma unroll
             for (uint32_t k = 0; k < F; k += V) {
@@ -344,7 +335,6 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
         }
         s_key[tid] = key;
         s_valid[tid] = (uint8_t)validmask;
-        s_dup[tid] = dup ? 1 : 0;
     }
     __syncthreads();
 
@@ -475,65 +465,79 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
     const uint32_t r_end = min(total, r_begin + rpg);
 
     if constexpr (SLOTS == 64) {
-        // One run per wave at a time, so the pending run's C rows are wave-uniform: they are read
-        // into scalars and every lane compares its own row against them — C compares whose
-        // results are the ballots, instead of 2C cross-lane reads, C ballots and a 64-bit
-        // find-first per pending corner (PMC: the kernel was VALU-bound on exactly that, ~100 vector
-        // instructions per run at every level).  The one-to-one matching this relies on needs the
-        // rows of a cell to be distinct; a cell with a hash collision among its own corners (s_dup)
-        // neither absorbs nor is absorbed.
+        // One run per wave at a time.  Which rows of the pending run reappear in the new one follows
+        // from the two cells alone: corner b' of the new cell is corner b' + delta of the pending
+        // cell whenever that is a corner at all (delta = cell' - cell, every axis within +-1).  The
+        // keys are wave-uniform, so delta is scalar and every lane derives its partner from its own
+        // corner bits — no row compares, cross-lane reads or ballots (PMC: the kernel was VALU-bound
+        // on those, ~100 vector instructions per run at every level).  Equal rows of different
+        // vertices (hash collisions) are simply not combined.
         uint32_t carry_row = NONE;
         float    carry_acc = 0;
-        // The run's head record (bounds, validity, row, first sample's weight and gradient) is read
+        uint32_t carry_lo = ~0u, carry_hi = ~0u;           // key of the pending run (~0: none)
+        // The run's head record (bounds, validity, key, first sample's weight and gradient) is read
         // one run ahead: a wave walks its runs serially, and the dependent LDS round trips
         // (bounds -> head -> samples) otherwise add up to most of a run's latency.
-        auto head_of = [&](uint32_t r, uint32_t& p0, uint32_t& p1, bool& lone, uint32_t& row, float& tw0,
+        auto head_of = [&](uint32_t r, uint32_t& p0, uint32_t& p1, uint64_t& k, bool& ok, float& tw0,
                            float& g0) {
             const bool     live = r < r_end;
             const uint32_t rr = live ? r : 0u;
             p0 = s_run_start[rr];
             p1 = live ? (uint32_t)s_run_start[rr + 1] : p0;
             const uint32_t q = p0 < 256u ? p0 : 255u;
-            lone = live && s_dup[q] != 0;
-            row = (live && ((s_valid[q] >> c) & 1u)) ? row_of(s_key[q]) : NONE;
+            k = live ? s_key[q] : ~0ull;
+            ok = live && ((s_valid[q] >> c) & 1u);
             tw0 = s_tw[q][c];
             g0 = s_g[q][f];
         };
-        uint32_t n_p0, n_p1, n_row;
-        bool     n_lone;
+        uint32_t n_p0, n_p1;
+        uint64_t n_key;
+        bool     n_ok;
         float    n_tw0, n_g0;
-        head_of(r_begin, n_p0, n_p1, n_lone, n_row, n_tw0, n_g0);
+        head_of(r_begin, n_p0, n_p1, n_key, n_ok, n_tw0, n_g0);
         for (uint32_t i = 0; i <= rpg; i++) {              // one extra round drains the pending run
             const uint32_t p0 = n_p0, p1 = n_p1;
-            uint32_t       my_row = n_row;
-            const bool     lone = n_lone;
-            float          acc = 0;
+            const uint32_t k_lo = __builtin_amdgcn_readfirstlane((uint32_t)n_key);
+            const uint32_t k_hi = __builtin_amdgcn_readfirstlane((uint32_t)(n_key >> 32));
+            const bool     ok = n_ok;
             const float    tw0 = n_tw0, g0 = n_g0;
-            head_of(i < rpg ? r_begin + i + 1 : r_end, n_p0, n_p1, n_lone, n_row, n_tw0, n_g0);
-            if (my_row != NONE) {
+            head_of(i < rpg ? r_begin + i + 1 : r_end, n_p0, n_p1, n_key, n_ok, n_tw0, n_g0);
+            uint32_t my_row = NONE;
+            float    acc = 0;
+            if (ok) {
+                my_row = row_of((uint64_t)k_hi << 32 | k_lo);
                 acc = tw0 * g0;
                 for (uint32_t p = p0 + 1; p < p1; p++) acc += s_tw[p][c] * s_g[p][f];
             }
-            uint32_t jm = C;                               // pending corner with my row, if any
-            uint64_t claimed = 0;                          // lanes of the pending run taken over
-            if (!lone) {
+            // scalar: is the new cell a neighbour of the pending one (same level)?
+            bool adj = (k_lo & k_hi) != ~0u && (carry_lo & carry_hi) != ~0u && (k_hi >> 20) == (carry_hi >> 20);
+            int  delta[D];
 #pragma unroll
-                for (uint32_t j = 0; j < C; j++) {
-                    const uint32_t pr = __builtin_amdgcn_readlane(carry_row, j * F);
-                    const bool     hit = my_row == pr && my_row != NONE;
-                    if (__ballot(hit) != 0) claimed |= ((1ull << F) - 1ull) << (j * F);
-                    jm = hit ? j : jm;
-                }
+            for (uint32_t d = 0; d < D; d++) {
+                const uint32_t a_new = d == 0 ? (k_lo & 0xFFFFu) : d == 1 ? (k_lo >> 16) : (k_hi & 0xFFFFu);
+                const uint32_t a_old = d == 0 ? (carry_lo & 0xFFFFu) : d == 1 ? (carry_lo >> 16) : (carry_hi & 0xFFFFu);
+                delta[d] = (int)a_new - (int)a_old;
+                adj = adj && delta[d] >= -1 && delta[d] <= 1;
             }
-            const float ca = __shfl(carry_acc, (int)((jm & (C - 1)) * F + f));
-            if (jm < C) acc += ca;
-            if (carry_row != NONE && !((claimed >> lane) & 1ull)) flush(carry_row, carry_acc);
-            if (lone) {                                    // goes straight out, nothing stays pending
-                if (my_row != NONE) flush(my_row, acc);
-                my_row = NONE;
+            bool     shared = adj, claimed = adj;          // my new corner is a pending one / my pending
+            uint32_t jm = 0;                               // corner is a new one
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                const int bit = (int)((c >> d) & 1u);
+                const int as_old = bit + delta[d], as_new = bit - delta[d];
+                shared = shared && (uint32_t)as_old <= 1u;
+                claimed = claimed && (uint32_t)as_new <= 1u;
+                jm |= ((uint32_t)as_old & 1u) << d;
             }
+            const float ca = __shfl(carry_acc, (int)(jm * F + f));
+            if (shared && ok) acc += ca;
+            // a claimed pending lane is absorbed by the new run only if that corner is live there
+            // (validity is a property of the vertex, so it is the pending lane's own validity)
+            if (carry_row != NONE && !claimed) flush(carry_row, carry_acc);
             carry_row = my_row;
             carry_acc = acc;
+            carry_lo = k_lo;
+            carry_hi = k_hi;
         }
         return;
     }
