@@ -29,6 +29,7 @@ struct FeatLayout {
     uint32_t ld;
     uint32_t col;
     uint32_t finest_first = 0;   // backward only: walk the level slots from the last one down
+    uint32_t n_slots = 0;        // backward only: 1-D grid, block id = chunk * n_slots + level slot
 };
 
 __device__ __forceinline__ size_t feat_index(FeatLayout lay, uint32_t slot, uint32_t N, uint32_t b,
