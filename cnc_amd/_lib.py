@@ -60,6 +60,7 @@ SIGNATURES = {
 RESTYPES = {"cnc_grid_encode_backward_binned_workspace": C.c_uint64}
 
 CNC_FLAG_STE_BINARY = 1
+CNC_FLAG_LEVELS_FINEST_FIRST = 2
 ABI_VERSION = 7          # cnc_abi_version() of the library this table was written for
 
 

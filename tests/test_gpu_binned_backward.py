@@ -180,3 +180,30 @@ def test_binned_backward_full_size_equals_atomic_kernel(cuda):
         want = grad[l].double().sum(0)
         got = b[int(offs[l]):int(offs[l + 1])].double().sum(0)
         assert (got - want).abs().max() <= 1e-4 * grad[l].abs().double().sum(0).max()
+
+
+@pytest.mark.parametrize("D,F", [(3, 8), (3, 2), (2, 8)])
+@pytest.mark.parametrize("N", [1, 300, 70001])
+def test_interleaved_level_schedule_gives_the_same_gradient(cuda, oracle, D, F, N):
+    """CNC_FLAG_LEVELS_FINEST_FIRST (mirror kwarg `interleave_levels`) only changes which block works
+    on which (chunk, level) — 1-D grid, level slot as the fast index, slots walked last to first — so
+    the plain entry must return the same sums (fp32 reordering aside) for ragged sizes and every
+    lane mapping (64, 16 and 32 lanes per run)."""
+    from cnc_amd.backends import gridencoder_backend as be
+    res = RES if D == 3 else [10, 18, 34, 66]
+    offs, resl, emb = make_grid(res, 10, D, F, seed=61)
+    x = _points(N, D, seed=62)
+    g = np.random.default_rng(63).normal(size=(len(res), N, F)).astype(np.float32)
+    _, acc64 = oracle.grid_encode_backward(g, x, emb, offs, resl, ste_binary=True, want_acc64=True)
+    t = lambda a: torch.as_tensor(a, device=cuda)
+    outs = []
+    for il in (False, True):
+        ge = torch.zeros(emb.shape, dtype=torch.float32, device=cuda)
+        be.grid_encode_backward(t(g), t(x), t(emb), t(offs), t(resl), ge, N, D, F, len(res), 0, 128, None, None,
+                                None, None, ste_binary=True, interleave_levels=il)
+        torch.cuda.synchronize()
+        outs.append(ge.cpu().numpy())
+    scale = max(np.abs(acc64).max(), 1e-30)
+    for got in outs:
+        assert np.abs(got - acc64).max() <= 1e-5 * scale
+    assert np.array_equal(outs[0] == 0, outs[1] == 0) or np.abs(outs[0] - outs[1]).max() <= 1e-5 * scale
