@@ -56,21 +56,42 @@ struct Corners {
             g[d] = (uint32_t)fl;
             pos[d] = p - fl;
         }
+        // Row index per corner = grid_row(q, hs, R), assembled from per-axis terms: every axis has
+        // only two candidate coordinates, so the 32-bit multiplies (quarter rate on CDNA) are done
+        // once per axis and value (2 D of them) instead of once per corner and axis (D 2^D), and the
+        // dense / hashed decision is made once (it is wave-uniform whenever the level is).
+        constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u,
+                                        2097192037u, 1434869437u, 2165219737u};
+        uint32_t qa[D][2], part[D][2];
+        uint32_t stride = 1, sd[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {                 // the stride walk of grid_row
+            sd[d] = stride;
+            if (stride <= hs) stride *= R;
+        }
+        const bool hashed = stride > hs;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            qa[d][0] = g[d];
+            qa[d][1] = min(g[d] + 1, R - 1);
+            const uint32_t m = hashed ? primes[d] : sd[d];
+#pragma unroll
+            for (uint32_t b = 0; b < 2; b++) part[d][b] = d == 0 ? (hashed ? qa[d][b] : qa[d][b] * m) : qa[d][b] * m;
+        }
+        const bool pow2 = (hs & (hs - 1)) == 0;
         float wn = 0;
 #pragma unroll
         for (uint32_t i = 0; i < C; i++) {
             float    wi = 1;
             uint32_t q[D];
+            uint32_t index = 0;
             bool     border = false;
 #pragma unroll
             for (uint32_t d = 0; d < D; d++) {
-                if ((i & (1u << d)) == 0) {
-                    wi *= 1 - pos[d];
-                    q[d] = g[d];
-                } else {
-                    wi *= pos[d];
-                    q[d] = min(g[d] + 1, R - 1);
-                }
+                const uint32_t bit = (i >> d) & 1u;
+                wi *= bit ? pos[d] : 1 - pos[d];
+                q[d] = qa[d][bit];
+                index = hashed ? index ^ part[d][bit] : index + part[d][bit];
                 border |= (q[d] == 0) | (q[d] == R - 1);
             }
             bool ok = !border;
@@ -79,9 +100,11 @@ struct Corners {
                 // for non-border ones, so skip the (expensive) scan otherwise
                 if (ok) ok = sat ? box_any_sat<D>(q, R, Rb, sat) : box_any<D>(q, R, Rb, vxl);
             }
+            if (pow2) index &= hs - 1;
+            else if (index >= hs) index %= hs;
             w[i] = wi;
             valid[i] = ok;
-            row[i] = ok ? grid_row<D>(q, hs, R) : 0u;
+            row[i] = ok ? index : 0u;
             wn += ok ? wi : 0.0f;
         }
         if (wn == 0) wn = 1e-9f;   // (float)(0.0 + 1e-9)
