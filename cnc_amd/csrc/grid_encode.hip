@@ -768,6 +768,13 @@ static bool layout_ok(FeatLayout lay, uint32_t F, uint32_t L)
     return lay.col + L * F <= lay.ld && lay.ld % V == 0 && lay.col % V == 0;
 }
 
+// grid_input_grad.hip
+int launch_dy_dx(const float* inputs, const float* emb, const int32_t* offsets, const int32_t* resolutions,
+                 float* dy_dx, uint32_t N, uint32_t D, uint32_t F, uint32_t L, const int32_t* mli, bool ste,
+                 hipStream_t s);
+int launch_input_backward(const float* grad, const float* dy_dx, float* grad_inputs, uint32_t N, uint32_t D,
+                          uint32_t F, uint32_t L, FeatLayout lay, hipStream_t s);
+
 }  // namespace cnc
 
 using namespace cnc;
@@ -781,14 +788,16 @@ extern "C" int cnc_grid_encode_forward(const float* inputs, const float* embeddi
                                        uint32_t out_col, void* stream)
 {
     (void)PV;
-    if (dy_dx) return CNC_ERR_UNSUPPORTED;
     if (N == 0 || L == 0) return CNC_OK;
     if (!inputs || !embeddings || !offsets || !resolutions || !outputs) return CNC_ERR_INVALID_VALUE;
     EncArgs a{inputs, embeddings, offsets, resolutions, outputs, nullptr, N, L, Rb,
               binary_vxl, min_level_id, (hipStream_t)stream, nullptr, binary_vxl ? occ_sat : nullptr,
               FeatLayout{out_ld, out_col}};
     if (!layout_ok(a.lay, F, L)) return CNC_ERR_INVALID_VALUE;
-    const int rc = dispatch_D<false>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
+    int rc = dispatch_D<false>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
+    if (rc == CNC_OK && dy_dx)   // the dy_dx branch of kernel_grid, as its own launch (not a hot path)
+        rc = launch_dy_dx(inputs, embeddings, offsets, resolutions, dy_dx, N, D, F, L, min_level_id,
+                          (flags & CNC_FLAG_STE_BINARY) != 0, (hipStream_t)stream);
     return rc != CNC_OK ? rc : launch_status();
 }
 
@@ -802,7 +811,7 @@ extern "C" int cnc_grid_encode_backward(const float* grad, const float* inputs,
                                         const int32_t* occ_sat, uint32_t grad_ld,
                                         uint32_t grad_col, void* stream)
 {
-    if (dy_dx || grad_inputs) return CNC_ERR_UNSUPPORTED;
+    if ((dy_dx == nullptr) != (grad_inputs == nullptr)) return CNC_ERR_INVALID_VALUE;   // both or neither
     if (N == 0 || L == 0) return CNC_OK;
     if (!grad || !inputs || !embeddings || !offsets || !resolutions || !grad_embeddings)
         return CNC_ERR_INVALID_VALUE;
@@ -811,7 +820,10 @@ extern "C" int cnc_grid_encode_backward(const float* grad, const float* inputs,
               binary_vxl ? occ_sat : nullptr,
               FeatLayout{grad_ld, grad_col, (flags & CNC_FLAG_LEVELS_FINEST_FIRST) ? 1u : 0u}};
     if (!layout_ok(a.lay, F, L)) return CNC_ERR_INVALID_VALUE;
-    const int rc = dispatch_D<true>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
+    int rc = dispatch_D<true>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
+    if (rc == CNC_OK && dy_dx)   // kernel_input_backward (gridencoder.cu:588-614)
+        rc = launch_input_backward(grad, dy_dx, grad_inputs, N, D, F, L, FeatLayout{grad_ld, grad_col},
+                                   (hipStream_t)stream);
     return rc != CNC_OK ? rc : launch_status();
 }
 
@@ -913,7 +925,7 @@ extern "C" const char* cnc_error_string(int code)
     case CNC_ERR_INVALID_VALUE:
         return "invalid argument (null pointer, bad size, n_features not in {1,2,4,8,16,32} or "
                "num_dim not in {1,2,3})";
-    case CNC_ERR_UNSUPPORTED: return "argument combination not supported by libcnc_hip (dy_dx / grad_inputs)";
+    case CNC_ERR_UNSUPPORTED: return "argument combination not supported by libcnc_hip";
     case CNC_ERR_LAUNCH: return "HIP kernel launch failed";
     default: return "unknown error";
     }

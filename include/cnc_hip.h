@@ -64,7 +64,10 @@ int         cnc_abi_version(void);              /* bumps when a signature below 
  *   offsets     [L+1] i32 (absolute rows; may be a slice of a longer table, ngp.py:90)
  *   resolutions [L] i32                      outputs    [L, N, F] f32 (level-major, :131)
  *   binary_vxl  NULL or bool[Rb^D]           min_level_id NULL or i32 [N] (per-point level window)
- *   dy_dx       NULL (reference never passes it: ngp.py:58-60,84) — non-NULL => CNC_ERR_UNSUPPORTED
+ *   dy_dx       NULL, or f32 [N, L, D, F]: d outputs / d inputs per level as the dy_dx branch of
+ *               kernel_grid computes it (gridencoder.cu:319-395: edges along each axis, weight (R-2) x
+ *               the other axes' weights, no renormalisation, no occupancy mask; zeros for points
+ *               outside [0,1]).  CNC itself never asks for it (ngp.py:58-60,84).
  *   PV is accepted and ignored, as in the reference (gridencoder.cu:304-308).                  */
 int cnc_grid_encode_forward(const float* inputs, const float* embeddings,
                             const int32_t* offsets, const int32_t* resolutions,
@@ -85,7 +88,8 @@ int cnc_grid_encode_forward(const float* inputs, const float* embeddings,
 
 /* grid_encode_backward (gridencoder.h:24-36, gridencoder.cu:808-866; kernel_grid_backward :399-585).
  *   grad [L, N, F] f32;  grad_embeddings [rows, F] f32, ACCUMULATED into (caller zero-fills,
- *   ngp.py:129).  dy_dx / grad_inputs must be NULL (dead path in the reference).               */
+ *   ngp.py:129).  dy_dx [N, L, D, F] and grad_inputs [N, D] are given together or both NULL:
+ *   grad_inputs[b][d] = sum_l sum_f grad[l][b][f] * dy_dx[b][l][d][f] (kernel_input_backward :588-614). */
 int cnc_grid_encode_backward(const float* grad, const float* inputs, const float* embeddings,
                              const int32_t* offsets, const int32_t* resolutions,
                              float* grad_embeddings,

@@ -127,6 +127,35 @@ def grid_encode_backward(grad, inputs, embeddings, offsets, resolutions, binary_
     return (g, acc) if want_acc64 else g
 
 
+def grid_dy_dx(inputs, embeddings, offsets, resolutions, n_levels_calc=None, min_level_id=None,
+               ste_binary=False):
+    """dy_dx [N, L, D, F] of kernel_grid's dy_dx branch (gridencoder.cu:319-395)."""
+    inputs = _c(inputs, np.float32)
+    emb = _c(embeddings, np.float32)
+    offsets = _c(offsets, np.int32)
+    resolutions = _c(resolutions, np.int32)
+    N, D = inputs.shape
+    F = emb.shape[1]
+    L = int(n_levels_calc) if n_levels_calc is not None else resolutions.shape[0]
+    mli = _c(min_level_id, np.int32)
+    out = np.empty((N, L, D, F), dtype=np.float32)
+    lib().orc_grid_dy_dx(_p(inputs), _p(emb), _p(offsets), _p(resolutions), _p(out), C.c_uint32(N),
+                         C.c_uint32(D), C.c_uint32(F), C.c_uint32(L), _p(mli), C.c_int(int(ste_binary)))
+    return out
+
+
+def input_backward(grad, dy_dx):
+    """kernel_input_backward (gridencoder.cu:588-614): grad [L, N, F], dy_dx [N, L, D, F] -> [N, D]."""
+    grad = _c(grad, np.float32)
+    dy_dx = _c(dy_dx, np.float32)
+    L, N, F = grad.shape
+    D = dy_dx.shape[2]
+    out = np.empty((N, D), dtype=np.float32)
+    lib().orc_input_backward(_p(grad), _p(dy_dx), _p(out), C.c_uint32(N), C.c_uint32(D), C.c_uint32(F),
+                             C.c_uint32(L))
+    return out
+
+
 def cnt_np_embed(inputs, embeddings, resolution, hashmap_size, axis):
     inputs = _c(inputs, np.int16)
     emb = _c(embeddings, np.float32)

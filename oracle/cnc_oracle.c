@@ -222,6 +222,89 @@ void orc_grid_encode_backward(const float* grad, const float* inputs, const floa
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * a4. dy_dx branch of kernel_grid — gridencoder.cu:319-395 — and kernel_input_backward — :588-614.
+ * Dead in CNC (ngp.py:58-60 refuses calc_grad_inputs, :84 passes dy_dx=None) but part of the
+ * `_gridencoder` interface, so it is restated like everything else.
+ * dy_dx [N, L, D, F].  Per input axis gd: the 2^(D-1) edges along gd, weight (R-2) * prod of the
+ * other axes' interpolation weights, (right - left) table values; NO renormalisation over valid
+ * corners and no occupancy mask here (the reference applies neither); vertices on the border ring
+ * read as 0.  Out-of-range points give zeros (:143-158).
+ * ------------------------------------------------------------------------------------------- */
+void orc_grid_dy_dx(const float* inputs, const float* emb, const int32_t* offsets,
+                    const int32_t* resolutions, float* dy_dx, uint32_t N, uint32_t D, uint32_t F,
+                    uint32_t L, const int32_t* min_level_id, int ste_binary)
+{
+    for (uint32_t k = 0; k < L; k++) {
+        for (uint32_t b = 0; b < N; b++) {
+            uint32_t level = (min_level_id ? (uint32_t)min_level_id[b] : 0u) + k;
+            const float* table = emb + (size_t)(uint32_t)offsets[level] * F;
+            uint32_t hs = (uint32_t)(offsets[level + 1] - offsets[level]);
+            uint32_t R = (uint32_t)resolutions[level];
+            const float* x = inputs + (size_t)b * D;
+            float* o = dy_dx + (((size_t)b * L + k) * D) * F;                  /* :323 */
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++) if (x[d] < 0 || x[d] > 1) oob = 1;
+            if (oob) { for (uint32_t j = 0; j < D * F; j++) o[j] = 0; continue; }
+            float pos[ORC_MAX_D];
+            uint32_t g[ORC_MAX_D];
+            for (uint32_t d = 0; d < D; d++) {                                  /* :171-177 */
+                float prod = x[d] * (float)(R - 2);
+                pos[d] = (float)((double)prod + 0.5);
+                g[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)g[d];
+            }
+            for (uint32_t gd = 0; gd < D; gd++) {
+                float acc[32];
+                for (uint32_t ch = 0; ch < F; ch++) acc[ch] = 0;
+                for (uint32_t idx = 0; idx < (1u << (D - 1)); idx++) {
+                    float w = (float)(R - 2);                                   /* :333 */
+                    uint32_t q[ORC_MAX_D];
+                    for (uint32_t nd = 0; nd + 1 < D; nd++) {                   /* :337-347 */
+                        uint32_t d = (nd >= gd) ? nd + 1 : nd;
+                        if ((idx & (1u << nd)) == 0) { w *= 1 - pos[d]; q[d] = g[d]; }
+                        else                         { w *= pos[d];     q[d] = u32min(g[d] + 1, R - 1); }
+                    }
+                    int zl = 0, zr = 0;
+                    uint32_t rl = 0, rr = 0;
+                    q[gd] = g[gd];                                              /* :349-361 */
+                    for (uint32_t d = 0; d < D; d++) if (q[d] == 0 || q[d] == R - 1) { zl = 1; break; }
+                    if (!zl) rl = orc_grid_index(D, q, hs, R);
+                    q[gd] = u32min(g[gd] + 1, R - 1);                           /* :363-374 */
+                    for (uint32_t d = 0; d < D; d++) if (q[d] == 0 || q[d] == R - 1) { zr = 1; break; }
+                    if (!zr) rr = orc_grid_index(D, q, hs, R);
+                    for (uint32_t ch = 0; ch < F; ch++) {                       /* :377-387 */
+                        float vl = 0, vr = 0;
+                        if (!zl) vl = table[(size_t)rl * F + ch];
+                        if (!zr) vr = table[(size_t)rr * F + ch];
+                        if (ste_binary) {  /* STE_binary.forward is applied to the table before the call */
+                            if (!zl) vl = (vl >= 0) ? 1.0f : -1.0f;
+                            if (!zr) vr = (vr >= 0) ? 1.0f : -1.0f;
+                        }
+                        float t = w * (vr - vl);
+                        acc[ch] = fmaf(t, 1.0f, acc[ch]);          /* += t * pos_deriv, pos_deriv = 1 */
+                    }
+                }
+                for (uint32_t ch = 0; ch < F; ch++) o[gd * F + ch] = acc[ch];   /* :390-393 */
+            }
+        }
+    }
+}
+
+void orc_input_backward(const float* grad, const float* dy_dx, float* grad_inputs, uint32_t N,
+                        uint32_t D, uint32_t F, uint32_t L)
+{
+    for (uint32_t t = 0; t < N * D; t++) {                                      /* :596-613 */
+        uint32_t b = t / D, d = t - b * D;
+        const float* dy = dy_dx + (size_t)b * L * D * F;
+        float result = 0;
+        for (uint32_t l = 0; l < L; l++)
+            for (uint32_t ch = 0; ch < F; ch++)
+                result = fmaf(grad[((size_t)l * N + b) * F + ch], dy[((size_t)l * D + d) * F + ch], result);
+        grad_inputs[t] = result;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
  * a6. cnt_np_embed / cnt_np_embed_backward — gridencoder.cu:873-915, 972-1020
  * ------------------------------------------------------------------------------------------- */
 static int orc_cnt_loc(const int16_t* p, uint32_t R, uint32_t F, uint32_t axis, uint32_t* q,

@@ -429,3 +429,49 @@ def test_baseline_config0_against_oracle_and_torch_cpu_fallback(cuda, oracle):
     torch.cuda.synchronize()
     ref = g_t_cpu.numpy()
     assert np.abs(ge2.cpu().numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("D,F", [(3, 8), (3, 2), (2, 4), (2, 16)])
+@pytest.mark.parametrize("ste", [False, True])
+def test_dy_dx_and_input_backward_bit_exact(cuda, oracle, D, F, ste):
+    """kernel_grid's dy_dx branch and kernel_input_backward (gridencoder.cu:319-395, :588-614): dead in
+    CNC but part of the `_gridencoder` interface.  Same operation order as the oracle -> bit-exact,
+    including out-of-range points, the border ring and a per-point level window."""
+    from cnc_amd.backends import gridencoder_backend as be
+    res = RES3 if D == 3 else RES2
+    offs, resl, emb = make_grid(res, 10, D, F, seed=70 + F)
+    x = _points(777, D, seed=71)
+    N, L = x.shape[0], len(res)
+    t = lambda a: torch.as_tensor(a, device=cuda)
+    out = torch.empty((L, N, F), device=cuda)
+    dy = torch.full((N, L, D, F), 7.0, device=cuda)
+    be.grid_encode_forward(t(x), t(emb), t(offs), t(resl), out, N, D, F, L, 0, 128, 0.0, dy, None, None,
+                           ste_binary=ste)
+    torch.cuda.synchronize()
+    want_dy = oracle.grid_dy_dx(x, emb, offs, resl, ste_binary=ste)
+    assert np.array_equal(dy.cpu().numpy(), want_dy)
+    assert np.array_equal(out.cpu().numpy(), oracle.grid_encode_forward(x, emb, offs, resl, ste_binary=ste))
+    g = np.random.default_rng(72).normal(size=(L, N, F)).astype(np.float32)
+    ge, gi = torch.zeros(emb.shape, device=cuda), torch.full((N, D), 3.0, device=cuda)
+    be.grid_encode_backward(t(g), t(x), t(emb), t(offs), t(resl), ge, N, D, F, L, 0, 128, dy, gi, None, None,
+                            ste_binary=ste)
+    torch.cuda.synchronize()
+    assert np.array_equal(gi.cpu().numpy(), oracle.input_backward(g, want_dy))
+    # the embedding gradient is unaffected by the extra outputs
+    ge2 = torch.zeros(emb.shape, device=cuda)
+    be.grid_encode_backward(t(g), t(x), t(emb), t(offs), t(resl), ge2, N, D, F, L, 0, 128, None, None, None, None,
+                            ste_binary=ste)
+    torch.cuda.synchronize()
+    assert torch.allclose(ge, ge2, rtol=0, atol=1e-4 * float(ge2.abs().max()))
+    # per-point level window (2 of the levels, starting at min_level_id[b])
+    mli = np.random.default_rng(73).integers(0, L - 1, size=N).astype(np.int32)
+    dy2 = torch.empty((N, 2, D, F), device=cuda)
+    out2 = torch.empty((2, N, F), device=cuda)
+    be.grid_encode_forward(t(x), t(emb), t(offs), t(resl), out2, N, D, F, 2, 0, 128, 0.0, dy2, None, t(mli),
+                           ste_binary=ste)
+    torch.cuda.synchronize()
+    assert np.array_equal(dy2.cpu().numpy(), oracle.grid_dy_dx(x, emb, offs, resl, n_levels_calc=2,
+                                                               min_level_id=mli, ste_binary=ste))
+    # dy_dx without grad_inputs (or the reverse) is a caller error
+    with pytest.raises(RuntimeError):
+        be.grid_encode_backward(t(g), t(x), t(emb), t(offs), t(resl), ge2, N, D, F, L, 0, 128, dy, None, None, None)

@@ -217,3 +217,41 @@ def test_torch_cpu_encoder_matches_c_restatement(oracle, F, ste):
     assert np.abs(g.numpy() - acc64).max() <= 2e-6 * scale
     assert np.abs(want_g - acc64).max() <= 2e-6 * scale
     assert np.array_equal(g.numpy() == 0, acc64 == 0)
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_dy_dx_is_the_derivative_of_the_interpolation(oracle, D):
+    """The dy_dx branch of kernel_grid (gridencoder.cu:319-395) restated in the oracle, against central
+    differences of the oracle's own forward on interior points (all corners valid there, so the
+    renormalised forward is plain multilinear interpolation and dy_dx is its exact gradient inside a
+    cell), and kernel_input_backward (:588-614) against a float64 contraction."""
+    from cnc_amd.synthetic import level_offsets
+    res = [6, 9, 14, 20, 31] if D == 3 else [10, 18, 34]
+    F = 4
+    offs = level_offsets(res, 10, D)
+    rng = np.random.default_rng(5)
+    emb = rng.standard_normal((int(offs[-1]), F)).astype(np.float32)
+    x = rng.uniform(0.3, 0.7, size=(200, D)).astype(np.float32)
+    dy = oracle.grid_dy_dx(x, emb, offs, res)
+    assert dy.shape == (200, len(res), D, F)
+    h = np.float32(2e-4)
+    for d in range(D):
+        xp, xm = x.copy(), x.copy()
+        xp[:, d] += h
+        xm[:, d] -= h
+        num = (oracle.grid_encode_forward(xp, emb, offs, res) - oracle.grid_encode_forward(xm, emb, offs, res)) \
+            / (xp[:, d] - xm[:, d])[None, :, None]                       # [L, N, F]
+        for l, R in enumerate(res):
+            # only points whose +-h neighbours stay in the same cell along d (piecewise linear)
+            s = x[:, d].astype(np.float64) * (R - 2) + 0.5
+            same = np.floor(s - h * (R - 2) * 1.01) == np.floor(s + h * (R - 2) * 1.01)
+            assert same.sum() > 50
+            np.testing.assert_allclose(dy[same, l, d, :], num[l, same, :], rtol=0, atol=2e-2 * (R - 2))
+    # out-of-range points give zeros, border vertices read as zero (no renormalisation here)
+    xo = np.array([[1.5] + [0.5] * (D - 1), [0.5] * D], np.float32)
+    dyo = oracle.grid_dy_dx(xo, emb, offs, res)
+    assert np.all(dyo[0] == 0) and np.any(dyo[1] != 0)
+    g = rng.standard_normal((len(res), 200, F)).astype(np.float32)
+    gi = oracle.input_backward(g, dy)
+    want = np.einsum("lnf,nldf->nd", g.astype(np.float64), dy.astype(np.float64))
+    np.testing.assert_allclose(gi, want, rtol=0, atol=1e-5 * np.abs(want).max())
