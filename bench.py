@@ -265,8 +265,10 @@ def main():
         nb = (enc.plan_binned_levels(synthetic.RES_16L, w["offsets_host"], D, F, CHUNK) or (0, 0))[0]
         parts = {"grid_encode_backward": f"one cnc_grid_encode_backward_binned call = k_grid_encode_bwd ({L - nb} coarse "
                                          f"levels, atomics) + k_bwd_bin + k_bwd_owner ({nb} finest levels, LDS "
-                                         "accumulation); avg_launch_ms is the whole call, = the sum of the three "
-                                         "kernels' rocprof averages",
+                                         "accumulation); avg_launch_ms is the whole call between two events on the "
+                                         "caller's stream.  The coarse kernel runs on a side stream next to the bin "
+                                         "and owner passes (disjoint table rows), so the call is a few % shorter than "
+                                         "the sum of the three kernels' rocprof averages",
                  "grid_encode_forward": "k_grid_encode_fwd_bits"}
         roofline = {"kernel": dom_name, "kernel_parts": parts[dom_name], "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,

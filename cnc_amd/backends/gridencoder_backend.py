@@ -90,7 +90,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
                          N, num_dim, n_features, n_levels, max_level, Rb, dy_dx=None,
                          grad_inputs=None, binary_vxl=None, min_level_id=None, *, ste_binary=False,
                          ste_clip_count=None, occ_sat=None, grad_ld=0, grad_col=0, binned=None,
-                         interleave_levels=False):
+                         interleave_levels=False, overlap_streams=True):
     """gridencoder.h:24-36.  `binned` (extension) = (n_binned, level_rows) from `plan_binned_levels`:
     take that many finest levels off the global-atomic path (cnc_grid_encode_backward_binned).
     `interleave_levels` (extension, same result): CNC_FLAG_LEVELS_FINEST_FIRST for the plain entry —
@@ -119,11 +119,41 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         L = _lib.lib()
         nbytes = int(L.cnc_grid_encode_backward_binned_workspace(int(N), n_binned, level_rows))
         ws = _workspace(grad.device, nbytes)
+        flags = _lib.CNC_FLAG_STE_BINARY if ste_binary else 0
+        k = int(n_levels) - n_binned          # coarse levels: atomic kernel; the rest: bin + owner passes
+        if k > 0 and n_binned > 0 and N >= _OVERLAP_MIN_POINTS and overlap_streams:
+            # The two halves write disjoint table rows and lean on different units (memory-side
+            # atomics vs. HBM reads / writes): the coarse half runs on a side stream, forked from and
+            # joined to the caller's stream with events (1.16 -> 1.11 ms per 2^20 samples).
+            cur = torch.cuda.current_stream(grad.device)
+            side = _side_stream(grad.device)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            lm = grad_ld == 0                  # level-major [L, N, F]: slice; point-major: shift the column
+            with torch.cuda.stream(side):
+                side.wait_event(fork)
+                rc0 = L.cnc_grid_encode_backward(
+                    ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
+                    ptr(grad_embeddings), int(N), int(num_dim), int(n_features), k, int(Rb), None, None, None,
+                    None, flags | _lib.CNC_FLAG_LEVELS_FINEST_FIRST, ptr(ste_clip_count), None, int(grad_ld),
+                    int(grad_col), stream())
+                join = torch.cuda.Event()
+                join.record(side)
+            g_f = grad[k:] if lm else grad
+            rc = L.cnc_grid_encode_backward_binned(
+                ptr(g_f), ptr(inputs), ptr(embeddings), ptr(offsets_list[k:]), ptr(resolutions_list[k:]),
+                ptr(grad_embeddings), int(N), int(num_dim), int(n_features), n_binned, flags,
+                ptr(ste_clip_count), int(grad_ld), int(grad_col) + (0 if lm else k * int(n_features)),
+                n_binned, level_rows, ptr(ws), ws.numel(), stream())
+            cur.wait_event(join)
+            check(rc0, "grid_encode_backward")
+            check(rc, "grid_encode_backward_binned")
+            return
         rc = L.cnc_grid_encode_backward_binned(
             ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
-            ptr(grad_embeddings), int(N), int(num_dim), int(n_features), int(n_levels),
-            _lib.CNC_FLAG_STE_BINARY if ste_binary else 0, ptr(ste_clip_count), int(grad_ld),
-            int(grad_col), n_binned, level_rows, ptr(ws), ws.numel(), stream())
+            ptr(grad_embeddings), int(N), int(num_dim), int(n_features), int(n_levels), flags,
+            ptr(ste_clip_count), int(grad_ld), int(grad_col), n_binned, level_rows, ptr(ws), ws.numel(),
+            stream())
         check(rc, "grid_encode_backward_binned")
         return
     rc = _lib.lib().cnc_grid_encode_backward(
@@ -137,6 +167,17 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
 
 
 _WORKSPACES = {}
+_SIDE_STREAMS = {}
+_OVERLAP_MIN_POINTS = 1 << 19      # below this the fork / join events cost more than the overlap gains
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[key] = st
+    return st
 
 
 def _workspace(device, nbytes):

@@ -207,3 +207,42 @@ def test_interleaved_level_schedule_gives_the_same_gradient(cuda, oracle, D, F, 
     for got in outs:
         assert np.abs(got - acc64).max() <= 1e-5 * scale
     assert np.array_equal(outs[0] == 0, outs[1] == 0) or np.abs(outs[0] - outs[1]).max() <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("point_major", [False, True])
+def test_two_stream_split_equals_single_call(cuda, point_major):
+    """Above 2^19 points the mirror runs the coarse (atomic) levels on a side stream next to the bin /
+    owner passes of the finest levels (disjoint table rows).  Same gradient as the one-stream call, for
+    the level-major and the point-major gradient layout, and correctly ordered against work queued
+    before and after on the caller's stream."""
+    from cnc_amd.backends import gridencoder_backend as be
+    from cnc_amd.synthetic import RES_16L, level_offsets
+    F, L, N = 8, 16, (1 << 19) + 1234
+    offs = level_offsets(RES_16L, 19, 3)
+    o_t, r_t = torch.as_tensor(offs, device=cuda), torch.tensor(RES_16L, dtype=torch.int32, device=cuda)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    emb = torch.sign(torch.rand((int(offs[-1]), F), generator=gen) * 2 - 1).to(cuda)
+    x = torch.rand((N, 3), generator=gen).to(cuda)
+    plan = be.plan_binned_levels(RES_16L, [int(v) for v in offs], 3, F, N)
+    assert plan is not None and 0 < plan[0] < L
+    g_lm = torch.randn((L, N, F), generator=gen).to(cuda)
+    outs = []
+    for overlap in (False, True):
+        if point_major:
+            g = torch.zeros((N, L * F + 8), device=cuda)
+            g[:, 4:4 + L * F] = g_lm.permute(1, 0, 2).reshape(N, L * F)       # queued just before the call
+            kw = dict(grad_ld=L * F + 8, grad_col=4)
+        else:
+            g = g_lm.clone()
+            kw = {}
+        ge = torch.empty_like(emb)
+        ge.zero_()                       # queued on the caller's stream right before the call
+        be.grid_encode_backward(g, x, emb, o_t, r_t, ge, N, 3, F, L, 0, 128, None, None, None, None,
+                                ste_binary=True, binned=plan, overlap_streams=overlap, **kw)
+        outs.append(ge.clone())          # queued right after: must see both halves
+    torch.cuda.synchronize()
+    scale = float(outs[0].abs().max())
+    assert scale > 0
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * scale
+    # both halves contributed: coarsest and finest level rows are non-zero
+    assert float(outs[1][: int(offs[1])].abs().max()) > 0 and float(outs[1][int(offs[-2]):].abs().max()) > 0
