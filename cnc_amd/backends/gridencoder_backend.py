@@ -6,6 +6,8 @@ non-CUDA / non-contiguous / wrong-dtype tensors.  Kernels run on the current tor
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _lib
@@ -121,7 +123,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         ws = _workspace(grad.device, nbytes)
         flags = _lib.CNC_FLAG_STE_BINARY if ste_binary else 0
         k = int(n_levels) - n_binned          # coarse levels: atomic kernel; the rest: bin + owner passes
-        if k > 0 and n_binned > 0 and N >= _OVERLAP_MIN_POINTS and overlap_streams:
+        if k > 0 and n_binned > 0 and N >= _OVERLAP_MIN_POINTS and overlap_streams and _OVERLAP_ENABLED:
             # The two halves write disjoint table rows and lean on different units (memory-side
             # atomics vs. HBM reads / writes): the coarse half runs on a side stream, forked from and
             # joined to the caller's stream with events (1.16 -> 1.11 ms per 2^20 samples).
@@ -169,6 +171,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
 _WORKSPACES = {}
 _SIDE_STREAMS = {}
 _OVERLAP_MIN_POINTS = 1 << 19      # below this the fork / join events cost more than the overlap gains
+_OVERLAP_ENABLED = os.environ.get("CNC_BWD_OVERLAP", "1") != "0"   # measurement switch (profiles/)
 
 
 def _side_stream(device):

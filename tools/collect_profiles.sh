@@ -13,5 +13,8 @@ CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $ROOT/bench.py > $OUT/stats.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1
+# the same bench with the coarse backward call NOT forked onto a side stream: the three backward kernels
+# then run back to back and the sum of their averages is the call duration bench.py reports
+CNC_BWD_OVERLAP=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_no_overlap -- python $ROOT/bench.py --no-cpu-baseline > $OUT/bench_no_overlap.json 2> $OUT/stats_no_overlap.log
 find $OUT -name "*kernel_trace.csv" -delete      # large; the stats csv is what is kept
 ls -R $OUT | head -40
