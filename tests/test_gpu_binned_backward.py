@@ -211,7 +211,7 @@ def test_interleaved_level_schedule_gives_the_same_gradient(cuda, oracle, D, F, 
 
 @pytest.mark.parametrize("point_major", [False, True])
 def test_two_stream_split_equals_single_call(cuda, point_major):
-    """Above 2^19 points the mirror runs the coarse (atomic) levels on a side stream next to the bin /
+    """From 2^16 points (every binned call) the mirror runs the coarse (atomic) levels on a side stream next to the bin /
     owner passes of the finest levels (disjoint table rows).  Same gradient as the one-stream call, for
     the level-major and the point-major gradient layout, and correctly ordered against work queued
     before and after on the caller's stream."""
