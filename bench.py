@@ -263,8 +263,8 @@ def main():
         if os.path.exists(tp):
             traffic = json.load(open(tp)).get(dom_name)
         nb = (enc.plan_binned_levels(synthetic.RES_16L, w["offsets_host"], D, F, CHUNK) or (0, 0))[0]
-        parts = {"grid_encode_backward": f"one cnc_grid_encode_backward_binned call = k_grid_encode_bwd ({L - nb} coarse "
-                                         f"levels, atomics) + k_bwd_bin + k_bwd_owner ({nb} finest levels, LDS "
+        parts = {"grid_encode_backward": f"one cnc_grid_encode_backward_binned call = k_grid_encode_bwd_merge ({L - nb} coarse "
+                                         f"levels, runs merged across rays, atomics) + k_bwd_bin + k_bwd_owner ({nb} finest levels, LDS "
                                          "accumulation); avg_launch_ms is the whole call between two events on the "
                                          "caller's stream.  The coarse kernel runs on a side stream next to the bin "
                                          "and owner passes (disjoint table rows), so the call is a few % shorter than "

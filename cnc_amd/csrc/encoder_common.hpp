@@ -41,6 +41,7 @@ struct Corners {
     uint32_t row[C];
     bool     valid[C];
     float    wn_re;
+    uint32_t cell[D];     // integer cell coordinates (floor of the scaled position)
 
     __device__ __forceinline__ void setup(const float (&x)[D], uint32_t R, uint32_t hs,
                                           uint32_t Rb, const uint8_t* __restrict__ vxl,
@@ -54,6 +55,7 @@ struct Corners {
             p = p + 0.5f;                      // == (float)((double)p + 0.5)
             const float fl = floorf(p);
             g[d] = (uint32_t)fl;
+            cell[d] = g[d];
             pos[d] = p - fl;
         }
         // Row index per corner = grid_row(q, hs, R), assembled from per-axis terms: every axis has

@@ -692,9 +692,22 @@ static void launch_fwd(const EncArgs& a)
                        a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N, a.Rb, a.vxl, a.mli, a.sat, a.lay);
 }
 
+// grid_encode_merge.hip
+void launch_bwd_merge(const float* grad, const float* inputs, const float* emb, const int32_t* offsets,
+                      const int32_t* resolutions, float* grad_emb, uint32_t N, uint32_t L,
+                      const uint32_t* clip_count, FeatLayout lay, bool ste, hipStream_t s);
+
 template <uint32_t D, uint32_t F, bool VXL, bool STE>
 static void launch_bwd(const EncArgs& a)
 {
+    if constexpr (D == 3 && F == 8 && !VXL) {
+        // coarse half of a binned call: runs merged across the rays of a 1024-sample block
+        if (a.lay.finest_first && !a.mli && (uint64_t)div_up(a.N, 256) * a.L < (1ull << 31)) {
+            launch_bwd_merge(a.grad, a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N, a.L, a.clip_count,
+                             a.lay, STE, a.stream);
+            return;
+        }
+    }
     if constexpr ((1u << D) * F <= 64) {
         const uint64_t blocks = (uint64_t)div_up(a.N, 256) * a.L;
         FeatLayout     lay = a.lay;

@@ -1,0 +1,229 @@
+// grid_encode_merge.hip — backward scatter of the coarse levels with run merging across rays.
+//
+// k_grid_encode_bwd (grid_encode.hip) works on 256 consecutive samples per block: less than one ray of
+// a marched frame (200-400 samples per ray), so the runs it merges are runs along ONE ray.  The rays of
+// neighbouring pixels cross the same cells: of the runs in 1024 consecutive samples (3-4 rays) only 0.29
+// (level 0) to 0.46 (resolution 214) open a cell no earlier run of the block visited; in 256 samples it is
+// 0.93-0.96.  This kernel takes 512 samples per block, chains the runs of equal cells through a small LDS
+// hash table and sends ONE set of atomics per distinct cell — the coarse levels are bound by the
+// memory-side atomic units, so the number of atomic instructions is what their time is
+// made of.  Block size measured on the 9 coarse levels of the bench grid (ms per 2^20 samples; the old
+// kernel: 0.523): 256 -> 0.485, 384 -> 0.548, 512 -> 0.432, 640 -> 0.629, 768 -> 0.444, 1024 -> 0.573:
+// more samples merge more, but the LDS they need leaves fewer waves per CU (512: 45 KB, 3 blocks).
+//
+// D = 3, F = 8 (one run per wave: 64 lanes = 8 corners x 8 features), no occupancy mask, no per-point
+// level window: the coarse half of a binned backward call.  Everything else stays on k_grid_encode_bwd.
+#include "common.hpp"
+#include "encoder_common.hpp"
+
+namespace cnc {
+
+constexpr uint32_t kMB = 512;             // samples (= threads) per block, a multiple of 64
+constexpr uint32_t kMW = kMB / 64;        // waves per block
+constexpr uint32_t kMSlots = kMB <= 512 ? 1024 : 2048;   // hash slots, power of two, >= 2 x the most runs a block can have
+
+template <bool STE>
+__global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
+    const float* __restrict__ grad, const float* __restrict__ inputs, const float* __restrict__ emb,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
+    float* __restrict__ grad_emb, uint32_t N, const uint32_t* __restrict__ clip_count, FeatLayout lay)
+{
+    constexpr uint32_t D = 3, F = 8, C = 8, NONE = 0xFFFFFFFFu, END = 0xFFFFu;
+    __shared__ float    s_tw[kMB][C];
+    __shared__ float    s_g[kMB][F];
+    __shared__ uint64_t s_key[kMB];
+    __shared__ uint16_t s_run_start[kMB + 1];
+    __shared__ uint8_t  s_valid[kMB];
+    __shared__ uint32_t h_slot[kMSlots];        // 0 = empty, else representative run + 1
+    __shared__ uint32_t l_head[kMB];            // per representative run: last run chained to its cell
+    __shared__ uint16_t s_run_next[kMB];
+    __shared__ uint16_t s_group[kMB];           // representative run of the g-th distinct cell
+    __shared__ uint32_t s_wave_heads[kMW], s_wave_claims[kMW];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool     mask_on = STE && (clip_count == nullptr || *clip_count != 0);
+    // 1-D grid, level slot as the fast index (see k_grid_encode_bwd), slots walked last to first
+    const uint32_t n_slots = lay.n_slots;
+    const uint32_t chunk = blockIdx.x / n_slots;
+    const uint32_t slot = n_slots - 1 - blockIdx.x % n_slots;
+    const uint32_t b = chunk * kMB + tid;
+    const uint32_t off = (uint32_t)offsets[slot];
+    const uint32_t hs = (uint32_t)offsets[slot + 1] - off;
+    const uint32_t R = (uint32_t)resolutions[slot];
+
+    for (uint32_t i = tid; i < kMSlots; i += kMB) h_slot[i] = 0;
+    l_head[tid] = END;
+
+    // ---- phase A: lane = sample ----
+    uint64_t key = ~0ull;
+    {
+        float    x[D];
+        uint32_t validmask = 0;
+        if (b < N && load_point<D>(inputs, b, x)) {
+            Corners<D, false> c;
+            c.setup(x, R, hs, 0, nullptr);
+            key = (uint64_t)c.cell[0] | (uint64_t)c.cell[1] << 16 | (uint64_t)c.cell[2] << 32;
+#pragma unroll
+            for (uint32_t i = 0; i < C; i++) {
+                s_tw[tid][i] = c.valid[i] ? c.w[i] * c.wn_re : 0.0f;
+                validmask |= (c.valid[i] ? 1u : 0u) << i;
+            }
+            const float* gp = grad + feat_index(lay, slot, N, b, F);
+            float        g0[4], g1[4];
+            load_vec<4>(gp, g0);
+            load_vec<4>(gp + 4, g1);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                s_g[tid][j] = g0[j];
+                s_g[tid][4 + j] = g1[j];
+            }
+        }
+        s_key[tid] = key;
+        s_valid[tid] = (uint8_t)validmask;
+    }
+    __syncthreads();
+
+    // ---- runs: consecutive samples with the same cell ----
+    const bool     head = tid == 0 || s_key[tid - 1] != key;
+    const uint64_t hb = __ballot(head);
+    if (lane == 0) s_wave_heads[wave] = (uint32_t)__popcll(hb);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kMW; w++) {
+        const uint32_t h = s_wave_heads[w];
+        before += w < wave ? h : 0u;
+        total += h;
+    }
+    const uint32_t my_run = before + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
+    if (head) s_run_start[my_run] = (uint16_t)tid;
+    if (tid == 0) s_run_start[total] = (uint16_t)kMB;
+    __syncthreads();
+
+    // ---- cells: chain the runs of equal cells ----
+    bool     claimer = false;
+    if (head && key != ~0ull) {
+        uint32_t sl = (((uint32_t)key ^ (uint32_t)(key >> 16) ^ (uint32_t)(key >> 32)) * 2654435761u) >> (32 - __builtin_ctz(kMSlots));
+        uint32_t rep;
+        for (;;) {
+            const uint32_t seen = atomicCAS(&h_slot[sl], 0u, my_run + 1);
+            if (seen == 0) { claimer = true; rep = my_run; break; }
+            rep = seen - 1;
+            if (s_key[s_run_start[rep]] == key) break;
+            sl = (sl + 1) & (kMSlots - 1);
+        }
+        s_run_next[my_run] = (uint16_t)atomicExch(&l_head[rep], my_run);
+    }
+    const uint64_t cb = __ballot(claimer);
+    if (lane == 0) s_wave_claims[wave] = (uint32_t)__popcll(cb);
+    __syncthreads();
+    uint32_t g_before = 0, n_cells = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kMW; w++) {
+        const uint32_t h = s_wave_claims[w];
+        g_before += w < wave ? h : 0u;
+        n_cells += h;
+    }
+    if (claimer) s_group[g_before + (uint32_t)__popcll(cb & ((1ull << lane) - 1ull))] = (uint16_t)my_run;
+    __syncthreads();
+
+    // ---- phase B: lane = (corner, feature); each wave walks a contiguous range of cells ----
+    const uint32_t c = lane / F, f = lane % F;
+    auto flush = [&](uint32_t row, float v) {
+        const size_t at = (size_t)row * F + f;
+        if (mask_on) {
+            const float e = emb[at];
+            if (!(e >= -1.0f && e <= 1.0f)) return;
+        }
+        unsafeAtomicAdd(grad_emb + at, v);
+    };
+    // row of my corner in cell k (the arithmetic of Corners::setup, level geometry is block-uniform)
+    uint32_t stride = 1, sd[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        sd[d] = stride;
+        if (stride <= hs) stride *= R;
+    }
+    const bool hashed = stride > hs, pow2 = (hs & (hs - 1)) == 0;
+    constexpr uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+    auto row_of = [&](uint32_t k_lo, uint32_t k_hi) -> uint32_t {
+        uint32_t index = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            const uint32_t gd = d == 0 ? (k_lo & 0xFFFFu) : d == 1 ? (k_lo >> 16) : (k_hi & 0xFFFFu);
+            const uint32_t qd = ((c >> d) & 1u) ? min(gd + 1, R - 1) : gd;
+            if (hashed) index ^= qd * primes[d];
+            else index += qd * sd[d];
+        }
+        if (pow2) index &= hs - 1;
+        else if (index >= hs) index %= hs;
+        return off + index;
+    };
+
+    const uint32_t cpw = (n_cells + kMW - 1) / kMW;
+    const uint32_t g_begin = wave * cpw, g_end = min(n_cells, g_begin + cpw);
+    uint32_t carry_row = NONE, carry_lo = ~0u, carry_hi = ~0u;
+    float    carry_acc = 0;
+    for (uint32_t i = 0; i <= cpw; i++) {                  // one extra round drains the pending cell
+        const uint32_t g = g_begin + i;
+        uint32_t       my_row = NONE, k_lo = ~0u, k_hi = ~0u;
+        float          acc = 0;
+        if (i < cpw && g < g_end) {
+            uint32_t r = l_head[s_group[g]];               // first run of the chain
+            uint32_t p0 = s_run_start[r];
+            const uint64_t k = s_key[p0];
+            k_lo = __builtin_amdgcn_readfirstlane((uint32_t)k);
+            k_hi = __builtin_amdgcn_readfirstlane((uint32_t)(k >> 32));
+            if ((s_valid[p0] >> c) & 1u) {
+                my_row = row_of(k_lo, k_hi);
+                for (;;) {
+                    const uint32_t p1 = s_run_start[r + 1];
+                    for (uint32_t p = p0; p < p1; p++) acc += s_tw[p][c] * s_g[p][f];
+                    r = s_run_next[r];
+                    if (r == END) break;
+                    p0 = s_run_start[r];
+                }
+            }
+        }
+        // which corners of the pending cell reappear in this one follows from the two cells alone
+        bool adj = (k_lo & k_hi) != ~0u && (carry_lo & carry_hi) != ~0u;
+        int  delta[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            const uint32_t a_new = d == 0 ? (k_lo & 0xFFFFu) : d == 1 ? (k_lo >> 16) : (k_hi & 0xFFFFu);
+            const uint32_t a_old = d == 0 ? (carry_lo & 0xFFFFu) : d == 1 ? (carry_lo >> 16) : (carry_hi & 0xFFFFu);
+            delta[d] = (int)a_new - (int)a_old;
+            adj = adj && delta[d] >= -1 && delta[d] <= 1;
+        }
+        bool     shared = adj, claimed = adj;
+        uint32_t jm = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            const int bit = (int)((c >> d) & 1u);
+            const int as_old = bit + delta[d], as_new = bit - delta[d];
+            shared = shared && (uint32_t)as_old <= 1u;
+            claimed = claimed && (uint32_t)as_new <= 1u;
+            jm |= ((uint32_t)as_old & 1u) << d;
+        }
+        const float ca = __shfl(carry_acc, (int)(jm * F + f));
+        if (shared && my_row != NONE) acc += ca;
+        if (carry_row != NONE && !claimed) flush(carry_row, carry_acc);
+        carry_row = my_row;
+        carry_acc = acc;
+        carry_lo = k_lo;
+        carry_hi = k_hi;
+    }
+}
+
+// grid_encode.hip launches this for the coarse half of a binned call (D = 3, F = 8)
+void launch_bwd_merge(const float* grad, const float* inputs, const float* emb, const int32_t* offsets,
+                      const int32_t* resolutions, float* grad_emb, uint32_t N, uint32_t L,
+                      const uint32_t* clip_count, FeatLayout lay, bool ste, hipStream_t s)
+{
+    lay.n_slots = L;
+    const dim3 grid(div_up(N, kMB) * L);
+    if (ste) hipLaunchKernelGGL((k_grid_encode_bwd_merge<true>), grid, dim3(kMB), 0, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
+    else hipLaunchKernelGGL((k_grid_encode_bwd_merge<false>), grid, dim3(kMB), 0, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
+}
+
+}  // namespace cnc
