@@ -42,8 +42,9 @@ by = {n: b for n, f, w, b, c in rows}
 pick = lambda pat: sum(v for k, v in by.items() if re.search(pat, k))
 traffic = {
     "grid_encode_forward": pick(r"k_grid_encode_fwd_bits"),
-    # one backward call = atomic kernel (coarse levels) + bin pass + owner pass (finest levels)
-    "grid_encode_backward": pick(r"k_grid_encode_bwd<") + pick(r"k_bwd_bin") + pick(r"k_bwd_owner"),
+    # one backward call = atomic kernel (coarse levels; run-merging variant in the bench) + bin pass +
+    # owner pass (finest levels)
+    "grid_encode_backward": pick(r"k_grid_encode_bwd(_merge)?<") + pick(r"k_bwd_bin") + pick(r"k_bwd_owner"),
     "_note": "HBM bytes per encoder call on a 2^20-sample chunk = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the "
              "call's kernels, from separate rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 "
              "--no-cpu-baseline` (profiles/r01_pmc_hbm_traffic.csv, tools/collect_profiles.sh); FETCH doubled per "
