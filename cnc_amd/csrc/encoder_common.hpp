@@ -42,6 +42,7 @@ struct Corners {
     bool     valid[C];
     float    wn_re;
     uint32_t cell[D];     // integer cell coordinates (floor of the scaled position)
+    float    frac[D];     // fractional position inside the cell
 
     __device__ __forceinline__ void setup(const float (&x)[D], uint32_t R, uint32_t hs,
                                           uint32_t Rb, const uint8_t* __restrict__ vxl,
@@ -57,6 +58,7 @@ struct Corners {
             g[d] = (uint32_t)fl;
             cell[d] = g[d];
             pos[d] = p - fl;
+            frac[d] = pos[d];
         }
         // Row index per corner = grid_row(q, hs, R), assembled from per-axis terms: every axis has
         // only two candidate coordinates, so the 32-bit multiplies (quarter rate on CDNA) are done

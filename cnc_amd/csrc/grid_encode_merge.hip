@@ -10,6 +10,9 @@
 // made of.  Block size measured on the 9 coarse levels of the bench grid (ms per 2^20 samples; the old
 // kernel: 0.523): 256 -> 0.485, 384 -> 0.548, 512 -> 0.432, 640 -> 0.629, 768 -> 0.444, 1024 -> 0.573:
 // more samples merge more, but the LDS they need leaves fewer waves per CU (512: 45 KB, 3 blocks).
+// With the per-sample weights rebuilt from 4 floats instead of 8 stored ones (37.5 KB, 4 blocks of 512 or
+// 77 KB, 2 blocks of 1024): 512 -> 0.426, 1024 -> 0.429 — by then the atomics are a sixth of the time
+// (without them 0.368) and the per-sample accumulation loop of phase B is what is left.
 //
 // D = 3, F = 8 (one run per wave: 64 lanes = 8 corners x 8 features), no occupancy mask, no per-point
 // level window: the coarse half of a binned backward call.  Everything else stays on k_grid_encode_bwd.
@@ -29,7 +32,9 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
     float* __restrict__ grad_emb, uint32_t N, const uint32_t* __restrict__ clip_count, FeatLayout lay)
 {
     constexpr uint32_t D = 3, F = 8, C = 8, NONE = 0xFFFFFFFFu, END = 0xFFFFu;
-    __shared__ float    s_tw[kMB][C];
+    // the three fractional positions and 1 / (sum of valid weights): the lane rebuilds its corner's
+    // weight from them (same products, same order as Corners::setup) — half the LDS of 8 stored weights
+    __shared__ __attribute__((aligned(16))) float s_w4[kMB][4];
     __shared__ float    s_g[kMB][F];
     __shared__ uint64_t s_key[kMB];
     __shared__ uint16_t s_run_start[kMB + 1];
@@ -64,10 +69,8 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
             c.setup(x, R, hs, 0, nullptr);
             key = (uint64_t)c.cell[0] | (uint64_t)c.cell[1] << 16 | (uint64_t)c.cell[2] << 32;
 #pragma unroll
-            for (uint32_t i = 0; i < C; i++) {
-                s_tw[tid][i] = c.valid[i] ? c.w[i] * c.wn_re : 0.0f;
-                validmask |= (c.valid[i] ? 1u : 0u) << i;
-            }
+            for (uint32_t i = 0; i < C; i++) validmask |= (c.valid[i] ? 1u : 0u) << i;
+            *reinterpret_cast<float4*>(s_w4[tid]) = make_float4(c.frac[0], c.frac[1], c.frac[2], c.wn_re);
             const float* gp = grad + feat_index(lay, slot, N, b, F);
             float        g0[4], g1[4];
             load_vec<4>(gp, g0);
@@ -129,6 +132,9 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
 
     // ---- phase B: lane = (corner, feature); each wave walks a contiguous range of cells ----
     const uint32_t c = lane / F, f = lane % F;
+    const float    sx = (c & 1u) ? 1.0f : -1.0f, ox = (c & 1u) ? 0.0f : 1.0f;
+    const float    sy = (c & 2u) ? 1.0f : -1.0f, oy = (c & 2u) ? 0.0f : 1.0f;
+    const float    sz = (c & 4u) ? 1.0f : -1.0f, oz = (c & 4u) ? 0.0f : 1.0f;
     auto flush = [&](uint32_t row, float v) {
         const size_t at = (size_t)row * F + f;
         if (mask_on) {
@@ -178,7 +184,13 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
                 my_row = row_of(k_lo, k_hi);
                 for (;;) {
                     const uint32_t p1 = s_run_start[r + 1];
-                    for (uint32_t p = p0; p < p1; p++) acc += s_tw[p][c] * s_g[p][f];
+                    for (uint32_t p = p0; p < p1; p++) {
+                        const float4 q = *reinterpret_cast<const float4*>(s_w4[p]);
+                        // bit ? frac : 1 - frac, as one fma with (+1, 0) or (-1, 1): exact either way
+                        const float wx = __builtin_fmaf(q.x, sx, ox), wy = __builtin_fmaf(q.y, sy, oy),
+                                    wz = __builtin_fmaf(q.z, sz, oz);
+                        acc += ((wx * wy) * wz) * q.w * s_g[p][f];
+                    }
                     r = s_run_next[r];
                     if (r == END) break;
                     p0 = s_run_start[r];
