@@ -12,7 +12,8 @@
 // more samples merge more, but the LDS they need leaves fewer waves per CU (512: 45 KB, 3 blocks).
 // With the per-sample weights rebuilt from 4 floats instead of 8 stored ones (37.5 KB, 4 blocks of 512 or
 // 77 KB, 2 blocks of 1024): 512 -> 0.426, 1024 -> 0.429 — by then the atomics are a sixth of the time
-// (without them 0.368) and the per-sample accumulation loop of phase B is what is left.
+// (without them 0.368) and the per-sample accumulation loop of phase B is what is left.  A sample-minor
+// LDS layout with 16-byte reads of 4 samples per lane (peeled to alignment) was slower: 0.461.
 //
 // D = 3, F = 8 (one run per wave: 64 lanes = 8 corners x 8 features), no occupancy mask, no per-point
 // level window: the coarse half of a binned backward call.  Everything else stays on k_grid_encode_bwd.
