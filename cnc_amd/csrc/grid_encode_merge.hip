@@ -22,6 +22,8 @@
 
 namespace cnc {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr uint32_t kMB = 512;             // samples (= threads) per block, a multiple of 64
 constexpr uint32_t kMW = kMB / 64;        // waves per block
 constexpr uint32_t kMSlots = kMB <= 512 ? 1024 : 2048;   // hash slots, power of two, >= 2 x the most runs a block can have
@@ -133,9 +135,10 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
 
     // ---- phase B: lane = (corner, feature); each wave walks a contiguous range of cells ----
     const uint32_t c = lane / F, f = lane % F;
-    const float    sx = (c & 1u) ? 1.0f : -1.0f, ox = (c & 1u) ? 0.0f : 1.0f;
-    const float    sy = (c & 2u) ? 1.0f : -1.0f, oy = (c & 2u) ? 0.0f : 1.0f;
-    const float    sz = (c & 4u) ? 1.0f : -1.0f, oz = (c & 4u) ? 0.0f : 1.0f;
+    const uint32_t mi = lane & 15u, mk = lane >> 4;        // MFMA operand index (corner / feature), sample slot
+    const float    sx = (mi & 1u) ? 1.0f : -1.0f, ox = (mi & 1u) ? 0.0f : 1.0f;
+    const float    sy = (mi & 2u) ? 1.0f : -1.0f, oy = (mi & 2u) ? 0.0f : 1.0f;
+    const float    sz = (mi & 4u) ? 1.0f : -1.0f, oz = (mi & 4u) ? 0.0f : 1.0f;
     auto flush = [&](uint32_t row, float v) {
         const size_t at = (size_t)row * F + f;
         if (mask_on) {
@@ -181,21 +184,38 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
             const uint64_t k = s_key[p0];
             k_lo = __builtin_amdgcn_readfirstlane((uint32_t)k);
             k_hi = __builtin_amdgcn_readfirstlane((uint32_t)(k >> 32));
-            if ((s_valid[p0] >> c) & 1u) {
-                my_row = row_of(k_lo, k_hi);
-                for (;;) {
-                    const uint32_t p1 = s_run_start[r + 1];
-                    for (uint32_t p = p0; p < p1; p++) {
-                        const float4 q = *reinterpret_cast<const float4*>(s_w4[p]);
+            // S[corner][feature] = sum over the chain's samples of w[corner] * g[feature]: a K = n
+            // product of an 8 x n and an n x 8 matrix, 4 samples per v_mfma_f32_16x16x4_f32 (rows /
+            // columns 8..15 of the tile stay zero).  Lane l feeds sample slot l / 16 with operand index
+            // l % 16: its corner's weight (rebuilt from the 3 fractions — once per (corner, sample)
+            // instead of once per (corner, feature, sample) as a lane-per-output loop would) and its
+            // feature's gradient.  The loop is wave-uniform: every lane walks the same chain.
+            f32x4 S = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (;;) {
+                const uint32_t p1 = s_run_start[r + 1];
+                for (uint32_t p = p0; p < p1; p += 4) {
+                    const uint32_t ps = p + mk;
+                    float          a = 0.0f, bv = 0.0f;
+                    if (ps < p1 && mi < 8u) {
+                        const float4 q = *reinterpret_cast<const float4*>(s_w4[ps]);
                         // bit ? frac : 1 - frac, as one fma with (+1, 0) or (-1, 1): exact either way
                         const float wx = __builtin_fmaf(q.x, sx, ox), wy = __builtin_fmaf(q.y, sy, oy),
                                     wz = __builtin_fmaf(q.z, sz, oz);
-                        acc += ((wx * wy) * wz) * q.w * s_g[p][f];
+                        a = ((wx * wy) * wz) * q.w;
+                        bv = s_g[ps][mi];
                     }
-                    r = s_run_next[r];
-                    if (r == END) break;
-                    p0 = s_run_start[r];
+                    S = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, S, 0, 0, 0);
                 }
+                r = s_run_next[r];
+                if (r == END) break;
+                p0 = s_run_start[r];
+            }
+            // tile element (row, col) sits in lane col + 16 * (row / 4), register row % 4
+            const int   src = (int)(f + 16u * (c >> 2));
+            const float e0 = __shfl(S[0], src), e1 = __shfl(S[1], src), e2 = __shfl(S[2], src), e3 = __shfl(S[3], src);
+            if ((s_valid[s_run_start[l_head[s_group[g]]]] >> c) & 1u) {
+                my_row = row_of(k_lo, k_hi);
+                acc = (c & 2u) ? ((c & 1u) ? e3 : e2) : ((c & 1u) ? e1 : e0);
             }
         }
         // which corners of the pending cell reappear in this one follows from the two cells alone
