@@ -34,7 +34,8 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
     float* __restrict__ grad_emb, uint32_t N, const uint32_t* __restrict__ clip_count, FeatLayout lay)
 {
-    constexpr uint32_t D = 3, F = 8, C = 8, NONE = 0xFFFFFFFFu, END = 0xFFFFu;
+    constexpr uint32_t D = 3, F = 8, C = 8, NONE = 0xFFFFFFFFu, END = 0x3FFu;
+    static_assert(kMB <= 512, "run records pack start / end / next into 10 bits each");
     // the three fractional positions and 1 / (sum of valid weights): the lane rebuilds its corner's
     // weight from them (same products, same order as Corners::setup) — half the LDS of 8 stored weights
     __shared__ __attribute__((aligned(16))) float s_w4[kMB][4];
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
     __shared__ uint8_t  s_valid[kMB];
     __shared__ uint32_t h_slot[kMSlots];        // 0 = empty, else representative run + 1
     __shared__ uint32_t l_head[kMB];            // per representative run: last run chained to its cell
-    __shared__ uint16_t s_run_next[kMB];
+    __shared__ uint32_t s_run_rec[kMB];         // start | end << 10 | next run of the cell << 20: one read per run
     __shared__ uint16_t s_group[kMB];           // representative run of the g-th distinct cell
     __shared__ uint32_t s_wave_heads[kMW], s_wave_claims[kMW];
 
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
             if (s_key[s_run_start[rep]] == key) break;
             sl = (sl + 1) & (kMSlots - 1);
         }
-        s_run_next[my_run] = (uint16_t)atomicExch(&l_head[rep], my_run);
+        const uint32_t next = atomicExch(&l_head[rep], my_run);
+        s_run_rec[my_run] = tid | (uint32_t)s_run_start[my_run + 1] << 10 | next << 20;
     }
     const uint64_t cb = __ballot(claimer);
     if (lane == 0) s_wave_claims[wave] = (uint32_t)__popcll(cb);
@@ -179,9 +181,9 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
         uint32_t       my_row = NONE, k_lo = ~0u, k_hi = ~0u;
         float          acc = 0;
         if (i < cpw && g < g_end) {
-            uint32_t r = l_head[s_group[g]];               // first run of the chain
-            uint32_t p0 = s_run_start[r];
-            const uint64_t k = s_key[p0];
+            uint32_t rec = s_run_rec[l_head[s_group[g]]];  // first run of the chain
+            const uint32_t head_p = rec & 0x3FFu;
+            const uint64_t k = s_key[head_p];
             k_lo = __builtin_amdgcn_readfirstlane((uint32_t)k);
             k_hi = __builtin_amdgcn_readfirstlane((uint32_t)(k >> 32));
             // S[corner][feature] = sum over the chain's samples of w[corner] * g[feature]: a K = n
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
             // feature's gradient.  The loop is wave-uniform: every lane walks the same chain.
             f32x4 S = {0.0f, 0.0f, 0.0f, 0.0f};
             for (;;) {
-                const uint32_t p1 = s_run_start[r + 1];
+                const uint32_t p0 = rec & 0x3FFu, p1 = (rec >> 10) & 0x3FFu, nxt = rec >> 20;
                 for (uint32_t p = p0; p < p1; p += 4) {
                     const uint32_t ps = p + mk;
                     float          a = 0.0f, bv = 0.0f;
@@ -206,14 +208,13 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
                     }
                     S = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, S, 0, 0, 0);
                 }
-                r = s_run_next[r];
-                if (r == END) break;
-                p0 = s_run_start[r];
+                if (nxt == END) break;
+                rec = s_run_rec[nxt];
             }
             // tile element (row, col) sits in lane col + 16 * (row / 4), register row % 4
             const int   src = (int)(f + 16u * (c >> 2));
             const float e0 = __shfl(S[0], src), e1 = __shfl(S[1], src), e2 = __shfl(S[2], src), e3 = __shfl(S[3], src);
-            if ((s_valid[s_run_start[l_head[s_group[g]]]] >> c) & 1u) {
+            if ((s_valid[head_p] >> c) & 1u) {
                 my_row = row_of(k_lo, k_hi);
                 acc = (c & 2u) ? ((c & 1u) ? e3 : e2) : ((c & 1u) ? e1 : e0);
             }
