@@ -40,13 +40,15 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
     // weight from them (same products, same order as Corners::setup) — half the LDS of 8 stored weights
     __shared__ __attribute__((aligned(16))) float s_w4[kMB][4];
     __shared__ float    s_g[kMB][F];
-    __shared__ uint64_t s_key[kMB];
+    // 16 bytes per thread, used twice: the sample keys (first half) and the hash table (second half)
+    // until the runs are chained, then one record per distinct cell {first run record, key, validity}
+    __shared__ __attribute__((aligned(16))) uint4 s_u[kMB];
+    uint64_t* const s_key = reinterpret_cast<uint64_t*>(s_u);
+    uint32_t* const h_slot = reinterpret_cast<uint32_t*>(s_u) + 2 * kMB;
+    static_assert(kMSlots * 4 <= kMB * 8, "hash table fits the second half of s_u");
     __shared__ uint16_t s_run_start[kMB + 1];
-    __shared__ uint8_t  s_valid[kMB];
-    __shared__ uint32_t h_slot[kMSlots];        // 0 = empty, else representative run + 1
     __shared__ uint32_t l_head[kMB];            // per representative run: last run chained to its cell
     __shared__ uint32_t s_run_rec[kMB];         // start | end << 10 | next run of the cell << 20: one read per run
-    __shared__ uint16_t s_group[kMB];           // representative run of the g-th distinct cell
     __shared__ uint32_t s_wave_heads[kMW], s_wave_claims[kMW];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,9 +67,9 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
 
     // ---- phase A: lane = sample ----
     uint64_t key = ~0ull;
+    uint32_t validmask = 0;
     {
         float    x[D];
-        uint32_t validmask = 0;
         if (b < N && load_point<D>(inputs, b, x)) {
             Corners<D, false> c;
             c.setup(x, R, hs, 0, nullptr);
@@ -86,7 +88,6 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
             }
         }
         s_key[tid] = key;
-        s_valid[tid] = (uint8_t)validmask;
     }
     __syncthreads();
 
@@ -132,7 +133,10 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
         g_before += w < wave ? h : 0u;
         n_cells += h;
     }
-    if (claimer) s_group[g_before + (uint32_t)__popcll(cb & ((1ull << lane) - 1ull))] = (uint16_t)my_run;
+    // (the sync above also ends the life of the keys and the hash table: s_u is rewritten here)
+    uint4 my_cell = make_uint4(0, 0, 0, 0);
+    if (claimer) my_cell = make_uint4(s_run_rec[l_head[my_run]], (uint32_t)key, (uint32_t)(key >> 32), validmask);
+    if (claimer) s_u[g_before + (uint32_t)__popcll(cb & ((1ull << lane) - 1ull))] = my_cell;
     __syncthreads();
 
     // ---- phase B: lane = (corner, feature); each wave walks a contiguous range of cells ----
@@ -181,11 +185,10 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
         uint32_t       my_row = NONE, k_lo = ~0u, k_hi = ~0u;
         float          acc = 0;
         if (i < cpw && g < g_end) {
-            uint32_t rec = s_run_rec[l_head[s_group[g]]];  // first run of the chain
-            const uint32_t head_p = rec & 0x3FFu;
-            const uint64_t k = s_key[head_p];
-            k_lo = __builtin_amdgcn_readfirstlane((uint32_t)k);
-            k_hi = __builtin_amdgcn_readfirstlane((uint32_t)(k >> 32));
+            const uint4 cell = s_u[g];                     // {first run of the chain, key, valid corners}
+            uint32_t    rec = cell.x;
+            k_lo = __builtin_amdgcn_readfirstlane(cell.y);
+            k_hi = __builtin_amdgcn_readfirstlane(cell.z);
             // S[corner][feature] = sum over the chain's samples of w[corner] * g[feature]: a K = n
             // product of an 8 x n and an n x 8 matrix, 4 samples per v_mfma_f32_16x16x4_f32 (rows /
             // columns 8..15 of the tile stay zero).  Lane l feeds sample slot l / 16 with operand index
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
             // tile element (row, col) sits in lane col + 16 * (row / 4), register row % 4
             const int   src = (int)(f + 16u * (c >> 2));
             const float e0 = __shfl(S[0], src), e1 = __shfl(S[1], src), e2 = __shfl(S[2], src), e3 = __shfl(S[3], src);
-            if ((s_valid[head_p] >> c) & 1u) {
+            if ((cell.w >> c) & 1u) {
                 my_row = row_of(k_lo, k_hi);
                 acc = (c & 2u) ? ((c & 1u) ? e3 : e2) : ((c & 1u) ? e1 : e0);
             }
