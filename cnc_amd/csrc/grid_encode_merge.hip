@@ -5,7 +5,7 @@
 // neighbouring pixels cross the same cells: of the runs in 1024 consecutive samples (3-4 rays) only 0.29
 // (level 0) to 0.46 (resolution 214) open a cell no earlier run of the block visited; in 256 samples it is
 // 0.93-0.96.  This kernel takes 512 samples per block, chains the runs of equal cells through a small LDS
-// hash table and sends ONE set of atomics per distinct cell — the coarse levels are bound by the
+// hash table and sends ONE set of atomics per distinct cell (kMB below: 1024 samples now) — the coarse levels are bound by the
 // memory-side atomic units, so the number of atomic instructions is what their time is
 // made of.  Block size measured on the 9 coarse levels of the bench grid (ms per 2^20 samples; the old
 // kernel: 0.523): 256 -> 0.485, 384 -> 0.548, 512 -> 0.432, 640 -> 0.629, 768 -> 0.444, 1024 -> 0.573:
@@ -14,6 +14,8 @@
 // 77 KB, 2 blocks of 1024): 512 -> 0.426, 1024 -> 0.429 — by then the atomics are a sixth of the time
 // (without them 0.368) and the per-sample accumulation loop of phase B is what is left.  A sample-minor
 // LDS layout with 16-byte reads of 4 samples per lane (peeled to alignment) was slower: 0.461.
+// After the accumulation moved to MFMA (0.403), the run and cell records were packed (0.384) the cost is
+// per distinct cell, and 1024 samples (75 KB, 2 blocks per CU, 0.3-0.45 cells per run) win: 0.365.
 //
 // D = 3, F = 8 (one run per wave: 64 lanes = 8 corners x 8 features), no occupancy mask, no per-point
 // level window: the coarse half of a binned backward call.  Everything else stays on k_grid_encode_bwd.
@@ -24,7 +26,7 @@ namespace cnc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr uint32_t kMB = 512;             // samples (= threads) per block, a multiple of 64
+constexpr uint32_t kMB = 1024;            // samples (= threads) per block, a multiple of 64
 constexpr uint32_t kMW = kMB / 64;        // waves per block
 constexpr uint32_t kMSlots = kMB <= 512 ? 1024 : 2048;   // hash slots, power of two, >= 2 x the most runs a block can have
 
@@ -34,8 +36,8 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
     float* __restrict__ grad_emb, uint32_t N, const uint32_t* __restrict__ clip_count, FeatLayout lay)
 {
-    constexpr uint32_t D = 3, F = 8, C = 8, NONE = 0xFFFFFFFFu, END = 0x3FFu;
-    static_assert(kMB <= 512, "run records pack start / end / next into 10 bits each");
+    constexpr uint32_t D = 3, F = 8, C = 8, NONE = 0xFFFFFFFFu, END = 0x7FFu;
+    static_assert(kMB <= 1024, "run records pack start (10 bits) / end (11) / next (11)");
     // the three fractional positions and 1 / (sum of valid weights): the lane rebuilds its corner's
     // weight from them (same products, same order as Corners::setup) — half the LDS of 8 stored weights
     __shared__ __attribute__((aligned(16))) float s_w4[kMB][4];
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
             sl = (sl + 1) & (kMSlots - 1);
         }
         const uint32_t next = atomicExch(&l_head[rep], my_run);
-        s_run_rec[my_run] = tid | (uint32_t)s_run_start[my_run + 1] << 10 | next << 20;
+        s_run_rec[my_run] = tid | (uint32_t)s_run_start[my_run + 1] << 10 | next << 21;
     }
     const uint64_t cb = __ballot(claimer);
     if (lane == 0) s_wave_claims[wave] = (uint32_t)__popcll(cb);
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
             // feature's gradient.  The loop is wave-uniform: every lane walks the same chain.
             f32x4 S = {0.0f, 0.0f, 0.0f, 0.0f};
             for (;;) {
-                const uint32_t p0 = rec & 0x3FFu, p1 = (rec >> 10) & 0x3FFu, nxt = rec >> 20;
+                const uint32_t p0 = rec & 0x3FFu, p1 = (rec >> 10) & 0x7FFu, nxt = rec >> 21;
                 for (uint32_t p = p0; p < p1; p += 4) {
                     const uint32_t ps = p + mk;
                     float          a = 0.0f, bv = 0.0f;
