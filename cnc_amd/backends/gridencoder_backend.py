@@ -125,28 +125,30 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         k = int(n_levels) - n_binned          # coarse levels: atomic kernel; the rest: bin + owner passes
         if k > 0 and n_binned > 0 and N >= _OVERLAP_MIN_POINTS and overlap_streams and _OVERLAP_ENABLED:
             # The two halves write disjoint table rows and lean on different units (memory-side
-            # atomics vs. HBM reads / writes): the coarse half runs on a side stream, forked from and
-            # joined to the caller's stream with events (1.16 -> 1.11 ms per 2^20 samples).
+            # atomics vs. HBM reads / writes): they run on two streams, forked from and joined to the
+            # caller's stream with events.  The bin + owner passes are the long pole, so they are issued
+            # FIRST (on the side stream) and the coarse kernel fills in next to them: 1.016 ms back to
+            # back, 0.963 with the coarse call first, 0.904 this way (per 2^20 samples).
             cur = torch.cuda.current_stream(grad.device)
             side = _side_stream(grad.device)
             fork = torch.cuda.Event()
             fork.record(cur)
             lm = grad_ld == 0                  # level-major [L, N, F]: slice; point-major: shift the column
+            g_f = grad[k:] if lm else grad
             with torch.cuda.stream(side):
                 side.wait_event(fork)
-                rc0 = L.cnc_grid_encode_backward(
-                    ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
-                    ptr(grad_embeddings), int(N), int(num_dim), int(n_features), k, int(Rb), None, None, None,
-                    None, flags | _lib.CNC_FLAG_LEVELS_FINEST_FIRST, ptr(ste_clip_count), None, int(grad_ld),
-                    int(grad_col), stream())
+                rc = L.cnc_grid_encode_backward_binned(
+                    ptr(g_f), ptr(inputs), ptr(embeddings), ptr(offsets_list[k:]), ptr(resolutions_list[k:]),
+                    ptr(grad_embeddings), int(N), int(num_dim), int(n_features), n_binned, flags,
+                    ptr(ste_clip_count), int(grad_ld), int(grad_col) + (0 if lm else k * int(n_features)),
+                    n_binned, level_rows, ptr(ws), ws.numel(), stream())
                 join = torch.cuda.Event()
                 join.record(side)
-            g_f = grad[k:] if lm else grad
-            rc = L.cnc_grid_encode_backward_binned(
-                ptr(g_f), ptr(inputs), ptr(embeddings), ptr(offsets_list[k:]), ptr(resolutions_list[k:]),
-                ptr(grad_embeddings), int(N), int(num_dim), int(n_features), n_binned, flags,
-                ptr(ste_clip_count), int(grad_ld), int(grad_col) + (0 if lm else k * int(n_features)),
-                n_binned, level_rows, ptr(ws), ws.numel(), stream())
+            rc0 = L.cnc_grid_encode_backward(
+                ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
+                ptr(grad_embeddings), int(N), int(num_dim), int(n_features), k, int(Rb), None, None, None,
+                None, flags | _lib.CNC_FLAG_LEVELS_FINEST_FIRST, ptr(ste_clip_count), None, int(grad_ld),
+                int(grad_col), stream())
             cur.wait_event(join)
             check(rc0, "grid_encode_backward")
             check(rc, "grid_encode_backward_binned")
