@@ -266,8 +266,8 @@ def main():
         parts = {"grid_encode_backward": f"one cnc_grid_encode_backward_binned call = k_grid_encode_bwd_merge ({L - nb} coarse "
                                          f"levels, runs merged across rays, atomics) + k_bwd_bin + k_bwd_owner ({nb} finest levels, LDS "
                                          "accumulation); avg_launch_ms is the whole call between two events on the "
-                                         "caller's stream.  The coarse kernel runs on a side stream next to the bin "
-                                         "and owner passes (disjoint table rows), so the call is a few % shorter than "
+                                         "caller's stream.  The bin and owner passes run on a side stream next to the "
+                                         "coarse kernel (disjoint table rows), so the call is a few % shorter than "
                                          "the sum of the three kernels' rocprof averages",
                  "grid_encode_forward": "k_grid_encode_fwd_bits"}
         roofline = {"kernel": dom_name, "kernel_parts": parts[dom_name], "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
