@@ -4,21 +4,25 @@
 // a marched frame (200-400 samples per ray), so the runs it merges are runs along ONE ray.  The rays of
 // neighbouring pixels cross the same cells: of the runs in 1024 consecutive samples (3-4 rays) only 0.29
 // (level 0) to 0.46 (resolution 214) open a cell no earlier run of the block visited; in 256 samples it is
-// 0.93-0.96.  This kernel takes 512 samples per block, chains the runs of equal cells through a small LDS
-// hash table and sends ONE set of atomics per distinct cell (kMB below: 1024 samples now) — the coarse levels are bound by the
-// memory-side atomic units, so the number of atomic instructions is what their time is
-// made of.  Block size measured on the 9 coarse levels of the bench grid (ms per 2^20 samples; the old
-// kernel: 0.523): 256 -> 0.485, 384 -> 0.548, 512 -> 0.432, 640 -> 0.629, 768 -> 0.444, 1024 -> 0.573:
-// more samples merge more, but the LDS they need leaves fewer waves per CU (512: 45 KB, 3 blocks).
-// With the per-sample weights rebuilt from 4 floats instead of 8 stored ones (37.5 KB, 4 blocks of 512 or
-// 77 KB, 2 blocks of 1024): 512 -> 0.426, 1024 -> 0.429 — by then the atomics are a sixth of the time
-// (without them 0.368) and the per-sample accumulation loop of phase B is what is left.  A sample-minor
-// LDS layout with 16-byte reads of 4 samples per lane (peeled to alignment) was slower: 0.461.
-// After the accumulation moved to MFMA (0.403), the run and cell records were packed (0.384) the cost is
-// per distinct cell, and 1024 samples (75 KB, 2 blocks per CU, 0.3-0.45 cells per run) win: 0.365.
+// 0.93-0.96.  This kernel takes kMB = 1024 samples per block, chains the runs of equal cells through a
+// small LDS hash table and sends ONE set of atomics per distinct cell — the coarse levels are bound by the
+// memory-side atomic units, so the number of atomic instructions is what their time was
+// made of.
 //
-// D = 3, F = 8 (one run per wave: 64 lanes = 8 corners x 8 features), no occupancy mask, no per-point
-// level window: the coarse half of a binned backward call.  Everything else stays on k_grid_encode_bwd.
+// How it got here (9 coarse levels of the bench grid, ms per 2^20 marched samples; k_grid_encode_bwd: 0.523):
+//   * first version, 8 stored weights per sample, block size 256 / 384 / 512 / 640 / 768 / 1024:
+//     0.485 / 0.548 / 0.432 / 0.629 / 0.444 / 0.573 — more samples merge more, but the LDS they need
+//     leaves fewer waves per CU;
+//   * weights rebuilt from 4 floats per sample (half the LDS): 512 -> 0.426, 1024 -> 0.429; by then the
+//     atomics were a sixth of the time (0.368 without them) and the per-sample loop was what was left
+//     (a sample-minor LDS layout with 16-byte reads of 4 samples per lane was slower: 0.461);
+//   * per-cell accumulation as an 8 x n by n x 8 product on v_mfma_f32_16x16x4_f32: 0.403;
+//   * one packed LDS word per run and one 16-byte record per cell: 0.384;
+//   * the cost now being per distinct cell, 1024 samples (75 KB of LDS, 2 blocks per CU): 0.365.
+//
+// D = 3, F = 8 (one cell per wave at a time: 64 lanes = 8 corners x 8 features), no occupancy mask, no
+// per-point level window: the coarse half of a binned backward call.  Everything else stays on
+// k_grid_encode_bwd.
 #include "common.hpp"
 #include "encoder_common.hpp"
 
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
     static_assert(kMSlots * 4 <= kMB * 8, "hash table fits the second half of s_u");
     __shared__ uint16_t s_run_start[kMB + 1];
     __shared__ uint32_t l_head[kMB];            // per representative run: last run chained to its cell
-    __shared__ uint32_t s_run_rec[kMB];         // start | end << 10 | next run of the cell << 20: one read per run
+    __shared__ uint32_t s_run_rec[kMB];         // start | end << 10 | next run of the cell << 21: one read per run
     __shared__ uint32_t s_wave_heads[kMW], s_wave_claims[kMW];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
