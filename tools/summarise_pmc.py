@@ -39,12 +39,17 @@ with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.csv"), "w") as fh:
     for n, f, w, b, c in rows:
         fh.write(f'"{n}",{f:.1f},{w:.1f},{b:.0f},{c}\n')
 by = {n: b for n, f, w, b, c in rows}
+cnt = {n: c for n, f, w, b, c in rows}
 pick = lambda pat: sum(v for k, v in by.items() if re.search(pat, k))
+# bytes per CALL for kernels that are dispatched more than once per call (the binned levels go out as
+# two groups): total bytes of the kernel / number of calls (= dispatches of the coarse kernel)
+total = lambda pat: sum(by[k] * cnt[k] for k in by if re.search(pat, k))
+calls = max(sum(cnt[k] for k in by if re.search(r"k_grid_encode_bwd(_merge)?<", k)), 1)
 traffic = {
     "grid_encode_forward": pick(r"k_grid_encode_fwd_bits"),
     # one backward call = atomic kernel (coarse levels; run-merging variant in the bench) + bin pass +
     # owner pass (finest levels)
-    "grid_encode_backward": pick(r"k_grid_encode_bwd(_merge)?<") + pick(r"k_bwd_bin") + pick(r"k_bwd_owner"),
+    "grid_encode_backward": (total(r"k_grid_encode_bwd(_merge)?<") + total(r"k_bwd_bin") + total(r"k_bwd_owner")) / calls,
     "_note": "HBM bytes per encoder call on a 2^20-sample chunk = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the "
              "call's kernels, from separate rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 "
              "--no-cpu-baseline` (profiles/r01_pmc_hbm_traffic.csv, tools/collect_profiles.sh); FETCH doubled per "
