@@ -4,7 +4,7 @@ ray-sample through the 16-level x 2^19 x F8 hash-grid encoder (forward), scatter
 (backward); at N>1 each rank does that for its own camera and the table gradient is all-reduced
 over RCCL.  Prints ONE JSON line (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]         (N > 1: spawns N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 metric: encoded ray-samples/s (BASELINE.json).  `value` counts every marched sample once per
@@ -125,6 +125,7 @@ def step(w, timed, world):
             o, xs, w["table"], w["offsets"], w["resolutions"], gt, n, D, F, L, 0, 128, None, None, None, None,
             ste_binary=True, ste_clip_count=w["clip"],
             binned=enc.plan_binned_levels(synthetic.RES_16L, w["offsets_host"], D, F, n)))
+    w["first_chunk"] = x[:min(CHUNK, S)]
     if world > 1:
         # the only exchange of the path: one flat-bucket all-reduce of the table gradient
         timed.launch("allreduce(grad_table)", gt.numel() * 4, lambda: w["bucket"].allreduce(average=True))
@@ -154,7 +155,7 @@ def cpu_baseline(w):
     oracle.grid_encode_backward(y, x, table, offs, res, threads=threads)
     dt = time.perf_counter() - t0
     port = {"value": S / dt, "unit": "ray-samples/s", "cores": threads, "kind": "port",
-            "sample": f"{n_rays_sub} rays of the same frame -> {S} samples, march(1 thread)+encode fwd+bwd (OpenMP x{threads}), {dt:.1f}s"}
+            "sample": f"{n_rays_sub} rays of the same frame -> {S} samples, march + encode fwd + bwd, all OpenMP x{threads}, {dt:.1f}s"}
     # the "PyTorch-CPU gridencoder fallback" BASELINE.json names: index math + index_select +
     # autograd's index_add_ (oracle/torch_cpu_encoder.py), on 2^16 samples from the middle of the same
     # sample stream, same table; the encoder only (the march above is not repeated)
@@ -172,26 +173,85 @@ def cpu_baseline(w):
     return port, torch_fallback
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N copies of this script, one rank per GPU,
+    with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); rank 0 prints the line."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if os.environ.get("CNC_BENCH_ONE_DEVICE") != "1" and torch.cuda.device_count() < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {torch.cuda.device_count()} GPU(s) visible")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+        if p.returncode != 0:          # one rank died: the others would wait in a collective forever
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+    return rc
+
+
+def train_step_entry(dev):
+    """The WHOLE model in the loop (configs[1]/[2]): 12x3-D (T=2^19) + 3x4 2-D (T=2^17) levels at F=8,
+    sample_num=150000, occupancy marcher, radiance-field MLPs, volume rendering, context models + entropy
+    loss, Adam — `cnc_amd.trainer.Trainer.train_step` on the procedural scene, 2^18 target samples per step."""
+    from cnc_amd.trainer import TrainConfig, Trainer
+    cfg = TrainConfig(n_features=8, sample_num=150000, image_size=400, out_dir="/tmp/cnc_bench_bits")
+    tr = Trainer(cfg, device=dev)
+    for step in range(80):                  # occupancy warm-up + adaptive ray budget settle
+        tr.train_step(step)
+    torch.cuda.synchronize()
+    n_steps, samples, rays = 60, 0, 0
+    t0 = time.perf_counter()
+    for step in range(80, 80 + n_steps):
+        s = tr.train_step(step)
+        if s is not None:
+            samples += s["n_rendering_samples"]
+            rays += s["num_rays"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"ms_per_step": dt / n_steps * 1e3, "rendered_samples_per_s": samples / dt, "rays_per_s": rays / dt,
+            "samples_per_step": samples / n_steps, "steps": n_steps, "timed_region": False,
+            "config": "full model, F=8, 12x3D(2^19)+3x4x2D(2^17), sample_num=150000, lmbda=2e-3, procedural ball "
+                      "scene, target 2^18 samples/step (includes the occupancy refresh every 16 steps)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # test hooks (not used by the driver): CNC_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # CNC_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N>1 control flow can be exercised on a
-    # single-GPU box
+    # single-GPU box (tests/test_gpu_bench_multi.py)
     if os.environ.get("CNC_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -200,6 +260,13 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
+        me = {"rank": rank, "device": str(dev), "world_size": torch.distributed.get_world_size(),
+              "backend": torch.distributed.get_backend()}
+        print(f"[bench rank {rank}] {me}", file=sys.stderr, flush=True)
+        ranks = [None] * world
+        torch.distributed.all_gather_object(ranks, me)
+    else:
+        ranks = [{"rank": 0, "device": str(dev), "world_size": 1, "backend": backend}]
 
     w = build_workload(dev, rank)
     timed = Timed()
@@ -221,8 +288,10 @@ def main():
     elapsed = time.perf_counter() - t0
     timed.collect()
 
-    # outside the timed region: the generic fp32-table gather (the `_gridencoder` drop-in entry
-    # point, no bit plane) on the last chunk-sized slice, for the record
+    # outside the timed region (rank 0): (i) the generic fp32-table gather (the `_gridencoder` drop-in
+    # entry point, no bit plane); (ii) the backward call's two halves one after the other on ONE stream
+    # (coarse levels = k_grid_encode_bwd_merge, finest levels = k_bwd_bin + k_bwd_owner), so each half
+    # has its own duration next to its own bound in `roofline.parts`
     extra = Timed()
     if rank == 0:
         n = CHUNK
@@ -231,6 +300,23 @@ def main():
             extra.launch("grid_encode_forward_fp32_table(uniform pts)", n, lambda: enc.grid_encode_forward(
                 xs, w["table"], w["offsets"], w["resolutions"], w["out"], n, D, F, L, 0, 128, 0.0, None, None, None,
                 ste_binary=True))
+        nb_plan = enc.plan_binned_levels(synthetic.RES_16L, w["offsets_host"], D, F, n)
+        if nb_plan is not None and w.get("first_chunk") is not None and w["first_chunk"].shape[0] == CHUNK:
+            xs_r, o_r = w["first_chunk"], w["out"]
+            nr = xs_r.shape[0]
+            enc.grid_encode_forward_bits(xs_r, w["bits"], w["offsets"], w["resolutions"], o_r, nr, D, F, L, 128)
+            nb = nb_plan[0]
+            k = L - nb
+            gt = w["grad_table"]
+            for _ in range(5):
+                extra.launch("bwd_coarse_levels(k_grid_encode_bwd_merge), alone", nr, lambda: enc.grid_encode_backward(
+                    o_r[:k], xs_r, w["table"], w["offsets"][:k + 1], w["resolutions"][:k], gt, nr, D, F, k, 0, 128,
+                    None, None, None, None, ste_binary=True, ste_clip_count=w["clip"], binned=None,
+                    interleave_levels=True))
+                extra.launch("bwd_finest_levels(k_bwd_bin+k_bwd_owner), alone", nr, lambda: enc.grid_encode_backward(
+                    o_r[k:], xs_r, w["table"], w["offsets"][k:], w["resolutions"][k:], gt, nr, D, F, nb, 0, 128,
+                    None, None, None, None, ste_binary=True, ste_clip_count=w["clip"], binned=(nb, nb_plan[1]),
+                    overlap_streams=False))
         torch.cuda.synchronize()
         extra.collect()
 
@@ -257,25 +343,61 @@ def main():
         # dominant kernel = the one with the most accumulated time in the timed region
         dom_name, bytes_per, k = (("grid_encode_backward", BYTES_BWD, kb) if kb[0] >= kf[0]
                                   else ("grid_encode_forward", BYTES_FWD, kf))
-        achieved = bytes_per * k[2] / k[0]      # algorithmic bytes / s, averaged over launches
-        traffic = None
+        launch_s = k[0] / k[1]
+        algorithmic = bytes_per * k[2] / k[0]   # SURVEY §8(d) bytes / s, averaged over launches
+        # Measured HBM bytes per launch (PMC FETCH_SIZE/WRITE_SIZE, profiles/traffic.json).  The kernels move
+        # FEWER bytes than the algorithmic count (bit-plane gather, cells merged before the table is touched),
+        # so the algorithmic rate can exceed the HBM peak and is no fraction of anything; `frac` is the
+        # measured traffic over the measured duration against the HBM peak.
+        tj = {}
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
-            traffic = json.load(open(tp)).get(dom_name)
+            tj = json.load(open(tp))
+        traffic = tj.get(dom_name)
+        measured = traffic / launch_s if traffic else None
         nb = (enc.plan_binned_levels(synthetic.RES_16L, w["offsets_host"], D, F, CHUNK) or (0, 0))[0]
-        parts = {"grid_encode_backward": f"one cnc_grid_encode_backward_binned call = k_grid_encode_bwd_merge ({L - nb} coarse "
-                                         f"levels, runs merged across rays, atomics) + k_bwd_bin + k_bwd_owner ({nb} finest levels, LDS "
-                                         "accumulation); avg_launch_ms is the whole call between two events on the "
-                                         "caller's stream.  The bin and owner passes run on a side stream next to the "
-                                         "coarse kernel (disjoint table rows), so the call is a few % shorter than "
-                                         "the sum of the three kernels' rocprof averages",
-                 "grid_encode_forward": "k_grid_encode_fwd_bits"}
-        roofline = {"kernel": dom_name, "kernel_parts": parts[dom_name], "bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic,
+        desc = {"grid_encode_backward": f"one cnc_grid_encode_backward_binned call = k_grid_encode_bwd_merge ({L - nb} coarse "
+                                        f"levels, runs merged across rays, atomics) + k_bwd_bin + k_bwd_owner ({nb} finest levels, LDS "
+                                        "accumulation); avg_launch_ms is the whole call between two events on the "
+                                        "caller's stream (side streams joined before the closing event)",
+                "grid_encode_forward": "k_grid_encode_fwd_bits"}
+        roofline = {"kernel": dom_name, "kernel_parts": desc[dom_name], "bound": "hbm",
+                    "achieved": None if measured is None else measured / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": None if measured is None else measured / HBM_PEAK, "traffic": traffic,
+                    "frac_basis": "measured HBM bytes per launch (profiles/traffic.json: 2*FETCH_SIZE + WRITE_SIZE, rocprofv3 "
+                                  "--pmc) / avg_launch_ms / 8 TB/s",
+                    "achieved_algorithmic": algorithmic / 1e9,
+                    "algorithmic_over_peak": algorithmic / HBM_PEAK,
+                    "traffic_over_algorithmic": None if not traffic else traffic / (bytes_per * k[2] / k[1]),
                     "bytes_per_sample": bytes_per, "samples_per_launch": k[2] / k[1],
-                    "avg_launch_ms": k[0] / k[1] * 1e3}
-        other = {"kernel": "grid_encode_forward", "achieved": BYTES_FWD * kf[2] / kf[0] / 1e9,
-                 "frac": BYTES_FWD * kf[2] / kf[0] / HBM_PEAK, "bytes_per_sample": BYTES_FWD}
+                    "avg_launch_ms": launch_s * 1e3}
+        # each half of the backward call against the bound it actually sits on
+        parts = {}
+        pc = extra.acc.get("bwd_coarse_levels(k_grid_encode_bwd_merge), alone")
+        pf = extra.acc.get("bwd_finest_levels(k_bwd_bin+k_bwd_owner), alone")
+        if pc:
+            dur = pc[0] / pc[1]
+            req = tj.get("k_grid_encode_bwd_merge_atomic_requests")
+            parts["k_grid_encode_bwd_merge"] = {
+                "avg_ms": dur * 1e3, "bound": "memory-side fp32 atomic requests (tools/atomic_probe.hip: 21 G requests/s)",
+                "atomic_requests_per_launch": req, "achieved_G_requests_per_s": None if not req else req / dur / 1e9,
+                "peak_G_requests_per_s": 21.0, "frac": None if not req else req / dur / 21e9}
+        if pf:
+            dur = pf[0] / pf[1]
+            tb = tj.get("k_bwd_bin+k_bwd_owner")
+            parts["k_bwd_bin+k_bwd_owner"] = {
+                "avg_ms": dur * 1e3, "bound": "hbm", "traffic": tb,
+                "achieved_GBps": None if not tb else tb / dur / 1e9, "peak_GBps": HBM_PEAK / 1e9,
+                "frac": None if not tb else tb / dur / HBM_PEAK}
+        roofline["parts"] = parts
+        tf = tj.get("grid_encode_forward")
+        fl = kf[0] / kf[1]
+        other = {"kernel": "grid_encode_forward", "bound": "L2->L1 line rate of the byte gathers (DESIGN 4.3); HBM only for "
+                                                           "the 512 B/sample output stream",
+                 "traffic": tf, "achieved": None if not tf else tf / fl / 1e9, "unit": "GB/s",
+                 "frac": None if not tf else tf / fl / HBM_PEAK,
+                 "achieved_algorithmic": BYTES_FWD * kf[2] / kf[0] / 1e9, "bytes_per_sample": BYTES_FWD,
+                 "avg_launch_ms": fl * 1e3}
         out = {
             "metric": "ray-samples/s/GPU (16Lx2^19xF8 grid)", "value": samples_all / elapsed_max,
             "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -287,11 +409,18 @@ def main():
                                    + (", grad table all-reduced (RCCL)" if world > 1 else ""),
                        "rays_per_gpu": 640000, "samples_per_step_rank0": samples // args.steps,
                        "chunk": CHUNK, "table_rows": 6120776, "n_features": F, "levels": L},
+            "ranks": ranks,
             "roofline": roofline, "roofline_forward": other, "kernels": kernels,
         }
+        if not args.no_train_step and world == 1:
+            ts = train_step_entry(dev)
+            out["train_step"] = ts
+            kernels["train_step(full model: march+field+render+context+adam)"] = {
+                "launches": ts["steps"], "avg_ms": ts["ms_per_step"], "units_per_s": ts["rendered_samples_per_s"],
+                "timed_region": False}
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             out["cpu_baseline"], out["cpu_baseline_torch"] = cpu_baseline(w)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -97,8 +97,10 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def stream(device=None) -> int:
+    """Raw hipStream_t of torch's current stream on `device` (a tensor's device; default: the
+    current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 # TORCH_CHECK-style argument checks of the reference's host wrappers

@@ -84,7 +84,7 @@ def grid_encode_forward(inputs, embeddings, offsets_list, resolutions_list, outp
         ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list), ptr(outputs),
         int(N), int(num_dim), int(n_features), int(n_levels), int(Rb), float(PV), ptr(dy_dx),
         ptr(binary_vxl), ptr(min_level_id), _lib.CNC_FLAG_STE_BINARY if ste_binary else 0,
-        ptr(_check_sat(occ_sat, binary_vxl)), int(out_ld), int(out_col), stream())
+        ptr(_check_sat(occ_sat, binary_vxl)), int(out_ld), int(out_col), stream(inputs.device))
     check(rc, "grid_encode_forward")
 
 
@@ -120,7 +120,6 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         n_binned, level_rows = int(binned[0]), int(binned[1])
         L = _lib.lib()
         nbytes = int(L.cnc_grid_encode_backward_binned_workspace(int(N), n_binned, level_rows))
-        ws = _workspace(grad.device, nbytes)
         flags = _lib.CNC_FLAG_STE_BINARY if ste_binary else 0
         k = int(n_levels) - n_binned          # coarse levels: atomic kernel; the rest: bin + owner passes
         if k > 0 and n_binned > 0 and N >= _OVERLAP_MIN_POINTS and overlap_streams and _OVERLAP_ENABLED:
@@ -140,16 +139,21 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
             joins, rc = [], 0
             for gi, (l0, l1) in enumerate(groups):
                 nb = l1 - l0
-                side = _side_stream(grad.device, gi)
-                wsg = _workspace(grad.device, int(L.cnc_grid_encode_backward_binned_workspace(int(N), nb, level_rows)), gi)
+                # side streams and scratch are per (device, caller stream, group): two caller streams
+                # (or threads) never share a scratch buffer that is still in flight
+                side = _side_stream(grad.device, (cur.cuda_stream, gi))
+                wsg = _workspace(grad.device, int(L.cnc_grid_encode_backward_binned_workspace(int(N), nb, level_rows)),
+                                 (cur.cuda_stream, gi))
                 g_f = grad[l0:l1] if lm else grad
+                for t_ in (grad, inputs, embeddings, grad_embeddings, wsg):
+                    t_.record_stream(side)       # the caching allocator must not recycle them under the side stream
                 with torch.cuda.stream(side):
                     side.wait_event(fork)
                     rcg = L.cnc_grid_encode_backward_binned(
                         ptr(g_f), ptr(inputs), ptr(embeddings), ptr(offsets_list[l0:]), ptr(resolutions_list[l0:]),
                         ptr(grad_embeddings), int(N), int(num_dim), int(n_features), nb, flags,
                         ptr(ste_clip_count), int(grad_ld), int(grad_col) + (0 if lm else l0 * int(n_features)),
-                        nb, level_rows, ptr(wsg), wsg.numel(), stream())
+                        nb, level_rows, ptr(wsg), wsg.numel(), stream(grad.device))
                     rc = rc or rcg
                     join = torch.cuda.Event()
                     join.record(side)
@@ -158,17 +162,18 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
                 ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
                 ptr(grad_embeddings), int(N), int(num_dim), int(n_features), k, int(Rb), None, None, None,
                 None, flags | _lib.CNC_FLAG_LEVELS_FINEST_FIRST, ptr(ste_clip_count), None, int(grad_ld),
-                int(grad_col), stream())
+                int(grad_col), stream(grad.device))
             for join in joins:
                 cur.wait_event(join)
             check(rc0, "grid_encode_backward")
             check(rc, "grid_encode_backward_binned")
             return
+        ws = _workspace(grad.device, nbytes, (torch.cuda.current_stream(grad.device).cuda_stream, 0))
         rc = L.cnc_grid_encode_backward_binned(
             ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
             ptr(grad_embeddings), int(N), int(num_dim), int(n_features), int(n_levels), flags,
             ptr(ste_clip_count), int(grad_ld), int(grad_col), n_binned, level_rows, ptr(ws), ws.numel(),
-            stream())
+            stream(grad.device))
         check(rc, "grid_encode_backward_binned")
         return
     rc = _lib.lib().cnc_grid_encode_backward(
@@ -177,7 +182,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         ptr(dy_dx), ptr(grad_inputs), ptr(binary_vxl), ptr(min_level_id),
         (_lib.CNC_FLAG_STE_BINARY if ste_binary else 0)
         | (_lib.CNC_FLAG_LEVELS_FINEST_FIRST if interleave_levels else 0), ptr(ste_clip_count),
-        ptr(_check_sat(occ_sat, binary_vxl)), int(grad_ld), int(grad_col), stream())
+        ptr(_check_sat(occ_sat, binary_vxl)), int(grad_ld), int(grad_col), stream(grad.device))
     check(rc, "grid_encode_backward")
 
 
@@ -243,7 +248,7 @@ def pack_sign_bits(embeddings, bits=None, clip_count=None):
     elif bits.numel() != n_bytes or bits.dtype != torch.uint8 or not bits.is_cuda:
         raise RuntimeError("bits must be a CUDA uint8 tensor of ceil(rows*F/8) bytes")
     rc = _lib.lib().cnc_pack_sign_bits(ptr(embeddings), ptr(bits), int(rows), int(F),
-                                       ptr(clip_count), stream())
+                                       ptr(clip_count), stream(embeddings.device))
     check(rc, "pack_sign_bits")
     return bits
 
@@ -270,7 +275,7 @@ def grid_encode_forward_bits(inputs, bits, offsets_list, resolutions_list, outpu
     rc = _lib.lib().cnc_grid_encode_forward_bits(
         ptr(inputs), ptr(bits), ptr(offsets_list), ptr(resolutions_list), ptr(outputs), int(N),
         int(num_dim), int(n_features), int(n_levels), int(Rb), ptr(binary_vxl), ptr(min_level_id),
-        ptr(_check_sat(occ_sat, binary_vxl)), int(out_ld), int(out_col), stream())
+        ptr(_check_sat(occ_sat, binary_vxl)), int(out_ld), int(out_col), stream(inputs.device))
     check(rc, "grid_encode_forward_bits")
 
 
@@ -286,7 +291,7 @@ def cnt_np_embed(inputs, embeddings_clip, outputs, N, resolution, n_features, ha
         raise RuntimeError("GridEncoding: n_features must be 1, 2, 4, 8, 16 or 32.")
     rc = _lib.lib().cnc_cnt_np_embed(ptr(inputs), ptr(embeddings_clip), ptr(outputs), int(N),
                                      int(resolution), int(n_features), int(hashmap_size), int(axis),
-                                     stream())
+                                     stream(inputs.device))
     check(rc, "cnt_np_embed")
 
 
@@ -306,7 +311,7 @@ def cnt_np_embed_backward(inputs, embeddings_clip, outputs_sum, grad, grad_embed
     rc = _lib.lib().cnc_cnt_np_embed_backward(ptr(inputs), ptr(embeddings_clip), ptr(outputs_sum),
                                               ptr(grad), ptr(grad_embeddings), int(N),
                                               int(resolution), int(n_features), int(hashmap_size),
-                                              int(axis), stream())
+                                              int(axis), stream(inputs.device))
     check(rc, "cnt_np_embed_backward")
 
 
@@ -327,7 +332,7 @@ class VotePlan:
         pix = [torch.empty(N, dtype=torch.int32, device=dev) for _ in range(3)]
         for axis in range(3):
             rc = L.cnc_cnt_np_plan(ptr(inputs_i16), N, self.resolution, self.hashmap_size, axis,
-                                   ptr(rows) if axis == 0 else None, ptr(pix[axis]), stream())
+                                   ptr(rows) if axis == 0 else None, ptr(pix[axis]), stream(inputs_i16.device))
             check(rc, "cnt_np_plan")
         valid = rows >= 0                       # 0xFFFFFFFF reads as -1
         rows, pix = rows[valid], [p[valid] for p in pix]
@@ -363,7 +368,7 @@ def cnt_np_embed_planned(plan, embeddings_clip, outputs, n_features, axis):
         raise RuntimeError("cnt_np_embed_planned: tensor sizes do not match the plan")
     rc = _lib.lib().cnc_cnt_np_embed_planned(ptr(plan.rows_by_pixel[axis]), ptr(plan.pixel_seg[axis]),
                                              ptr(embeddings_clip), ptr(outputs), plan.n_pixels,
-                                             int(n_features), stream())
+                                             int(n_features), stream(outputs.device))
     check(rc, "cnt_np_embed_planned")
 
 
@@ -379,5 +384,5 @@ def cnt_np_embed_planned_backward(plan, embeddings_clip, grad_over_sum, grad_emb
                                                       ptr(embeddings_clip), ptr(grad_over_sum),
                                                       ptr(grad_embeddings),
                                                       min(plan.hashmap_size, embeddings_clip.shape[0]),
-                                                      int(n_features), stream())
+                                                      int(n_features), stream(grad_embeddings.device))
     check(rc, "cnt_np_embed_planned_backward")

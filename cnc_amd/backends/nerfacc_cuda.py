@@ -69,7 +69,7 @@ def ray_aabb_intersect(rays_o, rays_d, aabbs, near_plane, far_plane, miss_value)
     hits = torch.empty((n_rays, n_aabbs), dtype=torch.bool, device=rays_o.device)
     rc = _lib.lib().cnc_ray_aabb_intersect(ptr(rays_o), ptr(rays_d), ptr(aabbs), n_rays, n_aabbs,
                                            float(near_plane), float(far_plane), float(miss_value),
-                                           ptr(t_mins), ptr(t_maxs), ptr(hits), stream())
+                                           ptr(t_mins), ptr(t_maxs), ptr(hits), stream(rays_o.device))
     check(rc, "ray_aabb_intersect")
     return [t_mins, t_maxs, hits]
 
@@ -100,7 +100,7 @@ def traverse_grids(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
                                   ptr(aabbs), ptr(hits), ptr(t_sorted), ptr(t_indices),
                                   ptr(near_planes), ptr(far_planes), float(step_size),
                                   float(cone_angle), int(traverse_steps_limit), int(first_pass),
-                                  C.byref(iv), C.byref(sm), ptr(term), stream())
+                                  C.byref(iv), C.byref(sm), ptr(term), stream(rays_o.device))
         check(rc, "traverse_grids")
 
     if over_allocate:
@@ -154,7 +154,7 @@ def sample_positions(rays_o, rays_d, ray_indices, t_a, t_b=None, aabb=None, want
         if aabb.numel() != 6:
             raise RuntimeError("sample_positions: aabb must hold 6 values")
     rc = _lib.lib().cnc_sample_positions(ptr(rays_o), ptr(rays_d), ptr(ray_indices), ptr(t_a), ptr(t_b),
-                                         ptr(aabb), S, ptr(pos), ptr(dirs), stream())
+                                         ptr(aabb), S, ptr(pos), ptr(dirs), stream(rays_o.device))
     check(rc, "sample_positions")
     return (pos, dirs) if want_dirs else pos
 
@@ -175,7 +175,7 @@ def _sum(fn_name, chunk_starts, chunk_cnts, inputs, normalize, backward):
         return outputs
     rc = getattr(_lib.lib(), fn_name)(ptr(chunk_starts), ptr(chunk_cnts), ptr(inputs), ptr(outputs),
                                       chunk_cnts.shape[0], inputs.shape[0], int(bool(normalize)),
-                                      int(bool(backward)), stream())
+                                      int(bool(backward)), stream(inputs.device))
     check(rc, fn_name)
     return outputs
 
@@ -194,7 +194,7 @@ def _prod_fwd(fn_name, chunk_starts, chunk_cnts, inputs):
     if inputs.shape[0] == 0:
         return outputs
     rc = getattr(_lib.lib(), fn_name)(ptr(chunk_starts), ptr(chunk_cnts), ptr(inputs), ptr(outputs),
-                                      chunk_cnts.shape[0], inputs.shape[0], stream())
+                                      chunk_cnts.shape[0], inputs.shape[0], stream(inputs.device))
     check(rc, fn_name)
     return outputs
 
@@ -216,7 +216,7 @@ def _prod_bwd(fn_name, chunk_starts, chunk_cnts, inputs, outputs, grad_outputs):
     rc = getattr(_lib.lib(), fn_name)(ptr(chunk_starts), ptr(chunk_cnts), ptr(inputs),
                                       ptr(outputs.contiguous()), ptr(grad_outputs),
                                       ptr(grad_inputs), chunk_cnts.shape[0], inputs.shape[0],
-                                      stream())
+                                      stream(inputs.device))
     check(rc, fn_name)
     return grad_inputs
 

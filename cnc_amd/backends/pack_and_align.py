@@ -20,7 +20,7 @@ def align_and_pack_forward(voxel_features, unique_count, unique_count_cumsum, N,
         raise RuntimeError("align_and_pack_forward: libcnc_hip builds the fp32 path only")
     rc = _lib.lib().cnc_align_and_pack_forward(ptr(voxel_features), ptr(unique_count),
                                                ptr(unique_count_cumsum.contiguous()), ptr(packed),
-                                               N, M, F, float(V), stream())
+                                               N, M, F, float(V), stream(voxel_features.device))
     check(rc, "align_and_pack_forward")
     return packed
 
@@ -37,7 +37,7 @@ def align_and_pack_backward(dL_packed_features, voxel_features, unique_count, un
         raise RuntimeError("align_and_pack_backward: libcnc_hip builds the fp32 path only")
     rc = _lib.lib().cnc_align_and_pack_backward(ptr(dL_packed_features), ptr(unique_count),
                                                 ptr(unique_count_cumsum), ptr(d_feat), N, M, F,
-                                                stream())
+                                                stream(voxel_features.device))
     check(rc, "align_and_pack_backward")
     return d_feat
 
@@ -63,7 +63,7 @@ def query_mask_3D(points_n_orig, binary_vxl, mask, overlap_area_pool, resolution
     D = _query_checks(points_n_orig, binary_vxl, mask, overlap_area_pool)
     rc = _lib.lib().cnc_query_mask_3D(ptr(points_n_orig), D, ptr(binary_vxl),
                                       int(binary_vxl.shape[0]), ptr(mask), ptr(overlap_area_pool),
-                                      int(resolution), int(mask.shape[0]), stream())
+                                      int(resolution), int(mask.shape[0]), stream(mask.device))
     check(rc, "query_mask_3D")
 
 
@@ -75,7 +75,7 @@ def query_mask_3D_qlist(points_n_orig_list, binary_vxl, mask, overlap_area_pool,
     rc = _lib.lib().cnc_query_mask_3D_qlist(ptr(points_n_orig_list), D, ptr(binary_vxl),
                                             int(binary_vxl.shape[0]), ptr(mask),
                                             ptr(overlap_area_pool), ptr(resolution_list),
-                                            int(mask.shape[0]), stream())
+                                            int(mask.shape[0]), stream(mask.device))
     check(rc, "query_mask_3D_qlist")
 
 
@@ -92,6 +92,6 @@ def segment_weighted_sum(values, weights, cumsum, mode=0):
     N, F = cumsum.shape[0] - 1, values.shape[1]
     out = torch.empty((N, F), dtype=torch.float32, device=values.device)
     rc = _lib.lib().cnc_segment_weighted_sum(ptr(values), ptr(weights), ptr(cumsum), ptr(out), N, F,
-                                             int(mode), stream())
+                                             int(mode), stream(values.device))
     check(rc, "segment_weighted_sum")
     return out

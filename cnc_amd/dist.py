@@ -29,13 +29,32 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("CNC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_device_index())
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_device_index()))
         else:
             dist.init_process_group(backend)
     return rank, local_rank, world
+
+
+def local_device_index() -> int:
+    """cuda index of this rank: LOCAL_RANK, or 0 for every rank under CNC_DIST_ONE_DEVICE=1 (test hook:
+    lets the N > 1 control flow run on a single-GPU box, with gloo as the backend)."""
+    if os.environ.get("CNC_DIST_ONE_DEVICE") == "1":
+        return 0
+    return env_world()[1]
+
+
+def _active() -> bool:
+    """True when there is a process group with more than one rank.  WORLD_SIZE > 1 in the environment
+    WITHOUT a process group is an error, not a silent single-rank run: replicas would drift apart."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size() > 1
+    if env_world()[2] > 1:
+        raise RuntimeError("WORLD_SIZE > 1 but torch.distributed is not initialised: call cnc_amd.dist.init() first")
+    return False
 
 
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
@@ -73,7 +92,7 @@ class GradBucket:
         self.flat.zero_()
 
     def allreduce(self, average: bool = True, async_op: bool = False):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not _active():
             return None
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
         if average and not async_op:
@@ -87,7 +106,7 @@ class GradBucket:
 
 def broadcast_module_buffers(module: torch.nn.Module, names: Iterable[str], src: int = 0) -> None:
     """Keep replica state (e.g. OccGridEstimator.occs / .binaries) identical to rank `src`."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return
     for n in names:
         t = getattr(module, n)
@@ -100,7 +119,7 @@ def broadcast_module_buffers(module: torch.nn.Module, names: Iterable[str], src:
 
 
 def max_over_ranks(x: float, device) -> float:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return x
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -108,7 +127,7 @@ def max_over_ranks(x: float, device) -> float:
 
 
 def sum_over_ranks(x: float, device) -> float:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return x
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -140,6 +140,7 @@ class GridEncoder(nn.Module):
         self.bitplane = bitplane and fused_ste
         self._bits = None
         self._bits_key = None
+        self._bits_src = None
         self._clip_count = None
         self._sat = None
         self._sat_key = None
@@ -161,7 +162,14 @@ class GridEncoder(nn.Module):
         self.n_output_dims = n_levels * n_features
 
     def reset_parameters(self):
-        self.params.data.uniform_(-1e-4, 1e-4)
+        # no_grad in-place write (not `.data`): bumps params._version, which keys the caches below
+        with torch.no_grad():
+            self.params.uniform_(-1e-4, 1e-4)
+        self.invalidate_caches()
+
+    def invalidate_caches(self):
+        """Forget the packed sign plane / clip counter (call after writing `params` through `.data`)."""
+        self._bits = self._bits_key = self._bits_src = self._clip_count = None
 
     def __repr__(self):
         return (f"GridEncoder: num_dim={self.num_dim} n_levels={self.n_levels} "
@@ -179,6 +187,7 @@ class GridEncoder(nn.Module):
                 self._bits = _backend.pack_sign_bits(params.detach().contiguous(), None, cc)
                 self._clip_count = cc
             self._bits_key = key
+            self._bits_src = params      # keep the storage alive so (data_ptr, version) stays unique
         return self._bits, self._clip_count
 
     def _binned_plan(self, n_points, lo=0, hi=None, binary_vxl=None):

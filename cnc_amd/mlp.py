@@ -172,7 +172,13 @@ class FusedMLPForward:
                 packed.append((w, b, hp))
                 kp = hp
             self._packed, self._key = packed, key
+            # pin the sources: a freed weight whose address and version are reused must not alias the key
+            self._src = [(l.weight, l.bias) for l in self.linears]
         return self._packed
+
+    def invalidate(self):
+        """Drop the packed copies (call after writing a weight through `.data`, which skips `_version`)."""
+        self._key = self._packed = None
 
     @torch.no_grad()
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
@@ -192,6 +198,6 @@ class FusedMLPForward:
         fn = _lib.lib().cnc_mlp_forward32 if self.rows_per_wave == 32 else _lib.lib().cnc_mlp_forward
         rc = fn(x2.data_ptr(), n, x2.stride(0), k0, w1.data_ptr(), b1.data_ptr(), h1,
                                         w2.data_ptr(), b2.data_ptr(), h2, _lib.ptr(w3), _lib.ptr(b3), h3,
-                                        y.data_ptr(), n_out, n_out, _lib.stream())
+                                        y.data_ptr(), n_out, n_out, _lib.stream(x.device))
         _lib.check(rc, "mlp_forward")
         return y.reshape(*lead, n_out)

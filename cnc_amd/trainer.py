@@ -183,8 +183,11 @@ def get_binary_vxl_size(binary_vxl):
 class Trainer:
     def __init__(self, cfg: TrainConfig, device="cuda"):
         self.cfg = cfg
-        self.rank, self.local_rank, self.world = cdist.env_world()
+        # world > 1: join the process group (RCCL; gloo under CNC_DIST_BACKEND) and take this rank's GPU
+        self.rank, self.local_rank, self.world = cdist.init()
         self.device = torch.device(device)
+        if self.world > 1 and self.device.type == "cuda":
+            self.device = torch.device("cuda", cdist.local_device_index())
         set_random_seed(cfg.seed)
         c = cfg
         aabb = torch.tensor(c.aabb, device=self.device)
@@ -328,7 +331,8 @@ class Trainer:
         e = self.field.mlp_base
         recs = [torch.ones_like(t.params.data) for t in (e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz)]
         for t in (e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz):
-            t.params.data.zero_()
+            t.params.zero_()             # under no_grad: bumps _version, which keys the sign-plane cache
+            t.invalidate_caches()
         recs = self.context.decode_binary_vxl_mixPg_3D2D(e.encoding_xyz, e.encoding_xy, e.encoding_xz,
                                                          e.encoding_yz, *recs, self.estimator.binaries, Pgs,
                                                          filename_prefix=prefix)

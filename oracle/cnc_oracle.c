@@ -177,48 +177,67 @@ void orc_grid_encode_forward(const float* inputs, const float* emb, const int32_
  * (level-slot, point, corner) and, when acc64 != NULL, a double-precision shadow is kept so
  * tests can bound the reordering error instead of guessing a tolerance.
  * ------------------------------------------------------------------------------------------- */
+static void orc_bwd_point(uint32_t k, uint32_t b, const float* grad, const float* inputs, const float* emb,
+                          const int32_t* offsets, const int32_t* resolutions, float* grad_emb,
+                          double* acc64, uint32_t N, uint32_t D, uint32_t F, uint32_t Rb,
+                          const uint8_t* vxl, const int32_t* min_level_id, int ste_binary, int atomic)
+{
+    uint32_t level = (min_level_id ? (uint32_t)min_level_id[b] : 0u) + k;
+    size_t base = (size_t)(uint32_t)offsets[level] * F;
+    uint32_t hs = (uint32_t)(offsets[level + 1] - offsets[level]);
+    uint32_t R = (uint32_t)resolutions[level];
+    const float* g = grad + ((size_t)k * N + b) * F;
+    orc_corners_t c;
+    if (!orc_corners(D, inputs + (size_t)b * D, R, hs, Rb, vxl, &c)) return;  /* :435-440 */
+    for (uint32_t i = 0; i < (1u << D); i++) {
+        if (!c.valid[i]) continue;
+        float t = c.w[i] * c.wn_re;
+        size_t at = base + (size_t)c.row[i] * F;
+        for (uint32_t ch = 0; ch < F; ch++) {
+            if (ste_binary) {           /* STE_binary.backward mask, ngp.py:35-39 */
+                float v = emb[at + ch];
+                if (!(v >= -1.0f && v <= 1.0f)) continue;
+            }
+            float contrib = t * g[ch];                                        /* :580 */
+            if (atomic) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+                grad_emb[at + ch] += contrib;
+            } else {
+                grad_emb[at + ch] += contrib;
+                if (acc64) acc64[at + ch] += (double)contrib;
+            }
+        }
+    }
+}
+
 void orc_grid_encode_backward(const float* grad, const float* inputs, const float* emb,
                               const int32_t* offsets, const int32_t* resolutions, float* grad_emb,
                               double* acc64, uint32_t N, uint32_t D, uint32_t F, uint32_t L,
                               uint32_t Rb, const uint8_t* vxl, const int32_t* min_level_id,
                               int ste_binary, int threads)
 {
-    (void)threads;
+    if (threads > 1 && acc64 && !min_level_id) {
+        /* float64 shadow wanted AND threads: the level slots write disjoint table rows, so one
+         * thread per level keeps the (point, corner) order of the serial loop inside each level —
+         * the same sums, bit for bit, as threads == 1 */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+        for (uint32_t k = 0; k < L; k++)
+            for (uint32_t b = 0; b < N; b++)
+                orc_bwd_point(k, b, grad, inputs, emb, offsets, resolutions, grad_emb, acc64, N, D, F, Rb, vxl,
+                              min_level_id, ste_binary, 0);
+        return;
+    }
 #ifdef _OPENMP
 #pragma omp parallel for collapse(2) schedule(static) num_threads(threads > 0 ? threads : 1)
 #endif
-    for (uint32_t k = 0; k < L; k++) {
-        for (uint32_t b = 0; b < N; b++) {
-            uint32_t level = (min_level_id ? (uint32_t)min_level_id[b] : 0u) + k;
-            size_t base = (size_t)(uint32_t)offsets[level] * F;
-            uint32_t hs = (uint32_t)(offsets[level + 1] - offsets[level]);
-            uint32_t R = (uint32_t)resolutions[level];
-            const float* g = grad + ((size_t)k * N + b) * F;
-            orc_corners_t c;
-            if (!orc_corners(D, inputs + (size_t)b * D, R, hs, Rb, vxl, &c)) continue; /* :435-440 */
-            for (uint32_t i = 0; i < (1u << D); i++) {
-                if (!c.valid[i]) continue;
-                float t = c.w[i] * c.wn_re;
-                size_t at = base + (size_t)c.row[i] * F;
-                for (uint32_t ch = 0; ch < F; ch++) {
-                    if (ste_binary) {           /* STE_binary.backward mask, ngp.py:35-39 */
-                        float v = emb[at + ch];
-                        if (!(v >= -1.0f && v <= 1.0f)) continue;
-                    }
-                    float contrib = t * g[ch];                                /* :580 */
-                    if (threads > 1) {
-#ifdef _OPENMP
-#pragma omp atomic
-#endif
-                        grad_emb[at + ch] += contrib;
-                    } else {
-                        grad_emb[at + ch] += contrib;
-                        if (acc64) acc64[at + ch] += (double)contrib;
-                    }
-                }
-            }
-        }
-    }
+    for (uint32_t k = 0; k < L; k++)
+        for (uint32_t b = 0; b < N; b++)
+            orc_bwd_point(k, b, grad, inputs, emb, offsets, resolutions, grad_emb, acc64, N, D, F, Rb, vxl,
+                          min_level_id, ste_binary, threads > 1);
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -511,6 +530,9 @@ void orc_traverse_grids(const float* rays_o, const float* rays_d, const uint8_t*
     const float eps = 1e-6f;
     const int res[3] = {resx, resy, resz};
     const int has_iv = iv && iv->chunk_cnts, has_sm = sm && sm->chunk_cnts;
+    /* rays are independent (each writes its own slots): one OpenMP thread per block of rays, like
+     * one CUDA thread per ray */
+    #pragma omp parallel for schedule(dynamic, 64) if (n_rays > 256)
     for (int32_t tid = 0; tid < n_rays; tid++) {
         if (rays_mask && !rays_mask[tid]) continue;                           /* :100 */
         if (has_iv && !first_pass && iv->chunk_cnts[tid] == 0) continue;      /* :103-106 */

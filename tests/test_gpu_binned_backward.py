@@ -246,3 +246,55 @@ def test_two_stream_split_equals_single_call(cuda, point_major):
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * scale
     # both halves contributed: coarsest and finest level rows are non-zero
     assert float(outs[1][: int(offs[1])].abs().max()) > 0 and float(outs[1][int(offs[-2]):].abs().max()) > 0
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_bench_chunk_backward_against_oracle(cuda, oracle, overlap):
+    """THE call bench.py times, oracle-checked at bench size: one 2^20-sample chunk from the middle of
+    bench.py's own marched 800x800 frame, 16L x 2^19 x F8, raw U(-1e-4, 1e-4) table with ste_binary, the
+    product's binned plan (coarse levels on k_grid_encode_bwd_merge with its cross-ray LDS hash chains,
+    finest levels on k_bwd_bin + k_bwd_owner), two-stream overlap off and on.  Every table entry must lie
+    within the float32 summation bound (n_e + 2) * eps * sum|terms| of the oracle's float64 sum, with n_e
+    the entry's own term count from the independent NumPy restatement (tests/np_twins.py)."""
+    import bench
+    import np_twins as tw
+    from cnc_amd.backends import gridencoder_backend as be
+    from cnc_amd.backends import nerfacc_cuda as ncu
+    from cnc_amd.nerfacc import grid as ngrid
+    w = bench.build_workload(cuda, 0)
+    iv, sm, _ = ngrid.traverse_grids(w["rays_o"], w["rays_d"], w["binaries"], w["aabbs"],
+                                     step_size=bench.STEP_SIZE, cone_angle=0.0)
+    x = ncu.sample_positions(w["rays_o"], w["rays_d"], sm.ray_indices, sm.vals, None, w["aabbs"][0])
+    S, N, L, F = x.shape[0], bench.CHUNK, bench.L, bench.F
+    assert S > 40 * N
+    c = (S // N) // 2
+    xs = x[c * N:(c + 1) * N].contiguous()
+    be.pack_sign_bits(w["table"], w["bits"], w["clip"])
+    out = w["out"]
+    be.grid_encode_forward_bits(xs, w["bits"], w["offsets"], w["resolutions"], out, N, 3, F, L, 128)
+    plan = be.plan_binned_levels(bench.synthetic.RES_16L, w["offsets_host"], 3, F, N)
+    assert plan is not None and 0 < plan[0] < L
+    gt = torch.zeros_like(w["table"])
+    be.grid_encode_backward(out, xs, w["table"], w["offsets"], w["resolutions"], gt, N, 3, F, L, 0, 128, None, None,
+                            None, None, ste_binary=True, ste_clip_count=w["clip"], binned=plan,
+                            overlap_streams=overlap)
+    torch.cuda.synchronize()
+    got = gt.cpu().numpy()
+    xn, g, table = xs.cpu().numpy(), out.cpu().numpy(), w["table"].cpu().numpy()
+    offs, res = w["offsets"].cpu().numpy(), w["resolutions"].cpu().numpy()
+    # forward of the same chunk, bit-exact (the gradient fed back is the oracle's own output too)
+    threads = oracle.max_threads()
+    assert np.array_equal(g, oracle.grid_encode_forward(xn, table, offs, res, ste_binary=True, threads=threads))
+    want32, acc64 = oracle.grid_encode_backward(g, xn, table, offs, res, ste_binary=True, want_acc64=True,
+                                                threads=threads)
+    _, abs64 = oracle.grid_encode_backward(np.abs(g), xn, table, offs, res, ste_binary=True, want_acc64=True,
+                                           threads=threads)
+    n_e = tw.grid_entry_counts(xn, offs, res)
+    assert n_e.max() > 10000          # the coarse levels really are many-to-one here
+    eps = np.finfo(np.float32).eps
+    bound = (n_e[:, None] + 2) * eps * abs64 + 1e-30
+    err = np.abs(got.astype(np.float64) - acc64)
+    assert np.all(err <= bound), f"worst entry: {np.max(err / bound):.3f} x its bound"
+    assert np.all(got[abs64 == 0] == 0)
+    # and globally far tighter than the worst case (errors do not line up)
+    assert err.max() <= 1e-5 * np.abs(acc64).max()

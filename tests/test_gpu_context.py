@@ -196,17 +196,18 @@ def test_segment_weighted_sum_kernel(cuda):
         assert torch.allclose(got2[nz].double(), (plain / torch.as_tensor(cnt, device=cuda)[:, None])[nz], atol=1e-5)
 
 
-def test_full_size_encode_decode_roundtrip(cuda, tmp_path):
-    """BASELINE config 3 sizes (12x3-D T=2^19 + 3x4 planes T=2^17, F=2 to keep it quick): encode ->
-    wipe -> decode reproduces every coded row; the 3-D chunking is the reference's (21 files);
-    coded size within 2 % of the entropy estimate + per-file termination overhead."""
+@pytest.mark.parametrize("F,sample_num", [(2, 200000), (8, 150000)])
+def test_full_size_encode_decode_roundtrip(cuda, tmp_path, F, sample_num):
+    """BASELINE configs[2] sizes (12x3-D T=2^19 + 3x4 planes T=2^17; F=8 / sample_num=150000 is the
+    configuration BASELINE.json names, F=2 / 200000 the reference script's default): encode -> wipe ->
+    decode reproduces every coded row; the 3-D chunking is the reference's (21 files); coded size
+    within 2 % of the entropy estimate + per-file termination overhead."""
     from cnc_amd import synthetic
     from cnc_amd.context import CNC_context_models
     from cnc_amd.gridencoder import GridEncoder
-    F = 2
     torch.manual_seed(3)
     m = CNC_context_models(num_dim=3, resolutions_list=synthetic.RES_3D_REF, resolutions_list_2D=synthetic.RES_2D_REF,
-                           log2_hashmap_size=19, log2_hashmap_size_2D=17, n_features=F, sample_num=200000,
+                           log2_hashmap_size=19, log2_hashmap_size_2D=17, n_features=F, sample_num=sample_num,
                            ste_binary=True, Pg_level=12, Pg_level_2D=4, Rb=128, skip_levels_3D=[0, 1, 2],
                            skip_levels_2D=[0], device=cuda)
     encs = [GridEncoder(3, F, synthetic.RES_3D_REF, 19, ste_binary=True).to(cuda)] + \
@@ -229,3 +230,43 @@ def test_full_size_encode_decode_roundtrip(cuda, tmp_path):
         coded = ~(dec == 1).all(dim=1)
         assert torch.equal(dec[coded], q[coded])
         assert coded.float().mean() > 0.2
+
+
+def test_configs2_training_pass_forward_backward(cuda):
+    """configs[2] (F=8, sample_num=150000, 12x3-D T=2^19 + 3x4 planes T=2^17): one training pass of
+    `forward_binary_vxl_mixPg_3D2D` + backward.  Size-independent properties: the estimate is a valid
+    bit rate (0 < bpp <= ~1 bit per binary parameter at initialisation, where nothing is predictable yet),
+    the same seed gives the same value (the window draw is the only randomness), gradients reach the four
+    tables and the context MLPs, are finite, and vanish on rows of levels that are never coded (3-D
+    levels 0-2 and plane level 0 are skipped)."""
+    from cnc_amd import synthetic
+    from cnc_amd.context import CNC_context_models
+    from cnc_amd.gridencoder import GridEncoder
+    F = 8
+    torch.manual_seed(5)
+    m = CNC_context_models(num_dim=3, resolutions_list=synthetic.RES_3D_REF, resolutions_list_2D=synthetic.RES_2D_REF,
+                           log2_hashmap_size=19, log2_hashmap_size_2D=17, n_features=F, sample_num=150000,
+                           max_context_layer_num=3, ste_binary=True, Pg_level=12, Pg_level_2D=4, Rb=128,
+                           step_update=16, skip_levels_3D=[0, 1, 2], skip_levels_2D=[0], device=cuda)
+    encs = [GridEncoder(3, F, synthetic.RES_3D_REF, 19, ste_binary=True).to(cuda)] + \
+           [GridEncoder(2, F, synthetic.RES_2D_REF, 17, ste_binary=True).to(cuda) for _ in range(3)]
+    binaries = synthetic.ball_binaries(128, radius=1.0, device=cuda)
+    vals = []
+    for rep in range(2):
+        torch.manual_seed(77)
+        for p in [q for e in encs for q in e.parameters()] + list(m.parameters()):
+            p.grad = None
+        bpp, mb = m.forward_binary_vxl_mixPg_3D2D(*encs, binaries, step=0)
+        bpp.backward()
+        vals.append(float(bpp))
+    assert vals[0] == vals[1]
+    assert 0.5 < vals[0] <= 1.05 and 0 < mb < 10
+    g3 = encs[0].params.grad
+    assert torch.isfinite(g3).all() and float(g3.abs().max()) > 0
+    off = encs[0].offsets_list
+    assert float(g3[int(off[3]):].abs().max()) > 0
+    for e in encs[1:]:
+        assert torch.isfinite(e.params.grad).all() and float(e.params.grad.abs().max()) > 0
+    ctx_grads = [p.grad for p in m.parameters() if p.grad is not None]
+    assert ctx_grads and all(torch.isfinite(g).all() for g in ctx_grads)
+    assert any(float(g.abs().max()) > 0 for g in ctx_grads)

@@ -271,3 +271,16 @@ def test_sample_positions_equals_torch_expression(cuda):
     p = o[ri] + d[ri] * ts[:, None]
     assert torch.equal(x, (p - aabb[:3]) / (aabb[3:] - aabb[:3]))
     assert C.sample_positions(o, d, ri[:0], ts[:0]).shape == (0, 3)
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_hip_marcher_against_the_reference_lookup_golden(cuda, k):
+    """tests/golden/march_query.npz: the HIP marcher emits exactly the candidate mid points that the
+    reference's own `nerfacc.grid._query` calls occupied (cell-face rounding cases excepted)."""
+    from cnc_amd.nerfacc import grid as ngrid
+    from test_np_twins import check_against_reference_lookup, march_query_case
+    o, d, b, aabb, step, cand_t, cand_ray, ref_occ = march_query_case(k)
+    t = lambda a: torch.as_tensor(a, device=cuda)
+    iv, sm, term = ngrid.traverse_grids(t(o), t(d), t(b), t(aabb), step_size=step, cone_angle=0.0)
+    check_against_reference_lookup(o, d, sm.vals.cpu().numpy(), sm.ray_indices.cpu().numpy(), cand_t, cand_ray,
+                                   ref_occ, b.shape[-1])
