@@ -54,6 +54,12 @@ SIGNATURES = {
     "cnc_exclusive_prod_forward": [_vp, _vp, _vp, _vp, _u32, _i64, _vp],
     "cnc_inclusive_prod_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _i64, _vp],
     "cnc_exclusive_prod_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _i64, _vp],
+    "cnc_volrend_forward": [_vp] * 15 + [_u32, _u32, _vp],
+    "cnc_volrend_backward": [_vp] * 19 + [_u32, _u32, _vp],
+    "cnc_render_visibility": [_vp] * 5 + [_i32, _f32, _f32, _vp, _vp, _vp, _u32, _vp],
+    "cnc_compact_samples": [_vp] * 9 + [_u32, _vp],
+    "cnc_interval_edges_to_samples": [_vp] * 9 + [_u32, _vp],
+    "cnc_pack_bounds": [_vp, _i64, _vp, _vp, _i64, _vp],
 }
 
 # entry points that return something other than a status code
@@ -61,7 +67,9 @@ RESTYPES = {"cnc_grid_encode_backward_binned_workspace": C.c_uint64}
 
 CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2
-ABI_VERSION = 7          # cnc_abi_version() of the library this table was written for
+CNC_VOLREND_ACCUMULATE = 1
+CNC_VOLREND_FINALIZE = 2
+ABI_VERSION = 8          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

@@ -19,8 +19,10 @@ class RaySegmentsSpec:
     """Mirror of RaySegmentsSpec (data_spec.hpp:6-13 / nerfacc.cpp:120-128): undefined tensors
     read as None from Python."""
 
+    # alloc_starts (extension): where each ray's slots begin in `vals` when the march over-allocated
+    # (chunk_starts is then recomputed from the true counts, data_spec.hpp:99-106, and no longer says)
     __slots__ = ("vals", "is_left", "is_right", "is_valid", "chunk_starts", "chunk_cnts",
-                 "ray_indices")
+                 "ray_indices", "alloc_starts")
 
     def __init__(self):
         for k in self.__slots__:
@@ -117,6 +119,7 @@ def traverse_grids(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
                 (samples.vals.numel() if compute_samples else 0)
         if n_out > 0:   # every ray masked out: nothing to march
             launch(rays_mask, 0, terminate_planes)
+        intervals.alloc_starts, samples.alloc_starts = intervals.chunk_starts, samples.chunk_starts
         intervals.compute_chunk_start()
         samples.compute_chunk_start()
     else:

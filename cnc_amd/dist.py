@@ -82,9 +82,11 @@ class GradBucket:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
             o += p.numel()
 
-    def bind(self) -> None:
+    def bind(self, force: bool = False) -> None:
+        """Point every param.grad at its slice.  A gradient that autograd put elsewhere is copied in first,
+        unless `force` (the caller is switching buckets and the old gradient must not leak into this one)."""
         for p, v in zip(self.params, self.views):
-            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+            if not force and p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
             p.grad = v
 
@@ -116,6 +118,16 @@ def broadcast_module_buffers(module: torch.nn.Module, names: Iterable[str], src:
             setattr(module, n, u.to(torch.bool))
         else:
             dist.broadcast(t, src)
+
+
+def broadcast_parameters(params: Iterable[torch.nn.Parameter], src: int = 0) -> None:
+    """Overwrite every rank's parameters with rank `src`'s (in place: optimiser state and views stay valid)."""
+    if not _active():
+        return
+    with torch.no_grad():
+        for p in params:
+            dist.broadcast(p.data, src)
+            p.add_(0)            # in-place no-op that bumps p._version: caches keyed on it (sign plane) refresh
 
 
 def max_over_ranks(x: float, device) -> float:

@@ -187,7 +187,8 @@ class GridEncoder(nn.Module):
                 self._bits = _backend.pack_sign_bits(params.detach().contiguous(), None, cc)
                 self._clip_count = cc
             self._bits_key = key
-            self._bits_src = params      # keep the storage alive so (data_ptr, version) stays unique
+            self._bits_src = (params,)   # keep the storage alive so (data_ptr, version) stays unique (a tuple:
+                                         # a bare Parameter attribute would register as a module parameter)
         return self._bits, self._clip_count
 
     def _binned_plan(self, n_points, lo=0, hi=None, binary_vxl=None):
@@ -209,7 +210,7 @@ class GridEncoder(nn.Module):
             with torch.no_grad():
                 self._sat = _backend.occupancy_sat(binary_vxl)
             self._sat_key = key
-            self._sat_src = binary_vxl      # keep the storage alive so data_ptr stays unique
+            self._sat_src = (binary_vxl,)   # keep the storage alive so data_ptr stays unique
         return self._sat
 
     # -- embeddings as the kernels should see them --------------------------------------------

@@ -1,9 +1,18 @@
-"""Occupancy-grid transmittance estimator (reference: nerfacc/estimators/occ_grid.py:14-443).
+"""Occupancy-grid estimator: which stretches of a ray are worth sampling.
 
-Same constructor, buffers (`resolution`, `aabbs`, `occs`, `binaries`, `grid_coords`,
-`grid_indices`) and methods (`sampling`, `update_every_n_steps`, `_update`,
-`mark_invisible_cells`) as the reference, so the CNC drivers and context models can use it
-unchanged.  The march itself is the HIP `traverse_grids` kernel.
+Interface of the reference's `nerfacc.estimators.occ_grid.OccGridEstimator` (occ_grid.py:14-443) — same
+constructor, buffers (`resolution`, `aabbs`, `occs`, `binaries`; non-persistent `grid_coords`,
+`grid_indices`), methods and RNG call order (so a seeded `_update` reproduces the reference's grid,
+tests/golden/occ_grid.npz) — on top of the HIP marcher and the fused visibility / compaction kernels:
+
+    sampling = traverse_grids (count + fill)            cnc_amd/csrc/march.hip
+             -> interval edges -> (ray, t_start, t_end)  k_edges_to_samples   (no boolean indexing)
+             -> sigma_fn / alpha_fn (the field)
+             -> transmittance test + survivor counts     k_visibility
+             -> stable compaction                         k_compact            (one host sync)
+
+`sampling` also remembers the (start, count) table of what it returned (`last_packed_info`), so the renderer
+does not have to rebuild it from `ray_indices`.
 """
 from __future__ import annotations
 
@@ -12,165 +21,184 @@ from typing import Callable, List, Optional, Tuple, Union
 import torch
 from torch import Tensor
 
-from ..grid import _enlarge_aabb, traverse_grids
-from ..volrend import render_visibility_from_alpha, render_visibility_from_density
 from .base import AbstractEstimator
+
+
+def _box_scaled_about_centre(box: Tensor, factor: float) -> Tensor:
+    lo, hi = box[:3], box[3:]
+    mid, half = (lo + hi) * 0.5, (hi - lo) * 0.5
+    return torch.cat([mid - half * factor, mid + half * factor])
+
+
+def _cell_lattice(res: Tensor) -> Tensor:
+    """Integer (x, y, z) of every cell, x slowest — the flattening order of `binaries`."""
+    nx, ny, nz = (int(v) for v in res.tolist())
+    xs, ys, zs = torch.arange(nx), torch.arange(ny), torch.arange(nz)
+    return torch.stack(torch.meshgrid(xs, ys, zs, indexing="ij"), dim=-1).reshape(-1, 3)
 
 
 class OccGridEstimator(AbstractEstimator):
     DIM: int = 3
 
-    def __init__(self, roi_aabb: Union[List[int], Tensor],
-                 resolution: Union[int, List[int], Tensor] = 128, levels: int = 1, **kwargs) -> None:
+    def __init__(self, roi_aabb: Union[List[int], Tensor], resolution: Union[int, List[int], Tensor] = 128,
+                 levels: int = 1, **kwargs) -> None:
         super().__init__()
         if "contraction_type" in kwargs:
             raise ValueError("`contraction_type` is not supported anymore for nerfacc >= 0.4.0.")
-        if isinstance(resolution, int):
-            resolution = [resolution] * self.DIM
-        if isinstance(resolution, (list, tuple)):
-            resolution = torch.tensor(resolution, dtype=torch.int32)
-        assert isinstance(resolution, Tensor), f"Invalid type: {resolution}!"
-        assert resolution.shape[0] == self.DIM, f"Invalid shape: {resolution}!"
-        if isinstance(roi_aabb, (list, tuple)):
-            roi_aabb = torch.tensor(roi_aabb, dtype=torch.float32)
-        assert isinstance(roi_aabb, Tensor), f"Invalid type: {roi_aabb}!"
-        assert roi_aabb.shape[0] == self.DIM * 2, f"Invalid shape: {roi_aabb}!"
+        res = resolution
+        if isinstance(res, int):
+            res = [res] * self.DIM
+        if not isinstance(res, Tensor):
+            res = torch.tensor(list(res), dtype=torch.int32)
+        box = roi_aabb if isinstance(roi_aabb, Tensor) else torch.tensor(list(roi_aabb), dtype=torch.float32)
+        if res.shape[0] != self.DIM:
+            raise AssertionError(f"Invalid shape: {res}!")
+        if box.shape[0] != 2 * self.DIM:
+            raise AssertionError(f"Invalid shape: {box}!")
 
-        # level i covers the roi scaled by 2^i about its centre
-        aabbs = torch.stack([_enlarge_aabb(roi_aabb, 2 ** i) for i in range(levels)], dim=0)
-        self.cells_per_lvl = int(resolution.prod().item())
         self.levels = levels
-        self.register_buffer("resolution", resolution)
-        self.register_buffer("aabbs", aabbs)
-        self.register_buffer("occs", torch.zeros(self.levels * self.cells_per_lvl))
-        self.register_buffer("binaries", torch.zeros([levels] + resolution.tolist(), dtype=torch.bool))
-        grid_coords = _meshgrid3d(resolution).reshape(self.cells_per_lvl, self.DIM)
-        self.register_buffer("grid_coords", grid_coords, persistent=False)
+        self.cells_per_lvl = int(res.prod().item())
+        # level k covers the region of interest scaled by 2^k about its centre
+        self.register_buffer("resolution", res)
+        self.register_buffer("aabbs", torch.stack([_box_scaled_about_centre(box, 2.0 ** k) for k in range(levels)]))
+        self.register_buffer("occs", torch.zeros(levels * self.cells_per_lvl))
+        self.register_buffer("binaries", torch.zeros([levels] + res.tolist(), dtype=torch.bool))
+        self.register_buffer("grid_coords", _cell_lattice(res), persistent=False)
         self.register_buffer("grid_indices", torch.arange(self.cells_per_lvl), persistent=False)
+        self.last_packed_info: Optional[Tensor] = None
+
+    # ----------------------------------------------------------------------------------- sampling
+    def _march(self, rays_o, rays_d, near_planes, far_planes, step, cone_angle):
+        """(ray_indices, t_starts, t_ends, starts, counts) of every sample inside occupied cells."""
+        from ...backends import nerfacc_cuda as _C
+        from ...backends import volrend_backend as _K
+        rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
+        t_lo, t_hi, hit = _C.ray_aabb_intersect(rays_o, rays_d, self.aabbs.contiguous(), -float("inf"),
+                                                float("inf"), float("inf"))
+        t_sorted, t_order = torch.sort(torch.cat([t_lo, t_hi], dim=-1), dim=-1)
+        every_ray = torch.ones(rays_o.shape[0], dtype=torch.bool, device=rays_o.device)
+        intervals, samples, _ = _C.traverse_grids(
+            rays_o, rays_d, every_ray, self.binaries.contiguous(), self.aabbs.contiguous(), t_sorted.contiguous(),
+            t_order.contiguous(), hit.contiguous(), near_planes.contiguous(), far_planes.contiguous(), step,
+            cone_angle, True, True, False, -1, False)
+        ray_indices, t_starts, t_ends, starts = _K.samples_from_intervals(intervals, samples.chunk_cnts,
+                                                                           total=samples.vals.shape[0])
+        return ray_indices, t_starts, t_ends, starts, samples.chunk_cnts
 
     @torch.no_grad()
     def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None,
-                 alpha_fn: Optional[Callable] = None, near_plane: float = 0.0,
-                 far_plane: float = 1e10, t_min: Optional[Tensor] = None,
-                 t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
+                 alpha_fn: Optional[Callable] = None, near_plane: float = 0.0, far_plane: float = 1e10,
+                 t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
                  early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
                  cone_angle: float = 0.0) -> Tuple[Tensor, Tensor, Tensor]:
-        """Returns (ray_indices, t_starts, t_ends) of the samples that survive occupancy skipping
-        and, if `sigma_fn` / `alpha_fn` is given, the transmittance / alpha visibility test."""
-        near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
-        far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
+        """Samples (ray_indices, t_starts, t_ends) along the rays: marched with `render_step_size` (growing
+        with `cone_angle`) through occupied cells between the near / far planes (optionally per-ray `t_min` /
+        `t_max`), jittered by up to one step when `stratified`; if a density (`sigma_fn`) or opacity
+        (`alpha_fn`) callback is given, samples behind transmittance < `early_stop_eps` — and, for
+        `alpha_thre` > 0, samples more transparent than min(alpha_thre, mean occupancy) — are dropped."""
+        from ...backends import volrend_backend as _K
+        n_rays = rays_o.shape[0]
+        near = torch.full((n_rays,), float(near_plane), dtype=rays_o.dtype, device=rays_o.device)
+        far = torch.full((n_rays,), float(far_plane), dtype=rays_o.dtype, device=rays_o.device)
         if t_min is not None:
-            near_planes = torch.clamp(near_planes, min=t_min)
+            near = torch.maximum(near, t_min)
         if t_max is not None:
-            far_planes = torch.clamp(far_planes, max=t_max)
+            far = torch.minimum(far, t_max)
         if stratified:
-            near_planes += torch.rand_like(near_planes) * render_step_size
-        intervals, samples, _ = traverse_grids(rays_o, rays_d, self.binaries, self.aabbs,
-                                               near_planes=near_planes, far_planes=far_planes,
-                                               step_size=render_step_size, cone_angle=cone_angle)
-        t_starts = intervals.vals[intervals.is_left]
-        t_ends = intervals.vals[intervals.is_right]
-        ray_indices = samples.ray_indices
-        packed_info = samples.packed_info
-
-        if (alpha_thre > 0.0 or early_stop_eps > 0.0) and (sigma_fn is not None or alpha_fn is not None):
-            alpha_thre = min(alpha_thre, self.occs.mean().item())
-            if sigma_fn is not None:
-                sigmas = (sigma_fn(t_starts, t_ends, ray_indices) if t_starts.shape[0] != 0
-                          else torch.empty((0,), device=t_starts.device))
-                assert sigmas.shape == t_starts.shape, "sigmas must have shape of (N,)! Got {}".format(sigmas.shape)
-                masks = render_visibility_from_density(t_starts=t_starts, t_ends=t_ends, sigmas=sigmas,
-                                                       packed_info=packed_info,
-                                                       early_stop_eps=early_stop_eps,
-                                                       alpha_thre=alpha_thre)
-            else:
-                alphas = (alpha_fn(t_starts, t_ends, ray_indices) if t_starts.shape[0] != 0
-                          else torch.empty((0,), device=t_starts.device))
-                assert alphas.shape == t_starts.shape, "alphas must have shape of (N,)! Got {}".format(alphas.shape)
-                masks = render_visibility_from_alpha(alphas=alphas, packed_info=packed_info,
-                                                     early_stop_eps=early_stop_eps,
-                                                     alpha_thre=alpha_thre)
-            ray_indices, t_starts, t_ends = ray_indices[masks], t_starts[masks], t_ends[masks]
+            near = near + torch.rand_like(near) * render_step_size
+        ray_indices, t_starts, t_ends, starts, counts = self._march(rays_o, rays_d, near, far, render_step_size,
+                                                                    cone_angle)
+        field = sigma_fn if sigma_fn is not None else alpha_fn
+        if field is not None and (alpha_thre > 0.0 or early_stop_eps > 0.0):
+            n = t_starts.shape[0]
+            values = field(t_starts, t_ends, ray_indices) if n else torch.empty((0,), device=t_starts.device)
+            if values.shape != t_starts.shape:
+                raise AssertionError("{} must have shape of (N,)! Got {}".format(
+                    "sigmas" if sigma_fn is not None else "alphas", values.shape))
+            # the threshold is capped by the grid's mean occupancy ON THE DEVICE (the reference reads it back)
+            cap = self.occs.mean().reshape(1) if alpha_thre > 0.0 else None
+            mask, kept = _K.render_visibility(starts, counts, values.float().contiguous(), t_starts, t_ends,
+                                              from_alpha=sigma_fn is None, early_stop_eps=early_stop_eps,
+                                              alpha_thre=alpha_thre, alpha_thre_cap=cap)
+            ray_indices, t_starts, t_ends, starts, counts = _K.compact_samples(starts, counts, mask, kept,
+                                                                               t_starts, t_ends)
+        self.last_packed_info = torch.stack([starts, counts], dim=-1)
         return ray_indices, t_starts, t_ends
 
+    # ------------------------------------------------------------------------------------- upkeep
     @torch.no_grad()
     def update_every_n_steps(self, step: int, occ_eval_fn: Callable, occ_thre: float = 1e-2,
                              ema_decay: float = 0.95, warmup_steps: int = 256, n: int = 16) -> None:
+        """Refresh the grid on every n-th training step (a no-op on the others)."""
         if not self.training:
-            raise RuntimeError("You should only call this function only during training. "
-                               "Please call _update() directly if you want to update the "
-                               "field during inference.")
-        if step % n == 0 and self.training:
-            self._update(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre, ema_decay=ema_decay,
-                         warmup_steps=warmup_steps)
-
-    @torch.no_grad()
-    def mark_invisible_cells(self, K: Tensor, c2w: Tensor, width: int, height: int,
-                             near_plane: float = 0.0, chunk: int = 32 ** 3) -> None:
-        """Set occs = -1 for cells no camera sees (or that sit in front of a camera's near plane)."""
-        assert K.dim() == 3 and K.shape[1:] == (3, 3)
-        assert c2w.dim() == 3 and (c2w.shape[1:] == (3, 4) or c2w.shape[1:] == (4, 4))
-        assert K.shape[0] == c2w.shape[0] or K.shape[0] == 1
-        n_cams = c2w.shape[0]
-        w2c_R = c2w[:, :3, :3].transpose(2, 1)
-        w2c_T = -w2c_R @ c2w[:, :3, 3:]
-        for lvl, indices in enumerate(self._get_all_cells()):
-            coords = self.grid_coords[indices]
-            lo, hi = self.aabbs[lvl, :3], self.aabbs[lvl, 3:]
-            for i in range(0, len(indices), chunk):
-                x = coords[i:i + chunk] / (self.resolution - 1)
-                idx = indices[i:i + chunk]
-                xyz_w = (lo + x * (hi - lo)).T
-                uvd = K @ (w2c_R @ xyz_w + w2c_T)
-                uv = uvd[:, :2] / uvd[:, 2:]
-                in_image = ((uvd[:, 2] >= 0) & (uv[:, 0] >= 0) & (uv[:, 0] < width)
-                            & (uv[:, 1] >= 0) & (uv[:, 1] < height))
-                seen = ((uvd[:, 2] >= near_plane) & in_image).sum(0) / n_cams
-                too_near = ((uvd[:, 2] < near_plane) & in_image).any(0)
-                valid = (seen > 0) & (~too_near)
-                self.occs[lvl * self.cells_per_lvl + idx] = torch.where(valid, 0.0, -1.0)
+            raise RuntimeError("You should only call this function only during training. Please call _update() "
+                               "directly if you want to update the field during inference.")
+        if step % n:
+            return
+        self._update(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre, ema_decay=ema_decay,
+                     warmup_steps=warmup_steps)
 
     @torch.no_grad()
     def _get_all_cells(self) -> List[Tensor]:
-        out = []
-        for lvl in range(self.levels):
-            cell_ids = lvl * self.cells_per_lvl + self.grid_indices
-            out.append(self.grid_indices[self.occs[cell_ids] >= 0.0])
-        return out
+        """Per level: indices of the cells that are not marked invisible (occs >= 0)."""
+        per_level = self.occs.view(self.levels, self.cells_per_lvl)
+        return [self.grid_indices[per_level[k] >= 0.0] for k in range(self.levels)]
 
     @torch.no_grad()
     def _sample_uniform_and_occupied_cells(self, n: int) -> List[Tensor]:
-        out = []
-        for lvl in range(self.levels):
-            uniform = torch.randint(self.cells_per_lvl, (n,), device=self.device)
-            uniform = uniform[self.occs[lvl * self.cells_per_lvl + uniform] >= 0.0]
-            occupied = torch.nonzero(self.binaries[lvl].flatten())[:, 0]
-            if n < len(occupied):
-                occupied = occupied[torch.randint(len(occupied), (n,), device=self.device)]
-            out.append(torch.cat([uniform, occupied], dim=0))
-        return out
+        """Per level: n uniformly drawn (visible) cells followed by up to n of the occupied ones."""
+        picks = []
+        per_level = self.occs.view(self.levels, self.cells_per_lvl)
+        for k in range(self.levels):
+            drawn = torch.randint(self.cells_per_lvl, (n,), device=self.device)
+            drawn = drawn[per_level[k][drawn] >= 0.0]
+            occupied = self.binaries[k].reshape(-1).nonzero()[:, 0]
+            if occupied.shape[0] > n:
+                occupied = occupied[torch.randint(occupied.shape[0], (n,), device=self.device)]
+            picks.append(torch.cat([drawn, occupied]))
+        return picks
 
     @torch.no_grad()
-    def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01,
-                ema_decay: float = 0.95, warmup_steps: int = 256) -> None:
-        """EMA update of `occs` from `occ_eval_fn` at jittered cell positions, then re-threshold."""
-        if step < warmup_steps:
-            lvl_indices = self._get_all_cells()
-        else:
-            lvl_indices = self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4)
-        for lvl, indices in enumerate(lvl_indices):
-            coords = self.grid_coords[indices]
-            x = (coords + torch.rand_like(coords, dtype=torch.float32)) / self.resolution
-            x = self.aabbs[lvl, :3] + x * (self.aabbs[lvl, 3:] - self.aabbs[lvl, :3])
-            occ = occ_eval_fn(x).squeeze(-1)
-            cell_ids = lvl * self.cells_per_lvl + indices
-            self.occs[cell_ids] = torch.maximum(self.occs[cell_ids] * ema_decay, occ)
-        thre = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
-        self.binaries = (self.occs > thre).view(self.binaries.shape)
+    def _update(self, step: int, occ_eval_fn: Callable, occ_thre: float = 0.01, ema_decay: float = 0.95,
+                warmup_steps: int = 256) -> None:
+        """occs <- max(decay * occs, occ_eval_fn(jittered cell position)) on every cell while warming up, on a
+        quarter uniformly drawn + up to a quarter occupied cells afterwards; binaries <- occs above
+        min(mean of the visible cells, occ_thre)."""
+        cells = (self._get_all_cells() if step < warmup_steps
+                 else self._sample_uniform_and_occupied_cells(self.cells_per_lvl // 4))
+        for k, idx in enumerate(cells):
+            corner = self.grid_coords[idx]
+            unit = (corner + torch.rand_like(corner, dtype=torch.float32)) / self.resolution
+            lo, hi = self.aabbs[k, :3], self.aabbs[k, 3:]
+            seen = occ_eval_fn(lo + unit * (hi - lo)).squeeze(-1)
+            slot = idx + k * self.cells_per_lvl
+            self.occs[slot] = torch.maximum(self.occs[slot] * ema_decay, seen)
+        level = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
+        self.binaries = (self.occs > level).view(self.binaries.shape)
 
-
-def _meshgrid3d(res: Tensor, device: Union[torch.device, str] = "cpu") -> Tensor:
-    assert len(res) == 3
-    rx, ry, rz = res.tolist()
-    axes = [torch.arange(r, dtype=torch.long) for r in (rx, ry, rz)]
-    return torch.stack(torch.meshgrid(axes, indexing="ij"), dim=-1).to(device)
+    @torch.no_grad()
+    def mark_invisible_cells(self, K: Tensor, c2w: Tensor, width: int, height: int, near_plane: float = 0.0,
+                             chunk: int = 32 ** 3) -> None:
+        """occs <- -1 for cells that no camera sees, or that lie between some camera and its near plane while
+        projecting into its image; 0 for the others.  K (n,3,3) or (1,3,3); c2w (n,3,4) or (n,4,4)."""
+        if K.dim() != 3 or tuple(K.shape[1:]) != (3, 3):
+            raise AssertionError("K must be (N, 3, 3)")
+        if c2w.dim() != 3 or tuple(c2w.shape[1:]) not in ((3, 4), (4, 4)):
+            raise AssertionError("c2w must be (N, 3, 4) or (N, 4, 4)")
+        if K.shape[0] not in (1, c2w.shape[0]):
+            raise AssertionError("K must hold one matrix, or one per camera")
+        rot_t = c2w[:, :3, :3].transpose(1, 2)                   # world -> camera rotation
+        shift = -(rot_t @ c2w[:, :3, 3:])                        # (n, 3, 1)
+        steps = (self.resolution - 1).to(torch.float32)
+        for k, idx in enumerate(self._get_all_cells()):
+            lo, hi = self.aabbs[k, :3], self.aabbs[k, 3:]
+            for a in range(0, idx.shape[0], chunk):
+                part = idx[a:a + chunk]
+                world = lo + (self.grid_coords[part] / steps) * (hi - lo)           # cell corners, (m, 3)
+                pix = K @ (rot_t @ world.T + shift)                                  # (n, 3, m): u*d, v*d, d
+                depth = pix[:, 2]
+                u, v = pix[:, 0] / depth, pix[:, 1] / depth
+                framed = (depth >= 0) & (u >= 0) & (u < width) & (v >= 0) & (v < height)
+                seen = (framed & (depth >= near_plane)).any(dim=0)
+                too_close = (framed & (depth < near_plane)).any(dim=0)
+                self.occs[part + k * self.cells_per_lvl] = torch.where(seen & ~too_close, 0.0, -1.0)

@@ -1,7 +1,14 @@
-"""Render harness: occupancy-grid sampling + volume rendering of a radiance field — host mirror of
-examples/utils.py (`set_random_seed` :77-80, `render_image_with_occgrid` :83-216,
-`render_image_with_occgrid_test` :316-489) and examples/datasets/utils.py (`Rays`, `namedtuple_map`).
-Same signatures and return tuples; every kernel underneath is HIP (cnc_amd.nerfacc, GridEncoder)."""
+"""Image rendering with an occupancy-grid sampler: the two functions the CNC drivers call,
+`render_image_with_occgrid` (training batches, chunked evaluation) and `render_image_with_occgrid_test`
+(whole-image evaluation that marches all rays a few steps at a time), plus `Rays`, `namedtuple_map`,
+`set_random_seed` and the scene lists — the names of the reference's examples/utils.py (:77-80, :83-216,
+:316-489) and examples/datasets/utils.py, with the same arguments and return tuples.
+
+What differs is underneath: sample positions, visibility filtering, compositing and the in-place
+accumulation of the iterative render are single HIP kernels (cnc_amd/csrc/march.hip, volrend.hip), and the
+(start, count) table of the samples is handed from the sampler to the compositor instead of being rebuilt
+from `ray_indices`.
+"""
 from __future__ import annotations
 
 import collections
@@ -12,19 +19,7 @@ import numpy as np
 import torch
 
 from .nerfacc import OccGridEstimator
-from .nerfacc.grid import ray_aabb_intersect, traverse_grids
-from .nerfacc.volrend import accumulate_along_rays_, render_weight_from_density, rendering
-
-
-def _sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends):
-    """(positions, directions) of the samples; the fused kernel on the GPU, the reference's
-    expression elsewhere (rays are never differentiated)."""
-    if rays_o.is_cuda and ray_indices.dtype == torch.int64:
-        from .backends import nerfacc_cuda as _C
-        return _C.sample_positions(rays_o.contiguous(), rays_d.contiguous(), ray_indices.contiguous(),
-                                   t_starts.contiguous(), t_ends.contiguous(), want_dirs=True)
-    o, d = rays_o[ray_indices], rays_d[ray_indices]
-    return o + d * (t_starts + t_ends)[:, None] / 2.0, d
+from .nerfacc.volrend import rendering
 
 Rays = collections.namedtuple("Rays", ("origins", "viewdirs"))
 
@@ -33,6 +28,7 @@ TANKS_SCENES = ["Barn", "Caterpillar", "Family", "Ignatius", "Truck"]
 
 
 def namedtuple_map(fn, tup):
+    """fn over the fields of a namedtuple, keeping None fields."""
     return type(tup)(*(None if x is None else fn(x) for x in tup))
 
 
@@ -42,59 +38,70 @@ def set_random_seed(seed):
     torch.manual_seed(seed)
 
 
-def _flatten(rays):
-    shape = rays.origins.shape
-    if len(shape) == 3:
-        n = shape[0] * shape[1]
-        rays = namedtuple_map(lambda r: r.reshape([n] + list(r.shape[2:])), rays)
-    else:
-        n = shape[0]
-    return rays, shape, n
+def _as_ray_list(rays):
+    """Rays of an image (H, W, 3) or a batch (N, 3) -> flat (N, 3) origins / directions + the leading shape."""
+    lead = tuple(rays.origins.shape[:-1])
+    if len(lead) == 2:
+        rays = namedtuple_map(lambda r: r.reshape(lead[0] * lead[1], *r.shape[2:]), rays)
+    return rays, lead
+
+
+def _mid_points(origins, dirs, ray_indices, t_starts, t_ends):
+    """o + d (t_start + t_end) / 2 and d for every sample: one kernel on the GPU."""
+    if origins.is_cuda and ray_indices.dtype == torch.int64:
+        from .backends import nerfacc_cuda as _C
+        return _C.sample_positions(origins.contiguous(), dirs.contiguous(), ray_indices.contiguous(),
+                                   t_starts.contiguous(), t_ends.contiguous(), want_dirs=True)
+    d = dirs[ray_indices]
+    return origins[ray_indices] + d * (t_starts + t_ends)[:, None] / 2.0, d
+
+
+class _FieldOnRays:
+    """The two callbacks the sampler / compositor want, bound to one set of rays."""
+
+    def __init__(self, field, origins, dirs, with_positions):
+        self.field, self.o, self.d, self.with_positions = field, origins, dirs, with_positions
+
+    def density(self, t_starts, t_ends, ray_indices):
+        x, _ = _mid_points(self.o, self.d, ray_indices, t_starts, t_ends)
+        return self.field.query_density(x).squeeze(-1)
+
+    def colour_and_density(self, t_starts, t_ends, ray_indices):
+        x, v = _mid_points(self.o, self.d, ray_indices, t_starts, t_ends)
+        rgb, sigma = self.field(x, v)
+        sigma = sigma.squeeze(-1)
+        return (rgb, sigma, x) if self.with_positions else (rgb, sigma)
 
 
 def render_image_with_occgrid(radiance_field: torch.nn.Module, estimator: OccGridEstimator, rays: Rays,
-                              near_plane: float = 0.0, far_plane: float = 1e10,
-                              render_step_size: float = 1e-3, render_bkgd: Optional[torch.Tensor] = None,
-                              cone_angle: float = 0.0, alpha_thre: float = 0.0,
-                              test_chunk_size: int = 8192, timestamps: Optional[torch.Tensor] = None,
-                              return_extra=False, tmp=None):
-    """Training / chunked-eval render: sample with the estimator (density pre-pass for visibility),
-    then query the field with gradients and composite.  Returns (rgb, opacity, depth, n_samples[, extras])."""
-    rays, rays_shape, num_rays = _flatten(rays)
-
-    def positions_of(t_starts, t_ends, ray_indices):
-        # o + d * (t_starts + t_ends) / 2 and d, one kernel (examples/utils.py:251-262)
-        return _sample_positions(chunk_rays.origins, chunk_rays.viewdirs, ray_indices, t_starts, t_ends)
-
-    def sigma_fn(t_starts, t_ends, ray_indices):
-        positions, _ = positions_of(t_starts, t_ends, ray_indices)
-        return radiance_field.query_density(positions).squeeze(-1)
-
-    def rgb_sigma_fn(t_starts, t_ends, ray_indices):
-        positions, dirs = positions_of(t_starts, t_ends, ray_indices)
-        rgbs, sigmas = radiance_field(positions, dirs)
-        return rgbs, sigmas.squeeze(-1), positions
-
-    chunk = torch.iinfo(torch.int32).max if radiance_field.training else test_chunk_size
-    results = []
-    extras = None
-    for i in range(0, num_rays, chunk):
-        chunk_rays = namedtuple_map(lambda r: r[i:i + chunk], rays)
+                              near_plane: float = 0.0, far_plane: float = 1e10, render_step_size: float = 1e-3,
+                              render_bkgd: Optional[torch.Tensor] = None, cone_angle: float = 0.0,
+                              alpha_thre: float = 0.0, test_chunk_size: int = 8192,
+                              timestamps: Optional[torch.Tensor] = None, return_extra=False, tmp=None):
+    """(rgb, opacity, depth, n_samples[, extras]) for a batch or an image of rays.  Training renders every
+    ray in one go with jittered sample offsets; evaluation goes `test_chunk_size` rays at a time.  For each
+    chunk the estimator picks the samples (a gradient-free density pass decides visibility), then the field is
+    queried with gradients and composited."""
+    if timestamps is not None:
+        raise NotImplementedError("time-dependent fields (dnerf) are outside the CNC path")
+    rays, lead = _as_ray_list(rays)
+    total = rays.origins.shape[0]
+    training = radiance_field.training
+    per_chunk = total if training else test_chunk_size
+    parts, n_samples, extras = [], 0, None
+    for first in range(0, total, max(per_chunk, 1)):
+        o, d = rays.origins[first:first + per_chunk], rays.viewdirs[first:first + per_chunk]
+        fn = _FieldOnRays(radiance_field, o, d, with_positions=True)
         ray_indices, t_starts, t_ends = estimator.sampling(
-            chunk_rays.origins, chunk_rays.viewdirs, sigma_fn=sigma_fn, near_plane=near_plane,
-            far_plane=far_plane, render_step_size=render_step_size, stratified=radiance_field.training,
-            cone_angle=cone_angle, alpha_thre=alpha_thre)
-        rgb, opacity, depth, extras = rendering(t_starts, t_ends, ray_indices,
-                                                n_rays=chunk_rays.origins.shape[0],
-                                                rgb_sigma_fn=rgb_sigma_fn, render_bkgd=render_bkgd)
-        results.append((rgb, opacity, depth, len(t_starts)))
-    colors = torch.cat([r[0] for r in results], dim=0)
-    opacities = torch.cat([r[1] for r in results], dim=0)
-    depths = torch.cat([r[2] for r in results], dim=0)
-    n_samples = sum(r[3] for r in results)
-    out = (colors.view((*rays_shape[:-1], -1)), opacities.view((*rays_shape[:-1], -1)),
-           depths.view((*rays_shape[:-1], -1)), n_samples)
-    return out + (extras,) if return_extra else out
+            o, d, sigma_fn=fn.density, near_plane=near_plane, far_plane=far_plane,
+            render_step_size=render_step_size, stratified=training, cone_angle=cone_angle, alpha_thre=alpha_thre)
+        rgb, opacity, depth, extras = rendering(t_starts, t_ends, ray_indices, n_rays=o.shape[0],
+                                                rgb_sigma_fn=fn.colour_and_density, render_bkgd=render_bkgd,
+                                                packed_info=getattr(estimator, "last_packed_info", None))
+        parts.append((rgb, opacity, depth))
+        n_samples += t_starts.shape[0]
+    rgb, opacity, depth = (torch.cat(p, dim=0).view(*lead, -1) for p in zip(*parts))
+    return (rgb, opacity, depth, n_samples, extras) if return_extra else (rgb, opacity, depth, n_samples)
 
 
 @torch.no_grad()
@@ -104,67 +111,70 @@ def render_image_with_occgrid_test(max_samples: int, radiance_field: torch.nn.Mo
                                    render_bkgd: Optional[torch.Tensor] = None, cone_angle: float = 0.0,
                                    alpha_thre: float = 0.0, early_stop_eps: float = 1e-4,
                                    timestamps: Optional[torch.Tensor] = None):
-    """Whole-image evaluation render: march all rays a bounded number of steps at a time (more steps
-    per round as rays die), accumulate in place, restart the survivors from their termination
-    planes (examples/utils.py:395-478)."""
-    rays, rays_shape, num_rays = _flatten(rays)
-    rays_o, rays_d = rays.origins, rays.viewdirs
-    device = rays_o.device
+    """Evaluation render of all rays together, a bounded number of march steps per round: rays that became
+    opaque (opacity > 1 - early_stop_eps) or left the grid drop out, the survivors continue from where they
+    stopped, and the fewer are alive the more steps each gets (num_rays // alive, at most 64).  Returns
+    (rgb, opacity, depth, n_samples)."""
+    if timestamps is not None:
+        raise NotImplementedError("time-dependent fields (dnerf) are outside the CNC path")
+    from .backends import nerfacc_cuda as _C
+    from .backends import volrend_backend as _K
+    rays, lead = _as_ray_list(rays)
+    o, d = rays.origins.contiguous(), rays.viewdirs.contiguous()
+    n, dev = o.shape[0], o.device
+    fn = _FieldOnRays(radiance_field, o, d, with_positions=False)
+    rgb = torch.zeros(n, 3, device=dev)
+    opacity = torch.zeros(n, 1, device=dev)
+    depth = torch.zeros(n, 1, device=dev)
 
-    def rgb_sigma_fn(t_starts, t_ends, ray_indices):
-        positions, d = _sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends)
-        rgbs, sigmas = radiance_field(positions, d)
-        return rgbs, sigmas.squeeze(-1)
-
-    opacity = torch.zeros(num_rays, 1, device=device)
-    depth = torch.zeros(num_rays, 1, device=device)
-    rgb = torch.zeros(num_rays, 3, device=device)
-    ray_mask = torch.ones(num_rays, device=device).bool()
-    min_samples = 1 if cone_angle == 0 else 4
-    iter_samples = total_samples = 0
-    near_planes = torch.full_like(rays_o[..., 0], fill_value=near_plane)
-    far_planes = torch.full_like(rays_o[..., 0], fill_value=far_plane)
-
-    t_mins, t_maxs, hits = ray_aabb_intersect(rays_o, rays_d, estimator.aabbs)
-    n_grids = estimator.binaries.size(0)
-    if n_grids > 1:
-        t_sorted, t_indices = torch.sort(torch.cat([t_mins, t_maxs], -1), -1)
+    # where each ray enters / leaves the grid boxes, sorted along the ray (one box: already in order)
+    boxes = estimator.aabbs.contiguous()
+    t_in, t_out, hit = _C.ray_aabb_intersect(o, d, boxes, -float("inf"), float("inf"), float("inf"))
+    crossings = torch.cat([t_in, t_out], dim=-1)
+    if boxes.shape[0] > 1:
+        crossings, order = torch.sort(crossings, dim=-1)
     else:
-        t_sorted = torch.cat([t_mins, t_maxs], -1)
-        t_indices = torch.arange(0, n_grids * 2, device=device, dtype=torch.int64).expand(num_rays, n_grids * 2)
-    opc_thre = 1 - early_stop_eps
-    rgbs = rgb
+        order = torch.arange(2, device=dev, dtype=torch.int64).expand(n, 2)
+    crossings, order, hit = crossings.contiguous(), order.contiguous(), hit.contiguous()
+    grids = estimator.binaries.contiguous()
 
-    while iter_samples < max_samples:
-        n_alive = ray_mask.sum().item()
+    alive = torch.ones(n, dtype=torch.bool, device=dev)
+    resume_at = torch.full((n,), float(near_plane), device=dev)
+    far = torch.full((n,), float(far_plane), device=dev)
+    fewest = 1 if cone_angle == 0 else 4
+    opaque = 1.0 - early_stop_eps
+    marched = shaded = 0
+    while marched < max_samples:
+        n_alive = int(alive.sum().item())
         if n_alive == 0:
             break
-        n_samples = max(min(num_rays // n_alive, 64), min_samples)
-        iter_samples += n_samples
-        intervals, samples, termination_planes = traverse_grids(
-            rays_o, rays_d, estimator.binaries, estimator.aabbs, near_planes, far_planes,
-            render_step_size, cone_angle, n_samples, True, ray_mask, t_sorted, t_indices, hits)
-        t_starts = intervals.vals[intervals.is_left]
-        t_ends = intervals.vals[intervals.is_right]
-        ray_indices = samples.ray_indices[samples.is_valid]
-        packed_info = samples.packed_info
-        rgbs, sigmas = rgb_sigma_fn(t_starts, t_ends, ray_indices)
-        weights, _, alphas = render_weight_from_density(
-            t_starts, t_ends, sigmas, ray_indices=ray_indices, n_rays=num_rays,
-            prefix_trans=1 - opacity[ray_indices].squeeze(-1))
-        if alpha_thre > 0:
-            vis = alphas >= alpha_thre
-            ray_indices, rgbs, weights, t_starts, t_ends = (ray_indices[vis], rgbs[vis], weights[vis],
-                                                            t_starts[vis], t_ends[vis])
-        accumulate_along_rays_(weights, values=rgbs, ray_indices=ray_indices, outputs=rgb)
-        accumulate_along_rays_(weights, values=None, ray_indices=ray_indices, outputs=opacity)
-        accumulate_along_rays_(weights, values=(t_starts + t_ends)[..., None] / 2.0,
-                               ray_indices=ray_indices, outputs=depth)
-        near_planes = termination_planes
-        ray_mask = torch.logical_and(opacity.view(-1) <= opc_thre, packed_info[:, 1] == n_samples)
-        total_samples += ray_indices.shape[0]
-
-    rgb = rgb + render_bkgd * (1.0 - opacity)
-    depth = depth / opacity.clamp_min(torch.finfo(rgbs.dtype).eps)
-    return (rgb.view((*rays_shape[:-1], -1)), opacity.view((*rays_shape[:-1], -1)),
-            depth.view((*rays_shape[:-1], -1)), total_samples)
+        steps = max(min(n // n_alive, 64), fewest)
+        marched += steps
+        intervals, samples, resume_at = _C.traverse_grids(o, d, alive, grids, boxes, crossings, order, hit,
+                                                          resume_at, far, render_step_size, cone_angle, True, True,
+                                                          True, steps, True)
+        counts = samples.chunk_cnts
+        ray_indices, t_starts, t_ends, starts = _K.samples_from_intervals(intervals, counts)
+        if t_starts.shape[0]:
+            rgbs, sigmas = fn.colour_and_density(t_starts, t_ends, ray_indices)
+            rgbs, sigmas = rgbs.float().contiguous(), sigmas.float().contiguous()
+            if alpha_thre > 0:
+                # transparent samples are left out of the sums (but still attenuate what lies behind them)
+                w, _, a, _, _, _ = _K.volrend_forward(starts, counts, t_starts, t_ends, sigmas,
+                                                      opacity_in=opacity.view(-1), want_rays=False)
+                w = torch.where(a >= alpha_thre, w, torch.zeros_like(w))[:, None]
+                shaded += int((a >= alpha_thre).sum().item())
+                rgb.index_add_(0, ray_indices, w * rgbs)
+                opacity.index_add_(0, ray_indices, w)
+                depth.index_add_(0, ray_indices, w * ((t_starts + t_ends)[:, None] / 2.0))
+            else:
+                # transmittance continues from what the earlier rounds left: prefix = 1 - opacity so far
+                _K.volrend_forward(starts, counts, t_starts, t_ends, sigmas, rgbs, opacity_in=opacity.view(-1),
+                                   want_samples=False, accumulate_into=(rgb, opacity, depth))
+                shaded += t_starts.shape[0]
+        # a ray goes on if it is not opaque yet and used its whole step budget (else it left the grid)
+        alive = (opacity.view(-1) <= opaque) & (counts == steps)
+    if render_bkgd is not None:
+        rgb = rgb + render_bkgd * (1.0 - opacity)
+    depth = depth / opacity.clamp_min(torch.finfo(rgb.dtype).eps)
+    return rgb.view(*lead, -1), opacity.view(*lead, -1), depth.view(*lead, -1), shaded

@@ -220,7 +220,9 @@ class Trainer:
 
         self.bucket = None
         if self.world > 1:
-            self.bucket = cdist.GradBucket(list(self.field.parameters()) + list(self.context.parameters()))
+            plist = list(self.field.parameters()) + list(self.context.parameters())
+            self.bucket = cdist.GradBucket(plist)          # ray-loss gradients (all-reduced)
+            self.bucket_ctx = cdist.GradBucket(plist)      # entropy-loss gradients (replica-identical)
             base = self.context.rand_like
 
             def synced_rand_like(t):
@@ -262,19 +264,37 @@ class Trainer:
             bpp = bits_per_param
         self.opt.zero_grad(set_to_none=self.bucket is None)
         self.opt2.zero_grad(set_to_none=self.bucket is None)
-        if self.bucket is not None:
-            self.bucket.zero()
-            self.bucket.bind()
-        (loss * self.loss_scale).backward()
-        if self.bucket is not None:
-            self.bucket.bind()
-            self.bucket.allreduce(average=True)
+        if self.bucket is None:
+            (loss * self.loss_scale).backward()
+        else:
+            # Data-parallel step.  The ray loss differs per rank, the entropy loss does not (same tables, same
+            # window draw on every rank): so only the ray-loss gradient is exchanged, and its all-reduce runs
+            # on the communicator's stream WHILE the context-model backward fills a second bucket.  The
+            # entropy gradient is equal across ranks only up to the order of its float atomics (~1e-9
+            # relative), so the replicas are re-aligned to rank 0 at every occupancy refresh (below).
+            A, B = self.bucket, self.bucket_ctx
+            A.zero()
+            A.bind(force=True)
+            (mse * self.loss_scale).backward()
+            work = A.allreduce(average=False, async_op=True)
+            if c.lmbda > 0:
+                B.zero()
+                B.bind(force=True)
+                (c.lmbda * bpp * self.loss_scale).backward()
+            if work is not None:
+                work.wait()
+            A.flat.div_(self.world)
+            if c.lmbda > 0:
+                A.flat.add_(B.flat)
+            A.bind(force=True)
         self.opt.step()
         if c.lmbda > 0:
             self.opt2.step()
         self.sched.step()
         if c.lmbda > 0:
             self.sched2.step()
+        if self.bucket is not None and (step + 1) % c.step_update == 0:
+            cdist.broadcast_parameters(self.bucket.params)        # 161 MB every `step_update` steps
         # the step's scalars in one device->host copy
         mse_f, bpp_f = torch.stack([mse.detach(), torch.as_tensor(bpp, device=mse.device).detach().float()]).tolist()
         return {"mse": mse_f, "psnr": -10.0 * math.log10(max(mse_f, 1e-12)), "bpp": bpp_f,

@@ -323,6 +323,64 @@ int cnc_exclusive_prod_backward(const int64_t* chunk_starts, const int64_t* chun
                                 const float* grad_outputs, float* grad_inputs, uint32_t n_rays,
                                 int64_t n_edges, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Fused per-ray volume rendering  —  replaces the ATen op chains of nerfacc/volrend.py and
+ * nerfacc/pack.py (the reference has no native code here: SURVEY.md §7 item 5 asks for the fusion).
+ * Samples are flattened and ray-ordered; chunk_starts / chunk_cnts i64 [n_rays] delimit each ray.
+ * ---------------------------------------------------------------------------------------- */
+#define CNC_VOLREND_ACCUMULATE 1u  /* colors/opacity/depth += this call's sums (iterative evaluation render,
+                                      examples/utils.py:444-463: accumulate_along_rays_ x3)                  */
+#define CNC_VOLREND_FINALIZE   2u  /* depth /= max(opacity, eps); colors += render_bkgd * (1 - opacity)
+                                      (volrend.py:136-140); not with ACCUMULATE                              */
+
+/* render_weight_from_density + accumulate_along_rays x3 (volrend.py:258-266,363 / :142-153,546 / :116-140):
+ *   alpha_i = 1 - exp(-sigma_i dt_i),  T_i = exp(-sum_{j<i} sigma_j dt_j) [* (1 - opacity_in[ray])],  w_i = T_i alpha_i
+ *   colors[ray] = sum w_i rgb_i,  opacity[ray] = sum w_i,  depth[ray] = sum w_i (t_start_i + t_end_i)/2
+ * The running sum keeps the float association of exclusive_sum (scan.cu) — weights / trans / alphas equal the op
+ * chain's; the per-ray sums have no defined order in the reference (atomics).
+ * Nullable: rgbs (then colors must be NULL), opacity_in (per RAY: prefix transmittance = 1 - opacity_in,
+ * utils.py:431-436 passes the same value per sample), render_bkgd [3], every output.                          */
+int cnc_volrend_forward(const int64_t* chunk_starts, const int64_t* chunk_cnts, const float* t_starts,
+                        const float* t_ends, const float* sigmas, const float* rgbs /* [S,3] */,
+                        const float* opacity_in, const float* prefix_trans /* [S], nullable */,
+                        const float* render_bkgd, float* weights, float* trans, float* alphas,
+                        float* colors /* [n_rays,3] */, float* opacity, float* depth,
+                        uint32_t n_rays, uint32_t flags, void* stream);
+/* Backward of the above: dL/dsigma [S], dL/drgb [S,3] from dL/d(colors, opacity, depth) per ray (each
+ * nullable = zero) and optionally dL/dweights, dL/dtrans, dL/dalphas per sample (the reference's op chain is
+ * differentiable through all three).  weights / trans / alphas are the forward's outputs;
+ * opacity / depth (the forward's FINAL outputs) are needed with CNC_VOLREND_FINALIZE only.               */
+int cnc_volrend_backward(const int64_t* chunk_starts, const int64_t* chunk_cnts, const float* t_starts,
+                         const float* t_ends, const float* rgbs, const float* weights, const float* trans,
+                         const float* alphas, const float* opacity, const float* depth, const float* render_bkgd,
+                         const float* grad_colors, const float* grad_opacity, const float* grad_depth,
+                         const float* grad_weights, const float* grad_trans, const float* grad_alphas,
+                         float* grad_sigmas, float* grad_rgbs, uint32_t n_rays, uint32_t flags, void* stream);
+/* render_visibility_from_density / _from_alpha (volrend.py:425-475) as used by OccGridEstimator.sampling
+ * (occ_grid.py:186-232): mask[s] = T_s >= early_stop_eps [&& alpha_s >= thre when thre > 0], thre =
+ * min(alpha_thre, *alpha_thre_cap) with the cap read on the DEVICE (the reference's occs.mean().item());
+ * kept [n_rays] (nullable) = survivors per ray.  from_alpha: values are alphas (t_* unused).              */
+int cnc_render_visibility(const int64_t* chunk_starts, const int64_t* chunk_cnts, const float* t_starts,
+                          const float* t_ends, const float* sigmas_or_alphas, int32_t from_alpha,
+                          float early_stop_eps, float alpha_thre, const float* alpha_thre_cap, uint8_t* mask,
+                          int64_t* kept, uint32_t n_rays, void* stream);
+/* ray_indices[mask], t_starts[mask], t_ends[mask] (occ_grid.py:233-237) as one stable compaction:
+ * survivor k of ray r goes to out_starts[r] + k (out_starts = exclusive cumsum of `kept`).               */
+int cnc_compact_samples(const int64_t* chunk_starts, const int64_t* chunk_cnts, const int64_t* out_starts,
+                        const uint8_t* mask, const float* t_starts, const float* t_ends, float* out_t_starts,
+                        float* out_t_ends, int64_t* out_ray_indices, uint32_t n_rays, void* stream);
+/* intervals.vals[is_left], intervals.vals[is_right], samples.ray_indices[is_valid] (occ_grid.py:176-178,
+ * utils.py:408-410): the k-th left / right edge of a ray opens / closes its k-th sample.  iv_chunk_starts may be
+ * the over-allocated layout of traverse_grids; out_starts [n_rays] = packed sample starts.                  */
+int cnc_interval_edges_to_samples(const int64_t* iv_chunk_starts, const int64_t* iv_chunk_cnts,
+                                  const float* iv_vals, const uint8_t* is_left, const uint8_t* is_right,
+                                  const int64_t* out_starts, float* out_t_starts, float* out_t_ends,
+                                  int64_t* out_ray_indices /* nullable */, uint32_t n_rays, void* stream);
+/* pack_info (pack.py:11-49) on sorted ray_indices: first[r] / last[r] = first / one-past-last sample of
+ * ray r; both [n_rays], zero-filled by the caller (rays without samples keep 0 / 0).                      */
+int cnc_pack_bounds(const int64_t* ray_indices, int64_t n_samples, int64_t* first, int64_t* last,
+                    int64_t n_rays, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -335,6 +335,45 @@ def prod_backward(inputs, outputs, grad_outputs, chunk_starts, chunk_cnts, exclu
     return gi
 
 
+# ----------------------------------------------------------------------------- volume rendering
+def render_weight_from_density(t_starts, t_ends, sigmas, chunk_starts, chunk_cnts, prefix_trans=None):
+    """nerfacc/volrend.py:258-266,363 on flattened samples: float32 op by op, the running optical depth
+    through the restated exclusive_sum tile tree (scan.cu), exp in float32.  (weights, trans, alphas)."""
+    ts, te, sg = (_c(a, np.float32) for a in (t_starts, t_ends, sigmas))
+    sdt = (sg * (te - ts)).astype(np.float32)
+    alphas = (np.float32(1.0) - np.exp(-sdt, dtype=np.float32)).astype(np.float32)
+    before = segmented_scan(sdt, chunk_starts, chunk_cnts, exclusive=True)
+    trans = np.exp(-before, dtype=np.float32)
+    if prefix_trans is not None:
+        trans = (trans * _c(prefix_trans, np.float32)).astype(np.float32)
+    return (trans * alphas).astype(np.float32), trans, alphas
+
+
+def composite(weights, rgbs, t_starts, t_ends, ray_indices, n_rays, render_bkgd=None, finalize=True):
+    """accumulate_along_rays x3 + the tail of `rendering` (volrend.py:116-140): the sums are taken in
+    float64 (the reference's atomics have no order), then rounded.  (colors, opacity, depth) float32."""
+    w = np.asarray(weights, np.float64)
+    ri = np.asarray(ray_indices, np.int64)
+    mid = ((_c(t_starts, np.float32) + _c(t_ends, np.float32)) / np.float32(2.0)).astype(np.float64)
+    col = np.zeros((n_rays, 3)); op = np.zeros((n_rays, 1)); dp = np.zeros((n_rays, 1))
+    np.add.at(col, ri, w[:, None] * np.asarray(rgbs, np.float32).astype(np.float64))
+    np.add.at(op, ri, w[:, None])
+    np.add.at(dp, ri, (w * mid)[:, None])
+    if finalize:
+        dp = dp / np.maximum(op, np.finfo(np.float32).eps)
+        if render_bkgd is not None:
+            col = col + np.asarray(render_bkgd, np.float64)[None, :] * (1.0 - op)
+    return col.astype(np.float32), op.astype(np.float32), dp.astype(np.float32)
+
+
+def render_visibility(trans, alphas, early_stop_eps=1e-4, alpha_thre=0.0):
+    """volrend.py:425-475."""
+    vis = np.asarray(trans) >= np.float32(early_stop_eps)
+    if alpha_thre > 0:
+        vis &= np.asarray(alphas) >= np.float32(alpha_thre)
+    return vis
+
+
 # ----------------------------------------------------------------------------- range coder
 def rc_encode(p_one: np.ndarray, symbols: np.ndarray, prob_is_cdf1: bool = False) -> bytes:
     """Binary arithmetic coding of symbols in {0,1} with P(sym=1)=p_one, CDF [0, 1-p, 1]

@@ -83,3 +83,11 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_dist_helpers_refuse_an_uninitialised_world():
+    code = ("import os,sys;sys.path.insert(0,%r);os.environ.update(WORLD_SIZE='2',RANK='0',LOCAL_RANK='0');"
+            "import torch;from cnc_amd import dist as d;p=torch.nn.Parameter(torch.zeros(4));b=d.GradBucket([p]);"
+            "b.allreduce()") % ROOT
+    r = __import__('subprocess').run([sys.executable, "-c", code], capture_output=True, text=True, env={k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')})
+    assert r.returncode != 0 and "not initialised" in r.stderr

@@ -1,0 +1,100 @@
+"""The N > 1 control flow on a 1-GPU box: every rank on cuda:0, gloo instead of RCCL (the
+CNC_BENCH_ONE_DEVICE / CNC_BENCH_BACKEND and CNC_DIST_ONE_DEVICE / CNC_DIST_BACKEND hooks).
+ * `python bench.py --gpus 2` spawns its own ranks, all-reduces the table gradient inside the timed
+   region and reports n_gpus = 2;
+ * a 2-rank `Trainer` joins the process group by itself and its replicas hold identical parameters at the
+   re-alignment points (ray-loss gradients all-reduced while the context backward runs; entropy-loss gradients
+   are replica-identical up to atomic order; parameters broadcast every `step_update` steps)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_bench_spawns_two_ranks_and_allreduces(cuda):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-train-step"], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=_clean_env(CNC_BENCH_ONE_DEVICE="1", CNC_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]              # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert [x["rank"] for x in out["ranks"]] == [0, 1] and all(x["world_size"] == 2 for x in out["ranks"])
+    assert "allreduce(grad_table)" in out["kernels"] and out["kernels"]["allreduce(grad_table)"]["launches"] == 1
+    # whole-job value: both ranks' samples over the slowest rank's time
+    assert out["value"] > 0 and out["config"]["samples_per_step_rank0"] > 6e7
+    assert out["value"] * out["ms_per_step"] * 1e-3 > 1.5 * out["config"]["samples_per_step_rank0"]
+    assert "[bench rank 1]" in r.stderr and "[bench rank 0]" in r.stderr
+
+
+def test_bench_refuses_a_world_that_contradicts_gpus(cuda):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300,
+                       env=_clean_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="1"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+_TRAINER_WORKER = r"""
+import os, sys, json, torch
+sys.path.insert(0, {root!r})
+from cnc_amd.trainer import TrainConfig, Trainer
+cfg = TrainConfig(lmbda=2e-3, Pg_level=5, Pg_level_2D=3, log2_hashmap_size=12, log2_hashmap_size_2D=9,
+                  sample_num=3000, max_context_layer_num=3, n_features=2, n_neurons=32,
+                  resolutions_list=(10, 14, 18, 26, 34), resolutions_list_2D=(18, 34, 66),
+                  skip_levels_3D=(0, 1, 2), skip_levels_2D=(0,), max_steps=20, init_batch_size=512,
+                  target_sample_batch_size=1 << 14, grid_resolution=16, render_step_size=2e-2,
+                  milestones=(100, 130), warmup_iters=20, test_views=2, image_size=48, out_dir={out!r},
+                  step_update=4)
+tr = Trainer(cfg, device="cuda")
+assert torch.distributed.is_initialized() and torch.distributed.get_world_size() == 2
+stats = [tr.train_step(s) for s in range(8)]        # replicas are re-aligned after steps 3 and 7
+sums = [float(p.detach().double().sum()) for p in list(tr.field.parameters()) + list(tr.context.parameters())]
+absum = [float(p.detach().double().abs().sum()) for p in list(tr.field.parameters()) + list(tr.context.parameters())]
+rays = [s["num_rays"] for s in stats if s]
+print("RESULT " + json.dumps(dict(rank=tr.rank, device=str(tr.device), sums=sums, absum=absum, rays=rays,
+                                  mse=[s["mse"] for s in stats if s],
+                                  binaries=int(tr.estimator.binaries.sum()))), flush=True)
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+"""
+
+
+def test_two_rank_trainer_replicas_stay_identical(cuda, tmp_path):
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_TRAINER_WORKER.format(root=ROOT, out=str(tmp_path / "bits")))
+    procs = []
+    for rank in range(2):
+        env = _clean_env(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                         MASTER_PORT=str(port), CNC_DIST_ONE_DEVICE="1", CNC_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=900)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]))
+    a, b = sorted(outs, key=lambda d: d["rank"])
+    assert a["device"] == b["device"] == "cuda:0"          # the one-device hook
+    assert a["sums"] == b["sums"] and a["absum"] == b["absum"]      # bit-identical replicas
+    assert a["binaries"] == b["binaries"] and a["rays"] == b["rays"]
+    assert a["mse"] != b["mse"]                             # ... trained on different rays
+    assert sum(a["absum"]) > 0

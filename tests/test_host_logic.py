@@ -63,7 +63,8 @@ def test_occ_grid_update_matches_reference():
 
 
 def test_ray_aabb_torch_twin_and_enlarge():
-    from cnc_amd.nerfacc.grid import _enlarge_aabb, _ray_aabb_intersect
+    from cnc_amd.nerfacc.estimators.occ_grid import OccGridEstimator
+    from cnc_amd.nerfacc.grid import _ray_aabb_intersect
     g = np.load(os.path.join(GOLD, "ray_aabb.npz"))
     for k in range(3):
         near, far, miss = (float(v) for v in g[f"nfm_{k}"])
@@ -71,8 +72,11 @@ def test_ray_aabb_torch_twin_and_enlarge():
                                         torch.from_numpy(g["aabbs"]), near, far, miss)
         assert np.array_equal(h.numpy(), g[f"hit_{k}"])
         assert np.array_equal(t0.numpy(), g[f"t0_{k}"]) and np.array_equal(t1.numpy(), g[f"t1_{k}"])
-    a = _enlarge_aabb(torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]), 2.0)
-    assert a.tolist() == [-3, -3, -3, 3, 3, 3]
+    # nested levels: level k covers the region of interest scaled by 2^k about its centre (occ_grid.py:64-70)
+    est = OccGridEstimator([-1.5, -1.0, -0.5, 1.5, 2.0, 2.5], resolution=4, levels=3)
+    assert est.aabbs[0].tolist() == [-1.5, -1.0, -0.5, 1.5, 2.0, 2.5]
+    assert est.aabbs[1].tolist() == [-3.0, -2.5, -2.0, 3.0, 3.5, 4.0]
+    assert est.aabbs[2].tolist() == [-6.0, -5.5, -5.0, 6.0, 6.5, 7.0]
 
 
 def test_batched_volrend_and_scans_cpu():
@@ -214,3 +218,38 @@ def test_plan_binned_levels_host_only():
     assert rows == 1 << 19 and n == sum(1 for r in RES_3D_REF if r >= 288)
     # a coarse level after a fine one breaks the suffix
     assert plan_binned_levels([600, 20], [0, 1 << 19, (1 << 19) + 8000], 3, 8, 1 << 20) is None
+
+
+def test_mark_invisible_cells_matches_reference():
+    """tests/golden/render.npz: the reference's OccGridEstimator.mark_invisible_cells on seeded cameras."""
+    from cnc_amd.nerfacc import OccGridEstimator
+    g = np.load(os.path.join(GOLD, "render.npz"))
+    est = OccGridEstimator(roi_aabb=[-1.0, -1.0, -1.0, 1.0, 1.0, 1.0], resolution=12, levels=2)
+    W, H = (int(v) for v in g["mic_WH"])
+    est.mark_invisible_cells(torch.from_numpy(g["mic_K"]), torch.from_numpy(g["mic_c2w"]), W, H,
+                             near_plane=float(g["mic_near"]), chunk=500)
+    assert np.array_equal(est.occs.numpy(), g["mic_occs"])
+    assert (est.occs < 0).any() and (est.occs == 0).any()
+    # cells marked invisible are never picked for an update
+    assert all((est.occs[k * est.cells_per_lvl + idx] >= 0).all() for k, idx in enumerate(est._get_all_cells()))
+
+
+def test_rendering_generic_route_on_cpu_matches_reference():
+    """`rendering` / `render_weight_from_density` on CPU tensors (batched layout and flattened-with-
+    ray_indices layout) against the reference's outputs in tests/golden/render.npz."""
+    import cnc_amd.nerfacc as n
+    g = np.load(os.path.join(GOLD, "render.npz"))
+    t0, t1, sg, rgb = (torch.from_numpy(g[k]) for k in ("t_starts", "t_ends", "sigmas", "rgbs"))
+    R, M = sg.shape
+    w, tr, al = n.render_weight_from_density(t0, t1, sg)                      # batched
+    assert torch.allclose(w, torch.from_numpy(g["plain_weights"]), rtol=1e-6, atol=1e-9)
+    ri = torch.arange(R).repeat_interleave(M)
+    w2, tr2, al2 = n.render_weight_from_density(t0.reshape(-1), t1.reshape(-1), sg.reshape(-1), ray_indices=ri, n_rays=R)
+    assert torch.allclose(w2.view(R, M), torch.from_numpy(g["plain_weights"]), rtol=1e-6, atol=1e-9)
+    col, op, dep, extras = n.rendering(t0.reshape(-1), t1.reshape(-1), ri, n_rays=R,
+                                       rgb_sigma_fn=lambda a, b, c: (rgb.reshape(-1, 3), sg.reshape(-1), None),
+                                       render_bkgd=torch.from_numpy(g["bkgd"]))
+    assert torch.allclose(col, torch.from_numpy(g["plain_colors_bkgd"]), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(op, torch.from_numpy(g["plain_opacity"]), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(dep, torch.from_numpy(g["plain_depth"]), rtol=1e-5, atol=1e-6)
+    assert set(extras) == {"weights", "alphas", "trans", "sigmas", "rgbs", "positions"}

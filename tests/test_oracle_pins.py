@@ -255,3 +255,37 @@ def test_dy_dx_is_the_derivative_of_the_interpolation(oracle, D):
     gi = oracle.input_backward(g, dy)
     want = np.einsum("lnf,nldf->nd", g.astype(np.float64), dy.astype(np.float64))
     np.testing.assert_allclose(gi, want, rtol=0, atol=1e-5 * np.abs(want).max())
+
+
+def _render_golden():
+    g = np.load(os.path.join(GOLD, "render.npz"))
+    R, M = g["sigmas"].shape
+    starts = np.arange(R, dtype=np.int64) * M
+    cnts = np.full(R, M, np.int64)
+    ri = np.repeat(np.arange(R, dtype=np.int64), M)
+    return g, R, M, starts, cnts, ri
+
+
+@pytest.mark.parametrize("case", ["plain", "prefix"])
+def test_volume_rendering_matches_reference_functions(oracle, case):
+    """tests/golden/render.npz: the reference's own render_weight_from_density / accumulate_along_rays /
+    rendering tail (batched branches, run on CPU by make_golden_render.py) vs the oracle's flattened
+    restatement on the same rays.  The reference's batched branch sums with torch.cumsum, the flattened one
+    (and the oracle) with the 32-wide tile tree: same values up to float32 association."""
+    g, R, M, starts, cnts, ri = _render_golden()
+    flat = lambda a: np.ascontiguousarray(a.reshape(R * M, *a.shape[2:]))
+    prefix = flat(g["prefix"]) if case == "prefix" else None
+    w, tr, al = oracle.render_weight_from_density(flat(g["t_starts"]), flat(g["t_ends"]), flat(g["sigmas"]), starts,
+                                                  cnts, prefix_trans=prefix)
+    # alpha = 1 - exp(-x): an ulp of exp() near 1 is 1.2e-7 ABSOLUTE on alpha, whatever its size
+    assert np.allclose(al, flat(g[f"{case}_alphas"]), rtol=2e-6, atol=2.5e-7)
+    assert np.allclose(tr, flat(g[f"{case}_trans"]), rtol=3e-5, atol=1e-9)     # exp of a 45-term sum
+    assert np.allclose(w, flat(g[f"{case}_weights"]), rtol=3e-5, atol=2.5e-7)
+    col, op, dsum = oracle.composite(w, flat(g["rgbs"]), flat(g["t_starts"]), flat(g["t_ends"]), ri, R, finalize=False)
+    assert np.allclose(col, g[f"{case}_colors"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(op, g[f"{case}_opacity"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(dsum, g[f"{case}_depth_sum"], rtol=1e-5, atol=1e-7)
+    col, op, dep = oracle.composite(w, flat(g["rgbs"]), flat(g["t_starts"]), flat(g["t_ends"]), ri, R,
+                                    render_bkgd=g["bkgd"], finalize=True)
+    assert np.allclose(col, g[f"{case}_colors_bkgd"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(dep, g[f"{case}_depth"], rtol=1e-5, atol=1e-6)
