@@ -276,6 +276,16 @@ class Bernoulli_entropy(nn.Module):
         return -torch.log2(p) * pos_mask + -torch.log2(1 - p) * neg_mask
 
 
+def _zero_order_bits(pos_num, neg_num, Pg):
+    """pos * -log2(Pg) + neg * -log2(1 - Pg) (utils_bpp_acc.py:478-485) with the logarithms' arguments
+    floored at 1e-9 — below the smallest non-zero frequency any table can have (1 / 2^22), so every value the
+    reference can produce is unchanged.  A level whose entries all share one sign (Pg = 0 or 1; it happens to
+    coded levels of small tables within a few Adam steps) then costs 0 bits and has a zero gradient, where
+    the literal expression is 0 * inf: NaN in the forward, and — for all levels computed in one vector, as
+    `level_stats` does — a NaN gradient into the table even when that level's value is never used."""
+    return pos_num * (-torch.log2(Pg.clamp_min(1e-9))) + neg_num * (-torch.log2((1 - Pg).clamp_min(1e-9)))
+
+
 class CNC_context_models(nn.Module):
     MAX_POINTS_NUM_TO_OOM = 20000000
 
@@ -484,8 +494,7 @@ class CNC_context_models(nn.Module):
         ttl = _level_consts(off, params_q.shape[1], params_q.device)[2]
         pos_num, neg_num = (ttl + sums) / 2.0, (ttl - sums) / 2.0
         Pg = pos_num / ttl
-        bits = pos_num * (-torch.log2(Pg)) + neg_num * (-torch.log2(1 - Pg))
-        return Pg, bits
+        return Pg, _zero_order_bits(pos_num, neg_num, Pg)
 
     def get_BiRF_wentropy_leveln(self, params_q, n, offsets_list=None):
         """Level frequency Pg_n = #(+1)/numel and the zero-order bit count (utils_bpp_acc.py:472-486)."""
@@ -496,8 +505,7 @@ class CNC_context_models(nn.Module):
         s = torch.sum(level)
         pos_num, neg_num = (ttl + s) / 2.0, (ttl - s) / 2.0
         Pg_n = pos_num / ttl
-        bits = pos_num * (-torch.log2(Pg_n)) + neg_num * (-torch.log2(1 - Pg_n))
-        return Pg_n, bits, ttl
+        return Pg_n, _zero_order_bits(pos_num, neg_num, Pg_n), ttl
 
     def init_binary_vxl_coords(self, scale=512):
         t = scale // self.binary_vxl_len

@@ -30,6 +30,9 @@ def test_train_encode_decode_roundtrip(cuda, tmp_path):
     assert first is not None and first["n_rendering_samples"] > 0 and first["bpp"] > 0
     last = tr.train(steps=150, log=None)
     assert last["mse"] < first["mse"] * 0.5                      # it learns
+    # no table went NaN on the way (a level whose entries all share a sign has Pg = 0 or 1: its zero-order
+    # bit count must stay finite, and so must its gradient)
+    assert all(torch.isfinite(p).all() for p in list(tr.field.parameters()) + list(tr.context.parameters()))
     assert last["num_rays"] != 512                                # adaptive ray budget kicked in
     psnr_before = tr.evaluate()
     assert psnr_before > 12.0
