@@ -167,12 +167,8 @@ class _cnt_np_embed_planned(Function):
         return None, grad_embeddings, None
 
 
-def encoder(x, p, file_name):
-    """Code x in {-1,+1} with P(x=+1)=p into `file_name` (.b); returns the size in bits
-    (utils_bpp_acc.py:77-93)."""
-    assert file_name[-2:] == ".b"
-    x = x.detach().to(torch.float32).cpu().contiguous().view(-1)
-    p = p.detach().to(torch.float32).cpu().contiguous().view(-1)
+def _encode_host(x, p, file_name):
+    """x, p: contiguous float32 HOST tensors.  Writes the .b file, returns its size in bits."""
     n = x.numel()
     L = _codec_lib()
     cap = int(L.cnc_rc_bound(n))
@@ -185,17 +181,93 @@ def encoder(x, p, file_name):
     return int(nbytes) * 8
 
 
+def _decode_host(p, file_name):
+    with open(file_name, "rb") as fin:
+        stream = np.frombuffer(fin.read(), dtype=np.uint8)
+    out = torch.empty(p.numel(), dtype=torch.float32)
+    _codec_lib().cnc_rc_decode_pm1(p.data_ptr(), p.numel(), stream.ctypes.data, stream.shape[0], out.data_ptr())
+    return out
+
+
+def encoder(x, p, file_name):
+    """Code x in {-1,+1} with P(x=+1)=p into `file_name` (.b); returns the size in bits
+    (utils_bpp_acc.py:77-93)."""
+    assert file_name[-2:] == ".b"
+    x = x.detach().to(torch.float32).cpu().contiguous().view(-1)
+    p = p.detach().to(torch.float32).cpu().contiguous().view(-1)
+    return _encode_host(x, p, file_name)
+
+
 def decoder(p, file_name):
     """Inverse of `encoder`: returns float32 ±1 on p's device (utils_bpp_acc.py:95-110)."""
     assert file_name[-2:] == ".b"
     dvc = p.device
-    p = p.detach().to(torch.float32).cpu().contiguous().view(-1)
-    with open(file_name, "rb") as fin:
-        stream = np.frombuffer(fin.read(), dtype=np.uint8)
-    out = torch.empty(p.numel(), dtype=torch.float32)
-    _codec_lib().cnc_rc_decode_pm1(p.data_ptr(), p.numel(), stream.ctypes.data, stream.shape[0],
-                                   out.data_ptr())
-    return out.to(dvc)
+    return _decode_host(p.detach().to(torch.float32).cpu().contiguous().view(-1), file_name).to(dvc)
+
+
+class CoderPool:
+    """The reference codes its 33 streams one after the other, each behind two blocking `.cpu()` copies
+    (utils_bpp_acc.py:77-110, call sites :722-804).  The streams are independent files, so here they are
+    coded CONCURRENTLY: `encode` / `decode` start a device->pinned-host copy on a side stream and hand the
+    rest (wait for the copy, run the C coder — ctypes drops the GIL —, touch the file) to a worker thread;
+    the GPU goes on computing the next stream's probabilities meanwhile.  Same bytes as `encoder` /
+    `decoder` (tests/test_gpu_context.py).  At most `max_in_flight` streams hold pinned buffers at once."""
+
+    def __init__(self, workers=None, max_in_flight=8):
+        import concurrent.futures as cf
+        import threading
+        self.pool = cf.ThreadPoolExecutor(max_workers=workers or min(8, os.cpu_count() or 1))
+        self.slots = threading.Semaphore(max_in_flight)
+        self.copy_stream = {}
+
+    def _to_host(self, t):
+        """float32 flat copy of `t` in pinned memory + the event that says it has arrived."""
+        t = t.detach().to(torch.float32).contiguous().view(-1)
+        if not t.is_cuda:
+            return t, None
+        side = self.copy_stream.setdefault(t.device, torch.cuda.Stream(device=t.device))
+        side.wait_stream(torch.cuda.current_stream(t.device))
+        host = torch.empty(t.numel(), dtype=torch.float32, pin_memory=True)
+        with torch.cuda.stream(side):
+            host.copy_(t, non_blocking=True)
+            t.record_stream(side)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return host, ev
+
+    def encode(self, x, p, file_name):
+        """Future of the stream's size in bits."""
+        assert file_name[-2:] == ".b"
+        self.slots.acquire()
+        (xh, ex), (ph, ep) = self._to_host(x), self._to_host(p)
+
+        def job():
+            try:
+                for ev in (ex, ep):
+                    if ev is not None:
+                        ev.synchronize()
+                return _encode_host(xh, ph, file_name)
+            finally:
+                self.slots.release()
+        return self.pool.submit(job)
+
+    def decode(self, p, file_name):
+        """Future of the decoded float32 +-1 HOST tensor (pinned when p lives on a GPU)."""
+        assert file_name[-2:] == ".b"
+        self.slots.acquire()
+        ph, ep = self._to_host(p)
+
+        def job():
+            try:
+                if ep is not None:
+                    ep.synchronize()
+                return _decode_host(ph, file_name)
+            finally:
+                self.slots.release()
+        return self.pool.submit(job)
+
+    def shutdown(self):
+        self.pool.shutdown(wait=True)
 
 
 class align_and_pack(Function):
@@ -276,6 +348,37 @@ class Bernoulli_entropy(nn.Module):
         return -torch.log2(p) * pos_mask + -torch.log2(1 - p) * neg_mask
 
 
+def _level_table_path(cache_dir, R, rows, D):
+    return os.path.join(cache_dir, f"ctx_level_R{R}_T{rows}_D{D}.pt")
+
+
+def _load_level_table(cache_dir, R, rows, D, device):
+    """(pos_sorted int16 [R^D, D], unique_value, unique_cnt) of one level from the cache, or None."""
+    if not cache_dir:
+        return None
+    path = _level_table_path(cache_dir, R, rows, D)
+    if not os.path.exists(path):
+        return None
+    try:
+        blob = torch.load(path, map_location="cpu")
+        if blob.get("key") != (R, rows, D) or blob["pos_sorted"].shape != (R ** D, D):
+            return None
+        return tuple(blob[k].to(device) for k in ("pos_sorted", "unique_value", "unique_cnt"))
+    except Exception:          # a truncated or foreign file is a cache miss, never an error
+        return None
+
+
+def _save_level_table(cache_dir, R, rows, D, pos_sorted, unique_value, unique_cnt):
+    if not cache_dir:
+        return
+    os.makedirs(cache_dir, exist_ok=True)
+    path = _level_table_path(cache_dir, R, rows, D)
+    tmp = f"{path}.{os.getpid()}.tmp"
+    torch.save({"key": (R, rows, D), "pos_sorted": pos_sorted.cpu(), "unique_value": unique_value.cpu(),
+                "unique_cnt": unique_cnt.cpu()}, tmp)
+    os.replace(tmp, path)      # atomic: concurrent ranks never see a half-written table
+
+
 def _zero_order_bits(pos_num, neg_num, Pg):
     """pos * -log2(Pg) + neg * -log2(1 - Pg) (utils_bpp_acc.py:478-485) with the logarithms' arguments
     floored at 1e-9 — below the smallest non-zero frequency any table can have (1 / 2^22), so every value the
@@ -296,8 +399,14 @@ class CNC_context_models(nn.Module):
                  ste_binary=False, ste_multistep=False, add_noise=False, Q=100, quantize_epoch=1000,
                  Pg_level=-1, Pg_level_2D=-1, Rb=128, step_update=16, skip_levels_3D=(0, 1, 2, 3),
                  skip_levels_2D=(0,), use_dimension_wise=True, use_overlap_area_pool=True,
-                 device="cuda", dimension_wise_resolution=514, fused_segments=True, planned_votes=True):
+                 device="cuda", dimension_wise_resolution=514, fused_segments=True, planned_votes=True,
+                 table_cache_dir=None):
         super().__init__()
+        # on-disk cache of the per-level sorted vertex tables: a pure function of
+        # (resolution, table rows, num_dim), so levels are shared between configurations.  Opt-in (argument
+        # or CNC_CTX_TABLE_CACHE): on an MI355X rebuilding all 12 levels takes 1.2 s, about what reading
+        # 1.3 GB from disk costs; on slower devices the cache pays.
+        table_cache_dir = table_cache_dir or os.environ.get("CNC_CTX_TABLE_CACHE") or None
         dev = torch.device(device)
         self.dev = dev
         # hash fusion as one segmented-reduction kernel instead of pack -> multiply -> sum over a
@@ -365,13 +474,20 @@ class CNC_context_models(nn.Module):
         zero = torch.zeros(1, dtype=torch.long, device=dev)
         for i in reversed(range(Pg_level)):
             R = int(resolutions_list[i].item())
-            pos_grid = my_meshgrid3D(0, R, device=dev).view(-1, 3)
-            indexes = get_grid_index(int(offsets_list[i + 1] - offsets_list[i]), R, pos_grid)
-            # stable: vertices of one slot stay in lattice order on every device (the reference's
-            # unstable CUDA sort leaves that order unspecified; nothing downstream depends on it)
-            indexes_sorted, order = torch.sort(indexes, descending=False, dim=0, stable=True)
-            pos_sorted = torch.index_select(pos_grid.to(torch.int16), dim=0, index=order)
-            unique_value, unique_cnt = torch.unique(indexes_sorted, return_counts=True)
+            rows_i = int(offsets_list[i + 1] - offsets_list[i])
+            cached = _load_level_table(table_cache_dir, R, rows_i, num_dim, dev)
+            if cached is not None:
+                pos_sorted, unique_value, unique_cnt = cached
+            else:
+                pos_grid = my_meshgrid3D(0, R, device=dev).view(-1, 3)
+                indexes = get_grid_index(rows_i, R, pos_grid)
+                # stable: vertices of one slot stay in lattice order on every device (the reference's
+                # unstable CUDA sort leaves that order unspecified; nothing downstream depends on it)
+                indexes_sorted, order = torch.sort(indexes, descending=False, dim=0, stable=True)
+                pos_sorted = torch.index_select(pos_grid.to(torch.int16), dim=0, index=order)
+                unique_value, unique_cnt = torch.unique(indexes_sorted, return_counts=True)
+                del pos_grid, indexes, indexes_sorted, order
+                _save_level_table(table_cache_dir, R, rows_i, num_dim, pos_sorted, unique_value, unique_cnt)
             if R <= self.resolution_thresh:
                 # dense levels: random slot order so a sampled window is spatially spread (:311-315)
                 shuffle = self.randperm(unique_value.nelement()).to(dev)
@@ -380,7 +496,6 @@ class CNC_context_models(nn.Module):
             cumsum_list.insert(0, torch.cat([zero, torch.cumsum(unique_cnt, dim=0)]).to(torch.long))
             count_list.insert(0, unique_cnt)
             pos_sorted_list.insert(0, pos_sorted)
-            del pos_grid, indexes, indexes_sorted, order
         self.unique_value_list = unique_value_list
         self.pos_grid_sorted_list = pos_sorted_list
 
@@ -746,7 +861,9 @@ class CNC_context_models(nn.Module):
         params_q_yz = self.get_STE_params(Encoding_yz)
         params_q_xyz = self.get_STE_params(Encoding_xyz)
         F = self.n_features
-        ttl_bit_sum, encode_bits = 0, 0
+        ttl_bit_sum = 0
+        coders = CoderPool()
+        streams = []            # futures: every stream is an independent file, coded while the next is prepared
 
         idx_coords2 = self.get_idx_coords2(binary_vxl) if self.use_dimension_wise else None
         finest_3D = params_q_xyz[self.offsets_list[-2]:self.offsets_list[-1]]
@@ -768,7 +885,7 @@ class CNC_context_models(nn.Module):
                     bits_n = torch.sum(self.entropy_model(values_q, mean))
                     xs = values_q.reshape(-1)
                     ps = torch.clamp(mean, min=1e-6, max=1 - 1e-6).reshape(-1)
-                encode_bits += encoder(xs, ps, fname)
+                streams.append(coders.encode(xs, ps, fname))
                 ttl_bit_sum = ttl_bit_sum + bits_n
 
         for n in range(self.n_levels):
@@ -777,7 +894,7 @@ class CNC_context_models(nn.Module):
             if not self._coded_3D(n):
                 xs = params_q_xyz[self.offsets_list[n]:self.offsets_list[n + 1]].reshape(-1)
                 ps = Pg_n.reshape(1).expand(xs.numel())
-                encode_bits += encoder(xs, ps, f"{filename_prefix}_3D{n}.b")
+                streams.append(coders.encode(xs, ps, f"{filename_prefix}_3D{n}.b"))
                 ttl_bit_sum = ttl_bit_sum + bits_n
                 continue
             for sn, v0, v1 in self._chunks_3D(n):
@@ -785,7 +902,9 @@ class CNC_context_models(nn.Module):
                 values_q = params_q_xyz[rows][mask_exist]
                 ttl_bit_sum = ttl_bit_sum + torch.sum(self.entropy_model(values_q, mean))
                 ps = torch.clamp(mean, min=1e-6, max=1 - 1e-6).reshape(-1)
-                encode_bits += encoder(values_q.reshape(-1), ps, f"{filename_prefix}_3D{n}_{sn}.b")
+                streams.append(coders.encode(values_q.reshape(-1), ps, f"{filename_prefix}_3D{n}_{sn}.b"))
+        encode_bits = sum(f.result() for f in streams)
+        coders.shutdown()
         return Pgs_dict, ttl_bit_sum.item() / 8.0 / 1024 / 1024, encode_bits / 8.0 / 1024 / 1024
 
     # ------------------------------------------------------------------------------- decode
@@ -796,38 +915,53 @@ class CNC_context_models(nn.Module):
         already decoded lower levels), then the three planes (which need the decoded finest 3-D
         level).  Rows never coded keep the caller's initial value (utils_bpp_acc.py:867-999)."""
         F = self.n_features
+        coders = CoderPool()
+        dev = params_q_xyz_rec.device
         with torch.no_grad():
+            # 3-D: level n needs levels < n decoded, but the chunks of ONE level only read lower levels:
+            # their probabilities are computed first, then the chunk streams are decoded concurrently
             for n in range(self.n_levels):
                 Pg_n = Pgs_dict["3D" + str(n)]
                 if not self._coded_3D(n):
                     rows = int(self.offsets_list[n + 1] - self.offsets_list[n])
-                    sout = decoder(Pg_n.reshape(1).expand(rows * F), f"{filename_prefix}_3D{n}.b")
-                    params_q_xyz_rec[self.offsets_list[n]:self.offsets_list[n + 1]] = sout.view(rows, F)
+                    sout = coders.decode(Pg_n.reshape(1).expand(rows * F), f"{filename_prefix}_3D{n}.b").result()
+                    params_q_xyz_rec[self.offsets_list[n]:self.offsets_list[n + 1]] = sout.to(dev).view(rows, F)
                     continue
+                pending = []
                 for sn, v0, v1 in self._chunks_3D(n):
                     mean, mask_exist, rows = self._level_chunk_3D(Encoding_xyz, n, v0, v1, Pg_n,
                                                                   binary_vxl, params_q_xyz_rec)
                     ps = torch.clamp(mean, min=1e-6, max=1 - 1e-6).reshape(-1)
-                    sout = decoder(ps, f"{filename_prefix}_3D{n}_{sn}.b")
-                    params_q_xyz_rec[rows[mask_exist]] = sout.view(*mean.shape)
+                    pending.append((coders.decode(ps, f"{filename_prefix}_3D{n}_{sn}.b"), rows[mask_exist], mean.shape))
+                for fut, dst, shape in pending:
+                    params_q_xyz_rec[dst] = fut.result().to(dev).view(*shape)
 
+            # planes: level n of a plane needs its own levels < n (and the finest 3-D level); the three planes
+            # are independent of each other, so each level is decoded for xy / xz / yz concurrently
             idx_coords2 = self.get_idx_coords2(binary_vxl) if self.use_dimension_wise else None
             finest_3D = params_q_xyz_rec[self.offsets_list[-2]:self.offsets_list[-1]]
+            planes = []
             for Ec, rec, axis in zip((Encoding_xy, Encoding_xz, Encoding_yz),
                                      (params_q_xy_rec, params_q_xz_rec, params_q_yz_rec), ("xy", "xz", "yz")):
                 binary_2D = self._project(binary_vxl, axis)
                 pn_frac = self.get_pn_embed_frac(finest_3D, idx_coords2, axis=axis) if self.use_dimension_wise else None
-                for n in range(self.n_levels_2D):
+                planes.append((Ec, rec, axis, binary_2D, pn_frac))
+            for n in range(self.n_levels_2D):
+                pending = []
+                for Ec, rec, axis, binary_2D, pn_frac in planes:
                     Pg_n = Pgs_dict[axis + str(n)]
                     fname = f"{filename_prefix}_{axis}{n}.b"
                     if not self._coded_2D(n):
                         rows = int(self.offsets_list_2D[n + 1] - self.offsets_list_2D[n])
-                        sout = decoder(Pg_n.reshape(1).expand(rows * F), fname)
-                        rec[self.offsets_list_2D[n]:self.offsets_list_2D[n + 1]] = sout.view(rows, F)
+                        dst = slice(int(self.offsets_list_2D[n]), int(self.offsets_list_2D[n + 1]))
+                        pending.append((coders.decode(Pg_n.reshape(1).expand(rows * F), fname), rec, dst))
                         continue
                     points_n, order, rows, unique_cnt = self._sorted_slots_2D(binary_2D, n)
                     mean = self._mean_2D(Ec, n, points_n, Pg_n, binary_2D, pn_frac, order, unique_cnt,
                                          outspace_params=rec, detach_pn=True)
                     ps = torch.clamp(mean, min=1e-6, max=1 - 1e-6).reshape(-1)
-                    rec[rows, :] = decoder(ps, fname).view(-1, F)
+                    pending.append((coders.decode(ps, fname), rec, rows))
+                for fut, rec, dst in pending:
+                    rec[dst] = fut.result().to(dev).view(-1, F)
+        coders.shutdown()
         return params_q_xyz_rec, params_q_xy_rec, params_q_xz_rec, params_q_yz_rec

@@ -180,8 +180,29 @@ def get_binary_vxl_size(binary_vxl):
     return Pg, bits.item() / 8.0 / 1024 / 1024, n
 
 
+class LoaderDataset:
+    """`SubjectLoader` / `SubjectLoader_Tanks` (cnc_amd.datasets) behind the three calls the Trainer makes:
+    `fetch()` = one training batch as the reference draws it (`train_dataset[randint(len)]`,
+    train_CNC_nerf_synthetic.py:305-306), `view(i)` = test image i, `update_num_rays`."""
+
+    def __init__(self, train_loader, test_loader):
+        self.train, self.test = train_loader, test_loader
+
+    def update_num_rays(self, n):
+        self.train.update_num_rays(int(n))
+
+    def fetch(self):
+        return self.train[int(torch.randint(0, len(self.train), (1,)).item())]
+
+    def view(self, i):
+        return self.test[i % len(self.test)]
+
+    def __len__(self):
+        return len(self.test)
+
+
 class Trainer:
-    def __init__(self, cfg: TrainConfig, device="cuda"):
+    def __init__(self, cfg: TrainConfig, device="cuda", dataset=None):
         self.cfg = cfg
         # world > 1: join the process group (RCCL; gloo under CNC_DIST_BACKEND) and take this rank's GPU
         self.rank, self.local_rank, self.world = cdist.init()
@@ -205,7 +226,10 @@ class Trainer:
             step_update=c.step_update, skip_levels_3D=c.skip_levels_3D, skip_levels_2D=c.skip_levels_2D,
             device=self.device,
             dimension_wise_resolution=c.dimension_wise_resolution or c.resolutions_list[-1])
-        self.dataset = SyntheticBallDataset(c.image_size, device=self.device, seed=c.seed + 1000 * self.rank)
+        # `dataset`: anything with fetch() / view(i) / update_num_rays(n) (LoaderDataset for real scenes); the
+        # procedural scene otherwise (no dataset ships with the repository)
+        self.dataset = dataset if dataset is not None else \
+            SyntheticBallDataset(c.image_size, device=self.device, seed=c.seed + 1000 * self.rank)
         self.dataset.update_num_rays(c.init_batch_size)
 
         self.opt = torch.optim.Adam(self.field.parameters(), lr=c.lr, eps=1e-15, weight_decay=c.weight_decay)

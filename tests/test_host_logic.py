@@ -253,3 +253,30 @@ def test_rendering_generic_route_on_cpu_matches_reference():
     assert torch.allclose(op, torch.from_numpy(g["plain_opacity"]), rtol=1e-5, atol=1e-6)
     assert torch.allclose(dep, torch.from_numpy(g["plain_depth"]), rtol=1e-5, atol=1e-6)
     assert set(extras) == {"weights", "alphas", "trans", "sigmas", "rgbs", "positions"}
+
+
+def test_context_table_disk_cache_roundtrip(tmp_path):
+    """the per-level sorted vertex tables come back from the on-disk cache identical to a
+    fresh build (same seed -> same shuffle of the dense levels, which is applied after loading); a corrupt
+    file is a cache miss."""
+    from cnc_amd.context import CNC_context_models
+    kw = dict(resolutions_list=[6, 9, 14, 20, 31], resolutions_list_2D=[10, 18, 34], log2_hashmap_size=10,
+              log2_hashmap_size_2D=9, n_features=2, sample_num=300, Pg_level=5, Pg_level_2D=3, Rb=8,
+              skip_levels_3D=(0, 1), skip_levels_2D=(0,), device="cpu", dimension_wise_resolution=18)
+    torch.manual_seed(3)
+    fresh = CNC_context_models(**kw)
+    torch.manual_seed(3)
+    first = CNC_context_models(**kw, table_cache_dir=str(tmp_path))          # builds + writes
+    files = sorted(os.listdir(tmp_path))
+    assert len(files) == 5 and all(f.startswith("ctx_level_R") and f.endswith(".pt") for f in files)
+    (tmp_path / files[0]).write_bytes(b"not a table")                           # corrupt one level
+    torch.manual_seed(3)
+    cached = CNC_context_models(**kw, table_cache_dir=str(tmp_path))         # 4 hits, 1 rebuild
+    for m in (first, cached):
+        for a, b in zip(fresh.pos_grid_sorted_list, m.pos_grid_sorted_list):
+            assert torch.equal(a, b)
+        for a, b in zip(fresh.unique_value_list, m.unique_value_list):
+            assert torch.equal(a, b)
+        assert torch.equal(fresh.unique_count_cumsum_list, m.unique_count_cumsum_list)
+        assert torch.equal(fresh.unique_count_list, m.unique_count_list)
+    assert os.path.getsize(tmp_path / files[0]) > 100                            # rewritten
