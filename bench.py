@@ -83,6 +83,9 @@ def build_workload(dev, rank):
     # one camera per rank on a circle (weak scaling: every GPU renders its own 800x800 view)
     o, d = synthetic.pinhole_rays(800, 800, 0.6911, 4.0, azimuth=0.7 + 0.785398 * rank, elevation=0.5)
     w["rays_o"], w["rays_d"] = o.to(dev), d.to(dev)
+    n = o.shape[0]
+    w["near"], w["far"] = torch.zeros(n, device=dev), torch.full((n,), float("inf"), device=dev)
+    w["t_order"] = torch.arange(2, device=dev, dtype=torch.int64).expand(n, 2).contiguous()
     from cnc_amd.dist import GradBucket
     w["table_param"] = torch.nn.Parameter(w["table"])
     w["bucket"] = GradBucket([w["table_param"]])
@@ -101,13 +104,19 @@ def step(w, timed, world):
     box = {}
 
     def march():
-        box["iv"], box["sm"], _ = ngrid.traverse_grids(rays_o, rays_d, w["binaries"], w["aabbs"],
-                                                       step_size=STEP_SIZE, cone_angle=0.0)
-    timed.launch("march(ray_aabb+traverse x2+cumsum)", n_rays, march)
-    sm = box["sm"]
-    S = sm.vals.shape[0]
-    # sample positions, normalised to the unit cube (radiance field's aabb mapping, ngp.py:518-519)
-    x = ngrid_cuda.sample_positions(rays_o, rays_d, sm.ray_indices, sm.vals, None, w["aabbs"][0])
+        # slab test + count pass + cumsum + fill pass of (ray, t_start, t_end): cnc_march_samples, the form of
+        # the march the renderer consumes (same t values and order as traverse_grids' interval edges)
+        t_lo, t_hi, hit = ngrid_cuda.ray_aabb_intersect(rays_o, rays_d, w["aabbs"], -float("inf"), float("inf"),
+                                                        float("inf"))
+        box["s"] = ngrid_cuda.march_samples(rays_o, rays_d, None, w["binaries"], w["aabbs"],
+                                            torch.cat([t_lo, t_hi], -1), w["t_order"], hit, w["near"], w["far"],
+                                            STEP_SIZE, 0.0)
+    timed.launch("march(ray_aabb+count+cumsum+fill)", n_rays, march)
+    ray_indices, t_starts, t_ends = box["s"][:3]
+    S = t_starts.shape[0]
+    # sample positions o + d (t_start + t_end) / 2 (rgb_sigma_fn, examples/utils.py:251-262), normalised to the
+    # unit cube (the radiance field's aabb mapping, ngp.py:518-519)
+    x = ngrid_cuda.sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends, w["aabbs"][0])
 
     gt = w["grad_table"]
     gt.zero_()                                         # zeros_like(embeddings), ngp.py:129
@@ -300,6 +309,10 @@ def main():
             extra.launch("grid_encode_forward_fp32_table(uniform pts)", n, lambda: enc.grid_encode_forward(
                 xs, w["table"], w["offsets"], w["resolutions"], w["out"], n, D, F, L, 0, 128, 0.0, None, None, None,
                 ste_binary=True))
+        for _ in range(3):      # the `nerfacc.csrc` drop-in entry (intervals + samples, 27 B / sample), for the record
+            extra.launch("traverse_grids drop-in (ray_aabb+traverse x2+cumsum)", w["rays_o"].shape[0],
+                         lambda: ngrid.traverse_grids(w["rays_o"], w["rays_d"], w["binaries"], w["aabbs"],
+                                                      step_size=STEP_SIZE, cone_angle=0.0))
         nb_plan = enc.plan_binned_levels(synthetic.RES_16L, w["offsets_host"], D, F, n)
         if nb_plan is not None and w.get("first_chunk") is not None and w["first_chunk"].shape[0] == CHUNK:
             xs_r, o_r = w["first_chunk"], w["out"]

@@ -140,6 +140,43 @@ def traverse_grids(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
     return intervals, samples, terminate_planes
 
 
+def march_samples(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
+                  step_size, cone_angle, traverse_steps_limit=-1, want_terminate_planes=False):
+    """(extension) The march as the renderer consumes it — see cnc_march_samples in include/cnc_hip.h.
+    Returns (ray_indices i64 [S], t_starts [S], t_ends [S], chunk_starts [n_rays], chunk_cnts [n_rays],
+    terminate_planes or None).  Count pass, exclusive cumsum + ONE host sync (the sample total sizes the
+    result, as in data_spec.hpp:86-96), fill pass."""
+    for name, t in (("rays_o", rays_o), ("rays_d", rays_d), ("binaries", binaries), ("aabbs", aabbs),
+                    ("t_sorted", t_sorted), ("t_indices", t_indices), ("hits", hits),
+                    ("near_planes", near_planes), ("far_planes", far_planes)):
+        check_input(t, name)
+    if rays_mask is not None:
+        check_input(rays_mask, "rays_mask")
+    n_rays, dev = rays_o.shape[0], rays_o.device
+    counts = torch.zeros(n_rays, dtype=torch.int64, device=dev)       # masked-out rays stay at 0
+    term = torch.empty(n_rays, dtype=rays_o.dtype, device=dev) if want_terminate_planes else None
+    L = _lib.lib()
+
+    def launch(starts, t0, t1, ri, tp):
+        rc = L.cnc_march_samples(ptr(rays_o), ptr(rays_d), ptr(rays_mask), n_rays, ptr(binaries), binaries.shape[0],
+                                 binaries.shape[1], binaries.shape[2], binaries.shape[3], ptr(aabbs), ptr(hits),
+                                 ptr(t_sorted), ptr(t_indices), ptr(near_planes), ptr(far_planes), float(step_size),
+                                 float(cone_angle), int(traverse_steps_limit), ptr(counts), ptr(starts), ptr(t0),
+                                 ptr(t1), ptr(ri), ptr(tp), stream(dev))
+        check(rc, "march_samples")
+
+    launch(None, None, None, None, term)
+    ends = torch.cumsum(counts, 0)
+    total = int(ends[-1].item()) if n_rays else 0
+    starts = ends - counts
+    t_starts = torch.empty(total, dtype=torch.float32, device=dev)
+    t_ends = torch.empty(total, dtype=torch.float32, device=dev)
+    ray_indices = torch.empty(total, dtype=torch.int64, device=dev)
+    if total:
+        launch(starts, t_starts, t_ends, ray_indices, None)
+    return ray_indices, t_starts, t_ends, starts, counts, term
+
+
 def sample_positions(rays_o, rays_d, ray_indices, t_a, t_b=None, aabb=None, want_dirs=False):
     """(extension) positions [S,3] (and directions) of ray samples in one kernel; see
     cnc_sample_positions in include/cnc_hip.h."""

@@ -13,6 +13,8 @@
 //   * per-ray outputs are written in (ray, t) order at chunk_starts[ray] exactly as the
 //     reference does, so the host mirror can reuse the reference's boolean-mask post-processing
 //     (nerfacc/estimators/occ_grid.py:188-189).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace cnc {
@@ -120,11 +122,48 @@ __device__ __forceinline__ void flush_stage(const Stage& st, const Seg& o, uint3
     }
 }
 
+// MODE 2 staging: 32 (t_start, t_end) pairs per lane.
+
+// Flush of the (t_start, t_end) rows: only rows that hold something are visited (a wave pauses whenever ONE of
+// its rays has filled its row; the rays that are still far from full keep theirs), two rows per step, 32 lanes
+// each: a row leaves as 128 contiguous bytes per float array and 256 for the int64 ray ids.
+template <int PROW>
+__device__ __forceinline__ void flush_pairs(const Stage& st, float* __restrict__ t_starts,
+                                            float* __restrict__ t_ends, int64_t* __restrict__ ray_indices,
+                                            uint32_t cnt, int64_t g, int32_t ray)
+{
+    constexpr uint32_t G = 64 / PROW;                    // rows written per step, PROW lanes each
+    constexpr int      kPP = PROW + 1;
+    const uint32_t lane = threadIdx.x, grp = lane / PROW, e = lane % PROW;
+    uint64_t todo = __ballot(cnt > 0);
+    while (todo) {
+        uint64_t m = todo;
+        for (uint32_t k = 0; k < grp; k++) m &= m - 1;   // group g takes the g-th pending row
+        const bool     has = m != 0;
+        const uint32_t src = has ? (uint32_t)__builtin_ctzll(m) : 0u;
+        const uint32_t c = (uint32_t)__shfl((int)cnt, (int)src);
+        const int64_t  gs = __shfl(g, (int)src);
+        const int32_t  r = __shfl(ray, (int)src);
+        if (has && e < c) {
+            const int64_t k = gs + e;
+            t_starts[k] = st.sm[src * kPP + e];
+            t_ends[k] = st.iv[src * kPP + e];
+            ray_indices[k] = r;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < G; k++) todo &= todo - 1;
+    }
+}
+
 // One lane marches one ray (a serial DDA).  FILL = false: count only (first pass).  FILL = true:
 // the march is resumable — a lane stops when its LDS staging row is full, the wave flushes all 64
 // rows with coalesced stores (flush_stage), and the lane continues exactly where it stopped
 // (same registers, same cell), so values and order equal the one-sweep march of grid.cu:68-318.
-template <bool FILL>
+// MODE 0: count only.  MODE 1: fill the reference's RaySegmentsSpec pair (intervals + samples).
+// MODE 2 (extension, cnc_march_samples): fill (t_start, t_end, ray) per sample and nothing else — what the
+// renderer consumes (occ_grid.py:176-178 derives exactly these from the edge flags) — 16 instead of 27 bytes
+// per sample, 32-entry staging rows and a flush that only touches rows that have something to write.
+template <int MODE, int PROW = 32>
 __global__ __launch_bounds__(64) void k_traverse(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const uint8_t* __restrict__ rays_mask, int32_t n_rays, const uint8_t* __restrict__ binaries,
@@ -135,14 +174,21 @@ __global__ __launch_bounds__(64) void k_traverse(
     Seg iv, Seg sm, float* __restrict__ terminate_planes)
 {
     extern __shared__ float s_dyn[];
+    constexpr bool FILL = MODE != 0;
+    constexpr bool PAIRS = MODE == 2;
+    constexpr int  kRow = PAIRS ? PROW : kStage;        // staged entries per lane
+    constexpr int  kPP = PROW + 1;
     const float eps = 1e-6f;
     const int   res[3] = {resx, resy, resz};
-    const bool  has_iv = iv.chunk_cnts != nullptr, has_sm = sm.chunk_cnts != nullptr;
+    const bool  has_iv = !PAIRS && iv.chunk_cnts != nullptr, has_sm = sm.chunk_cnts != nullptr;
     const uint32_t lane = threadIdx.x;
     const int32_t  tid = blockIdx.x * 64 + lane;
 
     Stage st{};
-    if constexpr (FILL) {
+    if constexpr (PAIRS) {
+        st.sm = s_dyn;                          // t_start of each staged sample
+        st.iv = s_dyn + 64 * kPP;        // t_end
+    } else if constexpr (FILL) {
         st.sm = s_dyn;
         st.iv = s_dyn + 64 * kStagePitch;
         st.ivf = (uint8_t*)(s_dyn + 2 * 64 * kStagePitch);
@@ -252,7 +298,7 @@ __global__ __launch_bounds__(64) void k_traverse(
                         while (limit <= 0 || n_sm < limit) {
                             if constexpr (FILL) {
                                 // no room for this step's entries: stop here, flush, come back
-                                if (st_sm >= (uint32_t)kStage || st_iv + 2 > (uint32_t)kStage) {
+                                if (st_sm >= (uint32_t)kRow || (!PAIRS && st_iv + 2 > (uint32_t)kStage)) {
                                     paused = true;
                                     break;
                                 }
@@ -287,7 +333,11 @@ __global__ __launch_bounds__(64) void k_traverse(
                                     n_iv += 1;
                                 }
                             }
-                            if constexpr (FILL) {
+                            if constexpr (PAIRS) {
+                                st.sm[lane * kPP + st_sm] = t_last;
+                                st.iv[lane * kPP + st_sm] = t_next;
+                                st_sm++;
+                            } else if constexpr (FILL) {
                                 if (has_sm) {
                                     st.sm[lane * kStagePitch + st_sm] = (t_next + t_last) * 0.5f;
                                     st_sm++;
@@ -317,7 +367,14 @@ __global__ __launch_bounds__(64) void k_traverse(
             if (!paused) finished = true;
         }
         if constexpr (!FILL) break;
-        if constexpr (FILL) {
+        if constexpr (PAIRS) {
+            __syncthreads();
+            flush_pairs<PROW>(st, sm.vals, iv.vals, sm.ray_indices, st_sm, cs_sm + fl_sm, tid);
+            fl_sm += st_sm;
+            st_sm = 0;
+            __syncthreads();
+            if (__ballot(!finished) == 0) break;
+        } else if constexpr (FILL) {
             __syncthreads();   // one wave per workgroup: orders the LDS writes before the reads
             if (has_sm) {
                 flush_stage<false>(st, sm, st_sm, cs_sm + fl_sm, tid);
@@ -431,17 +488,61 @@ extern "C" int cnc_traverse_grids(const float* rays_o, const float* rays_d,
     }
     const uint32_t blocks = div_up((uint32_t)n_rays, 64);
     if (first_pass) {
-        hipLaunchKernelGGL(k_traverse<false>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o,
+        hipLaunchKernelGGL(k_traverse<0>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o,
                            rays_d, rays_mask, n_rays, binaries, n_grids, resx, resy, resz, aabbs,
                            hits, t_sorted, t_indices, near_planes, far_planes, step_size,
                            cone_angle, traverse_steps_limit, iv, sm, terminate_planes);
     } else {
         const size_t lds = 64 * kStagePitch * (2 * sizeof(float) + 1);
-        hipLaunchKernelGGL(k_traverse<true>, dim3(blocks), dim3(64), lds, (hipStream_t)stream, rays_o,
+        hipLaunchKernelGGL(k_traverse<1>, dim3(blocks), dim3(64), lds, (hipStream_t)stream, rays_o,
                            rays_d, rays_mask, n_rays, binaries, n_grids, resx, resy, resz, aabbs,
                            hits, t_sorted, t_indices, near_planes, far_planes, step_size,
                            cone_angle, traverse_steps_limit, iv, sm, terminate_planes);
     }
+    return launch_status();
+}
+
+extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const uint8_t* rays_mask, int32_t n_rays,
+                                 const uint8_t* binaries, int32_t n_grids, int32_t resx, int32_t resy,
+                                 int32_t resz, const float* aabbs, const uint8_t* hits, const float* t_sorted,
+                                 const int64_t* t_indices, const float* near_planes, const float* far_planes,
+                                 float step_size, float cone_angle, int32_t traverse_steps_limit,
+                                 int64_t* chunk_cnts, const int64_t* chunk_starts, float* t_starts, float* t_ends,
+                                 int64_t* ray_indices, float* terminate_planes, void* stream)
+{
+    if (n_rays <= 0) return CNC_OK;
+    if (!rays_o || !rays_d || !binaries || !aabbs || !hits || !t_sorted || !t_indices || !near_planes ||
+        !far_planes || n_grids <= 0 || !chunk_cnts)
+        return CNC_ERR_INVALID_VALUE;
+    const uint32_t blocks = div_up((uint32_t)n_rays, 64);
+    Seg none{}, sm{};
+    sm.chunk_cnts = chunk_cnts;
+    if (!chunk_starts) {        // pass 1: counts only
+        hipLaunchKernelGGL(k_traverse<0>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
+                           n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices,
+                           near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, none, sm,
+                           terminate_planes);
+        return launch_status();
+    }
+    if (!t_starts || !t_ends || !ray_indices) return CNC_ERR_INVALID_VALUE;
+    Seg ends{};
+    sm.chunk_starts = const_cast<int64_t*>(chunk_starts);
+    sm.vals = t_starts;
+    sm.ray_indices = ray_indices;
+    ends.vals = t_ends;
+    // staging row length, measured on the 800x800 bench frame (count + fill, ms): 8 -> 3.53, 16 -> 2.55,
+    // 32 -> 2.32, 64 -> 2.89 (LDS then limits the waves per CU)
+    static const int row = getenv("CNC_PAIR_STAGE") ? atoi(getenv("CNC_PAIR_STAGE")) : 32;
+#define CNC_LAUNCH_PAIRS(R)                                                                                         \
+    hipLaunchKernelGGL((k_traverse<2, R>), dim3(blocks), dim3(64), 2 * 64 * (R + 1) * sizeof(float),              \
+                       (hipStream_t)stream, rays_o, rays_d, rays_mask, n_rays, binaries, n_grids, resx, resy, resz, \
+                       aabbs, hits, t_sorted, t_indices, near_planes, far_planes, step_size, cone_angle,            \
+                       traverse_steps_limit, ends, sm, terminate_planes)
+    if (row == 8) CNC_LAUNCH_PAIRS(8);
+    else if (row == 16) CNC_LAUNCH_PAIRS(16);
+    else if (row == 64) CNC_LAUNCH_PAIRS(64);
+    else CNC_LAUNCH_PAIRS(32);
+#undef CNC_LAUNCH_PAIRS
     return launch_status();
 }
 

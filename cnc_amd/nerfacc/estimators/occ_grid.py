@@ -5,8 +5,7 @@ constructor, buffers (`resolution`, `aabbs`, `occs`, `binaries`; non-persistent 
 `grid_indices`), methods and RNG call order (so a seeded `_update` reproduces the reference's grid,
 tests/golden/occ_grid.npz) — on top of the HIP marcher and the fused visibility / compaction kernels:
 
-    sampling = traverse_grids (count + fill)            cnc_amd/csrc/march.hip
-             -> interval edges -> (ray, t_start, t_end)  k_edges_to_samples   (no boolean indexing)
+    sampling = march (count + fill of (ray, t_start, t_end))   cnc_march_samples, cnc_amd/csrc/march.hip
              -> sigma_fn / alpha_fn (the field)
              -> transmittance test + survivor counts     k_visibility
              -> stable compaction                         k_compact            (one host sync)
@@ -71,19 +70,18 @@ class OccGridEstimator(AbstractEstimator):
     def _march(self, rays_o, rays_d, near_planes, far_planes, step, cone_angle):
         """(ray_indices, t_starts, t_ends, starts, counts) of every sample inside occupied cells."""
         from ...backends import nerfacc_cuda as _C
-        from ...backends import volrend_backend as _K
         rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
-        t_lo, t_hi, hit = _C.ray_aabb_intersect(rays_o, rays_d, self.aabbs.contiguous(), -float("inf"),
-                                                float("inf"), float("inf"))
-        t_sorted, t_order = torch.sort(torch.cat([t_lo, t_hi], dim=-1), dim=-1)
-        every_ray = torch.ones(rays_o.shape[0], dtype=torch.bool, device=rays_o.device)
-        intervals, samples, _ = _C.traverse_grids(
-            rays_o, rays_d, every_ray, self.binaries.contiguous(), self.aabbs.contiguous(), t_sorted.contiguous(),
-            t_order.contiguous(), hit.contiguous(), near_planes.contiguous(), far_planes.contiguous(), step,
-            cone_angle, True, True, False, -1, False)
-        ray_indices, t_starts, t_ends, starts = _K.samples_from_intervals(intervals, samples.chunk_cnts,
-                                                                           total=samples.vals.shape[0])
-        return ray_indices, t_starts, t_ends, starts, samples.chunk_cnts
+        boxes = self.aabbs.contiguous()
+        t_lo, t_hi, hit = _C.ray_aabb_intersect(rays_o, rays_d, boxes, -float("inf"), float("inf"), float("inf"))
+        crossings = torch.cat([t_lo, t_hi], dim=-1)
+        if boxes.shape[0] > 1:          # nested grids: the box crossings of a ray in order along it
+            crossings, order = torch.sort(crossings, dim=-1)
+        else:                           # one box: (entry, exit) is already sorted
+            order = torch.arange(2, device=rays_o.device, dtype=torch.int64).expand(rays_o.shape[0], 2)
+        ray_indices, t_starts, t_ends, starts, counts, _ = _C.march_samples(
+            rays_o, rays_d, None, self.binaries.contiguous(), boxes, crossings.contiguous(), order.contiguous(),
+            hit.contiguous(), near_planes.contiguous(), far_planes.contiguous(), step, cone_angle)
+        return ray_indices, t_starts, t_ends, starts, counts
 
     @torch.no_grad()
     def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None,

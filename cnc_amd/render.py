@@ -150,11 +150,9 @@ def render_image_with_occgrid_test(max_samples: int, radiance_field: torch.nn.Mo
             break
         steps = max(min(n // n_alive, 64), fewest)
         marched += steps
-        intervals, samples, resume_at = _C.traverse_grids(o, d, alive, grids, boxes, crossings, order, hit,
-                                                          resume_at, far, render_step_size, cone_angle, True, True,
-                                                          True, steps, True)
-        counts = samples.chunk_cnts
-        ray_indices, t_starts, t_ends, starts = _K.samples_from_intervals(intervals, counts)
+        ray_indices, t_starts, t_ends, starts, counts, resume_at = _C.march_samples(
+            o, d, alive, grids, boxes, crossings, order, hit, resume_at, far, render_step_size, cone_angle,
+            traverse_steps_limit=steps, want_terminate_planes=True)
         if t_starts.shape[0]:
             rgbs, sigmas = fn.colour_and_density(t_starts, t_ends, ray_indices)
             rgbs, sigmas = rgbs.float().contiguous(), sigmas.float().contiguous()

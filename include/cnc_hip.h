@@ -284,6 +284,24 @@ int cnc_traverse_grids(const float* rays_o, const float* rays_d, const uint8_t* 
                        const cnc_ray_segments_t* intervals, const cnc_ray_segments_t* samples,
                        float* terminate_planes, void* stream);
 
+/* (extension) The march as the renderer consumes it: (t_start, t_end, ray) per sample, nothing else — what
+ * OccGridEstimator.sampling / render_image_with_occgrid_test derive from traverse_grids' interval edges
+ * (occ_grid.py:176-178, utils.py:408-410), 16 instead of 27 bytes per sample and no boolean indexing.
+ * Same rays / grids / options as cnc_traverse_grids; same t values, same order.  Two calls:
+ *   chunk_starts == NULL : count pass — chunk_cnts [n_rays] receives the samples per ray;
+ *   chunk_starts != NULL : fill pass — t_starts / t_ends f32 [S], ray_indices i64 [S] are written at
+ *                          chunk_starts[ray] (the caller's exclusive cumsum of chunk_cnts); rays whose
+ *                          chunk_cnts is 0 are skipped.  With rays_mask + traverse_steps_limit the same
+ *                          two calls give the iterative evaluation render its packed samples directly.
+ * terminate_planes (nullable) [n_rays]: where each marched ray stopped.                             */
+int cnc_march_samples(const float* rays_o, const float* rays_d, const uint8_t* rays_mask, int32_t n_rays,
+                      const uint8_t* binaries, int32_t n_grids, int32_t resx, int32_t resy, int32_t resz,
+                      const float* aabbs, const uint8_t* hits, const float* t_sorted,
+                      const int64_t* t_indices, const float* near_planes, const float* far_planes,
+                      float step_size, float cone_angle, int32_t traverse_steps_limit,
+                      int64_t* chunk_cnts, const int64_t* chunk_starts, float* t_starts, float* t_ends,
+                      int64_t* ray_indices, float* terminate_planes, void* stream);
+
 /* (extension) Sample positions for the field in one pass: positions[s] = o[ray] + d[ray] * t_a[s], or
  * o + (d * (t_a[s] + t_b[s])) / 2 when t_b != NULL (rgb_sigma_fn, examples/utils.py:251-262, same
  * evaluation order); aabb != NULL (6 floats on the device) maps them to the unit cube,

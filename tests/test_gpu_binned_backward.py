@@ -262,9 +262,12 @@ def test_bench_chunk_backward_against_oracle(cuda, oracle, overlap):
     from cnc_amd.backends import nerfacc_cuda as ncu
     from cnc_amd.nerfacc import grid as ngrid
     w = bench.build_workload(cuda, 0)
-    iv, sm, _ = ngrid.traverse_grids(w["rays_o"], w["rays_d"], w["binaries"], w["aabbs"],
-                                     step_size=bench.STEP_SIZE, cone_angle=0.0)
-    x = ncu.sample_positions(w["rays_o"], w["rays_d"], sm.ray_indices, sm.vals, None, w["aabbs"][0])
+    box = {}
+    # bench.step's own march + positions
+    t_lo, t_hi, hit = ncu.ray_aabb_intersect(w["rays_o"], w["rays_d"], w["aabbs"], -float("inf"), float("inf"), float("inf"))
+    ri, ts, te = ncu.march_samples(w["rays_o"], w["rays_d"], None, w["binaries"], w["aabbs"], torch.cat([t_lo, t_hi], -1),
+                                   w["t_order"], hit, w["near"], w["far"], bench.STEP_SIZE, 0.0)[:3]
+    x = ncu.sample_positions(w["rays_o"], w["rays_d"], ri, ts, te, w["aabbs"][0])
     S, N, L, F = x.shape[0], bench.CHUNK, bench.L, bench.F
     assert S > 40 * N
     c = (S // N) // 2

@@ -284,3 +284,43 @@ def test_hip_marcher_against_the_reference_lookup_golden(cuda, k):
     iv, sm, term = ngrid.traverse_grids(t(o), t(d), t(b), t(aabb), step_size=step, cone_angle=0.0)
     check_against_reference_lookup(o, d, sm.vals.cpu().numpy(), sm.ray_indices.cpu().numpy(), cand_t, cand_ray,
                                    ref_occ, b.shape[-1])
+
+
+@pytest.mark.parametrize("limit,masked", [(-1, False), (9, True)])
+@pytest.mark.parametrize("res,step", [(32, 2e-2), (128, 5e-3)])
+def test_march_samples_equals_the_interval_edges(cuda, oracle, res, step, limit, masked):
+    """cnc_march_samples (extension: (ray, t_start, t_end) per sample straight from the march) against the
+    oracle's traverse_grids: t_starts == intervals.vals[is_left], t_ends == intervals.vals[is_right], same
+    rays, counts and termination planes — unlimited two-pass and step-limited with dead rays."""
+    from cnc_amd import synthetic
+    from cnc_amd.backends import nerfacc_cuda as C
+    o, d = synthetic.pinhole_rays(36, 36, 0.6911, 4.0, 0.3, 0.4)
+    binaries = synthetic.ball_binaries(res, radius=1.0)
+    binaries ^= torch.rand(binaries.shape, generator=torch.Generator().manual_seed(2)) < 0.04
+    aabbs = torch.tensor([[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5]])
+    n = o.shape[0]
+    near = torch.rand(n, generator=torch.Generator().manual_seed(3)) * step
+    far = torch.full((n,), 1e10)
+    mask = torch.ones(n, dtype=torch.bool)
+    if masked:
+        mask[::4] = False
+    oiv, osm, oterm = oracle.traverse_grids(o.numpy(), d.numpy(), binaries.numpy(), aabbs.numpy(), near.numpy(),
+                                            far.numpy(), step, 0.0, traverse_steps_limit=limit if limit > 0 else None,
+                                            over_allocate=limit > 0, rays_mask=mask.numpy())
+    T = lambda a: a.to(cuda)
+    t0, t1, hit = C.ray_aabb_intersect(T(o), T(d), T(aabbs), -float("inf"), float("inf"), float("inf"))
+    order = torch.arange(2, device=cuda).expand(n, 2).contiguous()
+    ri, ts, te, starts, counts, term = C.march_samples(T(o), T(d), T(mask) if masked else None, T(binaries), T(aabbs),
+                                                        torch.cat([t0, t1], -1), order, hit, T(near), T(far), step, 0.0,
+                                                        traverse_steps_limit=limit, want_terminate_planes=True)
+    want_cnt = np.asarray(osm["chunk_cnts"])
+    assert np.array_equal(counts.cpu().numpy(), want_cnt) and want_cnt.sum() > 2000
+    assert np.array_equal(starts.cpu().numpy(), np.cumsum(want_cnt) - want_cnt)
+    vals = np.asarray(oiv["vals"])
+    assert np.array_equal(ts.cpu().numpy(), vals[np.asarray(oiv["is_left"]).astype(bool)])
+    assert np.array_equal(te.cpu().numpy(), vals[np.asarray(oiv["is_right"]).astype(bool)])
+    assert np.array_equal(ri.cpu().numpy(), np.asarray(osm["ray_indices"])[np.asarray(osm["is_valid"]).astype(bool)])
+    live = mask.numpy() if limit > 0 else want_cnt > 0
+    assert np.array_equal(term.cpu().numpy()[live], np.asarray(oterm)[live])
+    if masked:
+        assert np.all(counts.cpu().numpy()[~mask.numpy()] == 0)
