@@ -30,6 +30,7 @@ import torch.nn as nn
 import torch.nn.functional as nnf
 from torch.autograd import Function
 
+from .backends import context_backend as _ctxk
 from .backends import gridencoder_backend as _backend
 from .backends import pack_and_align
 from .gridencoder import STE_binary, STE_multistep
@@ -314,16 +315,10 @@ class _segment_reduce(Function):
     @staticmethod
     def backward(ctx, g):
         cumsum, weights = ctx.saved_tensors
-        N = cumsum.shape[0] - 1
-        cnt = cumsum[1:] - cumsum[:-1]
-        row2slot = torch.repeat_interleave(torch.arange(N, device=g.device), cnt, output_size=ctx.T)
-        scale = weights if weights is not None else torch.ones(ctx.T, dtype=g.dtype, device=g.device)
+        wsum = None
         if ctx.mode == 1:
-            wsum = pack_and_align.segment_weighted_sum(scale.unsqueeze(-1).contiguous(), None, cumsum, 0)
-            scale = scale / wsum[row2slot, 0]
-        elif ctx.mode == 2:
-            scale = scale / cnt[row2slot].to(g.dtype)
-        return g.contiguous()[row2slot] * scale.unsqueeze(-1), None, None, None
+            wsum = pack_and_align.segment_weighted_sum(weights.unsqueeze(-1).contiguous(), None, cumsum, 0)
+        return _ctxk.segment_backward(g, cumsum, weights, wsum, ctx.T, ctx.mode), None, None, None
 
 
 def _cum(cnt):
@@ -400,8 +395,11 @@ class CNC_context_models(nn.Module):
                  Pg_level=-1, Pg_level_2D=-1, Rb=128, step_update=16, skip_levels_3D=(0, 1, 2, 3),
                  skip_levels_2D=(0,), use_dimension_wise=True, use_overlap_area_pool=True,
                  device="cuda", dimension_wise_resolution=514, fused_segments=True, planned_votes=True,
-                 table_cache_dir=None):
+                 table_cache_dir=None, fused_heads=True):
         super().__init__()
+        # prediction heads + Bernoulli rate as fused HIP kernels (cnc_amd/csrc/ctx_head.hip); False = the
+        # reference's op-by-op dataflow (cat -> Linear(s) -> clamp / log2 / masks / sum)
+        self.fused_heads = fused_heads
         # on-disk cache of the per-level sorted vertex tables: a pure function of
         # (resolution, table rows, num_dim), so levels are shared between configurations.  Opt-in (argument
         # or CNC_CTX_TABLE_CACHE): on an MI355X rebuilding all 12 levels takes 1.2 s, about what reading
@@ -663,17 +661,20 @@ class CNC_context_models(nn.Module):
         ctx_layers = min(n, self.max_context_layer_num)
         context = Encoding_2D(points_n, n - ctx_layers, n, outspace_params=outspace_params,
                               binary_vxl=binary_vxl_2D, PV=0)
-        Pg_col = Pg_n.reshape(1, 1).repeat(context.shape[0], 1)
+        context_pn = None
         if self.use_dimension_wise:
             context_pn = Encoding_2D.forward_given_params(points_n, self.pn_frac_offsets_list,
                                                           self.pn_frac_resolutions_list,
                                                           pn_embed_frac, binary_vxl_2D)
             if detach_pn:
                 context_pn = context_pn.detach()
-            context = torch.cat([context, context_pn, Pg_col], dim=-1)
+        if self.fused_heads and context.is_cuda:
+            # [context | context_pn | Pg] -> Linear, read in place by one kernel (no cat, no repeated Pg column)
+            mean = _ctxk.context_mlp(self.context_model_2D[n - 1], context, context_pn, Pg_n)
         else:
-            context = torch.cat([context, Pg_col], dim=-1)
-        mean = self.context_model_2D[n - 1](context)
+            Pg_col = Pg_n.reshape(1, 1).repeat(context.shape[0], 1)
+            parts = [context, Pg_col] if context_pn is None else [context, context_pn, Pg_col]
+            mean = self.context_model_2D[n - 1](torch.cat(parts, dim=-1))
         mean = torch.index_select(mean, dim=0, index=order)
         if self.fused_segments:
             return _segment_reduce.apply(mean, _cum(unique_cnt), None, 2)
@@ -729,8 +730,11 @@ class CNC_context_models(nn.Module):
         ctx_layers = min(n, self.max_context_layer_num)
         context = Encoding_xyz(points_n[mask], n - ctx_layers, n, outspace_params=outspace_params,
                                binary_vxl=binary_vxl.squeeze(), PV=0)
-        context = torch.cat([context, Pg_n.reshape(1, 1).repeat(context.shape[0], 1)], dim=-1)
-        mean = self._fuse_3D(self.context_model_3D(context), mask_cnt, overlap_w)
+        if self.fused_heads and context.is_cuda:
+            mean_pts = _ctxk.context_mlp(self.context_model_3D, context, None, Pg_n)
+        else:
+            mean_pts = self.context_model_3D(torch.cat([context, Pg_n.reshape(1, 1).repeat(context.shape[0], 1)], dim=-1))
+        mean = self._fuse_3D(mean_pts, mask_cnt, overlap_w)
         rows = self.unique_value_list[n][v0:v1] + self.offsets_list[n]
         return mean, mask_exist, rows
 
@@ -739,6 +743,13 @@ class CNC_context_models(nn.Module):
         indexes_sorted, order = torch.sort(indexes_2D, descending=False, dim=0, stable=True)
         unique_value, unique_cnt = torch.unique(indexes_sorted, return_counts=True)
         return points_n, order, unique_value.to(torch.long) + self.offsets_list_2D[n], unique_cnt
+
+    def _bits(self, table_q, rows, mean):
+        """Rate of the coded rows of a binarised table under the predicted P(+1): sum of
+        Bernoulli_entropy(table_q[rows], mean) — one kernel with the gather and the reduction when fused."""
+        if self.fused_heads and mean.is_cuda:
+            return _ctxk.bernoulli_bits(table_q, rows.contiguous(), mean)
+        return torch.sum(self.entropy_model(table_q[rows, :], mean))
 
     def _coded_2D(self, n):
         return not (n in self.skip_levels_2D or n >= self.Pg_level_2D)
@@ -789,7 +800,7 @@ class CNC_context_models(nn.Module):
                     with _range("ctx/2D_mean"):
                         mean = self._mean_2D(Ec, n, points_n, Pg_n, binary_2D[k], pn_frac, order, unique_cnt)
                     with _range("ctx/2D_entropy"):
-                        bits_n = torch.sum(self.entropy_model(p_q[rows, :], mean))
+                        bits_n = self._bits(p_q, rows, mean)
                 ttl_bit_sum = ttl_bit_sum + bits_n
             ttl_num_sum += p_q.numel()
 
@@ -830,7 +841,7 @@ class CNC_context_models(nn.Module):
                 pts_orig, pts_n, Pg_cols = torch.cat(pts_orig), torch.cat(pts_n), torch.cat(Pg_cols)
                 lvl_ids, cnts = torch.cat(lvl_ids), torch.cat(cnts)
                 # one gather for all levels: its backward is ONE scatter into a table-sized gradient
-                values_q = params_q_xyz[torch.cat(values_q)]
+                rows_3D = torch.cat(values_q)
             with _range("ctx/3D_query"):
                 mask, overlap = self.query_binary_vxl_qlist(pts_orig, binary_vxl, lvl_ids, return_overlap_area=True)
             with _range("ctx/3D_slot_masks"):
@@ -839,11 +850,15 @@ class CNC_context_models(nn.Module):
             with _range("ctx/3D_encode"):
                 context = Encoding_xyz.forward_diff_levels(pts_n[mask], lvl_ids[mask].to(torch.int) - L, L,
                                                            binary_vxl=binary_vxl.squeeze(), PV=1001)
-                context = torch.cat([context, Pg_cols[mask]], dim=-1)
+                pg_col = Pg_cols[mask]
+                if not (self.fused_heads and context.is_cuda):
+                    context = torch.cat([context, pg_col], dim=-1)
             with _range("ctx/3D_mlp_fuse"):
-                mean = self._fuse_3D(self.context_model_3D(context), mask_cnt, overlap_w)
+                mean_pts = (_ctxk.context_mlp(self.context_model_3D, context, pg_col)
+                            if self.fused_heads and context.is_cuda else self.context_model_3D(context))
+                mean = self._fuse_3D(mean_pts, mask_cnt, overlap_w)
             with _range("ctx/3D_entropy"):
-                bits = torch.sum(self.entropy_model(values_q[mask_exist], mean))
+                bits = self._bits(params_q_xyz, rows_3D[mask_exist], mean)
             ttl_bit_sum = ttl_bit_sum + bits / ttl_sample_valid * self.ttl_hashparams_num_valid_levels
 
         ttl_num_sum += params_q_xyz.numel()

@@ -1,0 +1,429 @@
+// ctx_head.hip — the context models' prediction heads and the Bernoulli rate, fused, for gfx950.
+//
+// In the reference (examples/utils_bpp_acc.py) every coded level runs, per training step,
+//     cat([context, context_pn, Pg]) -> Linear(+LeakyReLU, Linear, LeakyReLU, Linear) (:378-393, :561-566, :689-692)
+//     -> hash fusion (:567-572, :693-701) -> clamp / log2 / masks / sum (Bernoulli_entropy :1002-1013)
+// as ~30 ATen launches forward and ~60 backward, 9 plane levels + the batched 3-D levels per step.  Here:
+//
+//   k_ctx_mlp_fwd<NL,F>   one lane per vertex: the row [ctx | pn | Pg] is read in place (no cat), the whole
+//                         MLP (NL = 1: Linear(C->F); NL = 3: C->32->32->F with LeakyReLU 0.01) runs in
+//                         registers against weights held transposed in LDS (broadcast reads)
+//   k_ctx_mlp_bwd<NL,F>   recomputes the activations, back-propagates to the inputs, and reduces the weight
+//                         gradients over the 64 vertices of a wave through LDS tiles (each lane owns a fixed
+//                         set of weight elements, accumulates them in registers over the whole block, one
+//                         atomicAdd per element and block at the end)
+//   k_bernoulli_bits      bits = sum over (slot, feature) of -log2(p) [x=+1] / -log2(1-p) [x=-1], p = clamp(mean),
+//                         x gathered from the table by row; per-block partial sums (deterministic total)
+//   k_bernoulli_bits_bwd  d bits / d mean and d bits / d x in one pass
+//   k_segment_bwd         gradient of the hash fusion (cnc_segment_weighted_sum) w.r.t. the per-vertex values
+//
+// Arithmetic: fp32 with fmaf; the GEMMs these replace have no defined summation order either.  Tested against
+// torch autograd of the op chain (tests/test_gpu_ctx_head.py).
+#include "common.hpp"
+
+namespace cnc {
+
+constexpr int   kH = 32;            // hidden width of context_model_3D (utils_bpp_acc.py:378-384)
+constexpr float kSlope = 0.01f;     // nn.LeakyReLU() default
+constexpr int   kMaxC = 40;         // widest input row: 3 context levels x 8 + 8 (dimension-wise) + 1 (Pg) = 33
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.0f ? v : kSlope * v; }
+
+struct MlpArgs {
+    const float* in_a; uint32_t lda, Ca;      // [N, Ca] rows with leading dimension lda
+    const float* in_b; uint32_t ldb, Cb;      // [N, Cb] or null
+    const float* pg;                          // device scalar appended as the last column, or null
+    uint32_t     N, C;                        // C = Ca + Cb + (pg ? 1 : 0)
+    const float *W1, *b1, *W2, *b2, *W3, *b3; // nn.Linear layout [out, in]; W2 / W3 unused for NL == 1
+};
+
+// weights into LDS, TRANSPOSED ([in][out]) so that the per-input-element inner loops read consecutive words
+template <int NL, int F>
+__device__ __forceinline__ void load_weights(const MlpArgs& a, float* sW1t, float* sb1, float* sW2t, float* sb2,
+                                             float* sW3t, float* sb3)
+{
+    constexpr int H1 = NL == 1 ? F : kH;
+    for (uint32_t e = threadIdx.x; e < H1 * a.C; e += blockDim.x) {
+        const uint32_t j = e / a.C, c = e % a.C;
+        sW1t[c * H1 + j] = a.W1[e];
+    }
+    for (uint32_t e = threadIdx.x; e < H1; e += blockDim.x) sb1[e] = a.b1[e];
+    if constexpr (NL == 3) {
+        for (uint32_t e = threadIdx.x; e < kH * kH; e += blockDim.x) sW2t[(e % kH) * kH + e / kH] = a.W2[e];
+        for (uint32_t e = threadIdx.x; e < F * kH; e += blockDim.x) sW3t[(e % kH) * F + e / kH] = a.W3[e];
+        for (uint32_t e = threadIdx.x; e < kH; e += blockDim.x) sb2[e] = a.b2[e];
+        for (uint32_t e = threadIdx.x; e < F; e += blockDim.x) sb3[e] = a.b3[e];
+    }
+}
+
+__device__ __forceinline__ float input_at(const MlpArgs& a, uint32_t row, uint32_t c)
+{
+    if (c < a.Ca) return a.in_a[(size_t)row * a.lda + c];
+    if (c < a.Ca + a.Cb) return a.in_b[(size_t)row * a.ldb + (c - a.Ca)];
+    return a.pg[0];
+}
+
+// forward of one vertex; h1 / h2 hold the POST-activation hidden values (NL == 3)
+template <int NL, int F>
+__device__ __forceinline__ void mlp_row(const MlpArgs& a, uint32_t row, const float* sW1t, const float* sb1,
+                                        const float* sW2t, const float* sb2, const float* sW3t, const float* sb3,
+                                        float (&h1)[NL == 1 ? F : kH], float (&h2)[kH], float (&out)[F])
+{
+    constexpr int H1 = NL == 1 ? F : kH;
+#pragma unroll
+    for (int j = 0; j < H1; j++) h1[j] = sb1[j];
+    for (uint32_t c = 0; c < a.C; c++) {
+        const float v = input_at(a, row, c);
+        const float* w = sW1t + c * H1;
+#pragma unroll
+        for (int j = 0; j < H1; j++) h1[j] = __builtin_fmaf(w[j], v, h1[j]);
+    }
+    if constexpr (NL == 1) {
+#pragma unroll
+        for (int f = 0; f < F; f++) out[f] = h1[f];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kH; j++) { h1[j] = lrelu(h1[j]); h2[j] = sb2[j]; }
+#pragma unroll
+        for (int i = 0; i < kH; i++) {
+            const float* w = sW2t + i * kH;
+#pragma unroll
+            for (int j = 0; j < kH; j++) h2[j] = __builtin_fmaf(w[j], h1[i], h2[j]);
+        }
+#pragma unroll
+        for (int f = 0; f < F; f++) out[f] = sb3[f];
+#pragma unroll
+        for (int j = 0; j < kH; j++) {
+            h2[j] = lrelu(h2[j]);
+            const float* w = sW3t + j * F;
+#pragma unroll
+            for (int f = 0; f < F; f++) out[f] = __builtin_fmaf(w[f], h2[j], out[f]);
+        }
+    }
+}
+
+template <int NL, int F>
+__global__ __launch_bounds__(256) void k_ctx_mlp_fwd(MlpArgs a, float* __restrict__ out)
+{
+    constexpr int H1 = NL == 1 ? F : kH;
+    __shared__ float sW1t[kMaxC * H1], sb1[H1], sW2t[NL == 3 ? kH * kH : 1], sb2[kH], sW3t[NL == 3 ? kH * F : 1], sb3[F];
+    load_weights<NL, F>(a, sW1t, sb1, sW2t, sb2, sW3t, sb3);
+    __syncthreads();
+    for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < a.N; row += gridDim.x * blockDim.x) {
+        float h1[H1], h2[kH], o[F];
+        mlp_row<NL, F>(a, row, sW1t, sb1, sW2t, sb2, sW3t, sb3, h1, h2, o);
+#pragma unroll
+        for (int f = 0; f < F; f++) out[(size_t)row * F + f] = o[f];
+    }
+}
+
+struct MlpGrads {
+    const float* g_out;                       // [N, F]
+    float *g_a, *g_b, *g_pg;                  // [N, Ca], [N, Cb] or null, scalar accumulator or null
+    float *gW1, *gb1, *gW2, *gb2, *gW3, *gb3; // accumulated with atomicAdd: zeroed by the caller
+};
+
+// One wave reduces outer products over its 64 vertices: acc[k] += sum_v A[v][e / NB] * B[v][e % NB] for the
+// elements e = lane + 64 k < NA * NB this lane owns.  A / B tiles live in the wave's LDS region, pitch +1.
+template <int MAXK>
+__device__ __forceinline__ void outer_acc(const float* tA, uint32_t pitchA, uint32_t NA, const float* tB,
+                                          uint32_t pitchB, uint32_t NB, uint32_t lane, float (&acc)[MAXK])
+{
+    const uint32_t total = NA * NB;
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) {
+        const uint32_t e = lane + 64u * k;
+        if (e < total) {
+            const uint32_t ia = e / NB, ib = e % NB;
+            float s = 0.0f;
+#pragma unroll 8
+            for (uint32_t v = 0; v < 64; v++) s = __builtin_fmaf(tA[v * pitchA + ia], tB[v * pitchB + ib], s);
+            acc[k] += s;
+        }
+    }
+}
+
+template <int MAXK>
+__device__ __forceinline__ void flush_acc(float* g, uint32_t total, uint32_t lane, const float (&acc)[MAXK])
+{
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) {
+        const uint32_t e = lane + 64u * k;
+        if (e < total) atomicAdd(g + e, acc[k]);
+    }
+}
+
+constexpr int kBwdThreads = 128;    // two waves per block: each needs two 64-row LDS tiles (2 x 10.5 KB)
+
+template <int NL, int F>
+__global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads g)
+{
+    constexpr int H1 = NL == 1 ? F : kH;
+    constexpr int kPitch = kMaxC + 1;                         // tile pitch (words); covers 32 + 1 and C + 1
+    __shared__ float sW1t[kMaxC * H1], sb1[H1], sW2t[NL == 3 ? kH * kH : 1], sb2[kH], sW3t[NL == 3 ? kH * F : 1], sb3[F];
+    __shared__ float tiles[kBwdThreads / 64][2][64 * kPitch]; // per wave: tile A, tile B
+    load_weights<NL, F>(a, sW1t, sb1, sW2t, sb2, sW3t, sb3);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* tA = tiles[wave][0];
+    float* tB = tiles[wave][1];
+    // weight-gradient elements owned by this lane (accumulated over every batch of the block)
+    constexpr int K1 = (H1 * kMaxC + 63) / 64, K2 = NL == 3 ? kH * kH / 64 : 1, K3 = NL == 3 ? (F * kH + 63) / 64 : 1;
+    float aW1[K1] = {}, aW2[K2] = {}, aW3[K3] = {}, ab1 = 0, ab2 = 0, ab3 = 0, apg = 0;
+
+    const uint32_t n_batches = (a.N + kBwdThreads - 1) / kBwdThreads;
+    for (uint32_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+        const uint32_t row = batch * kBwdThreads + threadIdx.x;
+        const bool     on = row < a.N;
+        float h1[H1], h2[kH], o[F], d_o[F];
+        float d1[H1];                                          // gradient at the first layer's pre-activation
+#pragma unroll
+        for (int f = 0; f < F; f++) d_o[f] = on ? g.g_out[(size_t)row * F + f] : 0.0f;
+        if (on) mlp_row<NL, F>(a, row, sW1t, sb1, sW2t, sb2, sW3t, sb3, h1, h2, o);
+        else {
+#pragma unroll
+            for (int j = 0; j < H1; j++) h1[j] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kH; j++) h2[j] = 0.0f;
+        }
+        if constexpr (NL == 1) {
+#pragma unroll
+            for (int f = 0; f < F; f++) d1[f] = d_o[f];
+        } else {
+            float d2[kH];
+            // d2 = (W3^T d_out) * lrelu'(a2);  tiles: A = d_out [64][F], B = h2 [64][32] -> dW3
+#pragma unroll
+            for (int j = 0; j < kH; j++) {
+                float s = 0.0f;
+#pragma unroll
+                for (int f = 0; f < F; f++) s = __builtin_fmaf(sW3t[j * F + f], d_o[f], s);
+                d2[j] = h2[j] > 0.0f ? s : kSlope * s;
+                tB[lane * kPitch + j] = h2[j];
+            }
+#pragma unroll
+            for (int f = 0; f < F; f++) tA[lane * kPitch + f] = d_o[f];
+            __syncthreads();
+            outer_acc<K3>(tA, kPitch, F, tB, kPitch, kH, lane, aW3);
+            if (lane < F) {
+                float s = 0.0f;
+                for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitch + lane];
+                ab3 += s;
+            }
+            __syncthreads();
+            // d1 = (W2^T d2) * lrelu'(a1);  tiles: A = d2, B = h1 -> dW2
+#pragma unroll
+            for (int i = 0; i < kH; i++) {
+                float s = 0.0f;
+#pragma unroll
+                for (int j = 0; j < kH; j++) s = __builtin_fmaf(sW2t[i * kH + j], d2[j], s);
+                d1[i] = h1[i] > 0.0f ? s : kSlope * s;
+                tA[lane * kPitch + i] = d2[i];
+                tB[lane * kPitch + i] = h1[i];
+            }
+            __syncthreads();
+            outer_acc<K2>(tA, kPitch, kH, tB, kPitch, kH, lane, aW2);
+            if (lane < kH) {
+                float s = 0.0f;
+                for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitch + lane];
+                ab2 += s;
+            }
+            __syncthreads();
+        }
+        // input gradient, and tiles A = d1 [64][H1], B = inputs [64][C] -> dW1
+#pragma unroll
+        for (int j = 0; j < H1; j++) tA[lane * kPitch + j] = d1[j];
+        for (uint32_t c = 0; c < a.C; c++) {
+            float s = 0.0f;
+            const float* w = sW1t + c * H1;
+#pragma unroll
+            for (int j = 0; j < H1; j++) s = __builtin_fmaf(w[j], d1[j], s);
+            tB[lane * kPitch + c] = on ? input_at(a, row, c) : 0.0f;
+            if (on) {
+                if (c < a.Ca) g.g_a[(size_t)row * a.Ca + c] = s;
+                else if (c < a.Ca + a.Cb) { if (g.g_b) g.g_b[(size_t)row * a.Cb + (c - a.Ca)] = s; }
+                else apg += s;
+            }
+        }
+        __syncthreads();
+        outer_acc<K1>(tA, kPitch, H1, tB, kPitch, a.C, lane, aW1);
+        if (lane < H1) {
+            float s = 0.0f;
+            for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitch + lane];
+            ab1 += s;
+        }
+        __syncthreads();
+    }
+    flush_acc<K1>(g.gW1, H1 * a.C, lane, aW1);
+    if (lane < H1) atomicAdd(g.gb1 + lane, ab1);
+    if constexpr (NL == 3) {
+        flush_acc<K2>(g.gW2, kH * kH, lane, aW2);
+        flush_acc<K3>(g.gW3, F * kH, lane, aW3);
+        if (lane < kH) atomicAdd(g.gb2 + lane, ab2);
+        if (lane < F) atomicAdd(g.gb3 + lane, ab3);
+    }
+    if (g.g_pg) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) apg += __shfl_xor(apg, d);
+        if (lane == 0) atomicAdd(g.g_pg, apg);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bernoulli rate (utils_bpp_acc.py:1002-1013) with the table gather in front of it
+// ---------------------------------------------------------------------------------------------
+constexpr float kPmin = 1e-6f, kPmax = 1.0f - 1e-6f, kInvLn2 = 1.4426950408889634f;
+
+__global__ __launch_bounds__(256) void k_bernoulli_bits(const float* __restrict__ table, const int64_t* __restrict__ rows,
+                                                        const float* __restrict__ mean, uint64_t n, uint32_t F,
+                                                        float* __restrict__ partial)
+{
+    float s = 0.0f;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (uint64_t)gridDim.x * 256) {
+        const uint64_t slot = e / F;
+        const float    x = rows ? table[(size_t)rows[slot] * F + e % F] : table[e];
+        const float    p = fminf(fmaxf(mean[e], kPmin), kPmax);
+        s += -log2f(p) * ((1.0f + x) / 2.0f) + -log2f(1.0f - p) * ((1.0f - x) / 2.0f);
+    }
+    __shared__ float red[4];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_bernoulli_bits_bwd(const float* __restrict__ table, const int64_t* __restrict__ rows,
+                                                            const float* __restrict__ mean, const float* __restrict__ g,
+                                                            uint64_t n, uint32_t F, float* __restrict__ g_mean,
+                                                            float* __restrict__ g_x)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const float gs = g[0];
+    const uint64_t slot = e / F;
+    const float    x = rows ? table[(size_t)rows[slot] * F + e % F] : table[e];
+    const float    m = mean[e];
+    const float    p = fminf(fmaxf(m, kPmin), kPmax);
+    const float    pos = (1.0f + x) / 2.0f, neg = (1.0f - x) / 2.0f;
+    // clamp passes the gradient where min <= mean <= max
+    const bool inside = m >= kPmin && m <= kPmax;
+    if (g_mean) g_mean[e] = inside ? gs * (-pos / p + neg / (1.0f - p)) * kInvLn2 : 0.0f;
+    if (g_x) g_x[e] = gs * 0.5f * (-log2f(p) + log2f(1.0f - p));
+}
+
+// d/d values of cnc_segment_weighted_sum: row t of slot s gets g[s] * scale_t, scale = w_t (mode 0),
+// w_t / sum_slot(w) (mode 1), 1 / count (mode 2).  One lane per (row, feature); the slot by bisection.
+__global__ __launch_bounds__(256) void k_segment_bwd(const float* __restrict__ g, const int64_t* __restrict__ cumsum,
+                                                     const float* __restrict__ weights, const float* __restrict__ wsum,
+                                                     uint32_t n_slots, uint64_t T, uint32_t F, int mode,
+                                                     float* __restrict__ g_values)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= T * F) return;
+    const int64_t t = (int64_t)(e / F);
+    uint32_t lo = 0, hi = n_slots;                  // largest s with cumsum[s] <= t
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cumsum[mid] <= t) lo = mid; else hi = mid;
+    }
+    float scale = weights ? weights[t] : 1.0f;
+    if (mode == 1) scale = scale / wsum[lo];
+    else if (mode == 2) scale = scale / (float)(cumsum[lo + 1] - cumsum[lo]);
+    g_values[e] = g[(size_t)lo * F + e % F] * scale;
+}
+
+template <int NL>
+static int launch_mlp(bool backward, uint32_t F, const MlpArgs& a, float* out, const MlpGrads& g, hipStream_t s)
+{
+    const uint32_t blocks = min(div_up(a.N, 256), 2048u);
+    const uint32_t bwd_blocks = min(div_up(a.N, (uint32_t)kBwdThreads), 1024u);
+#define CNC_CTX_CASE(FF)                                                                                            \
+    if (F == FF) {                                                                                                  \
+        if (backward) hipLaunchKernelGGL((k_ctx_mlp_bwd<NL, FF>), dim3(bwd_blocks), dim3(kBwdThreads), 0, s, a, g);  \
+        else hipLaunchKernelGGL((k_ctx_mlp_fwd<NL, FF>), dim3(blocks), dim3(256), 0, s, a, out);                     \
+        return launch_status();                                                                                     \
+    }
+    CNC_CTX_CASE(1) CNC_CTX_CASE(2) CNC_CTX_CASE(4) CNC_CTX_CASE(8)
+#undef CNC_CTX_CASE
+    return CNC_ERR_UNSUPPORTED;
+}
+
+static bool mlp_args_ok(const MlpArgs& a, uint32_t n_layers)
+{
+    if (!a.in_a || !a.W1 || !a.b1 || a.C == 0 || a.C > (uint32_t)kMaxC || a.lda < a.Ca) return false;
+    if (a.Cb && (!a.in_b || a.ldb < a.Cb)) return false;
+    if (n_layers == 3 && (!a.W2 || !a.b2 || !a.W3 || !a.b3)) return false;
+    return n_layers == 1 || n_layers == 3;
+}
+
+}  // namespace cnc
+
+using namespace cnc;
+
+extern "C" int cnc_ctx_mlp_forward(const float* in_a, uint32_t lda, uint32_t Ca, const float* in_b, uint32_t ldb,
+                                   uint32_t Cb, const float* pg, uint32_t N, uint32_t n_layers, uint32_t F,
+                                   const float* W1, const float* b1, const float* W2, const float* b2,
+                                   const float* W3, const float* b3, float* out, void* stream)
+{
+    if (N == 0) return CNC_OK;
+    MlpArgs a{in_a, lda, Ca, in_b, ldb, in_b ? Cb : 0u, pg, N, Ca + (in_b ? Cb : 0u) + (pg ? 1u : 0u), W1, b1, W2, b2, W3, b3};
+    if (!out || !mlp_args_ok(a, n_layers)) return CNC_ERR_INVALID_VALUE;
+    MlpGrads none{};
+    return n_layers == 1 ? launch_mlp<1>(false, F, a, out, none, (hipStream_t)stream)
+                         : launch_mlp<3>(false, F, a, out, none, (hipStream_t)stream);
+}
+
+extern "C" int cnc_ctx_mlp_backward(const float* in_a, uint32_t lda, uint32_t Ca, const float* in_b, uint32_t ldb,
+                                    uint32_t Cb, const float* pg, uint32_t N, uint32_t n_layers, uint32_t F,
+                                    const float* W1, const float* b1, const float* W2, const float* b2,
+                                    const float* W3, const float* b3, const float* grad_out, float* grad_a,
+                                    float* grad_b, float* grad_pg, float* gW1, float* gb1, float* gW2, float* gb2,
+                                    float* gW3, float* gb3, void* stream)
+{
+    if (N == 0) return CNC_OK;
+    MlpArgs a{in_a, lda, Ca, in_b, ldb, in_b ? Cb : 0u, pg, N, Ca + (in_b ? Cb : 0u) + (pg ? 1u : 0u), W1, b1, W2, b2, W3, b3};
+    if (!grad_out || !grad_a || !gW1 || !gb1 || !mlp_args_ok(a, n_layers)) return CNC_ERR_INVALID_VALUE;
+    if (n_layers == 3 && (!gW2 || !gb2 || !gW3 || !gb3)) return CNC_ERR_INVALID_VALUE;
+    MlpGrads g{grad_out, grad_a, grad_b, pg ? grad_pg : nullptr, gW1, gb1, gW2, gb2, gW3, gb3};
+    return n_layers == 1 ? launch_mlp<1>(true, F, a, nullptr, g, (hipStream_t)stream)
+                         : launch_mlp<3>(true, F, a, nullptr, g, (hipStream_t)stream);
+}
+
+extern "C" uint32_t cnc_bernoulli_bits_partials(uint64_t n_slots, uint32_t F)
+{
+    const uint64_t blocks = (n_slots * F + 255) / 256;
+    return (uint32_t)(blocks < 1024 ? (blocks ? blocks : 1) : 1024);
+}
+
+extern "C" int cnc_bernoulli_bits_forward(const float* table, const int64_t* rows, const float* mean, uint64_t n_slots,
+                                          uint32_t F, float* partial, void* stream)
+{
+    if (!partial) return CNC_ERR_INVALID_VALUE;
+    if (n_slots && (!table || !mean)) return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_bernoulli_bits, dim3(cnc_bernoulli_bits_partials(n_slots, F)), dim3(256), 0, (hipStream_t)stream,
+                       table, rows, mean, n_slots * F, F, partial);
+    return launch_status();
+}
+
+extern "C" int cnc_bernoulli_bits_backward(const float* table, const int64_t* rows, const float* mean,
+                                           const float* grad_bits, uint64_t n_slots, uint32_t F, float* grad_mean,
+                                           float* grad_x, void* stream)
+{
+    if (n_slots == 0) return CNC_OK;
+    if (!table || !mean || !grad_bits) return CNC_ERR_INVALID_VALUE;
+    const uint64_t n = n_slots * F;
+    hipLaunchKernelGGL(k_bernoulli_bits_bwd, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table,
+                       rows, mean, grad_bits, n, F, grad_mean, grad_x);
+    return launch_status();
+}
+
+extern "C" int cnc_segment_weighted_sum_backward(const float* grad, const int64_t* cumsum, const float* weights,
+                                                 const float* wsum, uint32_t n_slots, uint64_t T, uint32_t F,
+                                                 int32_t mode, float* grad_values, void* stream)
+{
+    if (T == 0 || n_slots == 0) return CNC_OK;
+    if (!grad || !cumsum || !grad_values || (mode == 1 && (!weights || !wsum))) return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_segment_bwd, dim3((uint32_t)((T * F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad,
+                       cumsum, weights, wsum, n_slots, T, F, mode, grad_values);
+    return launch_status();
+}

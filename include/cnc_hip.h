@@ -399,6 +399,48 @@ int cnc_interval_edges_to_samples(const int64_t* iv_chunk_starts, const int64_t*
 int cnc_pack_bounds(const int64_t* ray_indices, int64_t n_samples, int64_t* first, int64_t* last,
                     int64_t n_rays, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Context-model heads and the Bernoulli rate  —  replace the ATen chains of examples/utils_bpp_acc.py
+ * (context MLPs :378-393 applied at :561-566 / :689-692, hash fusion :567-572 / :693-701,
+ * Bernoulli_entropy :1002-1013); SURVEY.md §7 item 6 / north_star: "the small context MLP ... as fused HIP
+ * kernels".
+ * ---------------------------------------------------------------------------------------- */
+
+/* y = MLP([in_a | in_b | *pg]) row by row, no concatenated copy: in_a [N, Ca] (leading dimension lda), in_b
+ * [N, Cb] or NULL, pg a DEVICE scalar appended as last column or NULL; Ca + Cb + 1 <= 40.
+ * n_layers 1: y = W1 x + b1 (the 2-D heads, Linear(C -> F));  n_layers 3: Linear(C,32) LeakyReLU(0.01)
+ * Linear(32,32) LeakyReLU Linear(32,F) (context_model_3D).  Weights in nn.Linear layout [out, in].
+ * F in {1,2,4,8}.  out [N, F].                                                                        */
+int cnc_ctx_mlp_forward(const float* in_a, uint32_t lda, uint32_t Ca, const float* in_b, uint32_t ldb,
+                        uint32_t Cb, const float* pg, uint32_t N, uint32_t n_layers, uint32_t F,
+                        const float* W1, const float* b1, const float* W2, const float* b2,
+                        const float* W3, const float* b3, float* out, void* stream);
+/* Backward: grad_a [N, Ca] written; grad_b [N, Cb] written when non-NULL; *grad_pg and every weight / bias
+ * gradient ACCUMULATED with atomics (the caller zero-fills them).                                      */
+int cnc_ctx_mlp_backward(const float* in_a, uint32_t lda, uint32_t Ca, const float* in_b, uint32_t ldb,
+                         uint32_t Cb, const float* pg, uint32_t N, uint32_t n_layers, uint32_t F,
+                         const float* W1, const float* b1, const float* W2, const float* b2,
+                         const float* W3, const float* b3, const float* grad_out, float* grad_a,
+                         float* grad_b, float* grad_pg, float* gW1, float* gb1, float* gW2, float* gb2,
+                         float* gW3, float* gb3, void* stream);
+/* bits = sum_{slot, f} -log2(p) (1 + x)/2 - log2(1 - p) (1 - x)/2, p = clamp(mean, 1e-6, 1 - 1e-6)
+ * (utils_bpp_acc.py:1005-1013), x = table[rows[slot], f] (rows NULL: x = table[slot, f]).  The kernel writes
+ * cnc_bernoulli_bits_partials(n_slots, F) per-block sums into `partial`; their sum is the result (summed by the
+ * caller: deterministic).                                                                              */
+uint32_t cnc_bernoulli_bits_partials(uint64_t n_slots, uint32_t F);
+int cnc_bernoulli_bits_forward(const float* table, const int64_t* rows, const float* mean, uint64_t n_slots,
+                               uint32_t F, float* partial, void* stream);
+/* grad_mean [n_slots, F] and grad_x [n_slots, F] (each nullable) for d(bits) scaled by the device scalar
+ * *grad_bits; the clamp passes the gradient where 1e-6 <= mean <= 1 - 1e-6.                            */
+int cnc_bernoulli_bits_backward(const float* table, const int64_t* rows, const float* mean,
+                                const float* grad_bits, uint64_t n_slots, uint32_t F, float* grad_mean,
+                                float* grad_x, void* stream);
+/* Gradient of cnc_segment_weighted_sum w.r.t. its values: grad_values [T, F] = grad[slot(t)] * scale_t,
+ * scale = w_t (mode 0), w_t / wsum[slot] (mode 1; wsum = the forward applied to the weights), 1/count (mode 2). */
+int cnc_segment_weighted_sum_backward(const float* grad, const int64_t* cumsum, const float* weights,
+                                      const float* wsum, uint32_t n_slots, uint64_t T, uint32_t F,
+                                      int32_t mode, float* grad_values, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
