@@ -134,7 +134,8 @@ def step(w, timed, world):
             o, xs, w["table"], w["offsets"], w["resolutions"], gt, n, D, F, L, 0, 128, None, None, None, None,
             ste_binary=True, ste_clip_count=w["clip"],
             binned=enc.plan_binned_levels(synthetic.RES_16L, w["offsets_host"], D, F, n)))
-    w["first_chunk"] = x[:min(CHUNK, S)]
+    mid = (S // CHUNK // 2) * CHUNK              # a chunk from the middle of the frame (the first one is atypical:
+    w["probe_chunk"] = x[mid:mid + min(CHUNK, S)]    # 36k grazing rays of ~30 samples, 2.1 ms against 1.1-1.16)
     if world > 1:
         # the only exchange of the path: one flat-bucket all-reduce of the table gradient
         timed.launch("allreduce(grad_table)", gt.numel() * 4, lambda: w["bucket"].allreduce(average=True))
@@ -314,8 +315,8 @@ def main():
                          lambda: ngrid.traverse_grids(w["rays_o"], w["rays_d"], w["binaries"], w["aabbs"],
                                                       step_size=STEP_SIZE, cone_angle=0.0))
         nb_plan = enc.plan_binned_levels(synthetic.RES_16L, w["offsets_host"], D, F, n)
-        if nb_plan is not None and w.get("first_chunk") is not None and w["first_chunk"].shape[0] == CHUNK:
-            xs_r, o_r = w["first_chunk"], w["out"]
+        if nb_plan is not None and w.get("probe_chunk") is not None and w["probe_chunk"].shape[0] == CHUNK:
+            xs_r, o_r = w["probe_chunk"], w["out"]
             nr = xs_r.shape[0]
             enc.grid_encode_forward_bits(xs_r, w["bits"], w["offsets"], w["resolutions"], o_r, nr, D, F, L, 128)
             nb = nb_plan[0]

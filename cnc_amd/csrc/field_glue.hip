@@ -1,0 +1,147 @@
+// field_glue.hip — the elementwise work around the radiance field's two MLPs, one kernel per stage.
+//
+// The reference (examples/radiance_fields/ngp.py) spells it as ~60 ATen launches per field evaluation:
+//   :516-521  x = (x - aabb_min) / (aabb_max - aabb_min);  selector = ((x > 0) & (x < 1)).all(-1)
+//   :527-535  density_before_activation, base_mlp_out = split(h, [1, geo]);  density = trunc_exp(d - 1) * selector
+//   :540-547  d = SH4((dir + 1) / 2)  [tiny-cuda-nn, restated in closed form];  h = cat([d, base_mlp_out])
+// Here:  k_field_prepare  positions -> unit-cube positions + selector
+//        k_field_post     base MLP output [N, 1 + geo] (+ view directions) -> density [N], head input [N, ld]
+//                         ( = [SH4(dir) | geo features | zero padding], no cat, no split)
+//        k_field_post_bwd gradients of density / head input -> gradient of the base MLP output
+// Same float operations in the same order as the op chain (the library is built with contraction off), so
+// the values are those of the unfused path.
+#include "common.hpp"
+
+namespace cnc {
+
+__global__ __launch_bounds__(256) void k_field_prepare(const float* __restrict__ pos, const float* __restrict__ aabb,
+                                                       uint32_t N, float* __restrict__ x_unit,
+                                                       uint8_t* __restrict__ selector)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    bool in = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float v = (pos[(size_t)i * 3 + a] - aabb[a]) / (aabb[3 + a] - aabb[a]);
+        x_unit[(size_t)i * 3 + a] = v;
+        in = in && v > 0.0f && v < 1.0f;
+    }
+    selector[i] = in ? 1 : 0;
+}
+
+// real spherical harmonics up to degree 4 of d (field.SHEncoding, term by term)
+__device__ __forceinline__ void sh4(float x, float y, float z, float (&o)[16])
+{
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * zz - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * xx - 0.54627421529603959f * yy;
+    o[9] = 0.59004358992664352f * y * (-3.0f * xx + yy);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * zz);
+    o[12] = 0.3731763325901154f * z * (5.0f * zz - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * zz);
+    o[14] = 1.4453057213202769f * z * (xx - yy);
+    o[15] = 0.59004358992664352f * x * (-xx + 3.0f * yy);
+}
+
+// one lane per (row, column of the head input); rows of `base` are [density_raw | geo features]
+__global__ __launch_bounds__(256) void k_field_post(const float* __restrict__ base, uint32_t ld_base, uint32_t geo,
+                                                    const uint8_t* __restrict__ selector, const float* __restrict__ dirs,
+                                                    uint32_t N, float* __restrict__ density, float* __restrict__ head_in,
+                                                    uint32_t ld_head)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t cols = head_in ? ld_head : 1;
+    if (e >= (uint64_t)N * cols) return;
+    const uint32_t i = (uint32_t)(e / cols), c = (uint32_t)(e % cols);
+    if (c == 0 && density) {
+        const float d = expf(base[(size_t)i * ld_base] - 1.0f);          // trunc_exp(x - 1)
+        density[i] = d * (selector ? (float)selector[i] : 1.0f);
+    }
+    if (!head_in) return;
+    float v = 0.0f;
+    if (c < 16) {
+        // the reference hands (dir + 1) / 2 to the encoding, which maps it back with * 2 - 1
+        float d3[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) d3[a] = ((dirs[(size_t)i * 3 + a] + 1.0f) / 2.0f) * 2.0f - 1.0f;
+        float o[16];
+        sh4(d3[0], d3[1], d3[2], o);
+        v = o[c];
+    } else if (c < 16 + geo) {
+        v = base[(size_t)i * ld_base + 1 + (c - 16)];
+    }
+    head_in[(size_t)i * ld_head + c] = v;
+}
+
+// d base[:, 0] = g_density * exp(min(x - 1, 15)) * selector (the clamped-gradient exp, ngp.py:318-334);
+// d base[:, 1 + k] = g_head[:, 16 + k]
+__global__ __launch_bounds__(256) void k_field_post_bwd(const float* __restrict__ base, uint32_t ld_base, uint32_t geo,
+                                                        const uint8_t* __restrict__ selector,
+                                                        const float* __restrict__ g_density,
+                                                        const float* __restrict__ g_head, uint32_t ld_head, uint32_t N,
+                                                        float* __restrict__ g_base)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t cols = 1 + geo;
+    if (e >= (uint64_t)N * cols) return;
+    const uint32_t i = (uint32_t)(e / cols), c = (uint32_t)(e % cols);
+    float v = 0.0f;
+    if (c == 0) {
+        if (g_density) {
+            const float s = selector ? (float)selector[i] : 1.0f;
+            v = (g_density[i] * s) * expf(fminf(base[(size_t)i * ld_base] - 1.0f, 15.0f));
+        }
+    } else if (g_head) {
+        v = g_head[(size_t)i * ld_head + 16 + (c - 1)];
+    }
+    g_base[(size_t)i * cols + c] = v;
+}
+
+}  // namespace cnc
+
+using namespace cnc;
+
+extern "C" int cnc_field_prepare(const float* positions, const float* aabb, uint32_t N, float* x_unit,
+                                 uint8_t* selector, void* stream)
+{
+    if (N == 0) return CNC_OK;
+    if (!positions || !aabb || !x_unit || !selector) return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_field_prepare, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, positions, aabb, N,
+                       x_unit, selector);
+    return launch_status();
+}
+
+extern "C" int cnc_field_post(const float* base_out, uint32_t ld_base, uint32_t geo_feat_dim, const uint8_t* selector,
+                              const float* dirs, uint32_t N, float* density, float* head_in, uint32_t ld_head,
+                              void* stream)
+{
+    if (N == 0) return CNC_OK;
+    if (!base_out || ld_base < 1 + geo_feat_dim || (!density && !head_in)) return CNC_ERR_INVALID_VALUE;
+    if (head_in && (!dirs || ld_head < 16 + geo_feat_dim)) return CNC_ERR_INVALID_VALUE;
+    const uint64_t n = (uint64_t)N * (head_in ? ld_head : 1);
+    hipLaunchKernelGGL(k_field_post, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base_out,
+                       ld_base, geo_feat_dim, selector, dirs, N, density, head_in, ld_head);
+    return launch_status();
+}
+
+extern "C" int cnc_field_post_backward(const float* base_out, uint32_t ld_base, uint32_t geo_feat_dim,
+                                       const uint8_t* selector, const float* grad_density, const float* grad_head_in,
+                                       uint32_t ld_head, uint32_t N, float* grad_base_out, void* stream)
+{
+    if (N == 0) return CNC_OK;
+    if (!base_out || !grad_base_out || ld_base < 1 + geo_feat_dim) return CNC_ERR_INVALID_VALUE;
+    if (grad_head_in && ld_head < 16 + geo_feat_dim) return CNC_ERR_INVALID_VALUE;
+    const uint64_t n = (uint64_t)N * (1 + geo_feat_dim);
+    hipLaunchKernelGGL(k_field_post_bwd, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base_out,
+                       ld_base, geo_feat_dim, selector, grad_density, grad_head_in, ld_head, N, grad_base_out);
+    return launch_status();
+}

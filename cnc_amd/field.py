@@ -253,9 +253,52 @@ class compose_3D_2D_embed(nn.Module):
         return run_layers(self.network, self.features(x))
 
 
+def _default_density_activation(x):
+    return trunc_exp(x - 1)
+
+
+class _FieldPost(Function):
+    """base MLP output [N, 1 + geo] -> (density [N, 1], head input [N, ld] = [SH4(dirs) | geo | 0]) in one
+    kernel, and one kernel back (cnc_amd/csrc/field_glue.hip): replaces split / trunc_exp / selector
+    multiply / SH encoding (~45 elementwise launches) / cat of ngp.py:527-547."""
+
+    @staticmethod
+    def forward(ctx, base_out, selector, dirs, geo):
+        from . import _lib
+        ctx.set_materialize_grads(False)
+        base_out = base_out.contiguous()
+        N, ldb = base_out.shape
+        dev = base_out.device
+        density = torch.empty((N, 1), dtype=torch.float32, device=dev)
+        ld = (16 + geo + 3) // 4 * 4
+        head_in = torch.empty((N, ld), dtype=torch.float32, device=dev) if dirs is not None else None
+        if dirs is not None:
+            dirs = dirs.contiguous()
+        _lib.check(_lib.lib().cnc_field_post(base_out.data_ptr(), ldb, geo, _lib.ptr(selector), _lib.ptr(dirs), N,
+                                             density.data_ptr(), _lib.ptr(head_in), ld, _lib.stream(dev)), "field_post")
+        ctx.save_for_backward(base_out, selector)
+        ctx.dims = (N, ldb, geo, ld)
+        if head_in is None:
+            return density, None
+        return density, head_in
+
+    @staticmethod
+    def backward(ctx, g_density, g_head):
+        from . import _lib
+        base_out, selector = ctx.saved_tensors
+        N, ldb, geo, ld = ctx.dims
+        g_base = torch.empty((N, ldb), dtype=torch.float32, device=base_out.device)
+        gd = None if g_density is None else g_density.contiguous()
+        gh = None if g_head is None else g_head.contiguous()
+        _lib.check(_lib.lib().cnc_field_post_backward(base_out.data_ptr(), ldb, geo, _lib.ptr(selector), _lib.ptr(gd),
+                                                      _lib.ptr(gh), ld, N, g_base.data_ptr(),
+                                                      _lib.stream(base_out.device)), "field_post_backward")
+        return g_base, None, None, None
+
+
 class NGPRadianceField_mygrid_2D3D(nn.Module):
     def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
-                 density_activation: Callable = lambda x: trunc_exp(x - 1), unbounded: bool = False,
+                 density_activation: Callable = _default_density_activation, unbounded: bool = False,
                  geo_feat_dim: int = 15,
                  resolutions_list=(16, 22, 31, 42, 57, 78, 106, 146, 199, 273, 374, 512),
                  log2_hashmap_size: int = 19, resolutions_list_2D=(64, 128, 256, 512, 1024),
@@ -273,6 +316,8 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         self.geo_feat_dim = min(127, max(15, n_features_per_level * 10 - 1))     # ngp.py:398-401
         self.resolutions_list, self.log2_hashmap_size = resolutions_list, log2_hashmap_size
         self.fused_head = os.environ.get("CNC_FUSED_HEAD", "1") == "1"
+        # normalise / selector, density activation, SH encoding and the head-input concat as single kernels
+        self.fused_glue = fused_features and not sh_fp16_round and os.environ.get("CNC_FUSED_GLUE", "1") == "1"
         self._head_fused = None
         self._head_shape_ok = n_neurons == 160       # the 32-row kernel is instantiated for 160-wide layers
         self.resolutions_list_2D, self.log2_hashmap_size_2D = resolutions_list_2D, log2_hashmap_size_2D
@@ -309,7 +354,29 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         self.mlp_base.encoding_yz.params = nn.Parameter(params_q_yz_rec)
         print("embedding_params updated!")
 
+    def _glue_ok(self, x):
+        return (self.fused_glue and x.is_cuda and x.dtype == torch.float32 and not self.unbounded and self.num_dim == 3
+                and self.density_activation is _default_density_activation and 1 + self.geo_feat_dim <= 128)
+
+    def _prepare(self, x):
+        """(unit-cube positions [N,3], selector u8 [N]) of world positions: one kernel."""
+        from . import _lib
+        p = x.reshape(-1, 3).contiguous()
+        N = p.shape[0]
+        x_unit = torch.empty_like(p)
+        selector = torch.empty(N, dtype=torch.uint8, device=p.device)
+        _lib.check(_lib.lib().cnc_field_prepare(p.data_ptr(), self.aabb.contiguous().data_ptr(), N, x_unit.data_ptr(),
+                                                selector.data_ptr(), _lib.stream(p.device)), "field_prepare")
+        return x_unit, selector
+
     def query_density(self, x, return_feat: bool = False):
+        if self._glue_ok(x):
+            lead = list(x.shape[:-1])
+            x_unit, selector = self._prepare(x)
+            h = self.mlp_base(x_unit)
+            density, _ = _FieldPost.apply(h, selector, None, self.geo_feat_dim)
+            density = density.view(lead + [1])
+            return (density, h[:, 1:].view(lead + [self.geo_feat_dim])) if return_feat else density
         if self.unbounded:
             x = contract_to_unisphere(x, self.aabb)
         else:
@@ -342,9 +409,29 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         rgb = rgb.reshape(list(embedding.shape[:-1]) + [3]).to(embedding)
         return torch.sigmoid(rgb) if apply_act else rgb
 
+    def _head(self, h):
+        """mlp_head on a [N, ld] input whose columns beyond the head's width are zero padding."""
+        n_in = self.mlp_head[0].in_features
+        if (self.fused_head and not torch.is_grad_enabled() and self._head_shape_ok and h.shape[0] >= (1 << 17)):
+            if self._head_fused is None:
+                from .mlp import FusedMLPForward
+                self._head_fused = FusedMLPForward(self.mlp_head, rows_per_wave=32)
+            return self._head_fused(h[:, :n_in])
+        first = self.mlp_head[0]
+        pad = h.shape[1] - n_in
+        return run_layers(self.mlp_head, h, first_weight=F.pad(first.weight, (0, pad)) if pad else first.weight)
+
     def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):
         if self.use_viewdirs and (directions is not None):
             assert positions.shape == directions.shape, f"{positions.shape} v.s. {directions.shape}"
+        if directions is not None and self.use_viewdirs and self.geo_feat_dim > 0 and self._glue_ok(positions) \
+                and directions.is_cuda and directions.dtype == torch.float32:
+            lead = list(positions.shape[:-1])
+            x_unit, selector = self._prepare(positions)
+            h = self.mlp_base(x_unit)
+            density, head_in = _FieldPost.apply(h, selector, directions.reshape(-1, 3), self.geo_feat_dim)
+            rgb = torch.sigmoid(self._head(head_in))
+            return rgb.view(lead + [3]), density.view(lead + [1])
         density, embedding = self.query_density(positions, return_feat=True)
         rgb = self._query_rgb(directions, embedding=embedding)
         return rgb, density

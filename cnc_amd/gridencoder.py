@@ -76,7 +76,11 @@ class _grid_encode(Function):
         N, num_dim = inputs.shape
         n_features = embeddings.shape[1]
         embeddings = embeddings.contiguous()
-        outputs = torch.empty(n_levels_calc, N, n_features, device=inputs.device, dtype=embeddings.dtype)
+        # The reference's kernel writes level-major [L, N, F] and the wrapper permutes to [N, L*F]
+        # (ngp.py:111); the kernels here take a row stride (out_ld), so the point-major result is
+        # written directly: same values, no permute copy (and none of the gradient in backward).
+        ld = n_levels_calc * n_features
+        outputs = torch.empty(N, ld, device=inputs.device, dtype=embeddings.dtype)
 
         scalar_window = isinstance(min_level_id, int)
         if scalar_window:
@@ -89,13 +93,12 @@ class _grid_encode(Function):
         if bits is not None and ste:
             # binarised table gathered from its bit plane (same values, 32x less table traffic)
             _backend.grid_encode_forward_bits(inputs, bits, offs, ress, outputs, N, num_dim,
-                                              n_features, n_levels_calc, Rb, binary_vxl, mli, occ_sat)
+                                              n_features, n_levels_calc, Rb, binary_vxl, mli, occ_sat,
+                                              out_ld=ld, out_col=0)
         else:
             _backend.grid_encode_forward(inputs, embeddings, offs, ress, outputs, N, num_dim,
                                          n_features, n_levels_calc, 0, Rb, PV, None, binary_vxl, mli,
-                                         ste_binary=ste, occ_sat=occ_sat)
-        # level-major [L, N, F] -> [N, L*F] (ngp.py:111)
-        outputs = outputs.permute(1, 0, 2).reshape(N, n_levels_calc * n_features)
+                                         ste_binary=ste, occ_sat=occ_sat, out_ld=ld, out_col=0)
         ctx.save_for_backward(inputs, embeddings, offs, ress, binary_vxl, mli, clip_count, occ_sat)
         ctx.dims = (N, num_dim, n_features, n_levels_calc, Rb, ste)
         ctx.binned = binned if (binary_vxl is None and mli is None) else None
@@ -105,12 +108,13 @@ class _grid_encode(Function):
     def backward(ctx, grad):
         inputs, embeddings, offs, ress, binary_vxl, mli, clip_count, occ_sat = ctx.saved_tensors
         N, num_dim, n_features, n_levels_calc, Rb, ste = ctx.dims
-        grad = grad.view(N, n_levels_calc, n_features).permute(1, 0, 2).contiguous()
+        grad = grad.contiguous()                       # [N, L*F], read in place (grad_ld)
         grad_embeddings = torch.zeros_like(embeddings)
         _backend.grid_encode_backward(grad, inputs, embeddings, offs, ress, grad_embeddings, N,
                                       num_dim, n_features, n_levels_calc, 0, Rb, None, None,
                                       binary_vxl, mli, ste_binary=ste, ste_clip_count=clip_count,
-                                      occ_sat=occ_sat, binned=ctx.binned)
+                                      occ_sat=occ_sat, binned=ctx.binned,
+                                      grad_ld=n_levels_calc * n_features, grad_col=0)
         return (None, grad_embeddings) + (None,) * 12
 
 

@@ -441,6 +441,30 @@ int cnc_segment_weighted_sum_backward(const float* grad, const int64_t* cumsum, 
                                       const float* wsum, uint32_t n_slots, uint64_t T, uint32_t F,
                                       int32_t mode, float* grad_values, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Elementwise glue of the radiance field  —  replaces ATen chains of examples/radiance_fields/ngp.py
+ * (no extension there).  Same float operations in the same order as the op chain.
+ * ---------------------------------------------------------------------------------------- */
+
+/* x_unit = (positions - aabb[:3]) / (aabb[3:] - aabb[:3]);  selector = all(0 < x_unit < 1)  (ngp.py:516-521).
+ * positions, x_unit [N,3]; aabb 6 floats on the device; selector u8 [N].                             */
+int cnc_field_prepare(const float* positions, const float* aabb, uint32_t N, float* x_unit,
+                      uint8_t* selector, void* stream);
+/* base_out [N, ld_base] = [density_raw | geo features (geo_feat_dim)]  ->
+ *   density [N]        = exp(density_raw - 1) * selector                          (ngp.py:527-535; nullable)
+ *   head_in [N, ld_head] = [SH degree-4 (16) of dirs | geo features | zeros]       (ngp.py:540-547; nullable)
+ * dirs [N,3] are the raw view directions (the (dir + 1) / 2 and its inverse are applied inside, as the
+ * reference and tiny-cuda-nn do between them).  selector nullable (= all ones).                       */
+int cnc_field_post(const float* base_out, uint32_t ld_base, uint32_t geo_feat_dim, const uint8_t* selector,
+                   const float* dirs, uint32_t N, float* density, float* head_in, uint32_t ld_head,
+                   void* stream);
+/* grad_base_out [N, 1 + geo] from grad_density [N] (nullable) and grad_head_in [N, ld_head] (nullable):
+ * column 0 = grad_density * selector * exp(min(density_raw - 1, 15)) (trunc_exp's clamped gradient,
+ * ngp.py:318-334), columns 1.. = grad_head_in[:, 16:16+geo].                                          */
+int cnc_field_post_backward(const float* base_out, uint32_t ld_base, uint32_t geo_feat_dim,
+                            const uint8_t* selector, const float* grad_density, const float* grad_head_in,
+                            uint32_t ld_head, uint32_t N, float* grad_base_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

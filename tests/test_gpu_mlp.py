@@ -70,3 +70,40 @@ def test_fused_mlp_32_row_kernel(cuda, dims, N, aligned):
         got = fused(x)
     assert got.shape == want.shape
     assert (got - want).abs().max() <= 2e-5 * (1 + want.abs().max())
+
+
+def test_field_glue_kernels_equal_the_op_chain(cuda):
+    """normalise + selector, density activation, SH-4 encoding and the head-input concat as single kernels
+    (cnc_amd/csrc/field_glue.hip) vs the reference's op chain (ngp.py:516-547): same rgb / density and the
+    same parameter gradients, with and without gradients enabled, for points inside and outside the box."""
+    from cnc_amd.field import NGPRadianceField_mygrid_2D3D
+    torch.manual_seed(0)
+    f = NGPRadianceField_mygrid_2D3D(aabb=[-1.5] * 3 + [1.5] * 3, n_features_per_level=8, n_neurons=160,
+                                     resolutions_list=(18, 24, 33, 44), log2_hashmap_size=12,
+                                     resolutions_list_2D=(130, 258), log2_hashmap_size_2D=10).to(cuda)
+    with torch.no_grad():
+        for p in f.parameters():
+            if p.dim() == 2 and p.shape[1] != 8:
+                p.mul_(3.0)                  # livelier MLPs than the default init
+    g = torch.Generator(device="cpu").manual_seed(1)
+    N = 5000
+    pos = ((torch.rand(N, 3, generator=g) * 3.4 - 1.7)).to(cuda)          # ~20 % outside the box
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).to(cuda)
+    go_rgb, go_den = torch.randn(N, 3, generator=g).to(cuda), torch.randn(N, 1, generator=g).to(cuda)
+    res = {}
+    for fused in (False, True):
+        f.fused_glue = fused
+        for p in f.parameters():
+            p.grad = None
+        rgb, den = f(pos, d)
+        ((rgb * go_rgb).sum() + (den * go_den).sum()).backward()
+        with torch.no_grad():
+            den_only = f.query_density(pos)
+            den2, feat = f.query_density(pos, return_feat=True)
+        res[fused] = (rgb.detach(), den.detach(), den_only, feat, [p.grad.clone() for p in f.parameters()])
+    a, b = res[False], res[True]
+    assert (b[1] == 0).float().mean() > 0.1 and (b[1] > 0).float().mean() > 0.5          # selector at work
+    assert torch.allclose(a[0], b[0], rtol=1e-5, atol=1e-6) and torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-7) and torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-6)
+    for ga, gb in zip(a[4], b[4]):
+        assert float((ga - gb).abs().max()) <= 2e-4 * max(float(ga.abs().max()), 1e-12)
