@@ -22,6 +22,12 @@ class RaySegments(C.Structure):
                 ("is_left", _vp), ("is_right", _vp), ("is_valid", _vp)]
 
 
+class CtxWindow(C.Structure):
+    """cnc_ctx_window_t (include/cnc_hip.h)."""
+    _fields_ = [("pos", _vp * 16), ("cnt", _vp * 16), ("val", _vp * 16), ("p_at", _i64 * 17), ("v_at", _i64 * 17),
+                ("row0", _i64 * 16), ("level", _i32 * 16), ("res", _i32 * 16), ("n_win", _i32)]
+
+
 # name -> argtypes, in the order of include/cnc_hip.h
 SIGNATURES = {
     "cnc_grid_encode_forward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _u32, _vp, _u32, _u32, _vp],
@@ -62,11 +68,14 @@ SIGNATURES = {
     "cnc_compact_samples": [_vp] * 9 + [_u32, _vp],
     "cnc_interval_edges_to_samples": [_vp] * 9 + [_u32, _vp],
     "cnc_pack_bounds": [_vp, _i64, _vp, _vp, _i64, _vp],
+    "cnc_level_stats_forward": [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
+    "cnc_level_stats_backward": [_vp, _vp, _u32, _u32, _vp, _vp, C.c_uint64, _vp, _vp],
     "cnc_field_prepare": [_vp, _vp, _u32, _vp, _vp, _vp],
     "cnc_field_post": [_vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp],
     "cnc_field_post_backward": [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _vp],
-    "cnc_ctx_mlp_forward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp, _vp],
-    "cnc_ctx_mlp_backward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp] * 10 + [_vp],
+    "cnc_ctx_mlp_forward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp, _vp],
+    "cnc_ctx_mlp_backward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp] * 10 + [_vp],
+    "cnc_ctx_window_gather": [_vp] * 8,
     "cnc_bernoulli_bits_partials": [C.c_uint64, _u32],
     "cnc_bernoulli_bits_forward": [_vp, _vp, _vp, C.c_uint64, _u32, _vp, _vp],
     "cnc_bernoulli_bits_backward": [_vp, _vp, _vp, _vp, C.c_uint64, _u32, _vp, _vp, _vp],
@@ -80,7 +89,7 @@ CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 11          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 13          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

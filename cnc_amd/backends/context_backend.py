@@ -23,11 +23,17 @@ class ContextMLP(Function):
     heads) or Linear-LeakyReLU-Linear-LeakyReLU-Linear (context_model_3D).  in_b / pg may be None."""
 
     @staticmethod
-    def forward(ctx, in_a, in_b, pg, W1, b1, W2, b2, W3, b3):
+    def forward(ctx, in_a, in_b, pg, W1, b1, W2, b2, W3, b3, pg_index=None):
         ctx.set_materialize_grads(False)
         in_a = _f32c(in_a.contiguous(), "in_a")
         in_b = None if in_b is None else _f32c(in_b.contiguous(), "in_b")
-        pgv = None if pg is None else _f32c(pg.reshape(1).contiguous(), "pg")
+        pgv = None if pg is None else _f32c(pg.reshape(-1).contiguous(), "pg")
+        if pg_index is not None:
+            check_input(pg_index, "pg_index")
+            if pg_index.dtype != torch.int64 or pg_index.shape[0] != in_a.shape[0] or pgv is None:
+                raise RuntimeError("pg_index must be int64 [N] and comes with a pg table")
+        elif pgv is not None and pgv.numel() != 1:
+            raise RuntimeError("pg must be a scalar unless pg_index is given")
         ws = [_f32c(w.contiguous(), "weight") if w is not None else None for w in (W1, b1, W2, b2, W3, b3)]
         n_layers = 1 if W2 is None else 3
         N, Ca = in_a.shape
@@ -36,43 +42,44 @@ class ContextMLP(Function):
         if ws[0].shape[1] != Ca + Cb + (pgv is not None):
             raise RuntimeError("context MLP: input width does not match the first layer")
         out = torch.empty((N, F), dtype=torch.float32, device=in_a.device)
-        check(_lib.lib().cnc_ctx_mlp_forward(ptr(in_a), Ca, Ca, ptr(in_b), Cb, Cb, ptr(pgv), N, n_layers, F,
+        check(_lib.lib().cnc_ctx_mlp_forward(ptr(in_a), Ca, Ca, ptr(in_b), Cb, Cb, ptr(pgv), ptr(pg_index), N, n_layers, F,
                                              *[ptr(w) for w in ws], ptr(out), stream(in_a.device)), "ctx_mlp_forward")
-        ctx.save_for_backward(in_a, in_b, pgv, *ws)
+        ctx.save_for_backward(in_a, in_b, pgv, pg_index, *ws)
         ctx.dims = (N, Ca, Cb, n_layers, F, None if pg is None else tuple(pg.shape))
         return out
 
     @staticmethod
     def backward(ctx, g):
-        in_a, in_b, pgv, *ws = ctx.saved_tensors
+        in_a, in_b, pgv, pg_index, *ws = ctx.saved_tensors
         N, Ca, Cb, n_layers, F, pg_shape = ctx.dims
         if g is None:
-            return (None,) * 9
+            return (None,) * 10
         g = _f32c(g.contiguous(), "grad_out")
         dev = in_a.device
         g_a = torch.empty_like(in_a)
         g_b = torch.empty_like(in_b) if (in_b is not None and ctx.needs_input_grad[1]) else None
-        g_pg = torch.zeros(1, dtype=torch.float32, device=dev) if pgv is not None else None
+        g_pg = torch.zeros(pgv.numel(), dtype=torch.float32, device=dev) if pgv is not None else None
         # every weight / bias gradient in ONE zero-filled buffer (the kernel accumulates with atomics)
         flat = torch.zeros(sum(w.numel() for w in ws if w is not None), dtype=torch.float32, device=dev)
         gws, at = [], 0
         for w in ws:
             gws.append(None if w is None else flat[at:at + w.numel()].view_as(w))
             at += 0 if w is None else w.numel()
-        check(_lib.lib().cnc_ctx_mlp_backward(ptr(in_a), Ca, Ca, ptr(in_b), Cb, Cb, ptr(pgv), N, n_layers, F,
+        check(_lib.lib().cnc_ctx_mlp_backward(ptr(in_a), Ca, Ca, ptr(in_b), Cb, Cb, ptr(pgv), ptr(pg_index), N, n_layers, F,
                                               *[ptr(w) for w in ws], ptr(g), ptr(g_a), ptr(g_b), ptr(g_pg),
                                               *[ptr(w) for w in gws], stream(dev)), "ctx_mlp_backward")
-        return (g_a, g_b, None if g_pg is None else g_pg.reshape(pg_shape), *gws)
+        return (g_a, g_b, None if g_pg is None else g_pg.reshape(pg_shape), *gws, None)
 
 
-def context_mlp(seq, in_a, in_b=None, pg=None):
-    """Apply an nn.Sequential of Linear / LeakyReLU layers (1 or 3 Linear) through the fused kernel."""
+def context_mlp(seq, in_a, in_b=None, pg=None, pg_index=None):
+    """Apply an nn.Sequential of Linear / LeakyReLU layers (1 or 3 Linear) through the fused kernel.  The input
+    row is [in_a | in_b | pg]; with `pg_index` (int64 [N]) pg is a table and row i takes pg[pg_index[i]]."""
     lin = [m for m in seq if isinstance(m, torch.nn.Linear)] if isinstance(seq, torch.nn.Sequential) else [seq]
     if len(lin) == 1:
-        return ContextMLP.apply(in_a, in_b, pg, lin[0].weight, lin[0].bias, None, None, None, None)
+        return ContextMLP.apply(in_a, in_b, pg, lin[0].weight, lin[0].bias, None, None, None, None, pg_index)
     if len(lin) == 3 and lin[0].out_features == 32 and lin[1].out_features == 32:
         return ContextMLP.apply(in_a, in_b, pg, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias,
-                                lin[2].weight, lin[2].bias)
+                                lin[2].weight, lin[2].bias, pg_index)
     raise RuntimeError("context_mlp: expected Linear(C,F) or Linear(C,32)-LeakyReLU-Linear(32,32)-LeakyReLU-Linear(32,F)")
 
 
@@ -127,3 +134,70 @@ def segment_backward(g, cumsum, weights, wsum, T, mode):
     check(_lib.lib().cnc_segment_weighted_sum_backward(ptr(g), ptr(cumsum), ptr(weights), ptr(wsum), S, T, F, int(mode),
                                                        ptr(out), stream(g.device)), "segment_weighted_sum_backward")
     return out
+
+
+class LevelStats(Function):
+    """(Pg [L], bits [L]) of every level of a binarised table in one pass (cnc_level_stats_*)."""
+
+    @staticmethod
+    def forward(ctx, table, off_host):
+        import ctypes as C
+        ctx.set_materialize_grads(False)
+        table = _f32c(table.contiguous(), "table")
+        L = len(off_host) - 1
+        F, dev = table.shape[1], table.device
+        offs = (C.c_int64 * (L + 1))(*[int(o) for o in off_host])
+        sums = torch.empty(L, dtype=torch.float64, device=dev)
+        Pg = torch.empty(L, dtype=torch.float32, device=dev)
+        bits = torch.empty(L, dtype=torch.float32, device=dev)
+        check(_lib.lib().cnc_level_stats_forward(ptr(table), C.cast(offs, C.c_void_p), L, F, ptr(sums), ptr(Pg), ptr(bits),
+                                                 stream(dev)), "level_stats_forward")
+        ctx.save_for_backward(sums)
+        ctx.meta = (offs, L, F, table.shape[0])
+        return Pg, bits
+
+    @staticmethod
+    def backward(ctx, g_Pg, g_bits):
+        import ctypes as C
+        (sums,) = ctx.saved_tensors
+        offs, L, F, rows = ctx.meta
+        if g_Pg is None and g_bits is None:
+            return None, None
+        g = torch.empty((rows, F), dtype=torch.float32, device=sums.device)
+        gp = None if g_Pg is None else g_Pg.contiguous()
+        gb = None if g_bits is None else g_bits.contiguous()
+        check(_lib.lib().cnc_level_stats_backward(ptr(sums), C.cast(offs, C.c_void_p), L, F, ptr(gp), ptr(gb), rows,
+                                                  ptr(g), stream(sums.device)), "level_stats_backward")
+        return g, None
+
+
+def level_stats(table, off_host):
+    return LevelStats.apply(table, tuple(off_host))
+
+
+def window_gather(levels, device):
+    """levels: list of dicts {pos (int16 [*,3] window slice), cnt, val (int64 window slices), level, res, row0}.
+    Returns (pts i16 [P,3], pts_n f32 [P,3], level_ids i64 [P], resolutions i64 [P], slot_counts i64 [V],
+    table_rows i64 [V]) concatenated over the levels — one kernel (cnc_ctx_window_gather)."""
+    import ctypes as C
+    w = _lib.CtxWindow()
+    w.n_win = len(levels)
+    P = V = 0
+    for i, lv in enumerate(levels):
+        for name in ("pos", "cnt", "val"):
+            check_input(lv[name], name)
+        w.pos[i], w.cnt[i], w.val[i] = lv["pos"].data_ptr(), lv["cnt"].data_ptr(), lv["val"].data_ptr()
+        w.p_at[i], w.v_at[i] = P, V
+        w.row0[i], w.level[i], w.res[i] = int(lv["row0"]), int(lv["level"]), int(lv["res"])
+        P += lv["pos"].shape[0]
+        V += lv["cnt"].shape[0]
+    w.p_at[len(levels)], w.v_at[len(levels)] = P, V
+    pts = torch.empty((P, 3), dtype=torch.int16, device=device)
+    pts_n = torch.empty((P, 3), dtype=torch.float32, device=device)
+    lvl = torch.empty(P, dtype=torch.int64, device=device)
+    res = torch.empty(P, dtype=torch.int64, device=device)
+    cnts = torch.empty(V, dtype=torch.int64, device=device)
+    rows = torch.empty(V, dtype=torch.int64, device=device)
+    check(_lib.lib().cnc_ctx_window_gather(C.byref(w), ptr(pts), ptr(pts_n), ptr(lvl), ptr(res), ptr(cnts), ptr(rows),
+                                           stream(device)), "ctx_window_gather")
+    return pts, pts_n, lvl, res, cnts, rows

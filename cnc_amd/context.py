@@ -457,6 +457,7 @@ class CNC_context_models(nn.Module):
         offsets_list = self.offsets_list
         # host copies: slicing a table with device scalars costs a device->host sync per slice
         self._off3_host = [int(v) for v in self.offsets_list.tolist()]
+        self._res3_host = [int(v) for v in resolutions_list.tolist()]
         self._off2_host = [int(v) for v in self.offsets_list_2D.tolist()]
 
         # finest level that is still stored densely (utils_bpp_acc.py:288-293)
@@ -603,6 +604,8 @@ class CNC_context_models(nn.Module):
         One pass over the table instead of L sliced reductions and ~10 scalar kernels per level; the
         level sums are differences of a float64 running sum of the row sums (exact for +-1 tables)."""
         off = tuple(off_host)
+        if self.fused_heads and params_q.is_cuda and len(off) <= 33:
+            return _ctxk.level_stats(params_q, off)
         sums = _LevelSums.apply(params_q, off)
         ttl = _level_consts(off, params_q.shape[1], params_q.device)[2]
         pos_num, neg_num = (ttl + sums) / 2.0, (ttl - sums) / 2.0
@@ -691,7 +694,7 @@ class CNC_context_models(nn.Module):
             return torch.sum(mean * overlap_w, dim=1)
         return torch.sum(mean, dim=1) / mask_cnt.unsqueeze(-1)
 
-    def _slot_masks(self, mask, overlap, unique_cnt):
+    def _slot_masks(self, mask, overlap, unique_cnt, idx=None):
         """Per slot: number of its vertices next to occupied space, whether any is, and the
         normalised overlap weights of those vertices (utils_bpp_acc.py:668-682)."""
         if self.fused_segments:
@@ -699,7 +702,8 @@ class CNC_context_models(nn.Module):
                                                            None, _cum(unique_cnt.contiguous()), 0)[:, 0]
             mask_exist = per_slot > 0
             mask_cnt = per_slot.to(torch.long)[mask_exist]
-            return mask_cnt, mask_exist, torch.clamp(overlap[mask], min=1).to(torch.float)
+            picked = overlap[mask] if idx is None else overlap.index_select(0, idx)
+            return mask_cnt, mask_exist, torch.clamp(picked, min=1).to(torch.float)
         mask_packed = align_and_pack.apply(mask.unsqueeze(-1).to(torch.float), unique_cnt, 0)
         per_slot = torch.sum(mask_packed[:, :, 0], dim=1)
         mask_exist = per_slot > 0
@@ -815,50 +819,60 @@ class CNC_context_models(nn.Module):
         p0s = self.unique_count_cumsum_list[self.utils_nlevel_idx, v0s]
         p1s = self.unique_count_cumsum_list[self.utils_nlevel_idx, v1s]
 
-        pts_orig, pts_n, Pg_cols, lvl_ids, cnts, values_q = [], [], [], [], [], []
         with _range("ctx/level_Pg"):
             Pg_all, bits_all = self.level_stats(params_q_xyz, self._off3_host)
-        _g = _range("ctx/3D_gather")
-        _g.__enter__()
         # the window bounds of every level in ONE device->host copy
         v0s, v1s, p0s, p1s = torch.stack([v0s, v1s, p0s, p1s]).tolist()
+        coded = [n for n in range(self.n_levels) if self._coded_3D(n)]
         for n in range(self.n_levels):
-            Pg_n, bits_n = Pg_all[n], bits_all[n]
-            if not self._coded_3D(n):
-                ttl_bit_sum = ttl_bit_sum + bits_n
-                continue
-            po = self.pos_grid_sorted_list[n][p0s[n]:p1s[n]]
-            pts_orig.append(po)
-            pts_n.append((po - 0.5) / self.scales_list[n, :])
-            Pg_cols.append(Pg_n.reshape(1, 1).repeat(po.shape[0], 1))
-            lvl_ids.append(torch.full((po.shape[0],), n, dtype=torch.long, device=self.dev))
-            cnts.append(self.unique_count_list[n, v0s[n]:v1s[n]])
-            values_q.append(self.unique_value_list[n][v0s[n]:v1s[n]] + self._off3_host[n])   # table rows
-        _g.__exit__(None, None, None)
-
-        if pts_orig:
-            with _range("ctx/3D_cat"):
-                pts_orig, pts_n, Pg_cols = torch.cat(pts_orig), torch.cat(pts_n), torch.cat(Pg_cols)
-                lvl_ids, cnts = torch.cat(lvl_ids), torch.cat(cnts)
-                # one gather for all levels: its backward is ONE scatter into a table-sized gradient
-                rows_3D = torch.cat(values_q)
+            if n not in coded:
+                ttl_bit_sum = ttl_bit_sum + bits_all[n]
+        fused = self.fused_heads and params_q_xyz.is_cuda and len(coded) <= 16
+        L = self.max_context_layer_num
+        if coded and fused:
+            with _range("ctx/3D_gather"):
+                # vertices, positions, level / resolution per vertex, slot counts and table rows of every coded
+                # level's window, concatenated: one kernel
+                pts_orig, pts_n, lvl_ids, res_pts, cnts, rows_3D = _ctxk.window_gather(
+                    [dict(pos=self.pos_grid_sorted_list[n][p0s[n]:p1s[n]], cnt=self.unique_count_list[n, v0s[n]:v1s[n]],
+                          val=self.unique_value_list[n][v0s[n]:v1s[n]], level=n, res=self._res3_host[n],
+                          row0=self._off3_host[n]) for n in coded], self.dev)
             with _range("ctx/3D_query"):
-                mask, overlap = self.query_binary_vxl_qlist(pts_orig, binary_vxl, lvl_ids, return_overlap_area=True)
+                mask, overlap = self._query(pts_orig, binary_vxl, resolution_list=res_pts)
+                idx = torch.nonzero(mask).squeeze(1)          # the vertices next to occupied space (one sync)
             with _range("ctx/3D_slot_masks"):
-                mask_cnt, mask_exist, overlap_w = self._slot_masks(mask, overlap, cnts)
-            L = self.max_context_layer_num
+                mask_cnt, mask_exist, overlap_w = self._slot_masks(mask, overlap, cnts, idx)
             with _range("ctx/3D_encode"):
-                context = Encoding_xyz.forward_diff_levels(pts_n[mask], lvl_ids[mask].to(torch.int) - L, L,
+                lvl_m = lvl_ids.index_select(0, idx)
+                context = Encoding_xyz.forward_diff_levels(pts_n.index_select(0, idx), (lvl_m - L).to(torch.int), L,
                                                            binary_vxl=binary_vxl.squeeze(), PV=1001)
-                pg_col = Pg_cols[mask]
-                if not (self.fused_heads and context.is_cuda):
-                    context = torch.cat([context, pg_col], dim=-1)
             with _range("ctx/3D_mlp_fuse"):
-                mean_pts = (_ctxk.context_mlp(self.context_model_3D, context, pg_col)
-                            if self.fused_heads and context.is_cuda else self.context_model_3D(context))
+                # the input row is [context | Pg of the vertex's level]: the column is read from Pg_all by level
+                mean_pts = _ctxk.context_mlp(self.context_model_3D, context, None, Pg_all, lvl_m)
                 mean = self._fuse_3D(mean_pts, mask_cnt, overlap_w)
             with _range("ctx/3D_entropy"):
                 bits = self._bits(params_q_xyz, rows_3D[mask_exist], mean)
+            ttl_bit_sum = ttl_bit_sum + bits / ttl_sample_valid * self.ttl_hashparams_num_valid_levels
+        elif coded:
+            pts_orig, pts_n, Pg_cols, lvl_ids, cnts, values_q = [], [], [], [], [], []
+            for n in coded:
+                po = self.pos_grid_sorted_list[n][p0s[n]:p1s[n]]
+                pts_orig.append(po)
+                pts_n.append((po - 0.5) / self.scales_list[n, :])
+                Pg_cols.append(Pg_all[n].reshape(1, 1).repeat(po.shape[0], 1))
+                lvl_ids.append(torch.full((po.shape[0],), n, dtype=torch.long, device=self.dev))
+                cnts.append(self.unique_count_list[n, v0s[n]:v1s[n]])
+                values_q.append(self.unique_value_list[n][v0s[n]:v1s[n]] + self._off3_host[n])   # table rows
+            pts_orig, pts_n, Pg_cols = torch.cat(pts_orig), torch.cat(pts_n), torch.cat(Pg_cols)
+            lvl_ids, cnts = torch.cat(lvl_ids), torch.cat(cnts)
+            rows_3D = torch.cat(values_q)
+            mask, overlap = self.query_binary_vxl_qlist(pts_orig, binary_vxl, lvl_ids, return_overlap_area=True)
+            mask_cnt, mask_exist, overlap_w = self._slot_masks(mask, overlap, cnts)
+            context = Encoding_xyz.forward_diff_levels(pts_n[mask], lvl_ids[mask].to(torch.int) - L, L,
+                                                       binary_vxl=binary_vxl.squeeze(), PV=1001)
+            context = torch.cat([context, Pg_cols[mask]], dim=-1)
+            mean = self._fuse_3D(self.context_model_3D(context), mask_cnt, overlap_w)
+            bits = self._bits(params_q_xyz, rows_3D[mask_exist], mean)
             ttl_bit_sum = ttl_bit_sum + bits / ttl_sample_valid * self.ttl_hashparams_num_valid_levels
 
         ttl_num_sum += params_q_xyz.numel()

@@ -33,6 +33,7 @@ struct MlpArgs {
     const float* in_a; uint32_t lda, Ca;      // [N, Ca] rows with leading dimension lda
     const float* in_b; uint32_t ldb, Cb;      // [N, Cb] or null
     const float* pg;                          // device scalar appended as the last column, or null
+    const int64_t* pg_index;                  // null, or per-row index into pg[] (rows of different levels)
     uint32_t     N, C;                        // C = Ca + Cb + (pg ? 1 : 0)
     const float *W1, *b1, *W2, *b2, *W3, *b3; // nn.Linear layout [out, in]; W2 / W3 unused for NL == 1
 };
@@ -60,7 +61,7 @@ __device__ __forceinline__ float input_at(const MlpArgs& a, uint32_t row, uint32
 {
     if (c < a.Ca) return a.in_a[(size_t)row * a.lda + c];
     if (c < a.Ca + a.Cb) return a.in_b[(size_t)row * a.ldb + (c - a.Ca)];
-    return a.pg[0];
+    return a.pg[a.pg_index ? a.pg_index[row] : 0];
 }
 
 // forward of one vertex; h1 / h2 hold the POST-activation hidden values (NL == 3)
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
     // weight-gradient elements owned by this lane (accumulated over every batch of the block)
     constexpr int K1 = (H1 * kMaxC + 63) / 64, K2 = NL == 3 ? kH * kH / 64 : 1, K3 = NL == 3 ? (F * kH + 63) / 64 : 1;
     float aW1[K1] = {}, aW2[K2] = {}, aW3[K3] = {}, ab1 = 0, ab2 = 0, ab3 = 0, apg = 0;
+    int64_t pg_at = -1;            // pg_index mode: the table entry this WAVE is accumulating for (wave-uniform)
 
     const uint32_t n_batches = (a.N + kBwdThreads - 1) / kBwdThreads;
     for (uint32_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
         // input gradient, and tiles A = d1 [64][H1], B = inputs [64][C] -> dW1
 #pragma unroll
         for (int j = 0; j < H1; j++) tA[lane * kPitch + j] = d1[j];
+        float   s_pg = 0.0f;       // this row's gradient of the Pg column
         for (uint32_t c = 0; c < a.C; c++) {
             float s = 0.0f;
             const float* w = sW1t + c * H1;
@@ -241,7 +244,31 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
             if (on) {
                 if (c < a.Ca) g.g_a[(size_t)row * a.Ca + c] = s;
                 else if (c < a.Ca + a.Cb) { if (g.g_b) g.g_b[(size_t)row * a.Cb + (c - a.Ca)] = s; }
+                else if (a.pg_index) s_pg = s;
                 else apg += s;
+            }
+        }
+        if (g.g_pg && a.pg_index) {
+            // rows of one level are contiguous, so a wave almost always holds ONE table entry: reduce over the
+            // wave and keep a running sum per wave, flushed with one atomic when the entry changes.  (One atomic
+            // per lane on <= 16 addresses serialised the whole kernel: 9.6 ms instead of 0.7.)
+            const int64_t  idx = on ? a.pg_index[row] : -1;
+            const uint64_t live = __ballot(on);
+            if (live) {
+                const int64_t first = __shfl(idx, __builtin_ctzll(live));
+                if (__ballot(on && idx != first) == 0) {
+                    float v = on ? s_pg : 0.0f;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+                    if (first != pg_at) {
+                        if (pg_at >= 0 && lane == 0) atomicAdd(g.g_pg + pg_at, apg);
+                        pg_at = first;
+                        apg = 0.0f;
+                    }
+                    apg += v;
+                } else if (on) {
+                    atomicAdd(g.g_pg + idx, s_pg);       // a wave straddling two levels
+                }
             }
         }
         __syncthreads();
@@ -261,7 +288,9 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
         if (lane < kH) atomicAdd(g.gb2 + lane, ab2);
         if (lane < F) atomicAdd(g.gb3 + lane, ab3);
     }
-    if (g.g_pg) {
+    if (g.g_pg && a.pg_index) {
+        if (pg_at >= 0 && lane == 0) atomicAdd(g.g_pg + pg_at, apg);
+    } else if (g.g_pg) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) apg += __shfl_xor(apg, d);
         if (lane == 0) atomicAdd(g.g_pg, apg);
@@ -361,12 +390,14 @@ static bool mlp_args_ok(const MlpArgs& a, uint32_t n_layers)
 using namespace cnc;
 
 extern "C" int cnc_ctx_mlp_forward(const float* in_a, uint32_t lda, uint32_t Ca, const float* in_b, uint32_t ldb,
-                                   uint32_t Cb, const float* pg, uint32_t N, uint32_t n_layers, uint32_t F,
+                                   uint32_t Cb, const float* pg, const int64_t* pg_index, uint32_t N,
+                                   uint32_t n_layers, uint32_t F,
                                    const float* W1, const float* b1, const float* W2, const float* b2,
                                    const float* W3, const float* b3, float* out, void* stream)
 {
     if (N == 0) return CNC_OK;
-    MlpArgs a{in_a, lda, Ca, in_b, ldb, in_b ? Cb : 0u, pg, N, Ca + (in_b ? Cb : 0u) + (pg ? 1u : 0u), W1, b1, W2, b2, W3, b3};
+    MlpArgs a{in_a, lda, Ca, in_b, ldb, in_b ? Cb : 0u, pg, pg ? pg_index : nullptr, N,
+              Ca + (in_b ? Cb : 0u) + (pg ? 1u : 0u), W1, b1, W2, b2, W3, b3};
     if (!out || !mlp_args_ok(a, n_layers)) return CNC_ERR_INVALID_VALUE;
     MlpGrads none{};
     return n_layers == 1 ? launch_mlp<1>(false, F, a, out, none, (hipStream_t)stream)
@@ -374,14 +405,16 @@ extern "C" int cnc_ctx_mlp_forward(const float* in_a, uint32_t lda, uint32_t Ca,
 }
 
 extern "C" int cnc_ctx_mlp_backward(const float* in_a, uint32_t lda, uint32_t Ca, const float* in_b, uint32_t ldb,
-                                    uint32_t Cb, const float* pg, uint32_t N, uint32_t n_layers, uint32_t F,
+                                    uint32_t Cb, const float* pg, const int64_t* pg_index, uint32_t N,
+                                    uint32_t n_layers, uint32_t F,
                                     const float* W1, const float* b1, const float* W2, const float* b2,
                                     const float* W3, const float* b3, const float* grad_out, float* grad_a,
                                     float* grad_b, float* grad_pg, float* gW1, float* gb1, float* gW2, float* gb2,
                                     float* gW3, float* gb3, void* stream)
 {
     if (N == 0) return CNC_OK;
-    MlpArgs a{in_a, lda, Ca, in_b, ldb, in_b ? Cb : 0u, pg, N, Ca + (in_b ? Cb : 0u) + (pg ? 1u : 0u), W1, b1, W2, b2, W3, b3};
+    MlpArgs a{in_a, lda, Ca, in_b, ldb, in_b ? Cb : 0u, pg, pg ? pg_index : nullptr, N,
+              Ca + (in_b ? Cb : 0u) + (pg ? 1u : 0u), W1, b1, W2, b2, W3, b3};
     if (!grad_out || !grad_a || !gW1 || !gb1 || !mlp_args_ok(a, n_layers)) return CNC_ERR_INVALID_VALUE;
     if (n_layers == 3 && (!gW2 || !gb2 || !gW3 || !gb3)) return CNC_ERR_INVALID_VALUE;
     MlpGrads g{grad_out, grad_a, grad_b, pg ? grad_pg : nullptr, gW1, gb1, gW2, gb2, gW3, gb3};
@@ -426,4 +459,203 @@ extern "C" int cnc_segment_weighted_sum_backward(const float* grad, const int64_
     hipLaunchKernelGGL(k_segment_bwd, dim3((uint32_t)((T * F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad,
                        cumsum, weights, wsum, n_slots, T, F, mode, grad_values);
     return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Level statistics of a binarised table (get_BiRF_wentropy_leveln, utils_bpp_acc.py:472-486) for ALL levels
+// of a table in one pass: sums[l] = sum of the entries of level l (float64 accumulation: exact for +-1
+// entries, so the total does not depend on the order of the atomics), then Pg and the zero-order bit count.
+// ---------------------------------------------------------------------------------------------
+namespace cnc {
+
+constexpr int kMaxLevels = 32;
+
+struct LevelOffsets {
+    int64_t off[kMaxLevels + 1];      // row offsets, off[n_levels] = end
+    int32_t n_levels;
+};
+
+__device__ __forceinline__ int level_of(const LevelOffsets& lo, int64_t row)
+{
+    int l = 0;
+    while (l + 1 < lo.n_levels && row >= lo.off[l + 1]) l++;
+    return l;
+}
+
+__global__ __launch_bounds__(256) void k_level_sums(const float* __restrict__ table, LevelOffsets lo, uint32_t F,
+                                                    double* __restrict__ sums)
+{
+    __shared__ double s_acc[kMaxLevels];
+    if (threadIdx.x < kMaxLevels) s_acc[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int64_t r0 = lo.off[0], r1 = lo.off[lo.n_levels];
+    // a block covers 256 x 8 consecutive rows; a lane sums rows r, r + 256, ...
+    const int64_t base = r0 + (int64_t)blockIdx.x * 2048;
+    int    cur = -1;
+    double acc = 0.0;
+    for (int k = 0; k < 8; k++) {
+        const int64_t r = base + k * 256 + threadIdx.x;
+        if (r >= r1) break;
+        const int l = level_of(lo, r);
+        if (l != cur) {
+            if (cur >= 0) atomicAdd(&s_acc[cur], acc);
+            cur = l;
+            acc = 0.0;
+        }
+        float s = 0.0f;
+        for (uint32_t f = 0; f < F; f++) s += table[(size_t)r * F + f];
+        acc += (double)s;
+    }
+    if (cur >= 0) atomicAdd(&s_acc[cur], acc);
+    __syncthreads();
+    if (threadIdx.x < lo.n_levels && s_acc[threadIdx.x] != 0.0) atomicAdd(&sums[threadIdx.x], s_acc[threadIdx.x]);
+}
+
+// pos = (ttl + s) / 2, neg = (ttl - s) / 2, Pg = pos / ttl,
+// bits = pos * -log2(max(Pg, 1e-9)) + neg * -log2(max(1 - Pg, 1e-9))       (cnc_amd.context._zero_order_bits)
+__global__ void k_level_stats(const double* __restrict__ sums, LevelOffsets lo, uint32_t F, float* __restrict__ Pg,
+                              float* __restrict__ bits)
+{
+    const int l = threadIdx.x;
+    if (l >= lo.n_levels) return;
+    const float ttl = (float)((lo.off[l + 1] - lo.off[l]) * (int64_t)F);
+    const float s = (float)sums[l];
+    const float pos = (ttl + s) / 2.0f, neg = (ttl - s) / 2.0f;
+    const float p = pos / ttl;
+    Pg[l] = p;
+    bits[l] = pos * (-log2f(fmaxf(p, 1e-9f))) + neg * (-log2f(fmaxf(1.0f - p, 1e-9f)));
+}
+
+// grad_table[r, :] = d sums[level(r)], d sums = g_Pg dPg/ds + g_bits dbits/ds
+__global__ __launch_bounds__(256) void k_level_stats_bwd(const double* __restrict__ sums, LevelOffsets lo, uint32_t F,
+                                                         const float* __restrict__ g_Pg, const float* __restrict__ g_bits,
+                                                         uint64_t total_rows, float* __restrict__ g_table)
+{
+    __shared__ float s_d[kMaxLevels];
+    if ((int)threadIdx.x < lo.n_levels) {
+        const int   l = threadIdx.x;
+        const float ttl = (float)((lo.off[l + 1] - lo.off[l]) * (int64_t)F);
+        const float s = (float)sums[l];
+        const float pos = (ttl + s) / 2.0f, neg = (ttl - s) / 2.0f;
+        const float p = pos / ttl, q = 1.0f - p;
+        const float A = -log2f(fmaxf(p, 1e-9f)), B = -log2f(fmaxf(q, 1e-9f));
+        const float dA = p > 1e-9f ? -kInvLn2 / p : 0.0f;            // dA / dPg
+        const float dB = q > 1e-9f ? kInvLn2 / q : 0.0f;             // dB / dPg
+        const float dp = 0.5f / ttl;                                 // dPg / ds
+        const float dbits = 0.5f * A - 0.5f * B + (pos * dA + neg * dB) * dp;
+        s_d[l] = (g_Pg ? g_Pg[l] * dp : 0.0f) + (g_bits ? g_bits[l] * dbits : 0.0f);
+    }
+    __syncthreads();
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total_rows * F) return;
+    const int64_t r = (int64_t)(e / F);
+    g_table[e] = (r >= lo.off[0] && r < lo.off[lo.n_levels]) ? s_d[level_of(lo, r)] : 0.0f;
+}
+
+}  // namespace cnc
+
+extern "C" int cnc_level_stats_forward(const float* table, const int64_t* offsets_host, uint32_t n_levels, uint32_t F,
+                                       double* sums, float* Pg, float* bits, void* stream)
+{
+    if (n_levels == 0 || n_levels > (uint32_t)cnc::kMaxLevels || !table || !offsets_host || !sums || !Pg || !bits)
+        return CNC_ERR_INVALID_VALUE;
+    cnc::LevelOffsets lo{};
+    lo.n_levels = (int32_t)n_levels;
+    for (uint32_t i = 0; i <= n_levels; i++) lo.off[i] = offsets_host[i];
+    const int64_t rows = lo.off[n_levels] - lo.off[0];
+    if (hipMemsetAsync(sums, 0, n_levels * sizeof(double), (hipStream_t)stream) != hipSuccess) return CNC_ERR_LAUNCH;
+    if (rows > 0)
+        hipLaunchKernelGGL(cnc::k_level_sums, dim3((uint32_t)((rows + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream,
+                           table, lo, F, sums);
+    hipLaunchKernelGGL(cnc::k_level_stats, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, lo, F, Pg, bits);
+    return cnc::launch_status();
+}
+
+extern "C" int cnc_level_stats_backward(const double* sums, const int64_t* offsets_host, uint32_t n_levels, uint32_t F,
+                                        const float* grad_Pg, const float* grad_bits, uint64_t total_rows,
+                                        float* grad_table, void* stream)
+{
+    if (total_rows == 0) return CNC_OK;
+    if (n_levels == 0 || n_levels > (uint32_t)cnc::kMaxLevels || !sums || !offsets_host || !grad_table)
+        return CNC_ERR_INVALID_VALUE;
+    cnc::LevelOffsets lo{};
+    lo.n_levels = (int32_t)n_levels;
+    for (uint32_t i = 0; i <= n_levels; i++) lo.off[i] = offsets_host[i];
+    hipLaunchKernelGGL(cnc::k_level_stats_bwd, dim3((uint32_t)((total_rows * F + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, sums, lo, F, grad_Pg, grad_bits, total_rows, grad_table);
+    return cnc::launch_status();
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The per-step sample of the 3-D context pass (utils_bpp_acc.py:619-667): for every coded level a window of
+// hash slots [v0, v1) and the vertices [p0, p1) that land in them.  One kernel writes the concatenation over
+// the levels of: the vertices (int16), their positions (x - 0.5) / (R - 2), level id and resolution per
+// vertex, and per slot the collision count and the absolute table row.
+// ---------------------------------------------------------------------------------------------
+namespace cnc {
+
+constexpr int kMaxWin = 16;
+
+struct WindowDesc {
+    const int16_t* pos[kMaxWin];       // pos_grid_sorted_list[n] + 3 * p0
+    const int64_t* cnt[kMaxWin];       // unique_count_list[n] + v0
+    const int64_t* val[kMaxWin];       // unique_value_list[n] + v0
+    int64_t        p_at[kMaxWin + 1];  // output offset of the level's vertices (p_at[n_win] = P)
+    int64_t        v_at[kMaxWin + 1];  // output offset of the level's slots (v_at[n_win] = V)
+    int64_t        row0[kMaxWin];      // table row offset of the level
+    int32_t        level[kMaxWin], res[kMaxWin];
+    int32_t        n_win;
+};
+
+__global__ __launch_bounds__(256) void k_ctx_window_gather(WindowDesc d, int16_t* __restrict__ pts, float* __restrict__ pts_n,
+                                                           int64_t* __restrict__ lvl, int64_t* __restrict__ res,
+                                                           int64_t* __restrict__ cnts, int64_t* __restrict__ rows)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t P = d.p_at[d.n_win], V = d.v_at[d.n_win];
+    if (t < P) {
+        int w = 0;
+        while (w + 1 < d.n_win && t >= d.p_at[w + 1]) w++;
+        const int64_t  k = t - d.p_at[w];
+        const float    scale = (float)(d.res[w] - 2);
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int16_t q = d.pos[w][k * 3 + a];
+            pts[t * 3 + a] = q;
+            pts_n[t * 3 + a] = ((float)q - 0.5f) / scale;
+        }
+        lvl[t] = d.level[w];
+        res[t] = d.res[w];
+    }
+    if (t < V) {
+        int w = 0;
+        while (w + 1 < d.n_win && t >= d.v_at[w + 1]) w++;
+        const int64_t k = t - d.v_at[w];
+        cnts[t] = d.cnt[w][k];
+        rows[t] = d.val[w][k] + d.row0[w];
+    }
+}
+
+}  // namespace cnc
+
+extern "C" int cnc_ctx_window_gather(const cnc_ctx_window_t* win, int16_t* pts, float* pts_n, int64_t* level_ids,
+                                     int64_t* resolutions, int64_t* slot_counts, int64_t* table_rows, void* stream)
+{
+    if (!win || win->n_win <= 0 || win->n_win > cnc::kMaxWin) return CNC_ERR_INVALID_VALUE;
+    cnc::WindowDesc d{};
+    d.n_win = win->n_win;
+    for (int i = 0; i < win->n_win; i++) {
+        d.pos[i] = win->pos[i]; d.cnt[i] = win->cnt[i]; d.val[i] = win->val[i];
+        d.p_at[i] = win->p_at[i]; d.v_at[i] = win->v_at[i]; d.row0[i] = win->row0[i];
+        d.level[i] = win->level[i]; d.res[i] = win->res[i];
+    }
+    d.p_at[win->n_win] = win->p_at[win->n_win];
+    d.v_at[win->n_win] = win->v_at[win->n_win];
+    const int64_t n = d.p_at[d.n_win] > d.v_at[d.n_win] ? d.p_at[d.n_win] : d.v_at[d.n_win];
+    if (n == 0) return CNC_OK;
+    if (!pts || !pts_n || !level_ids || !resolutions || !slot_counts || !table_rows) return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(cnc::k_ctx_window_gather, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d,
+                       pts, pts_n, level_ids, resolutions, slot_counts, table_rows);
+    return cnc::launch_status();
 }

@@ -407,22 +407,44 @@ int cnc_pack_bounds(const int64_t* ray_indices, int64_t n_samples, int64_t* firs
  * ---------------------------------------------------------------------------------------- */
 
 /* y = MLP([in_a | in_b | *pg]) row by row, no concatenated copy: in_a [N, Ca] (leading dimension lda), in_b
- * [N, Cb] or NULL, pg a DEVICE scalar appended as last column or NULL; Ca + Cb + 1 <= 40.
+ * [N, Cb] or NULL, pg a DEVICE scalar appended as last column or NULL (with pg_index i64 [N]: a table, row i
+ * takes pg[pg_index[i]] — rows of several levels in one call, each with its level's Pg); Ca + Cb + 1 <= 40.
  * n_layers 1: y = W1 x + b1 (the 2-D heads, Linear(C -> F));  n_layers 3: Linear(C,32) LeakyReLU(0.01)
  * Linear(32,32) LeakyReLU Linear(32,F) (context_model_3D).  Weights in nn.Linear layout [out, in].
  * F in {1,2,4,8}.  out [N, F].                                                                        */
 int cnc_ctx_mlp_forward(const float* in_a, uint32_t lda, uint32_t Ca, const float* in_b, uint32_t ldb,
-                        uint32_t Cb, const float* pg, uint32_t N, uint32_t n_layers, uint32_t F,
+                        uint32_t Cb, const float* pg, const int64_t* pg_index, uint32_t N, uint32_t n_layers,
+                        uint32_t F,
                         const float* W1, const float* b1, const float* W2, const float* b2,
                         const float* W3, const float* b3, float* out, void* stream);
 /* Backward: grad_a [N, Ca] written; grad_b [N, Cb] written when non-NULL; *grad_pg and every weight / bias
  * gradient ACCUMULATED with atomics (the caller zero-fills them).                                      */
 int cnc_ctx_mlp_backward(const float* in_a, uint32_t lda, uint32_t Ca, const float* in_b, uint32_t ldb,
-                         uint32_t Cb, const float* pg, uint32_t N, uint32_t n_layers, uint32_t F,
+                         uint32_t Cb, const float* pg, const int64_t* pg_index, uint32_t N, uint32_t n_layers,
+                         uint32_t F,
                          const float* W1, const float* b1, const float* W2, const float* b2,
                          const float* W3, const float* b3, const float* grad_out, float* grad_a,
                          float* grad_b, float* grad_pg, float* gW1, float* gb1, float* gW2, float* gb2,
                          float* gW3, float* gb3, void* stream);
+/* The per-step sample of the 3-D context pass (utils_bpp_acc.py:619-667), all coded levels at once: level i
+ * contributes the vertices pos[i][0 .. p_at[i+1]-p_at[i]) (int16 triples, already offset to the window start)
+ * and the slots cnt[i] / val[i][0 .. v_at[i+1]-v_at[i]).  Written, concatenated over the levels: pts i16 [P,3],
+ * pts_n f32 [P,3] = (x - 0.5) / (res - 2), level_ids / resolutions i64 [P], slot_counts i64 [V],
+ * table_rows i64 [V] = val + row0.  The descriptor lives on the HOST (device pointers inside).        */
+typedef struct {
+    const int16_t* pos[16];
+    const int64_t* cnt[16];
+    const int64_t* val[16];
+    int64_t        p_at[17];
+    int64_t        v_at[17];
+    int64_t        row0[16];
+    int32_t        level[16];
+    int32_t        res[16];
+    int32_t        n_win;
+} cnc_ctx_window_t;
+int cnc_ctx_window_gather(const cnc_ctx_window_t* win, int16_t* pts, float* pts_n, int64_t* level_ids,
+                          int64_t* resolutions, int64_t* slot_counts, int64_t* table_rows, void* stream);
+
 /* bits = sum_{slot, f} -log2(p) (1 + x)/2 - log2(1 - p) (1 - x)/2, p = clamp(mean, 1e-6, 1 - 1e-6)
  * (utils_bpp_acc.py:1005-1013), x = table[rows[slot], f] (rows NULL: x = table[slot, f]).  The kernel writes
  * cnc_bernoulli_bits_partials(n_slots, F) per-block sums into `partial`; their sum is the result (summed by the
@@ -440,6 +462,18 @@ int cnc_bernoulli_bits_backward(const float* table, const int64_t* rows, const f
 int cnc_segment_weighted_sum_backward(const float* grad, const int64_t* cumsum, const float* weights,
                                       const float* wsum, uint32_t n_slots, uint64_t T, uint32_t F,
                                       int32_t mode, float* grad_values, void* stream);
+
+/* Level statistics of a binarised table, all levels in one pass (get_BiRF_wentropy_leveln,
+ * utils_bpp_acc.py:472-486): sums[l] = sum of table[off[l]:off[l+1], :] (float64: exact for +-1 entries),
+ * Pg[l] = #(+1) / numel, bits[l] = the zero-order bit count with the logarithms' arguments floored at 1e-9.
+ * offsets_host: HOST array of n_levels + 1 row offsets (<= 32 levels).  sums f64 [n_levels] (scratch kept for
+ * the backward), Pg / bits f32 [n_levels].                                                              */
+int cnc_level_stats_forward(const float* table, const int64_t* offsets_host, uint32_t n_levels, uint32_t F,
+                            double* sums, float* Pg, float* bits, void* stream);
+/* grad_table [total_rows, F] = (grad_Pg dPg/dsum + grad_bits dbits/dsum)[level(row)], 0 outside the levels. */
+int cnc_level_stats_backward(const double* sums, const int64_t* offsets_host, uint32_t n_levels, uint32_t F,
+                             const float* grad_Pg, const float* grad_bits, uint64_t total_rows,
+                             float* grad_table, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Elementwise glue of the radiance field  —  replaces ATen chains of examples/radiance_fields/ngp.py

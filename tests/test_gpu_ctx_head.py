@@ -144,3 +144,65 @@ def test_context_pass_fused_heads_equals_op_chain(cuda):
         # float32 sums of ~1e5-1e6 signed terms in two orders (GEMM reduction vs LDS tiles + atomics): both carry
         # eps * sum|terms|, which after cancellation is ~1e-4 of the result (vs float64: test_context_mlp_*)
         assert float((a - b).abs().max()) <= 3e-3 * scale
+
+
+def test_level_stats_kernel(cuda):
+    """All levels' Pg / zero-order bits in one pass vs the per-level formula (utils_bpp_acc.py:472-486, with the
+    1e-9 floor of cnc_amd.context._zero_order_bits), forward and backward, including a level whose entries
+    all share a sign (Pg = 0: 0 bits, zero gradient, no NaN) and rows outside the levels."""
+    from cnc_amd.backends import context_backend as K
+    from cnc_amd.context import _zero_order_bits
+    g = torch.Generator().manual_seed(3)
+    off = (8, 332, 844, 1356, 5000)             # the first 8 rows and the tail belong to no level
+    rows, F = 5200, 8
+    t = torch.where(torch.rand(rows, F, generator=g) > 0.3, 1.0, -1.0)
+    t[844:1356] = -1.0                           # Pg = 0
+    gp, gb = torch.randn(4, generator=g), torch.randn(4, generator=g)
+    t64 = t.clone().requires_grad_()
+    Pg_ref, bits_ref = [], []
+    for a, b in zip(off[:-1], off[1:]):
+        lvl = t64[a:b]
+        s = lvl.sum()
+        ttl = lvl.numel()
+        pos, neg = (ttl + s) / 2.0, (ttl - s) / 2.0
+        Pg_ref.append(pos / ttl)
+        bits_ref.append(_zero_order_bits(pos, neg, pos / ttl))
+    Pg_ref, bits_ref = torch.stack(Pg_ref), torch.stack(bits_ref)
+    ((Pg_ref * gp).sum() + (bits_ref * gb).sum()).backward()
+    td = t.to(cuda).requires_grad_()
+    Pg, bits = K.level_stats(td, off)
+    ((Pg * gp.to(cuda)).sum() + (bits * gb.to(cuda)).sum()).backward()
+    assert torch.allclose(Pg.cpu(), Pg_ref.detach(), rtol=1e-6, atol=0) and float(Pg[2]) == 0.0
+    assert torch.allclose(bits.cpu(), bits_ref.detach(), rtol=2e-6, atol=1e-3) and float(bits[2]) == 0.0
+    assert torch.isfinite(td.grad).all()
+    assert torch.allclose(td.grad.cpu(), t64.grad, rtol=2e-5, atol=1e-7)
+    assert float(td.grad[:8].abs().max()) == 0 and float(td.grad[5000:].abs().max()) == 0
+
+
+def test_context_mlp_with_per_row_pg_table(cuda):
+    """pg as a table indexed per row (rows of several levels in one call): forward equals the op chain on
+    [in_a | pg[idx]], the table's gradient is the per-entry sum — runs of equal indices (one atomic per
+    wave) and a scrambled tail (per-lane atomics)."""
+    from cnc_amd.backends import context_backend as K
+    g = torch.Generator().manual_seed(21)
+    N, Ca, F, T = 20000, 24, 8, 12
+    seq = nn.Sequential(nn.Linear(Ca + 1, 32), nn.LeakyReLU(), nn.Linear(32, 32), nn.LeakyReLU(), nn.Linear(32, F))
+    a = torch.randn(N, Ca, generator=g)
+    idx = torch.sort(torch.randint(3, T, (N,), generator=g))[0]
+    idx[-700:] = torch.randint(0, T, (700,), generator=g)
+    pg = torch.rand(T, generator=g)
+    go = torch.randn(N, F, generator=g)
+    ref = nn.Sequential(*[type(m)(m.in_features, m.out_features) if isinstance(m, nn.Linear) else nn.LeakyReLU() for m in seq])
+    ref.load_state_dict(seq.state_dict())
+    ref = ref.double()
+    a64, pg64 = a.double().requires_grad_(), pg.double().requires_grad_()
+    y64 = ref(torch.cat([a64, pg64[idx][:, None]], dim=-1))
+    (y64 * go.double()).sum().backward()
+    seq = seq.to(cuda)
+    ad, pgd = a.to(cuda).requires_grad_(), pg.to(cuda).requires_grad_()
+    y = K.context_mlp(seq, ad, None, pgd, idx.to(cuda))
+    (y * go.to(cuda)).sum().backward()
+    assert torch.allclose(y.double().cpu(), y64.detach(), rtol=2e-5, atol=2e-5)
+    assert torch.allclose(ad.grad.double().cpu(), a64.grad, rtol=2e-5, atol=2e-5)
+    assert torch.allclose(pgd.grad.double().cpu(), pg64.grad, rtol=1e-4, atol=1e-3)
+    assert float(pgd.grad[:3].abs().max()) >= 0 and float(pg64.grad.abs().max()) > 1
