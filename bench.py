@@ -219,12 +219,12 @@ def train_step_entry(dev):
     cfg = TrainConfig(n_features=8, sample_num=150000, image_size=400, out_dir="/tmp/cnc_bench_bits")
     tr = Trainer(cfg, device=dev)
     for step in range(80):                  # occupancy warm-up + adaptive ray budget settle
-        tr.train_step(step)
+        tr.train_step(step, want_stats=False)
     torch.cuda.synchronize()
     n_steps, samples, rays = 60, 0, 0
     t0 = time.perf_counter()
     for step in range(80, 80 + n_steps):
-        s = tr.train_step(step)
+        s = tr.train_step(step, want_stats=False)       # loss scalars are read back on log steps only (as train:368)
         if s is not None:
             samples += s["n_rendering_samples"]
             rays += s["num_rays"]

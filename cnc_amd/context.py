@@ -658,7 +658,7 @@ class CNC_context_models(nn.Module):
 
     # ---- shared per-level arithmetic -------------------------------------------------------
     def _mean_2D(self, Encoding_2D, n, points_n, Pg_n, binary_vxl_2D, pn_embed_frac, order,
-                 unique_cnt, outspace_params=None, detach_pn=False):
+                 unique_cnt, outspace_params=None, detach_pn=False, cum=None):
         """P(+1) per distinct hash slot of 2-D level n: context = lower levels (+ dimension-wise
         3-D vote fraction) -> linear head -> mean over the vertices colliding in the slot."""
         ctx_layers = min(n, self.max_context_layer_num)
@@ -680,7 +680,7 @@ class CNC_context_models(nn.Module):
             mean = self.context_model_2D[n - 1](torch.cat(parts, dim=-1))
         mean = torch.index_select(mean, dim=0, index=order)
         if self.fused_segments:
-            return _segment_reduce.apply(mean, _cum(unique_cnt), None, 2)
+            return _segment_reduce.apply(mean, _cum(unique_cnt) if cum is None else cum, None, 2)
         mean = align_and_pack.apply(mean, unique_cnt, 0.0, 2)
         return torch.sum(mean, dim=1) / unique_cnt.unsqueeze(-1)
 
@@ -696,13 +696,20 @@ class CNC_context_models(nn.Module):
 
     def _slot_masks(self, mask, overlap, unique_cnt, idx=None):
         """Per slot: number of its vertices next to occupied space, whether any is, and the
-        normalised overlap weights of those vertices (utils_bpp_acc.py:668-682)."""
+        normalised overlap weights of those vertices (utils_bpp_acc.py:668-682).  With `idx` (the indices of
+        the True entries of `mask`) the second result is the INDEX list of the slots rather than a bool mask."""
         if self.fused_segments:
             per_slot = pack_and_align.segment_weighted_sum(mask.unsqueeze(-1).to(torch.float).contiguous(),
                                                            None, _cum(unique_cnt.contiguous()), 0)[:, 0]
             mask_exist = per_slot > 0
-            mask_cnt = per_slot.to(torch.long)[mask_exist]
-            picked = overlap[mask] if idx is None else overlap.index_select(0, idx)
+            if idx is None:
+                mask_cnt = per_slot.to(torch.long)[mask_exist]
+                picked = overlap[mask]
+            else:
+                # index lists instead of boolean masks: ONE sync for the slots, reused by the caller for the table rows
+                mask_exist = torch.nonzero(mask_exist).squeeze(1)
+                mask_cnt = per_slot.to(torch.long).index_select(0, mask_exist)
+                picked = overlap.index_select(0, idx)
             return mask_cnt, mask_exist, torch.clamp(picked, min=1).to(torch.float)
         mask_packed = align_and_pack.apply(mask.unsqueeze(-1).to(torch.float), unique_cnt, 0)
         per_slot = torch.sum(mask_packed[:, :, 0], dim=1)
@@ -763,7 +770,7 @@ class CNC_context_models(nn.Module):
 
     # ------------------------------------------------------------------------------- training
     def forward_binary_vxl_mixPg_3D2D(self, Encoding_xyz, Encoding_xy, Encoding_xz, Encoding_yz,
-                                      binary_vxl=None, verbose=False, sample_num=None, step=0):
+                                      binary_vxl=None, verbose=False, sample_num=None, step=0, sync_MB=True):
         """Entropy estimate (bits per parameter) of the four binarised tables under the context
         models; differentiable w.r.t. tables and context models (utils_bpp_acc.py:533-706)."""
         with _range("ctx/ste_params"):
@@ -784,8 +791,10 @@ class CNC_context_models(nn.Module):
         idx_coords2 = self.idx_coords2_tmp
         binary_2D = [self._project(binary_vxl, a) for a in axes]
         if refresh:
+            # vertex lists, slot order and the slots' cumulative counts are fixed until the next refresh
             self.batched_inputs_list = [
-                [self._sorted_slots_2D(binary_2D[k], n) for n in range(self.n_levels_2D) if self._coded_2D(n)]
+                [(lambda t: t + (_cum(t[3]),))(self._sorted_slots_2D(binary_2D[k], n))
+                 for n in range(self.n_levels_2D) if self._coded_2D(n)]
                 for k in range(3)]
 
         finest_3D = params_q_xyz[self._off3_host[-2]:self._off3_host[-1]]
@@ -800,9 +809,9 @@ class CNC_context_models(nn.Module):
             for n in range(self.n_levels_2D):
                 Pg_n, bits_n = Pg_all[n], bits_all[n]
                 if self._coded_2D(n):
-                    points_n, order, rows, unique_cnt = next(batches)
+                    points_n, order, rows, unique_cnt, cum = next(batches)
                     with _range("ctx/2D_mean"):
-                        mean = self._mean_2D(Ec, n, points_n, Pg_n, binary_2D[k], pn_frac, order, unique_cnt)
+                        mean = self._mean_2D(Ec, n, points_n, Pg_n, binary_2D[k], pn_frac, order, unique_cnt, cum=cum)
                     with _range("ctx/2D_entropy"):
                         bits_n = self._bits(p_q, rows, mean)
                 ttl_bit_sum = ttl_bit_sum + bits_n
@@ -851,7 +860,8 @@ class CNC_context_models(nn.Module):
                 mean_pts = _ctxk.context_mlp(self.context_model_3D, context, None, Pg_all, lvl_m)
                 mean = self._fuse_3D(mean_pts, mask_cnt, overlap_w)
             with _range("ctx/3D_entropy"):
-                bits = self._bits(params_q_xyz, rows_3D[mask_exist], mean)
+                coded_rows = rows_3D[mask_exist] if mask_exist.dtype == torch.bool else rows_3D.index_select(0, mask_exist)
+                bits = self._bits(params_q_xyz, coded_rows, mean)
             ttl_bit_sum = ttl_bit_sum + bits / ttl_sample_valid * self.ttl_hashparams_num_valid_levels
         elif coded:
             pts_orig, pts_n, Pg_cols, lvl_ids, cnts, values_q = [], [], [], [], [], []
@@ -877,7 +887,10 @@ class CNC_context_models(nn.Module):
 
         ttl_num_sum += params_q_xyz.numel()
         bits_per_param = ttl_bit_sum / ttl_num_sum
-        return bits_per_param, ttl_bit_sum.item() / 8 / 1024 / 1024
+        # second value: the estimate in MB as a Python float like the reference (a device->host sync), or — with
+        # sync_MB=False — the 0-dim device tensor, for callers that only read it when they log
+        est_MB = ttl_bit_sum.detach() / 8 / 1024 / 1024
+        return bits_per_param, (est_MB.item() if sync_MB else est_MB)
 
     # ------------------------------------------------------------------------------- encode
     def encode_binary_vxl_mixPg_3D2D(self, Encoding_xyz, Encoding_xy, Encoding_xz, Encoding_yz,

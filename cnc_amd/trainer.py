@@ -256,7 +256,10 @@ class Trainer:
             self.context.rand_like = synced_rand_like
 
     # -------------------------------------------------------------------------------- training
-    def train_step(self, step: int) -> Optional[Dict[str, float]]:
+    def train_step(self, step: int, want_stats: bool = True) -> Optional[Dict[str, float]]:
+        """One optimisation step.  `want_stats=False` leaves mse / psnr / bpp / embed_bits_MB out of the result
+        (reading them back is a device->host sync per step; the reference only looks at them every 200 steps,
+        train:368-381) — `n_rendering_samples` and `num_rays` are always there."""
         c = self.cfg
         self.field.train(); self.estimator.train(); self.context.train()
         data = self.dataset.fetch()
@@ -283,7 +286,7 @@ class Trainer:
             e = self.field.mlp_base
             bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(
                 e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
-                sample_num=None, step=step)
+                sample_num=None, step=step, sync_MB=False)
             loss = loss + c.lmbda * bits_per_param
             bpp = bits_per_param
         self.opt.zero_grad(set_to_none=self.bucket is None)
@@ -319,18 +322,22 @@ class Trainer:
             self.sched2.step()
         if self.bucket is not None and (step + 1) % c.step_update == 0:
             cdist.broadcast_parameters(self.bucket.params)        # 161 MB every `step_update` steps
+        if not want_stats:
+            return {"n_rendering_samples": n_samples, "num_rays": len(pixels)}
         # the step's scalars in one device->host copy
-        mse_f, bpp_f = torch.stack([mse.detach(), torch.as_tensor(bpp, device=mse.device).detach().float()]).tolist()
+        mse_f, bpp_f, mb_f = torch.stack([mse.detach(), torch.as_tensor(bpp, device=mse.device).detach().float(),
+                                          torch.as_tensor(mb, device=mse.device).detach().float()]).tolist()
         return {"mse": mse_f, "psnr": -10.0 * math.log10(max(mse_f, 1e-12)), "bpp": bpp_f,
-                "embed_bits_MB": mb, "n_rendering_samples": n_samples, "num_rays": len(pixels)}
+                "embed_bits_MB": mb_f, "n_rendering_samples": n_samples, "num_rays": len(pixels)}
 
     def train(self, steps: Optional[int] = None, log=print):
         steps = self.cfg.max_steps if steps is None else steps
         tic = time.time()
         last = None
         for step in range(steps + 1):
-            s = self.train_step(step)
-            if s is not None:
+            logging = step % self.cfg.log_every == 0 or step == steps
+            s = self.train_step(step, want_stats=logging)
+            if s is not None and logging:
                 last = s
             if log and s is not None and step % self.cfg.log_every == 0 and self.rank == 0:
                 log(f"elapsed_time={time.time() - tic:.2f}s | step={step} | psnr={s['psnr']:.2f} | "
