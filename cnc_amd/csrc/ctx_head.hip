@@ -64,6 +64,38 @@ __device__ __forceinline__ float input_at(const MlpArgs& a, uint32_t row, uint32
     return a.pg[a.pg_index ? a.pg_index[row] : 0];
 }
 
+// Columns [c0, c0 + 4) of a row as one 16-byte access when the segment allows it (base pointer and leading
+// dimension multiples of 4 floats — true for the encoder outputs, which are 8 k wide), scalar otherwise.
+__device__ __forceinline__ bool seg_vec_ok(const float* p, uint32_t ld, uint32_t n)
+{
+    return (((uintptr_t)p | (uintptr_t)(ld * sizeof(float))) & 15u) == 0 && (n & 3u) == 0;
+}
+
+// calls fn(c, value) for every column of the input row [in_a | in_b | pg]; 16-byte loads where possible
+// (statically unrolled: a runtime-indexed float[4] here sent the NL = 3 kernels to scratch memory)
+template <class Fn>
+__device__ __forceinline__ void for_each_input(const MlpArgs& a, uint32_t row, Fn fn)
+{
+    uint32_t c = 0;
+    auto seg = [&](const float* base, uint32_t ld, uint32_t n) {
+        const float* r = base + (size_t)row * ld;
+        if (seg_vec_ok(base, ld, n)) {
+            for (uint32_t k = 0; k < n; k += 4, c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(r + k);
+                fn(c, v.x);
+                fn(c + 1, v.y);
+                fn(c + 2, v.z);
+                fn(c + 3, v.w);
+            }
+        } else {
+            for (uint32_t k = 0; k < n; k++, c++) fn(c, r[k]);
+        }
+    };
+    seg(a.in_a, a.lda, a.Ca);
+    if (a.Cb) seg(a.in_b, a.ldb, a.Cb);
+    if (a.pg) fn(c, a.pg[a.pg_index ? a.pg_index[row] : 0]);
+}
+
 // forward of one vertex; h1 / h2 hold the POST-activation hidden values (NL == 3)
 template <int NL, int F>
 __device__ __forceinline__ void mlp_row(const MlpArgs& a, uint32_t row, const float* sW1t, const float* sb1,
@@ -73,12 +105,11 @@ __device__ __forceinline__ void mlp_row(const MlpArgs& a, uint32_t row, const fl
     constexpr int H1 = NL == 1 ? F : kH;
 #pragma unroll
     for (int j = 0; j < H1; j++) h1[j] = sb1[j];
-    for (uint32_t c = 0; c < a.C; c++) {
-        const float v = input_at(a, row, c);
+    for_each_input(a, row, [&](uint32_t c, float v) {
         const float* w = sW1t + c * H1;
 #pragma unroll
         for (int j = 0; j < H1; j++) h1[j] = __builtin_fmaf(w[j], v, h1[j]);
-    }
+    });
     if constexpr (NL == 1) {
 #pragma unroll
         for (int f = 0; f < F; f++) out[f] = h1[f];
@@ -90,6 +121,9 @@ __device__ __forceinline__ void mlp_row(const MlpArgs& a, uint32_t row, const fl
             const float* w = sW2t + i * kH;
 #pragma unroll
             for (int j = 0; j < kH; j++) h2[j] = __builtin_fmaf(w[j], h1[i], h2[j]);
+            // keep the scheduler from hoisting all 1024 weight reads of the unrolled layer to the top (that took
+            // 256 VGPRs + 256 AGPRs + 932 B of scratch per lane)
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int f = 0; f < F; f++) out[f] = sb3[f];
@@ -99,6 +133,7 @@ __device__ __forceinline__ void mlp_row(const MlpArgs& a, uint32_t row, const fl
             const float* w = sW3t + j * F;
 #pragma unroll
             for (int f = 0; f < F; f++) out[f] = __builtin_fmaf(w[f], h2[j], out[f]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -181,8 +216,8 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
         float d1[H1];                                          // gradient at the first layer's pre-activation
 #pragma unroll
         for (int f = 0; f < F; f++) d_o[f] = on ? g.g_out[(size_t)row * F + f] : 0.0f;
-        if (on) mlp_row<NL, F>(a, row, sW1t, sb1, sW2t, sb2, sW3t, sb3, h1, h2, o);
-        else {
+        if (on && NL == 3) mlp_row<NL, F>(a, row, sW1t, sb1, sW2t, sb2, sW3t, sb3, h1, h2, o);   // a single Linear
+        else {                                                                                   // needs no activations
 #pragma unroll
             for (int j = 0; j < H1; j++) h1[j] = 0.0f;
 #pragma unroll
@@ -201,6 +236,7 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
                 for (int f = 0; f < F; f++) s = __builtin_fmaf(sW3t[j * F + f], d_o[f], s);
                 d2[j] = h2[j] > 0.0f ? s : kSlope * s;
                 tB[lane * kPitch + j] = h2[j];
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int f = 0; f < F; f++) tA[lane * kPitch + f] = d_o[f];
@@ -221,6 +257,7 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
                 d1[i] = h1[i] > 0.0f ? s : kSlope * s;
                 tA[lane * kPitch + i] = d2[i];
                 tB[lane * kPitch + i] = h1[i];
+                __builtin_amdgcn_sched_barrier(0);       // as in mlp_row: do not hoist the whole layer's weight reads
             }
             __syncthreads();
             outer_acc<K2>(tA, kPitch, kH, tB, kPitch, kH, lane, aW2);
@@ -235,18 +272,42 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
 #pragma unroll
         for (int j = 0; j < H1; j++) tA[lane * kPitch + j] = d1[j];
         float   s_pg = 0.0f;       // this row's gradient of the Pg column
-        for (uint32_t c = 0; c < a.C; c++) {
-            float s = 0.0f;
+        auto d_in = [&](uint32_t c) {      // d input[c] = sum_j W1[j][c] d1[j]
+            float        s = 0.0f;
             const float* w = sW1t + c * H1;
 #pragma unroll
             for (int j = 0; j < H1; j++) s = __builtin_fmaf(w[j], d1[j], s);
-            tB[lane * kPitch + c] = on ? input_at(a, row, c) : 0.0f;
-            if (on) {
-                if (c < a.Ca) g.g_a[(size_t)row * a.Ca + c] = s;
-                else if (c < a.Ca + a.Cb) { if (g.g_b) g.g_b[(size_t)row * a.Cb + (c - a.Ca)] = s; }
-                else if (a.pg_index) s_pg = s;
+            return s;
+        };
+        if (on) {
+            uint32_t c = 0;
+            auto     seg = [&](const float* base, uint32_t ld, uint32_t n, float* gout) {
+                const float* r = base + (size_t)row * ld;
+                float*       go = gout ? gout + (size_t)row * n : nullptr;
+                if (seg_vec_ok(base, ld, n) && (!gout || seg_vec_ok(gout, n, n))) {
+                    for (uint32_t k = 0; k < n; k += 4, c += 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(r + k);
+                        tB[lane * kPitch + c] = v.x; tB[lane * kPitch + c + 1] = v.y;
+                        tB[lane * kPitch + c + 2] = v.z; tB[lane * kPitch + c + 3] = v.w;
+                        if (go) *reinterpret_cast<float4*>(go + k) = make_float4(d_in(c), d_in(c + 1), d_in(c + 2), d_in(c + 3));
+                    }
+                } else {
+                    for (uint32_t k = 0; k < n; k++, c++) {
+                        tB[lane * kPitch + c] = r[k];
+                        if (go) go[k] = d_in(c);
+                    }
+                }
+            };
+            seg(a.in_a, a.lda, a.Ca, g.g_a);
+            if (a.Cb) seg(a.in_b, a.ldb, a.Cb, g.g_b);
+            if (a.pg) {
+                tB[lane * kPitch + c] = a.pg[a.pg_index ? a.pg_index[row] : 0];
+                const float s = d_in(c);
+                if (a.pg_index) s_pg = s;
                 else apg += s;
             }
+        } else {
+            for (uint32_t c = 0; c < a.C; c++) tB[lane * kPitch + c] = 0.0f;
         }
         if (g.g_pg && a.pg_index) {
             // rows of one level are contiguous, so a wave almost always holds ONE table entry: reduce over the
