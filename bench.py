@@ -310,6 +310,7 @@ def main():
             extra.launch("grid_encode_forward_fp32_table(uniform pts)", n, lambda: enc.grid_encode_forward(
                 xs, w["table"], w["offsets"], w["resolutions"], w["out"], n, D, F, L, 0, 128, 0.0, None, None, None,
                 ste_binary=True))
+        ngrid.traverse_grids(w["rays_o"], w["rays_d"], w["binaries"], w["aabbs"], step_size=STEP_SIZE, cone_angle=0.0)
         for _ in range(3):      # the `nerfacc.csrc` drop-in entry (intervals + samples, 27 B / sample), for the record
             extra.launch("traverse_grids drop-in (ray_aabb+traverse x2+cumsum)", w["rays_o"].shape[0],
                          lambda: ngrid.traverse_grids(w["rays_o"], w["rays_d"], w["binaries"], w["aabbs"],

@@ -145,8 +145,9 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
                 wsg = _workspace(grad.device, int(L.cnc_grid_encode_backward_binned_workspace(int(N), nb, level_rows)),
                                  (cur.cuda_stream, gi))
                 g_f = grad[l0:l1] if lm else grad
-                for t_ in (grad, inputs, embeddings, grad_embeddings, wsg):
-                    t_.record_stream(side)       # the caching allocator must not recycle them under the side stream
+                if _RECORD_STREAM:
+                    for t_ in (grad, inputs, embeddings, grad_embeddings, wsg):
+                        t_.record_stream(side)   # the caching allocator must not recycle them under the side stream
                 with torch.cuda.stream(side):
                     side.wait_event(fork)
                     rcg = L.cnc_grid_encode_backward_binned(
@@ -190,6 +191,7 @@ _WORKSPACES = {}
 _SIDE_STREAMS = {}
 _OVERLAP_MIN_POINTS = 1 << 16      # = the smallest binned call; 2^16..2^18 points gain 10-16 %, 2^20 points 4-6 %
 _SPLIT_FINE = os.environ.get("CNC_BWD_SPLIT_FINE", "1") != "0"
+_RECORD_STREAM = os.environ.get("CNC_BWD_RECORD_STREAM", "1") != "0"
 _OVERLAP_ENABLED = os.environ.get("CNC_BWD_OVERLAP", "1") != "0"   # measurement switch (profiles/)
 
 

@@ -64,8 +64,13 @@ for sub, dst in (("stats", "r02_bench_kernel_stats.csv"), ("stats_no_overlap", "
     hits = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(P, dst))
-for f, dst in (("bench.json", "r02_bench.json"), ("bench_no_overlap.json", "r02_bench_no_overlap.json"), ("train.log", "r02_train_step.log")):
+for f, dst in (("bench.json", "r02_bench.json"), ("bench_no_overlap.json", "r02_bench_no_overlap.json")):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(P, dst))
+if os.path.exists(os.path.join(src, "train.log")):      # only the result line (the rest is rocprofv3 chatter)
+    keep = [l for l in open(os.path.join(src, "train.log")) if l.startswith("train step") or l.startswith("setup")]
+    open(os.path.join(P, "r02_train_step.log"), "w").write(
+        "# tools/bench_train.py --no-profile under rocprofv3 --kernel-trace --stats (tracing overhead included;\n"
+        "# untraced: tools/profile_train_step.py / bench.py train_step)\n" + "".join(keep))
 print(open(os.path.join(P, "r02_pmc_hbm_traffic.csv")).read())
 print(json.dumps(traffic, indent=1))
