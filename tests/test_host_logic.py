@@ -280,3 +280,35 @@ def test_context_table_disk_cache_roundtrip(tmp_path):
         assert torch.equal(fresh.unique_count_cumsum_list, m.unique_count_cumsum_list)
         assert torch.equal(fresh.unique_count_list, m.unique_count_list)
     assert os.path.getsize(tmp_path / files[0]) > 100                            # rewritten
+
+
+def test_tanks_loader_on_a_fabricated_scene(tmp_path):
+    """SubjectLoader_Tanks (NSVF layout): OpenCV camera (y down, +z forward), file-name split, bbox -> aabb * 1.2
+    and the step-size rule (tanks.py:135-137)."""
+    from PIL import Image
+    from cnc_amd.datasets import SubjectLoader_Tanks
+    root = tmp_path / "TanksAndTemple" / "Barn"
+    (root / "rgb").mkdir(parents=True)
+    (root / "pose").mkdir()
+    H, W = 6, 10
+    rng = np.random.default_rng(1)
+    for name in ("0_a", "0_b", "1_a"):
+        Image.fromarray(rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8), "RGB").save(root / "rgb" / f"{name}.png")
+        c2w = np.eye(4)
+        c2w[:3, 3] = [0.5, -0.25, -3.0]
+        np.savetxt(root / "pose" / f"{name}.txt", c2w)
+    np.savetxt(root / "intrinsics.txt", np.array([[20.0, 0, W / 2, 0], [0, 20.0, H / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]]))
+    np.savetxt(root / "bbox.txt", np.array([[-1.0, -2.0, -0.5, 1.0, 2.0, 0.5, 0.2]]))
+    tr = SubjectLoader_Tanks("Barn", str(tmp_path / "TanksAndTemple"), "train", num_rays=32)
+    te = SubjectLoader_Tanks("Barn", str(tmp_path / "TanksAndTemple"), "test")
+    assert len(tr) == 2 and len(te) == 1 and tr.training and not te.training
+    assert torch.allclose(tr.aabb, torch.tensor([-1.2, -2.4, -0.6, 1.2, 2.4, 0.6])) and tr.render_step_size == 4e-3
+    d = te[0]
+    assert d["pixels"].shape == (H, W, 3) and torch.equal(d["color_bkgd"], torch.ones(3))
+    # RGB images read as opaque RGBA: the pixel is the image colour
+    img = np.asarray(Image.open(root / "rgb" / "1_a.png"), np.float32) / 255.0
+    assert np.allclose(d["pixels"].numpy(), img, atol=1e-6)
+    want = np.array([(3 - W / 2 + 0.5) / 20.0, (2 - H / 2 + 0.5) / 20.0, 1.0]); want /= np.linalg.norm(want)
+    assert np.allclose(d["rays"].viewdirs[2, 3].numpy(), want, atol=1e-6)          # row y=2, column x=3; y points down
+    assert torch.equal(d["rays"].origins[0, 0], torch.tensor([0.5, -0.25, -3.0]))
+    assert tr[0]["pixels"].shape == (32, 3)
