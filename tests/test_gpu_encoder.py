@@ -285,6 +285,34 @@ def test_gridencoder_bit_plane_cache_tracks_in_place_updates(cuda):
     assert (a.params.grad - b.params.grad).abs().max() <= 1e-5 * b.params.grad.abs().max()
 
 
+def test_gridencoder_caches_survive_reset_and_dot_data_writes(cuda):
+    """`reset_parameters()` and writes through `.data` (which do not bump `_version`) followed by
+    `invalidate_caches()` must not leave a stale sign plane behind; the plane attributes never register as
+    module parameters / buffers."""
+    from cnc_amd.gridencoder import GridEncoder
+    torch.manual_seed(1)
+    a = GridEncoder(3, 8, RES3, 10, ste_binary=True, bitplane=True).to(cuda)
+    ref = GridEncoder(3, 8, RES3, 10, ste_binary=True, bitplane=False).to(cuda)
+    x = torch.rand(2000, 3, device=cuda)
+    y0 = a(x).clone()
+    assert [n for n, _ in a.named_parameters()] == ["params"]            # _bits_src is not a parameter
+    a.reset_parameters()
+    with torch.no_grad():
+        ref.params.copy_(a.params)
+    y1 = a(x)
+    assert torch.equal(y1, ref(x)) and not torch.equal(y1, y0)
+    a.params.data.mul_(-1.0)                 # no version bump
+    a.invalidate_caches()
+    with torch.no_grad():
+        ref.params.mul_(-1.0)
+    assert torch.equal(a(x), ref(x))
+    other = torch.randn_like(a.params)       # outspace_params of another tensor, then back
+    with torch.no_grad():
+        ref.params.copy_(other)
+    assert torch.equal(a(x, outspace_params=other), ref(x))
+    assert [n for n, _ in a.named_parameters()] == ["params"]
+
+
 @pytest.mark.parametrize("outliers", [False, True])
 def test_backward_ste_clip_count_hint(cuda, oracle, outliers):
     """pack_sign_bits counts |v| > 1; backward skips the STE-mask gather iff the count is 0 and
