@@ -192,6 +192,7 @@ _SIDE_STREAMS = {}
 _OVERLAP_MIN_POINTS = 1 << 16      # = the smallest binned call; 2^16..2^18 points gain 10-16 %, 2^20 points 4-6 %
 _SPLIT_FINE = os.environ.get("CNC_BWD_SPLIT_FINE", "1") != "0"
 _RECORD_STREAM = os.environ.get("CNC_BWD_RECORD_STREAM", "1") != "0"
+_SIDE_PRIORITY = int(os.environ.get("CNC_BWD_SIDE_PRIORITY", "0"))     # measurement switch: -1 = high
 _OVERLAP_ENABLED = os.environ.get("CNC_BWD_OVERLAP", "1") != "0"   # measurement switch (profiles/)
 
 
@@ -199,7 +200,7 @@ def _side_stream(device, which=0):
     key = (device.type, device.index, which)
     st = _SIDE_STREAMS.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=device)
+        st = torch.cuda.Stream(device=device, priority=_SIDE_PRIORITY)
         _SIDE_STREAMS[key] = st
     return st
 
