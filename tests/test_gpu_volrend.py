@@ -233,3 +233,41 @@ def test_samples_from_intervals_both_layouts(cuda, oracle):
         assert torch.equal(ri, sm.ray_indices[sm.is_valid])
         assert torch.equal(starts, torch.cumsum(sm.chunk_cnts, 0) - sm.chunk_cnts)
         assert a.shape[0] > 1000
+
+
+def test_full_frame_identities(cuda):
+    """BASELINE size (the bench's 800x800 frame, 68 M samples): size-independent identities of the fused
+    compositing — per ray sum(w) = 1 - exp(-sum(sigma dt)) (telescoping), weights in [0, 1], transmittance
+    non-increasing along a ray, colours of a constant-colour field = colour * opacity, and the backward's
+    sum over a ray of d(opacity)/d(sigma_k) * ... matches the closed form d(opacity)/d(sigma_k) = dt_k * T_end."""
+    import bench
+    from cnc_amd.backends import nerfacc_cuda as C
+    from cnc_amd.backends import volrend_backend as K
+    w = bench.build_workload(cuda, 0)
+    t_lo, t_hi, hit = C.ray_aabb_intersect(w["rays_o"], w["rays_d"], w["aabbs"], -float("inf"), float("inf"), float("inf"))
+    ri, ts, te, starts, counts, _ = C.march_samples(w["rays_o"], w["rays_d"], None, w["binaries"], w["aabbs"],
+                                                     torch.cat([t_lo, t_hi], -1), w["t_order"], hit, w["near"], w["far"],
+                                                     bench.STEP_SIZE, 0.0)
+    S, R = ts.shape[0], counts.shape[0]
+    assert S > 6e7
+    g = torch.Generator(device=cuda).manual_seed(1)
+    sig = torch.rand(S, device=cuda, generator=g) * 8.0
+    colour = torch.tensor([0.25, 0.5, 0.75], device=cuda)
+    rgb = colour.expand(S, 3).contiguous()
+    wts, tr, al, col, op, dep = K.volrend_forward(starts, counts, ts, te, sig, rgb)
+    tau = torch.zeros(R, device=cuda, dtype=torch.float64).index_add_(0, ri, (sig * (te - ts)).double())
+    want_op = 1.0 - torch.exp(-tau)
+    assert float((op.view(-1).double() - want_op).abs().max()) < 2e-5
+    assert float(wts.min()) >= 0.0 and float(wts.max()) <= 1.0 and float(al.max()) <= 1.0
+    assert torch.allclose(col, op * colour, atol=2e-6)
+    same_ray = ri[1:] == ri[:-1]
+    # a parallel prefix sum associates differently per element: monotone up to a few ulps of the running sum
+    assert bool((tr[1:][same_ray] <= tr[:-1][same_ray] * (1 + 4e-6)).all())
+    first = torch.ones(S, dtype=torch.bool, device=cuda)
+    first[1:] = ~same_ray
+    assert bool((tr[first] == 1.0).all())
+    # backward: d opacity / d sigma_k = dt_k * exp(-tau_ray)  (every sample of a ray shares T_end)
+    g_sig, _ = K.volrend_backward(starts, counts, ts, te, None, wts, tr, al,
+                                  grad_opacity=torch.ones(R, 1, device=cuda), want_grad_rgbs=False)
+    want = (te - ts).double() * torch.exp(-tau)[ri]
+    assert float((g_sig.double() - want).abs().max()) < 1e-7 + 2e-5 * float(want.max())
