@@ -15,7 +15,9 @@
 //                        items if the x-neighbours straddle a slab edge).  Per workgroup the items are
 //                        counted in an LDS histogram, space is reserved with ONE global atomic per
 //                        (workgroup, non-empty bin), and the items are written at LDS-ranked slots.
-//   pass 2  k_bwd_owner  one wave owns one slab: 256 rows x F floats of accumulators in LDS.  It
+//   pass 2  k_bwd_owner  one wave owns one slab (a bin far above the mean load is shared by several
+//                        waves, which then add their partial slabs atomically): 256 rows x F floats
+//                        of accumulators in LDS.  It
 //                        streams its bin (items coalesced, the sample's gradient row gathered one
 //                        batch ahead; the weights travel in the item, computed in pass 1 exactly as
 //                        the scatter kernel computes them) and adds into LDS with plain
@@ -60,6 +62,7 @@ struct BinnedArgs {
     uint32_t        first_level;     // binned levels are [first_level, first_level + gridDim.y)
     uint32_t        bins;            // slabs per level = ceil(level_rows / 256)
     uint32_t        cap;             // item slots per bin
+    uint32_t        part;            // items one owner wave takes (a fuller bin is shared by several waves)
     uint32_t*       bin_count;       // [n_binned][bins]
     Item*           items;           // [n_binned][bins][cap]
     const uint32_t* clip_count;
@@ -215,15 +218,21 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
     __shared__ __attribute__((aligned(16))) float s_acc[kSlab * F];
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kSlab];
     static_assert(kSlab * sizeof(uint32_t) == 64 * sizeof(uint4), "one uint4 per lane clears the tickets");
-    const uint32_t bin = blockIdx.x, lane = threadIdx.x;
+    // blockIdx.x = part * bins + bin: the waves that take the second, third ... `part` items of a bin are
+    // scheduled after every bin's first wave — they exist only for bins far above the mean (thin slices of
+    // space hash unevenly onto the slabs: up to 7.7x the mean at resolution 296 on the first chunk of the
+    // bench frame, where one wave per bin made the pass 2x slower than on the other chunks)
+    const uint32_t bin = blockIdx.x % a.bins, part = blockIdx.x / a.bins, lane = threadIdx.x;
     const uint32_t slot = a.first_level + blockIdx.y;
     const uint32_t off = (uint32_t)a.offsets[slot];
     const uint32_t hs = (uint32_t)a.offsets[slot + 1] - off;
     if (bin * kSlab >= hs) return;
     uint32_t n = a.bin_count[(size_t)blockIdx.y * a.bins + bin];
-    if (n == 0) return;                 // nothing landed here: the table slab stays as it is
     n = n < a.cap ? n : a.cap;
-    const Item* my = a.items + ((size_t)blockIdx.y * a.bins + bin) * a.cap;
+    if (n <= part * a.part) return;     // nothing (more) landed here: the table slab stays as it is
+    const bool  shared_slab = n > a.part;
+    const Item* my = a.items + ((size_t)blockIdx.y * a.bins + bin) * a.cap + (size_t)part * a.part;
+    n = min(n - part * a.part, a.part);
 
     for (uint32_t k = lane * 4; k < kSlab * F; k += 64 * 4)     // 16-byte LDS stores
         *reinterpret_cast<float4*>(s_acc + k) = make_float4(0, 0, 0, 0);
@@ -310,11 +319,28 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
     }
     __syncthreads();
 
-    // ---- slab -> gradient table (this wave is the only writer of these rows in this pass) ----
+    // ---- slab -> gradient table ----
     const bool     mask_on = STE && (a.clip_count == nullptr || *a.clip_count != 0);
     const uint32_t rows = min(kSlab, hs - bin * kSlab);
     const size_t   base = ((size_t)off + (size_t)bin * kSlab) * F;
     constexpr uint32_t NI = kSlab * F / (64 * V);     // 8 at F = 8: all loads issued before the first use
+    if (shared_slab) {
+        // several waves hold partial sums of this slab: coalesced atomics instead of the read-modify-write
+#pragma unroll
+        for (uint32_t i = 0; i < NI; i++) {
+            const uint32_t k = (i * 64 + lane) * V;
+            if (k < rows * F) {
+                float e[V];
+                if (mask_on) load_vec<V>(a.emb + base + k, e);
+#pragma unroll
+                for (uint32_t q = 0; q < V; q++)
+                    if (!mask_on || (e[q] >= -1.0f && e[q] <= 1.0f))
+                        unsafeAtomicAdd(a.grad_emb + base + k + q, s_acc[acc_index<F>(k / F, k % F + q)]);
+            }
+        }
+        return;
+    }
+    // this wave is the only writer of these rows in this pass
     float t[NI][V], e[NI][V];
 #pragma unroll
     for (uint32_t i = 0; i < NI; i++) {
@@ -341,7 +367,7 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
 template <uint32_t F>
 static void launch_binned(const BinnedArgs& a, uint32_t n_binned, bool ste, hipStream_t s)
 {
-    const dim3 g1(div_up(a.N, 1024 * kBinSamplesPerThread), n_binned), g2(a.bins, n_binned);
+    const dim3 g1(div_up(a.N, 1024 * kBinSamplesPerThread), n_binned), g2(a.bins * div_up(a.cap, a.part), n_binned);
     if (ste) {
         hipLaunchKernelGGL((k_bwd_bin<F, true>), g1, dim3(1024), 0, s, a);
         hipLaunchKernelGGL((k_bwd_owner<F, true>), g2, dim3(64), 0, s, a);
@@ -355,12 +381,25 @@ static void launch_binned(const BinnedArgs& a, uint32_t n_binned, bool ste, hipS
 
 using namespace cnc;
 
-// 2x the mean bin load (4 items per sample and level spread over the slabs), at least one batch
+// mean bin load: 4 items per sample and level spread over the slabs
+static uint64_t mean_load(uint32_t N, uint32_t bins) { return (4ull * N + bins - 1) / bins; }
+
+// 8x the mean bin load, at least one batch.  Samples from a thin slice of space hash unevenly onto the slabs
+// (the high bits of a row come from (y, z) alone): the fullest bin held 7.7x the mean on the first chunk
+// of the bench frame at resolution 296, 2.4x in the middle of the frame.
 static uint32_t default_cap(uint32_t N, uint32_t bins)
 {
-    const uint64_t mean = (4ull * N + bins - 1) / bins;
-    const uint64_t cap = 2 * mean + 64;
+    const uint64_t cap = 8 * mean_load(N, bins) + 64;
     return (uint32_t)(cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap);
+}
+
+// items per owner wave: 2x the mean (one wave per bin unless the bin is that far above it), whole batches
+static uint32_t owner_part(uint32_t N, uint32_t bins, uint64_t cap)
+{
+    uint64_t part = (2 * mean_load(N, bins) + 63) / 64 * 64;     // 1.25x / 1.5x / 3x: the same; 1x: 13 % slower
+    if (part < 64) part = 64;
+    while ((cap + part - 1) / part > 16) part *= 2;      // a roomy caller-sized workspace: at most 16 waves per bin
+    return (uint32_t)(part > 0xFFFFFFFFull ? 0xFFFFFFFFull : part);
 }
 
 extern "C" uint64_t cnc_grid_encode_backward_binned_workspace(uint32_t N, uint32_t n_binned,
@@ -415,7 +454,7 @@ extern "C" int cnc_grid_encode_backward_binned(const float* grad, const float* i
     uint32_t*   ws = (uint32_t*)workspace;
     if (hipMemsetAsync(ws, 0, heads * 4, s) != hipSuccess) return CNC_ERR_LAUNCH;
     BinnedArgs a{grad, inputs, embeddings, offsets, resolutions, grad_embeddings, N, L - n_binned,
-                 bins, (uint32_t)cap, ws, (Item*)((char*)workspace + heads * kHeadBytes), ste_clip_count,
+                 bins, (uint32_t)cap, owner_part(N, bins, cap), ws, (Item*)((char*)workspace + heads * kHeadBytes), ste_clip_count,
                  FeatLayout{grad_ld, grad_col}};
     const bool ste = (flags & CNC_FLAG_STE_BINARY) != 0;
     switch (F) {

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
     float* __restrict__ grad_emb, uint32_t N, const uint32_t* __restrict__ clip_count, FeatLayout lay)
 {
-    constexpr uint32_t D = 3, F = 8, C = 8, NONE = 0xFFFFFFFFu, END = 0x7FFu;
+    constexpr uint32_t D = 3, F = 8, C = 8, END = 0x7FFu;
     static_assert(kMB <= 1024, "run records pack start (10 bits) / end (11) / next (11)");
     // the three fractional positions and 1 / (sum of valid weights): the lane rebuilds its corner's
     // weight from them (same products, same order as Corners::setup) — half the LDS of 8 stored weights
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
 
     // ---- phase B: lane = (corner, feature); each wave walks a contiguous range of cells ----
     const uint32_t c = lane / F, f = lane % F;
-    const uint32_t mi = lane & 15u, mk = lane >> 4;        // MFMA operand index (corner / feature), sample slot
+    const uint32_t mi = lane & 15u, mk = lane >> 4;        // MFMA operand index (corner / feature of run A | B), sample slot
+    const bool     half_b = (mi & 8u) != 0;
     const float    sx = (mi & 1u) ? 1.0f : -1.0f, ox = (mi & 1u) ? 0.0f : 1.0f;
     const float    sy = (mi & 2u) ? 1.0f : -1.0f, oy = (mi & 2u) ? 0.0f : 1.0f;
     const float    sz = (mi & 4u) ? 1.0f : -1.0f, oz = (mi & 4u) ? 0.0f : 1.0f;
@@ -168,93 +169,75 @@ __global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
     }
     const bool hashed = stride > hs, pow2 = (hs & (hs - 1)) == 0;
     constexpr uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+    // the cell is wave-uniform: both candidates per axis (cell, cell + 1 clamped; times the stride or the
+    // hash prime) are scalar work, the lane only selects by its corner bits
+    const bool cx = (c & 1u) != 0, cy = (c & 2u) != 0, cz = (c & 4u) != 0;
+    const uint32_t m1 = hashed ? primes[1] : sd[1], m2 = hashed ? primes[2] : sd[2];
     auto row_of = [&](uint32_t k_lo, uint32_t k_hi) -> uint32_t {
-        uint32_t index = 0;
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            const uint32_t gd = d == 0 ? (k_lo & 0xFFFFu) : d == 1 ? (k_lo >> 16) : (k_hi & 0xFFFFu);
-            const uint32_t qd = ((c >> d) & 1u) ? min(gd + 1, R - 1) : gd;
-            if (hashed) index ^= qd * primes[d];
-            else index += qd * sd[d];
-        }
+        const uint32_t gx = k_lo & 0xFFFFu, gy = k_lo >> 16, gz = k_hi & 0xFFFFu;
+        const uint32_t x0 = gx, x1 = min(gx + 1, R - 1);
+        const uint32_t y0 = gy * m1, y1 = min(gy + 1, R - 1) * m1;
+        const uint32_t z0 = gz * m2, z1 = min(gz + 1, R - 1) * m2;
+        const uint32_t px = cx ? x1 : x0, py = cy ? y1 : y0, pz = cz ? z1 : z0;
+        uint32_t index = hashed ? (px ^ py ^ pz) : (px + py + pz);
         if (pow2) index &= hs - 1;
         else if (index >= hs) index %= hs;
         return off + index;
     };
 
-    const uint32_t cpw = (n_cells + kMW - 1) / kMW;
-    const uint32_t g_begin = wave * cpw, g_end = min(n_cells, g_begin + cpw);
-    uint32_t carry_row = NONE, carry_lo = ~0u, carry_hi = ~0u;
-    float    carry_acc = 0;
-    for (uint32_t i = 0; i <= cpw; i++) {                  // one extra round drains the pending cell
-        const uint32_t g = g_begin + i;
-        uint32_t       my_row = NONE, k_lo = ~0u, k_hi = ~0u;
-        float          acc = 0;
-        if (i < cpw && g < g_end) {
-            const uint4 cell = s_u[g];                     // {first run of the chain, key, valid corners}
-            uint32_t    rec = cell.x;
-            k_lo = __builtin_amdgcn_readfirstlane(cell.y);
-            k_hi = __builtin_amdgcn_readfirstlane(cell.z);
-            // S[corner][feature] = sum over the chain's samples of w[corner] * g[feature]: a K = n
-            // product of an 8 x n and an n x 8 matrix, 4 samples per v_mfma_f32_16x16x4_f32 (rows /
-            // columns 8..15 of the tile stay zero).  Lane l feeds sample slot l / 16 with operand index
-            // l % 16: its corner's weight (rebuilt from the 3 fractions — once per (corner, sample)
-            // instead of once per (corner, feature, sample) as a lane-per-output loop would) and its
-            // feature's gradient.  The loop is wave-uniform: every lane walks the same chain.
-            f32x4 S = {0.0f, 0.0f, 0.0f, 0.0f};
-            for (;;) {
-                const uint32_t p0 = rec & 0x3FFu, p1 = (rec >> 10) & 0x7FFu, nxt = rec >> 21;
-                for (uint32_t p = p0; p < p1; p += 4) {
-                    const uint32_t ps = p + mk;
-                    float          a = 0.0f, bv = 0.0f;
-                    if (ps < p1 && mi < 8u) {
-                        const float4 q = *reinterpret_cast<const float4*>(s_w4[ps]);
-                        // bit ? frac : 1 - frac, as one fma with (+1, 0) or (-1, 1): exact either way
-                        const float wx = __builtin_fmaf(q.x, sx, ox), wy = __builtin_fmaf(q.y, sy, oy),
-                                    wz = __builtin_fmaf(q.z, sz, oz);
-                        a = ((wx * wy) * wz) * q.w;
-                        bv = s_g[ps][mi];
-                    }
-                    S = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, S, 0, 0, 0);
+    // Rows two consecutive cells share (a ray leaving through a face) are NOT combined in registers here as
+    // k_grid_encode_bwd does: with the cells merged across rays the atomics are no longer what the time is
+    // made of, and the match (cell delta, partner lane, one more cross-lane read per cell) cost more issue
+    // slots than the saved requests: 0.330 -> 0.305 ms for the 9 coarse levels, 1.091 -> 1.060 ms for the
+    // whole backward call next to the bin / owner passes.
+    for (uint32_t g = wave; g < n_cells; g += kMW) {
+        const uint4 cell = s_u[g];                         // {first run of the chain, key, valid corners}
+        uint32_t    rec = cell.x;
+        const uint32_t k_lo = __builtin_amdgcn_readfirstlane(cell.y);
+        const uint32_t k_hi = __builtin_amdgcn_readfirstlane(cell.z);
+        // S[corner][feature] = sum over the chain's samples of w[corner] * g[feature]: a K = n product of
+        // an 8 x n and an n x 8 matrix on v_mfma_f32_16x16x4_f32.  Lane l feeds sample slot l / 16 with
+        // operand index l % 16: its corner's weight (rebuilt from the 3 fractions — once per (corner, sample)
+        // instead of once per (corner, feature, sample) as a lane-per-output loop would) and its feature's
+        // gradient.  Two runs per step: operand rows / columns 0..7 carry run A, 8..15 run B (the next run
+        // of the chain, or the second half of a lone run), so the tile's two diagonal 8 x 8 blocks are two
+        // partial sums and every lane has work (8 samples per instruction; the off-diagonal A x B cross
+        // terms are dropped).  The loop is wave-uniform: every lane walks the same chain.
+        f32x4 S = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (;;) {
+            uint32_t a0 = rec & 0x3FFu, a1 = (rec >> 10) & 0x7FFu, b0, b1, nxt = rec >> 21;
+            if (nxt != END) {
+                const uint32_t rb = s_run_rec[nxt];
+                b0 = rb & 0x3FFu, b1 = (rb >> 10) & 0x7FFu, nxt = rb >> 21;
+            } else {
+                b1 = a1;
+                a1 = b0 = min(a1, a0 + ((((a1 - a0 + 1u) >> 1) + 3u) & ~3u));
+            }
+            const uint32_t steps = max(a1 - a0, b1 - b0);
+            const uint32_t m0 = half_b ? b0 : a0, m1 = half_b ? b1 : a1;
+            for (uint32_t p = 0; p < steps; p += 4) {
+                const uint32_t ps = m0 + p + mk;
+                float          a = 0.0f, bv = 0.0f;
+                if (ps < m1) {
+                    const float4 q = *reinterpret_cast<const float4*>(s_w4[ps]);
+                    // bit ? frac : 1 - frac, as one fma with (+1, 0) or (-1, 1): exact either way
+                    const float wx = __builtin_fmaf(q.x, sx, ox), wy = __builtin_fmaf(q.y, sy, oy),
+                                wz = __builtin_fmaf(q.z, sz, oz);
+                    a = ((wx * wy) * wz) * q.w;
+                    bv = s_g[ps][mi & 7u];
                 }
-                if (nxt == END) break;
-                rec = s_run_rec[nxt];
+                S = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, S, 0, 0, 0);
             }
-            // tile element (row, col) sits in lane col + 16 * (row / 4), register row % 4
-            const int   src = (int)(f + 16u * (c >> 2));
-            const float e0 = __shfl(S[0], src), e1 = __shfl(S[1], src), e2 = __shfl(S[2], src), e3 = __shfl(S[3], src);
-            if ((cell.w >> c) & 1u) {
-                my_row = row_of(k_lo, k_hi);
-                acc = (c & 2u) ? ((c & 1u) ? e3 : e2) : ((c & 1u) ? e1 : e0);
-            }
+            if (nxt == END) break;
+            rec = s_run_rec[nxt];
         }
-        // which corners of the pending cell reappear in this one follows from the two cells alone
-        bool adj = (k_lo & k_hi) != ~0u && (carry_lo & carry_hi) != ~0u;
-        int  delta[D];
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            const uint32_t a_new = d == 0 ? (k_lo & 0xFFFFu) : d == 1 ? (k_lo >> 16) : (k_hi & 0xFFFFu);
-            const uint32_t a_old = d == 0 ? (carry_lo & 0xFFFFu) : d == 1 ? (carry_lo >> 16) : (carry_hi & 0xFFFFu);
-            delta[d] = (int)a_new - (int)a_old;
-            adj = adj && delta[d] >= -1 && delta[d] <= 1;
-        }
-        bool     shared = adj, claimed = adj;
-        uint32_t jm = 0;
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            const int bit = (int)((c >> d) & 1u);
-            const int as_old = bit + delta[d], as_new = bit - delta[d];
-            shared = shared && (uint32_t)as_old <= 1u;
-            claimed = claimed && (uint32_t)as_new <= 1u;
-            jm |= ((uint32_t)as_old & 1u) << d;
-        }
-        const float ca = __shfl(carry_acc, (int)(jm * F + f));
-        if (shared && my_row != NONE) acc += ca;
-        if (carry_row != NONE && !claimed) flush(carry_row, carry_acc);
-        carry_row = my_row;
-        carry_acc = acc;
-        carry_lo = k_lo;
-        carry_hi = k_hi;
+        // tile element (row, col) sits in lane col + 16 * (row / 4), register row % 4; block B is 8 rows
+        // and 8 columns further on = 40 lanes
+        const int   src = (int)(f + 16u * (c >> 2));
+        const float e0 = __shfl(S[0], src) + __shfl(S[0], src + 40), e1 = __shfl(S[1], src) + __shfl(S[1], src + 40),
+                    e2 = __shfl(S[2], src) + __shfl(S[2], src + 40), e3 = __shfl(S[3], src) + __shfl(S[3], src + 40);
+        if ((cell.w >> c) & 1u)
+            flush(row_of(k_lo, k_hi), (c & 2u) ? ((c & 1u) ? e3 : e2) : ((c & 1u) ? e1 : e0));
     }
 }
 

@@ -123,13 +123,14 @@ int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* bits,
 
 /* Same gradient as cnc_grid_encode_backward (no binary_vxl / min_level_id), with the n_binned FINEST
  * levels taken off the global-atomic path (D = 3, F in {2,4,8}): their (sample, corner-pair)
- * contributions are binned by 256-row table slab and summed in LDS by one wave per slab
- * (cnc_amd/csrc/grid_encode_binned.hip).  Pays where every sample sits in its own cell, i.e. levels
+ * contributions are binned by 256-row table slab and summed in LDS by one wave per slab (several for a
+ * bin far above the mean load; cnc_amd/csrc/grid_encode_binned.hip).  Pays where every sample sits in its own cell, i.e. levels
  * finer than the sample spacing; coarser levels stay on the run-merging atomic kernel.
  *   level_rows: upper bound of rows per binned level (offsets[l+1]-offsets[l], <= 2^20); a level
  *               with more rows than that is routed to atomics on the device, results unchanged.
  *   workspace : device scratch of cnc_grid_encode_backward_binned_workspace(N, n_binned,
- *               level_rows) bytes (more = deeper bins; a full bin spills to atomics).  The library
+ *               level_rows) bytes = bins of 8x the mean load (more = deeper bins; a full bin spills to
+ *               atomics).  The library
  *               clears the part it needs; contents are dead after the call.
  *   The slab owners add into grad_embeddings with plain read-modify-writes: calls that target the
  *   same grad_embeddings must be stream-ordered, not concurrent (the atomic entry point has no such
