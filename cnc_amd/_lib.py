@@ -50,6 +50,7 @@ SIGNATURES = {
     "cnc_align_and_pack_forward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _f32, _vp],
     "cnc_align_and_pack_backward": [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp],
     "cnc_segment_weighted_sum": [_vp, _vp, _vp, _vp, _u32, _u32, _i32, _vp],
+    "cnc_segment_weighted_sum_gathered": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _i32, _vp],
     "cnc_ray_aabb_intersect": [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
     "cnc_traverse_grids": [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                            _f32, _f32, _i32, _i32, C.POINTER(RaySegments), C.POINTER(RaySegments), _vp, _vp],
@@ -71,6 +72,7 @@ SIGNATURES = {
     "cnc_level_stats_forward": [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
     "cnc_level_stats_backward": [_vp, _vp, _u32, _u32, _vp, _vp, C.c_uint64, _vp, _vp],
     "cnc_field_prepare": [_vp, _vp, _u32, _vp, _vp, _vp],
+    "cnc_field_sinusoid": [_vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp],
     "cnc_field_post": [_vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp],
     "cnc_field_post_backward": [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _vp],
     "cnc_ctx_mlp_forward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp, _vp],
@@ -80,6 +82,7 @@ SIGNATURES = {
     "cnc_bernoulli_bits_forward": [_vp, _vp, _vp, C.c_uint64, _u32, _vp, _vp],
     "cnc_bernoulli_bits_backward": [_vp, _vp, _vp, _vp, C.c_uint64, _u32, _vp, _vp, _vp],
     "cnc_segment_weighted_sum_backward": [_vp, _vp, _vp, _vp, _u32, C.c_uint64, _u32, _i32, _vp, _vp],
+    "cnc_segment_weighted_sum_gathered_backward": [_vp, _vp, _vp, _vp, _vp, _u32, C.c_uint64, _u32, _i32, _vp, _vp],
 }
 
 # entry points that return something other than a status code
@@ -89,7 +92,7 @@ CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 13          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 14          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

@@ -126,13 +126,14 @@ def bernoulli_bits(table, rows, mean):
     return BernoulliBits.apply(table, rows, mean)
 
 
-def segment_backward(g, cumsum, weights, wsum, T, mode):
-    """d values of cnc_segment_weighted_sum (pack_and_align.segment_weighted_sum)."""
+def segment_backward(g, cumsum, weights, wsum, T, mode, order=None):
+    """d values of cnc_segment_weighted_sum{,_gathered} (pack_and_align.segment_weighted_sum)."""
     g = _f32c(g.contiguous(), "grad")
     S, F = g.shape
     out = torch.empty((T, F), dtype=torch.float32, device=g.device)
-    check(_lib.lib().cnc_segment_weighted_sum_backward(ptr(g), ptr(cumsum), ptr(weights), ptr(wsum), S, T, F, int(mode),
-                                                       ptr(out), stream(g.device)), "segment_weighted_sum_backward")
+    check(_lib.lib().cnc_segment_weighted_sum_gathered_backward(ptr(g), ptr(order), ptr(cumsum), ptr(weights), ptr(wsum), S, T,
+                                                                F, int(mode), ptr(out), stream(g.device)),
+          "segment_weighted_sum_backward")
     return out
 
 

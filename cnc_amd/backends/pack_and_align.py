@@ -79,10 +79,10 @@ def query_mask_3D_qlist(points_n_orig_list, binary_vxl, mask, overlap_area_pool,
     check(rc, "query_mask_3D_qlist")
 
 
-def segment_weighted_sum(values, weights, cumsum, mode=0):
+def segment_weighted_sum(values, weights, cumsum, mode=0, order=None):
     """(extension) per-slot (weighted) sum / weighted mean / mean of ragged rows, see
-    cnc_segment_weighted_sum in include/cnc_hip.h.  values [T,F] f32, weights [T] f32 or None,
-    cumsum int64 [N+1] -> [N,F]."""
+    cnc_segment_weighted_sum{,_gathered} in include/cnc_hip.h.  values [T,F] f32, weights [T] f32 or None,
+    cumsum int64 [N+1] -> [N,F]; `order` (int64 [T]): ragged row r is values[order[r]]."""
     check_input(values, "values")
     check_input(cumsum, "cumsum")
     if weights is not None:
@@ -91,7 +91,11 @@ def segment_weighted_sum(values, weights, cumsum, mode=0):
         raise RuntimeError("segment_weighted_sum: values must be float32 and cumsum int64")
     N, F = cumsum.shape[0] - 1, values.shape[1]
     out = torch.empty((N, F), dtype=torch.float32, device=values.device)
-    rc = _lib.lib().cnc_segment_weighted_sum(ptr(values), ptr(weights), ptr(cumsum), ptr(out), N, F,
-                                             int(mode), stream(values.device))
+    if order is not None:
+        check_input(order, "order")
+        if order.dtype != torch.int64 or order.shape[0] != values.shape[0]:
+            raise RuntimeError("segment_weighted_sum: order must be int64 [T]")
+    rc = _lib.lib().cnc_segment_weighted_sum_gathered(ptr(values), ptr(order), ptr(weights), ptr(cumsum), ptr(out), N, F,
+                                                      int(mode), stream(values.device))
     check(rc, "segment_weighted_sum")
     return out

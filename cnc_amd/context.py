@@ -303,22 +303,22 @@ class _segment_reduce(Function):
     cnc_segment_weighted_sum): mode 0 sum(w*v), 1 sum(w*v)/sum(w), 2 mean.  Gradient w.r.t. values."""
 
     @staticmethod
-    def forward(ctx, values, cumsum, weights, mode):
+    def forward(ctx, values, cumsum, weights, mode, order=None):
         values = values.contiguous()
         if weights is not None:
             weights = weights.contiguous()
-        out = pack_and_align.segment_weighted_sum(values, weights, cumsum, mode)
-        ctx.save_for_backward(cumsum, weights)
+        out = pack_and_align.segment_weighted_sum(values, weights, cumsum, mode, order)
+        ctx.save_for_backward(cumsum, weights, order)
         ctx.mode, ctx.T = mode, values.shape[0]
         return out
 
     @staticmethod
     def backward(ctx, g):
-        cumsum, weights = ctx.saved_tensors
+        cumsum, weights, order = ctx.saved_tensors
         wsum = None
         if ctx.mode == 1:
             wsum = pack_and_align.segment_weighted_sum(weights.unsqueeze(-1).contiguous(), None, cumsum, 0)
-        return _ctxk.segment_backward(g, cumsum, weights, wsum, ctx.T, ctx.mode), None, None, None
+        return _ctxk.segment_backward(g, cumsum, weights, wsum, ctx.T, ctx.mode, order), None, None, None, None
 
 
 def _cum(cnt):
@@ -678,9 +678,10 @@ class CNC_context_models(nn.Module):
             Pg_col = Pg_n.reshape(1, 1).repeat(context.shape[0], 1)
             parts = [context, Pg_col] if context_pn is None else [context, context_pn, Pg_col]
             mean = self.context_model_2D[n - 1](torch.cat(parts, dim=-1))
-        mean = torch.index_select(mean, dim=0, index=order)
         if self.fused_segments:
-            return _segment_reduce.apply(mean, _cum(unique_cnt) if cum is None else cum, None, 2)
+            # the sort by hash slot (index_select(mean, 0, order)) is folded into the reduction
+            return _segment_reduce.apply(mean, _cum(unique_cnt) if cum is None else cum, None, 2, order)
+        mean = torch.index_select(mean, dim=0, index=order)
         mean = align_and_pack.apply(mean, unique_cnt, 0.0, 2)
         return torch.sum(mean, dim=1) / unique_cnt.unsqueeze(-1)
 

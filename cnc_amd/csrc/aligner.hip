@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_segment_wsum(const float* __restrict__ 
                                                       const float* __restrict__ w,
                                                       const int64_t* __restrict__ cumsum,
                                                       float* __restrict__ out, uint32_t N,
-                                                      int mode)
+                                                      int mode, const int64_t* __restrict__ order)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = t / F, f = t % F;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_segment_wsum(const float* __restrict__ 
     float acc = 0, wsum = 0;
     for (int64_t r = s; r < e; r++) {
         const float wr = w ? w[r] : 1.0f;
-        acc += wr * v[r * F + f];
+        acc += wr * v[(order ? order[r] : r) * F + f];
         wsum += wr;
     }
     if (mode == 1) acc = acc / wsum;
@@ -203,15 +203,15 @@ extern "C" int cnc_align_and_pack_backward(const float* dL_packed, const int64_t
     return launch_status();
 }
 
-extern "C" int cnc_segment_weighted_sum(const float* values, const float* weights,
-                                        const int64_t* cumsum, float* out, uint32_t N, uint32_t F,
-                                        int32_t mode, void* stream)
+extern "C" int cnc_segment_weighted_sum_gathered(const float* values, const int64_t* order, const float* weights,
+                                                 const int64_t* cumsum, float* out, uint32_t N, uint32_t F,
+                                                 int32_t mode, void* stream)
 {
     if (N == 0) return CNC_OK;
     if (!values || !cumsum || !out || mode < 0 || mode > 2) return CNC_ERR_INVALID_VALUE;
     hipStream_t s = (hipStream_t)stream;
     const dim3  block(256);
-#define CNC_SEG(FF) hipLaunchKernelGGL((k_segment_wsum<FF>), dim3(div_up(N * FF, 256)), block, 0, s, values, weights, cumsum, out, N, mode)
+#define CNC_SEG(FF) hipLaunchKernelGGL((k_segment_wsum<FF>), dim3(div_up(N * FF, 256)), block, 0, s, values, weights, cumsum, out, N, mode, order)
     switch (F) {
     case 1: CNC_SEG(1); break;
     case 2: CNC_SEG(2); break;
@@ -223,4 +223,11 @@ extern "C" int cnc_segment_weighted_sum(const float* values, const float* weight
     }
 #undef CNC_SEG
     return launch_status();
+}
+
+extern "C" int cnc_segment_weighted_sum(const float* values, const float* weights,
+                                        const int64_t* cumsum, float* out, uint32_t N, uint32_t F,
+                                        int32_t mode, void* stream)
+{
+    return cnc_segment_weighted_sum_gathered(values, nullptr, weights, cumsum, out, N, F, mode, stream);
 }

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k_bernoulli_bits_bwd(const float* __restr
 __global__ __launch_bounds__(256) void k_segment_bwd(const float* __restrict__ g, const int64_t* __restrict__ cumsum,
                                                      const float* __restrict__ weights, const float* __restrict__ wsum,
                                                      uint32_t n_slots, uint64_t T, uint32_t F, int mode,
-                                                     float* __restrict__ g_values)
+                                                     float* __restrict__ g_values, const int64_t* __restrict__ order)
 {
     const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= T * F) return;
@@ -419,7 +419,8 @@ __global__ __launch_bounds__(256) void k_segment_bwd(const float* __restrict__ g
     float scale = weights ? weights[t] : 1.0f;
     if (mode == 1) scale = scale / wsum[lo];
     else if (mode == 2) scale = scale / (float)(cumsum[lo + 1] - cumsum[lo]);
-    g_values[e] = g[(size_t)lo * F + e % F] * scale;
+    // with a row permutation the reduction read values[order[t]]: that is where the gradient goes (one writer each)
+    g_values[order ? (uint64_t)order[t] * F + e % F : e] = g[(size_t)lo * F + e % F] * scale;
 }
 
 template <int NL>
@@ -511,15 +512,24 @@ extern "C" int cnc_bernoulli_bits_backward(const float* table, const int64_t* ro
     return launch_status();
 }
 
-extern "C" int cnc_segment_weighted_sum_backward(const float* grad, const int64_t* cumsum, const float* weights,
-                                                 const float* wsum, uint32_t n_slots, uint64_t T, uint32_t F,
-                                                 int32_t mode, float* grad_values, void* stream)
+extern "C" int cnc_segment_weighted_sum_gathered_backward(const float* grad, const int64_t* order,
+                                                          const int64_t* cumsum, const float* weights,
+                                                          const float* wsum, uint32_t n_slots, uint64_t T, uint32_t F,
+                                                          int32_t mode, float* grad_values, void* stream)
 {
     if (T == 0 || n_slots == 0) return CNC_OK;
     if (!grad || !cumsum || !grad_values || (mode == 1 && (!weights || !wsum))) return CNC_ERR_INVALID_VALUE;
     hipLaunchKernelGGL(k_segment_bwd, dim3((uint32_t)((T * F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad,
-                       cumsum, weights, wsum, n_slots, T, F, mode, grad_values);
+                       cumsum, weights, wsum, n_slots, T, F, mode, grad_values, order);
     return launch_status();
+}
+
+extern "C" int cnc_segment_weighted_sum_backward(const float* grad, const int64_t* cumsum, const float* weights,
+                                                 const float* wsum, uint32_t n_slots, uint64_t T, uint32_t F,
+                                                 int32_t mode, float* grad_values, void* stream)
+{
+    return cnc_segment_weighted_sum_gathered_backward(grad, nullptr, cumsum, weights, wsum, n_slots, T, F, mode,
+                                                      grad_values, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

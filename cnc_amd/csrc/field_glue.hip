@@ -4,7 +4,9 @@
 //   :516-521  x = (x - aabb_min) / (aabb_max - aabb_min);  selector = ((x > 0) & (x < 1)).all(-1)
 //   :527-535  density_before_activation, base_mlp_out = split(h, [1, geo]);  density = trunc_exp(d - 1) * selector
 //   :540-547  d = SH4((dir + 1) / 2)  [tiny-cuda-nn, restated in closed form];  h = cat([d, base_mlp_out])
+//   :583-599  embed(x) = [x | sin(2^k x) | cos(2^k x)], k = 0..9  (the Embedder's loop over frequencies and functions)
 // Here:  k_field_prepare  positions -> unit-cube positions + selector
+//        k_field_sinusoid [x | sin(f_k x) | cos(f_k x) | zero padding] into columns of the base MLP's input matrix
 //        k_field_post     base MLP output [N, 1 + geo] (+ view directions) -> density [N], head input [N, ld]
 //                         ( = [SH4(dir) | geo features | zero padding], no cat, no split)
 //        k_field_post_bwd gradients of density / head input -> gradient of the base MLP output
@@ -28,6 +30,25 @@ __global__ __launch_bounds__(256) void k_field_prepare(const float* __restrict__
         in = in && v > 0.0f && v < 1.0f;
     }
     selector[i] = in ? 1 : 0;
+}
+
+// one lane per (row, column): column j of [x (3) | for each frequency k: sin(f_k x) (3), cos(f_k x) (3) | zeros]
+__global__ __launch_bounds__(256) void k_field_sinusoid(const float* __restrict__ x, const float* __restrict__ freqs,
+                                                        uint32_t n_freqs, uint32_t N, float* __restrict__ out,
+                                                        uint32_t ld, uint32_t col, uint32_t width)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (uint64_t)N * width) return;
+    const uint32_t i = (uint32_t)(t / width), j = (uint32_t)(t % width);
+    float v = 0.0f;
+    if (j < 3) {
+        v = x[(size_t)i * 3 + j];
+    } else if (j < 3 + 6 * n_freqs) {
+        const uint32_t k = (j - 3) / 6, r = (j - 3) % 6;
+        const float arg = x[(size_t)i * 3 + r % 3] * freqs[k];
+        v = r < 3 ? sinf(arg) : cosf(arg);
+    }
+    out[(size_t)i * ld + col + j] = v;
 }
 
 // real spherical harmonics up to degree 4 of d (field.SHEncoding, term by term)
@@ -117,6 +138,18 @@ extern "C" int cnc_field_prepare(const float* positions, const float* aabb, uint
     if (!positions || !aabb || !x_unit || !selector) return CNC_ERR_INVALID_VALUE;
     hipLaunchKernelGGL(k_field_prepare, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, positions, aabb, N,
                        x_unit, selector);
+    return launch_status();
+}
+
+extern "C" int cnc_field_sinusoid(const float* x, const float* freqs, uint32_t n_freqs, uint32_t N, float* out,
+                                  uint32_t ld, uint32_t col, void* stream)
+{
+    if (N == 0) return CNC_OK;
+    if (!x || !freqs || !out || col > ld || ld - col < 3 + 6 * n_freqs) return CNC_ERR_INVALID_VALUE;
+    const uint32_t width = ld - col;       // the columns behind the embedding are the matrix's zero padding
+    const uint64_t total = (uint64_t)N * width;
+    hipLaunchKernelGGL(k_field_sinusoid, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       freqs, n_freqs, N, out, ld, col, width);
     return launch_status();
 }
 

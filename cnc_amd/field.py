@@ -154,17 +154,14 @@ class _FusedFeatures(Function):
             saved.append(clip)
         c0 = cols[4]
         if owner.embed_fn is not None:
-            # x | sin(2^k x) | cos(2^k x), k = 0..9 (ngp.py:583-599), written in place
-            n_f = owner._freqs.numel()
-            feat[:, c0:c0 + 3] = x
+            # x | sin(2^k x) | cos(2^k x), k = 0..9 (ngp.py:583-599) and the zero padding behind it: one kernel
+            from . import _lib
             if owner._freqs.device != x.device:
                 owner._freqs = owner._freqs.to(x.device)
-            arg = x[:, None, :] * owner._freqs[None, :, None]
-            v = feat[:, c0 + 3:c0 + 3 + 6 * n_f].view(N, n_f, 2, 3)
-            torch.sin(arg, out=v[:, :, 0, :])
-            torch.cos(arg, out=v[:, :, 1, :])
-            c0 += 3 + 6 * n_f
-        if c0 < ld:
+            fr = owner._freqs.to(torch.float32).contiguous()
+            _lib.check(_lib.lib().cnc_field_sinusoid(xs[0].data_ptr(), fr.data_ptr(), fr.numel(), N, feat.data_ptr(), ld,
+                                                     c0, _lib.stream(x.device)), "field_sinusoid")
+        elif c0 < ld:
             feat[:, c0:].zero_()
         ctx.save_for_backward(*xs, *params, *saved)
         ctx.owner = owner

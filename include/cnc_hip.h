@@ -246,6 +246,12 @@ int cnc_align_and_pack_backward(const float* dL_packed, const int64_t* cnt, cons
  * 668-669,681-682,688-695).  weights may be NULL (= 1).  values [T,F] f32, cumsum i64 [N+1].       */
 int cnc_segment_weighted_sum(const float* values, const float* weights, const int64_t* cumsum,
                              float* out, uint32_t N, uint32_t F, int32_t mode, void* stream);
+/* The same with the rows taken through a permutation: row r of the ragged list is values[order[r]] (weights stay
+ * indexed by r).  Folds the `torch.index_select(mean, 0, order)` that sorts the per-vertex predictions by hash
+ * slot (utils_bpp_acc.py:563) into the reduction.  order NULL = identity.                                        */
+int cnc_segment_weighted_sum_gathered(const float* values, const int64_t* order, const float* weights,
+                                      const int64_t* cumsum, float* out, uint32_t N, uint32_t F, int32_t mode,
+                                      void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Occupancy-grid marcher — replaces nerfacc/cuda/csrc/nerfacc.cpp:41-66 (grid.cu)
@@ -463,6 +469,12 @@ int cnc_bernoulli_bits_backward(const float* table, const int64_t* rows, const f
 int cnc_segment_weighted_sum_backward(const float* grad, const int64_t* cumsum, const float* weights,
                                       const float* wsum, uint32_t n_slots, uint64_t T, uint32_t F,
                                       int32_t mode, float* grad_values, void* stream);
+/* ... of cnc_segment_weighted_sum_gathered: the gradient of ragged row t is stored at grad_values[order[t]]
+ * (order must be a permutation of [0, T): every row of grad_values is written exactly once).                  */
+int cnc_segment_weighted_sum_gathered_backward(const float* grad, const int64_t* order, const int64_t* cumsum,
+                                               const float* weights, const float* wsum, uint32_t n_slots,
+                                               uint64_t T, uint32_t F, int32_t mode, float* grad_values,
+                                               void* stream);
 
 /* Level statistics of a binarised table, all levels in one pass (get_BiRF_wentropy_leveln,
  * utils_bpp_acc.py:472-486): sums[l] = sum of table[off[l]:off[l+1], :] (float64: exact for +-1 entries),
@@ -493,6 +505,13 @@ int cnc_field_prepare(const float* positions, const float* aabb, uint32_t N, flo
 int cnc_field_post(const float* base_out, uint32_t ld_base, uint32_t geo_feat_dim, const uint8_t* selector,
                    const float* dirs, uint32_t N, float* density, float* head_in, uint32_t ld_head,
                    void* stream);
+/* out[i, col:ld] = [x_i (3) | sin(freqs[k] x_i) (3), cos(freqs[k] x_i) (3) for k < n_freqs | zeros]: the Embedder
+ * of ngp.py:583-599 (include_input, periodic_fns = [sin, cos]) written into the base MLP's input matrix
+ * (row stride ld, first column col; everything from col to ld is written).  x [N,3], freqs [n_freqs] on the
+ * device.  arg = x * freq in float32, sinf / cosf: the values of torch.sin / torch.cos on the same device.    */
+int cnc_field_sinusoid(const float* x, const float* freqs, uint32_t n_freqs, uint32_t N, float* out, uint32_t ld,
+                       uint32_t col, void* stream);
+
 /* grad_base_out [N, 1 + geo] from grad_density [N] (nullable) and grad_head_in [N, ld_head] (nullable):
  * column 0 = grad_density * selector * exp(min(density_raw - 1, 15)) (trunc_exp's clamped gradient,
  * ngp.py:318-334), columns 1.. = grad_head_in[:, 16:16+geo].                                          */

@@ -112,6 +112,15 @@ def test_segment_reduce_backward_kernel(cuda, mode):
     got = _segment_reduce.apply(vd, _cum(cnt.to(cuda)), None if w is None else w.to(cuda), mode)
     (got[nz.to(cuda)] * go.to(cuda)[nz.to(cuda)]).sum().backward()
     assert torch.allclose(vd.grad.double().cpu(), v64.grad, rtol=2e-5, atol=1e-6)
+    # the same through a row permutation (cnc_segment_weighted_sum_gathered): ragged row r = values[order[r]]
+    order = torch.randperm(T, generator=g)
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(T)
+    vp = v[inv].to(cuda).requires_grad_()               # vp[order[r]] = v[r]
+    got_p = _segment_reduce.apply(vp, _cum(cnt.to(cuda)), None if w is None else w.to(cuda), mode, order.to(cuda))
+    assert torch.equal(got_p[nz.to(cuda)], got[nz.to(cuda)])
+    (got_p[nz.to(cuda)] * go.to(cuda)[nz.to(cuda)]).sum().backward()
+    assert torch.equal(vp.grad[order.to(cuda)], vd.grad)
 
 
 def test_context_pass_fused_heads_equals_op_chain(cuda):
