@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
+from . import _caches
 from .backends import gridencoder_backend as _backend
 
 
@@ -164,6 +165,7 @@ class GridEncoder(nn.Module):
         self.params = nn.Parameter(torch.empty(offsets[-1], n_features))
         self.reset_parameters()
         self.n_output_dims = n_levels * n_features
+        _caches.register(self)     # fused optimizers do not bump params._version
 
     def reset_parameters(self):
         # no_grad in-place write (not `.data`): bumps params._version, which keys the caches below
@@ -172,7 +174,8 @@ class GridEncoder(nn.Module):
         self.invalidate_caches()
 
     def invalidate_caches(self):
-        """Forget the packed sign plane / clip counter (call after writing `params` through `.data`)."""
+        """Forget the packed sign plane / clip counter (call after writing `params` through `.data`; optimizer
+        steps do it through cnc_amd._caches)."""
         self._bits = self._bits_key = self._bits_src = self._clip_count = None
 
     def __repr__(self):

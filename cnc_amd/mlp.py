@@ -16,6 +16,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _caches
+
 
 def _split(n_rows: int) -> int:
     """Number of row slabs: ~1024+ rows per slab, power of two, at most 256."""
@@ -155,6 +157,7 @@ class FusedMLPForward:
             raise ValueError("FusedMLPForward: widths <= 160 and biases required")
         self._key = None
         self._packed = None
+        _caches.register(self)     # fused optimizers do not bump Tensor._version
 
     def _pack(self):
         key = tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version)
@@ -179,6 +182,8 @@ class FusedMLPForward:
     def invalidate(self):
         """Drop the packed copies (call after writing a weight through `.data`, which skips `_version`)."""
         self._key = self._packed = None
+
+    invalidate_caches = invalidate
 
     @torch.no_grad()
     def __call__(self, x: torch.Tensor) -> torch.Tensor:

