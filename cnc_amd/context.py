@@ -790,7 +790,11 @@ class CNC_context_models(nn.Module):
                                                 self.dimension_wise_resolution, 2 ** self.log2_hashmap_size)
                               if self.planned_votes else None)
         idx_coords2 = self.idx_coords2_tmp
-        binary_2D = [self._project(binary_vxl, a) for a in axes]
+        if refresh or getattr(self, "_binary_2D_src", None) is not binary_vxl:
+            # the projections (and, keyed on them, the encoders' summed-area tables) live until the occupancy changes
+            self._binary_2D = [self._project(binary_vxl, a) for a in axes]
+            self._binary_2D_src = binary_vxl
+        binary_2D = self._binary_2D
         if refresh:
             # vertex lists, slot order and the slots' cumulative counts are fixed until the next refresh
             self.batched_inputs_list = [

@@ -32,23 +32,29 @@ __global__ __launch_bounds__(256) void k_field_prepare(const float* __restrict__
     selector[i] = in ? 1 : 0;
 }
 
-// one lane per (row, column): column j of [x (3) | for each frequency k: sin(f_k x) (3), cos(f_k x) (3) | zeros]
+// [x (3) | for each frequency k: sin(f_k x) (3), cos(f_k x) (3) | zeros]: one lane per (row, unit), a unit being
+// one input coordinate, one (frequency, coordinate) pair — sin and cos from ONE argument reduction (sincosf
+// returns the values of sinf and cosf) — or one padding column
 __global__ __launch_bounds__(256) void k_field_sinusoid(const float* __restrict__ x, const float* __restrict__ freqs,
                                                         uint32_t n_freqs, uint32_t N, float* __restrict__ out,
                                                         uint32_t ld, uint32_t col, uint32_t width)
 {
+    const uint32_t units = 3 + 3 * n_freqs + (width - 3 - 6 * n_freqs);
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (uint64_t)N * width) return;
-    const uint32_t i = (uint32_t)(t / width), j = (uint32_t)(t % width);
-    float v = 0.0f;
-    if (j < 3) {
-        v = x[(size_t)i * 3 + j];
-    } else if (j < 3 + 6 * n_freqs) {
-        const uint32_t k = (j - 3) / 6, r = (j - 3) % 6;
-        const float arg = x[(size_t)i * 3 + r % 3] * freqs[k];
-        v = r < 3 ? sinf(arg) : cosf(arg);
+    if (t >= (uint64_t)N * units) return;
+    const uint32_t i = (uint32_t)(t / units), u = (uint32_t)(t % units);
+    float* o = out + (size_t)i * ld + col;
+    if (u < 3) {
+        o[u] = x[(size_t)i * 3 + u];
+    } else if (u < 3 + 3 * n_freqs) {
+        const uint32_t k = (u - 3) / 3, a = (u - 3) % 3;
+        float sn, cs;
+        sincosf(x[(size_t)i * 3 + a] * freqs[k], &sn, &cs);
+        o[3 + 6 * k + a] = sn;
+        o[3 + 6 * k + 3 + a] = cs;
+    } else {
+        o[3 + 6 * n_freqs + (u - 3 - 3 * n_freqs)] = 0.0f;
     }
-    out[(size_t)i * ld + col + j] = v;
 }
 
 // real spherical harmonics up to degree 4 of d (field.SHEncoding, term by term)
@@ -147,7 +153,7 @@ extern "C" int cnc_field_sinusoid(const float* x, const float* freqs, uint32_t n
     if (N == 0) return CNC_OK;
     if (!x || !freqs || !out || col > ld || ld - col < 3 + 6 * n_freqs) return CNC_ERR_INVALID_VALUE;
     const uint32_t width = ld - col;       // the columns behind the embedding are the matrix's zero padding
-    const uint64_t total = (uint64_t)N * width;
+    const uint64_t total = (uint64_t)N * (width - 3 * n_freqs);
     hipLaunchKernelGGL(k_field_sinusoid, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
                        freqs, n_freqs, N, out, ld, col, width);
     return launch_status();
