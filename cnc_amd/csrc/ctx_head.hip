@@ -402,25 +402,29 @@ __global__ __launch_bounds__(256) void k_bernoulli_bits_bwd(const float* __restr
 }
 
 // d/d values of cnc_segment_weighted_sum: row t of slot s gets g[s] * scale_t, scale = w_t (mode 0),
-// w_t / sum_slot(w) (mode 1), 1 / count (mode 2).  One lane per (row, feature); the slot by bisection.
+// w_t / sum_slot(w) (mode 1), 1 / count (mode 2).  One lane per (slot, feature) walking the slot's rows, like the
+// forward (a lane per (row, feature) had to find its slot by bisection: 17 dependent loads per element at 150 k
+// slots — 0.33 ms per training step against 0.11 for the forward).
 __global__ __launch_bounds__(256) void k_segment_bwd(const float* __restrict__ g, const int64_t* __restrict__ cumsum,
                                                      const float* __restrict__ weights, const float* __restrict__ wsum,
                                                      uint32_t n_slots, uint64_t T, uint32_t F, int mode,
                                                      float* __restrict__ g_values, const int64_t* __restrict__ order)
 {
     const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= T * F) return;
-    const int64_t t = (int64_t)(e / F);
-    uint32_t lo = 0, hi = n_slots;                  // largest s with cumsum[s] <= t
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (cumsum[mid] <= t) lo = mid; else hi = mid;
+    if (e >= (uint64_t)n_slots * F) return;
+    const uint32_t s = (uint32_t)(e / F), f = (uint32_t)(e % F);
+    const int64_t  t0 = cumsum[s], t1 = min(cumsum[s + 1], (int64_t)T);
+    if (t1 <= t0) return;
+    const float gs = g[e];
+    float       per_slot = 1.0f;
+    if (mode == 1) per_slot = wsum[s];
+    else if (mode == 2) per_slot = (float)(t1 - t0);
+    for (int64_t t = t0; t < t1; t++) {
+        float scale = weights ? weights[t] : 1.0f;
+        if (mode != 0) scale = scale / per_slot;
+        // with a row permutation the reduction read values[order[t]]: that is where the gradient goes (one writer each)
+        g_values[(uint64_t)(order ? order[t] : t) * F + f] = gs * scale;
     }
-    float scale = weights ? weights[t] : 1.0f;
-    if (mode == 1) scale = scale / wsum[lo];
-    else if (mode == 2) scale = scale / (float)(cumsum[lo + 1] - cumsum[lo]);
-    // with a row permutation the reduction read values[order[t]]: that is where the gradient goes (one writer each)
-    g_values[order ? (uint64_t)order[t] * F + e % F : e] = g[(size_t)lo * F + e % F] * scale;
 }
 
 template <int NL>
@@ -519,7 +523,8 @@ extern "C" int cnc_segment_weighted_sum_gathered_backward(const float* grad, con
 {
     if (T == 0 || n_slots == 0) return CNC_OK;
     if (!grad || !cumsum || !grad_values || (mode == 1 && (!weights || !wsum))) return CNC_ERR_INVALID_VALUE;
-    hipLaunchKernelGGL(k_segment_bwd, dim3((uint32_t)((T * F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad,
+    // rows behind the last slot (none for a cumsum that ends at T) get no gradient: the buffer is the caller's
+    hipLaunchKernelGGL(k_segment_bwd, dim3((uint32_t)(((uint64_t)n_slots * F + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad,
                        cumsum, weights, wsum, n_slots, T, F, mode, grad_values, order);
     return launch_status();
 }
