@@ -72,6 +72,8 @@ SIGNATURES = {
     "cnc_level_stats_forward": [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
     "cnc_level_stats_backward": [_vp, _vp, _u32, _u32, _vp, _vp, C.c_uint64, _vp, _vp],
     "cnc_field_prepare": [_vp, _vp, _u32, _vp, _vp, _vp],
+    "cnc_ste_binary_forward": [_vp, _vp, C.c_uint64, _vp],
+    "cnc_ste_binary_backward": [_vp, _vp, _vp, C.c_uint64, _vp],
     "cnc_field_sinusoid": [_vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp],
     "cnc_field_post": [_vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp],
     "cnc_field_post_backward": [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _vp],
@@ -92,7 +94,7 @@ CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 14          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 15          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

@@ -57,6 +57,41 @@ __global__ __launch_bounds__(256) void k_field_sinusoid(const float* __restrict_
     }
 }
 
+// STE_binary (ngp.py:22-39) in one pass each way.  forward: (x >= 0) * 1 + (x < 0) * -1 of clamp(x, -1, 1) (NaN -> 0);
+// backward: grad * (clamp(x, -1, 1) == x).  The op chains are 4 and 5 ATen kernels over the whole table.
+__global__ __launch_bounds__(256) void k_ste_binary_fwd(const float* __restrict__ x, float* __restrict__ out, uint64_t n)
+{
+    const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        float4       o;
+        o.x = (v.x >= 0.0f ? 1.0f : 0.0f) + (v.x < 0.0f ? -1.0f : 0.0f);
+        o.y = (v.y >= 0.0f ? 1.0f : 0.0f) + (v.y < 0.0f ? -1.0f : 0.0f);
+        o.z = (v.z >= 0.0f ? 1.0f : 0.0f) + (v.z < 0.0f ? -1.0f : 0.0f);
+        o.w = (v.w >= 0.0f ? 1.0f : 0.0f) + (v.w < 0.0f ? -1.0f : 0.0f);
+        *reinterpret_cast<float4*>(out + i) = o;
+    } else {
+        for (uint64_t k = i; k < n; k++) out[k] = (x[k] >= 0.0f ? 1.0f : 0.0f) + (x[k] < 0.0f ? -1.0f : 0.0f);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ste_binary_bwd(const float* __restrict__ x, const float* __restrict__ g,
+                                                        float* __restrict__ out, uint64_t n)
+{
+    const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        const float4 v = *reinterpret_cast<const float4*>(x + i), gv = *reinterpret_cast<const float4*>(g + i);
+        float4       o;
+        o.x = gv.x * ((v.x >= -1.0f && v.x <= 1.0f) ? 1.0f : 0.0f);
+        o.y = gv.y * ((v.y >= -1.0f && v.y <= 1.0f) ? 1.0f : 0.0f);
+        o.z = gv.z * ((v.z >= -1.0f && v.z <= 1.0f) ? 1.0f : 0.0f);
+        o.w = gv.w * ((v.w >= -1.0f && v.w <= 1.0f) ? 1.0f : 0.0f);
+        *reinterpret_cast<float4*>(out + i) = o;
+    } else {
+        for (uint64_t k = i; k < n; k++) out[k] = g[k] * ((x[k] >= -1.0f && x[k] <= 1.0f) ? 1.0f : 0.0f);
+    }
+}
+
 // real spherical harmonics up to degree 4 of d (field.SHEncoding, term by term)
 __device__ __forceinline__ void sh4(float x, float y, float z, float (&o)[16])
 {
@@ -144,6 +179,24 @@ extern "C" int cnc_field_prepare(const float* positions, const float* aabb, uint
     if (!positions || !aabb || !x_unit || !selector) return CNC_ERR_INVALID_VALUE;
     hipLaunchKernelGGL(k_field_prepare, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, positions, aabb, N,
                        x_unit, selector);
+    return launch_status();
+}
+
+extern "C" int cnc_ste_binary_forward(const float* x, float* out, uint64_t n, void* stream)
+{
+    if (n == 0) return CNC_OK;
+    if (!x || !out || ((uintptr_t)x | (uintptr_t)out) % 16) return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_ste_binary_fwd, dim3((uint32_t)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, x, out, n);
+    return launch_status();
+}
+
+extern "C" int cnc_ste_binary_backward(const float* x, const float* grad_out, float* grad_in, uint64_t n, void* stream)
+{
+    if (n == 0) return CNC_OK;
+    if (!x || !grad_out || !grad_in || ((uintptr_t)x | (uintptr_t)grad_out | (uintptr_t)grad_in) % 16)
+        return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_ste_binary_bwd, dim3((uint32_t)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, x, grad_out,
+                       grad_in, n);
     return launch_status();
 }
 

@@ -31,13 +31,30 @@ class STE_binary(Function):
     """+1 where clamp(x,-1,1) >= 0 else -1; gradient passes where |x| <= 1 (ngp.py:22-39)."""
 
     @staticmethod
+    def _kernel_ok(*ts):
+        return all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts)
+
+    @staticmethod
     def forward(ctx, input):
         ctx.save_for_backward(input)
-        return torch.where(input >= 0, 1.0, -1.0).to(input.dtype)
+        if STE_binary._kernel_ok(input):
+            from . import _lib
+            out = torch.empty_like(input)
+            _lib.check(_lib.lib().cnc_ste_binary_forward(input.data_ptr(), out.data_ptr(), input.numel(),
+                                                         _lib.stream(input.device)), "ste_binary_forward")
+            return out
+        c = torch.clamp(input, min=-1, max=1)
+        return ((c >= 0) * 1.0 + (c < 0) * -1.0).to(input.dtype)
 
     @staticmethod
     def backward(ctx, grad_output):
         (input,) = ctx.saved_tensors
+        if STE_binary._kernel_ok(input, grad_output):
+            from . import _lib
+            out = torch.empty_like(input)
+            _lib.check(_lib.lib().cnc_ste_binary_backward(input.data_ptr(), grad_output.data_ptr(), out.data_ptr(),
+                                                          input.numel(), _lib.stream(input.device)), "ste_binary_backward")
+            return out
         return grad_output * ((input >= -1) & (input <= 1)).to(grad_output.dtype)
 
 

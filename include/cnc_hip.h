@@ -505,6 +505,12 @@ int cnc_field_prepare(const float* positions, const float* aabb, uint32_t N, flo
 int cnc_field_post(const float* base_out, uint32_t ld_base, uint32_t geo_feat_dim, const uint8_t* selector,
                    const float* dirs, uint32_t N, float* density, float* head_in, uint32_t ld_head,
                    void* stream);
+/* STE_binary of ngp.py:22-39 over n floats (16-byte aligned buffers), one pass each way:
+ *   forward : out = (c >= 0) * 1 + (c < 0) * -1 with c = clamp(x, -1, 1)   (+1 / -1; NaN -> 0)
+ *   backward: grad_in = grad_out * (clamp(x, -1, 1) == x)                                                     */
+int cnc_ste_binary_forward(const float* x, float* out, uint64_t n, void* stream);
+int cnc_ste_binary_backward(const float* x, const float* grad_out, float* grad_in, uint64_t n, void* stream);
+
 /* out[i, col:ld] = [x_i (3) | sin(freqs[k] x_i) (3), cos(freqs[k] x_i) (3) for k < n_freqs | zeros]: the Embedder
  * of ngp.py:583-599 (include_input, periodic_fns = [sin, cos]) written into the base MLP's input matrix
  * (row stride ld, first column col; everything from col to ld is written).  x [N,3], freqs [n_freqs] on the

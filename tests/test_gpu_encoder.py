@@ -509,3 +509,24 @@ def test_dy_dx_and_input_backward_bit_exact(cuda, oracle, D, F, ste):
     # dy_dx without grad_inputs (or the reverse) is a caller error
     with pytest.raises(RuntimeError):
         be.grid_encode_backward(t(g), t(x), t(emb), t(offs), t(resl), ge2, N, D, F, L, 0, 128, dy, None, None, None)
+
+
+@pytest.mark.parametrize("n", [1, 5, 4096, 100003 * 8])
+def test_ste_binary_kernels_equal_the_op_chain(cuda, n):
+    """cnc_ste_binary_{forward,backward} vs the reference's op chain (ngp.py:22-39) on the same device: +1 / -1
+    (0 for NaN), gradient passed where clamp(x, -1, 1) == x — edges at 0, -0, +-1, beyond, inf, NaN."""
+    from cnc_amd.gridencoder import STE_binary
+    g = torch.Generator(device="cpu").manual_seed(n)
+    x = (torch.rand(n, generator=g) * 3 - 1.5)
+    edge = torch.tensor([0.0, -0.0, 1.0, -1.0, 1.0000001, -1.0000001, float("inf"), -float("inf"), float("nan")])
+    x[: min(n, edge.numel())] = edge[: min(n, edge.numel())]
+    x = x.to(cuda).requires_grad_()
+    go = torch.randn(n, generator=g).to(cuda)
+    y = STE_binary.apply(x)
+    y.backward(go)
+    xd = x.detach()
+    c = torch.clamp(xd, min=-1, max=1)
+    want = (c >= 0) * 1.0 + (c < 0) * -1.0
+    assert torch.equal(y.detach().nan_to_num(nan=7.0), want.nan_to_num(nan=7.0))
+    want_g = go * ((c == xd) + 0.0)
+    assert torch.equal(x.grad, want_g)
