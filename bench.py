@@ -398,6 +398,8 @@ def main():
             req = tj.get("k_grid_encode_bwd_merge_atomic_requests")
             parts["k_grid_encode_bwd_merge"] = {
                 "avg_ms": dur * 1e3, "bound": "memory-side fp32 atomic requests (tools/atomic_probe.hip: 21 G requests/s)",
+                "note": "since the cells are merged across rays the kernel is vector-issue-bound, not request-bound: without "
+                        "its atomics it runs 10 % faster, without the MFMA accumulation 35 % (DESIGN 4.2b, second pass)",
                 "atomic_requests_per_launch": req, "achieved_G_requests_per_s": None if not req else req / dur / 1e9,
                 "peak_G_requests_per_s": 21.0, "frac": None if not req else req / dur / 21e9}
         if pf:
