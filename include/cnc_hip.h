@@ -501,7 +501,8 @@ int cnc_field_prepare(const float* positions, const float* aabb, uint32_t N, flo
  *   density [N]        = exp(density_raw - 1) * selector                          (ngp.py:527-535; nullable)
  *   head_in [N, ld_head] = [SH degree-4 (16) of dirs | geo features | zeros]       (ngp.py:540-547; nullable)
  * dirs [N,3] are the raw view directions (the (dir + 1) / 2 and its inverse are applied inside, as the
- * reference and tiny-cuda-nn do between them).  selector nullable (= all ones).                       */
+ * reference and tiny-cuda-nn do between them).  selector nullable (= all ones).  ld_head a multiple of 4
+ * and head_in 16-byte aligned (rows are written with 16-byte stores).                                  */
 int cnc_field_post(const float* base_out, uint32_t ld_base, uint32_t geo_feat_dim, const uint8_t* selector,
                    const float* dirs, uint32_t N, float* density, float* head_in, uint32_t ld_head,
                    void* stream);
