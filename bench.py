@@ -245,15 +245,15 @@ def main():
     ap.add_argument("--no-train-step", action="store_true")
     args = ap.parse_args()
 
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus) if args.gpus > 1 else "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # test hooks (not used by the driver): CNC_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
     # CNC_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N>1 control flow can be exercised on a
     # single-GPU box (tests/test_gpu_bench_multi.py)

@@ -328,3 +328,18 @@ def test_fused_optimizer_step_drops_version_keyed_caches():
     if enc.params._version != v0:
         pytest.skip("this torch bumps _version in the fused optimizer")
     assert enc._bits is None and enc._bits_key is None
+
+
+def test_bench_refuses_a_world_that_contradicts_gpus():
+    """`bench.py --gpus N` under a launcher that started a different number of ranks must stop, not report a line
+    whose n_gpus is wrong; and without a GPU it must stop too (no CPU fallback in the measured path)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        env.pop("WORLD_SIZE")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")], env=env, capture_output=True, text=True)
+        assert r.returncode != 0 and "needs an MI355X" in r.stderr
