@@ -330,6 +330,7 @@ class VotePlan:
         N, dev = inputs_i16.shape[0], inputs_i16.device
         self.resolution, self.hashmap_size = int(resolution), int(hashmap_size)
         self.n_pixels = (self.resolution - 2) ** 2
+        self._masks = self._masks_key = self._masks_src = None
         L = _lib.lib()
         rows = torch.empty(N, dtype=torch.int32, device=dev)
         pix = [torch.empty(N, dtype=torch.int32, device=dev) for _ in range(3)]
@@ -369,9 +370,19 @@ def cnt_np_embed_planned(plan, embeddings_clip, outputs, n_features, axis):
     _require_f32(outputs, "outputs")
     if outputs.numel() != plan.n_pixels * n_features * 2:
         raise RuntimeError("cnt_np_embed_planned: tensor sizes do not match the plan")
-    rc = _lib.lib().cnc_cnt_np_embed_planned(ptr(plan.rows_by_pixel[axis]), ptr(plan.pixel_seg[axis]),
-                                             ptr(embeddings_clip), ptr(outputs), plan.n_pixels,
-                                             int(n_features), stream(outputs.device))
+    L = _lib.lib()
+    # the votes (embedding > 0.9) as one word per table row, packed once per table version and shared by the three
+    # projections of a step: the per-vertex gather is then 4 bytes from a 2 MB array instead of a 4 F byte row
+    key = (embeddings_clip.data_ptr(), embeddings_clip._version, tuple(embeddings_clip.shape))
+    if plan._masks_key != key:
+        n_rows = min(plan.hashmap_size, embeddings_clip.shape[0])
+        masks = torch.empty(n_rows, dtype=torch.int32, device=embeddings_clip.device)
+        check(L.cnc_cnt_vote_masks(ptr(embeddings_clip), n_rows, int(n_features), ptr(masks),
+                                   stream(outputs.device)), "cnt_vote_masks")
+        plan._masks, plan._masks_key, plan._masks_src = masks, key, embeddings_clip
+    rc = L.cnc_cnt_np_embed_planned_masked(ptr(plan.rows_by_pixel[axis]), ptr(plan.pixel_seg[axis]),
+                                           ptr(plan._masks), ptr(outputs), plan.n_pixels,
+                                           int(n_features), stream(outputs.device))
     check(rc, "cnt_np_embed_planned")
 
 

@@ -180,6 +180,12 @@ int cnc_cnt_np_embed_planned(const uint32_t* rows_by_pixel, const int32_t* pixel
 int cnc_cnt_np_embed_planned_backward(const uint32_t* pixels_by_row, const int32_t* row_seg,
                                       const float* embeddings_clip, const float* grad_over_sum,
                                       float* grad_embeddings, uint32_t n_rows, uint32_t F, void* stream);
+/* The same forward counts in two steps, for callers that project one table onto several planes (the three calls
+ * of utils_bpp_acc.py:590-600 vote on the same embeddings): masks[r] bit ch = (embeddings_clip[r][ch] > 0.9),
+ * F <= 32, packed once; then a 4-byte gather per vertex instead of a 4 F byte row.  Counts are integers: equal. */
+int cnc_cnt_vote_masks(const float* embeddings_clip, uint32_t n_rows, uint32_t F, uint32_t* masks, void* stream);
+int cnc_cnt_np_embed_planned_masked(const uint32_t* rows_by_pixel, const int32_t* pixel_seg, const uint32_t* masks,
+                                    float* outputs, uint32_t n_pixels, uint32_t F, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Radiance-field MLP (gradient-free evaluations) — stands in for the cuBLAS GEMM chain behind
