@@ -45,6 +45,7 @@ SIGNATURES = {
     "cnc_cnt_np_plan": [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
     "cnc_cnt_np_embed_planned": [_vp, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_cnt_np_embed_planned_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp],
+    "cnc_cnt_np_embed_planned_backward3": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_cnt_vote_masks": [_vp, _u32, _u32, _vp, _vp],
     "cnc_cnt_np_embed_planned_masked": [_vp, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_query_mask_3D": [_vp, _u32, _vp, _u32, _vp, _vp, _i32, _u32, _vp],
@@ -96,7 +97,7 @@ CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 16          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 17          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

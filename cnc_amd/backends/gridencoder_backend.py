@@ -400,3 +400,20 @@ def cnt_np_embed_planned_backward(plan, embeddings_clip, grad_over_sum, grad_emb
                                                       min(plan.hashmap_size, embeddings_clip.shape[0]),
                                                       int(n_features), stream(grad_embeddings.device))
     check(rc, "cnt_np_embed_planned_backward")
+
+
+def cnt_np_embed_planned_backward3(plan, embeddings_clip, grads_over_sum, grad_embeddings, n_features):
+    """The three planes' `cnt_np_embed_planned_backward` in one pass; `grad_embeddings` is written, not accumulated."""
+    ts = [("embeddings_clip", embeddings_clip), ("grad_embeddings", grad_embeddings)] + \
+         [(f"grad_over_sum[{i}]", g) for i, g in enumerate(grads_over_sum)]
+    _common_checks(ts)
+    for name, t in ts:
+        _require_f32(t, name)
+    if len(grads_over_sum) != 3 or any(g.numel() != plan.n_pixels * n_features * 2 for g in grads_over_sum) \
+            or grad_embeddings.shape != embeddings_clip.shape or embeddings_clip.shape[0] > plan.hashmap_size:
+        raise RuntimeError("cnt_np_embed_planned_backward3: tensor sizes do not match the plan")
+    rc = _lib.lib().cnc_cnt_np_embed_planned_backward3(
+        ptr(plan.pixels_by_row[0]), ptr(plan.pixels_by_row[1]), ptr(plan.pixels_by_row[2]), ptr(plan.row_seg),
+        ptr(embeddings_clip), ptr(grads_over_sum[0]), ptr(grads_over_sum[1]), ptr(grads_over_sum[2]),
+        ptr(grad_embeddings), embeddings_clip.shape[0], int(n_features), stream(grad_embeddings.device))
+    check(rc, "cnt_np_embed_planned_backward3")

@@ -168,6 +168,36 @@ class _cnt_np_embed_planned(Function):
         return None, grad_embeddings, None
 
 
+class _cnt_np_embed_planned3(Function):
+    """The three projections (xy, xz, yz) of `_cnt_np_embed_planned` as ONE autograd node: the forward shares the
+    packed votes, the backward is one pass over the table rows that WRITES the table gradient (no zero-fill, no
+    accumulation of three table-sized tensors)."""
+
+    @staticmethod
+    def forward(ctx, plan, embeddings):
+        n_features = embeddings.shape[-1]
+        embeddings = embeddings.contiguous()
+        scale = plan.resolution - 2
+        outs, sums = [], []
+        for axis_id in range(3):
+            pn_embed = torch.empty([scale, scale, n_features, 2], device=embeddings.device)
+            _backend.cnt_np_embed_planned(plan, embeddings, pn_embed, n_features, axis_id)
+            pn_sum = torch.sum(pn_embed, dim=-1, keepdim=True) + 1e-6
+            outs.append(pn_embed / pn_sum)
+            sums.append(pn_sum)
+        ctx.save_for_backward(embeddings, *sums)
+        ctx.plan = plan
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_xy, g_xz, g_yz):
+        embeddings, *sums = ctx.saved_tensors
+        gs = [(torch.reciprocal(sm) * g).contiguous() for sm, g in zip(sums, (g_xy, g_xz, g_yz))]   # gridencoder.cu:1035-1040
+        grad_embeddings = torch.empty_like(embeddings)
+        _backend.cnt_np_embed_planned_backward3(ctx.plan, embeddings, gs, grad_embeddings, embeddings.shape[-1])
+        return None, grad_embeddings
+
+
 def _encode_host(x, p, file_name):
     """x, p: contiguous float32 HOST tensors.  Writes the .b file, returns its size in bits."""
     n = x.numel()
@@ -652,6 +682,15 @@ class CNC_context_models(nn.Module):
         frac = nnf.pad(frac, pad=[1, 1, 1, 1])                              # ring of zeros
         return frac.squeeze(0).permute(1, 2, 0).contiguous().view(-1, self.n_features)
 
+    def get_pn_embed_frac_planes(self, embeddings_3D_q, plan):
+        """`get_pn_embed_frac` for the xy, xz and yz planes at once (one autograd node, see `_cnt_np_embed_planned3`)."""
+        out = []
+        for frac in _cnt_np_embed_planned3.apply(plan, embeddings_3D_q):
+            frac = frac[..., 0].permute(2, 0, 1).unsqueeze(0).contiguous()      # [1, F, R-2, R-2]
+            frac = nnf.pad(frac, pad=[1, 1, 1, 1])                              # ring of zeros
+            out.append(frac.squeeze(0).permute(1, 2, 0).contiguous().view(-1, self.n_features))
+        return out
+
     @staticmethod
     def _project(binary_vxl, axis):
         return torch.any(binary_vxl.squeeze(0), dim={"xy": 2, "xz": 1, "yz": 0}[axis])
@@ -803,11 +842,18 @@ class CNC_context_models(nn.Module):
                 for k in range(3)]
 
         finest_3D = params_q_xyz[self._off3_host[-2]:self._off3_host[-1]]
+        pn_fracs = None
+        if self.use_dimension_wise and self.vote_plan is not None and finest_3D.shape[0] <= self.vote_plan.hashmap_size:
+            with _range("ctx/pn_frac"):
+                pn_fracs = self.get_pn_embed_frac_planes(finest_3D, self.vote_plan)
         for k, (Ec, p_q) in enumerate(zip((Encoding_xy, Encoding_xz, Encoding_yz),
                                           (params_q_xy, params_q_xz, params_q_yz))):
             with _range("ctx/pn_frac"):
-                pn_frac = (self.get_pn_embed_frac(finest_3D, idx_coords2, axis=axes[k], plan=self.vote_plan)
-                           if self.use_dimension_wise else None)
+                if pn_fracs is not None:
+                    pn_frac = pn_fracs[k]
+                else:
+                    pn_frac = (self.get_pn_embed_frac(finest_3D, idx_coords2, axis=axes[k], plan=self.vote_plan)
+                               if self.use_dimension_wise else None)
             batches = iter(self.batched_inputs_list[k])
             with _range("ctx/level_Pg"):
                 Pg_all, bits_all = self.level_stats(p_q, self._off2_host)

@@ -155,6 +155,55 @@ __global__ __launch_bounds__(64) void k_cnt_votes_bwd(const uint32_t* __restrict
     if (vs == 0) grad_emb[(size_t)r * F + ch] += pos ? acc : -acc;
 }
 
+// backward of the three projections in one pass: the row's vertices are the same for the three planes (one row_seg),
+// only their pixels differ.  grad_emb is WRITTEN (rows without vertices get 0): no zero-fill, no accumulation of three
+// table-sized tensors by the caller.
+struct Votes3 {
+    const uint32_t* pixels_by_row[3];
+    const float*    G[3];
+};
+
+template <uint32_t F>
+__global__ __launch_bounds__(64) void k_cnt_votes_bwd3(Votes3 v3, const int32_t* __restrict__ seg,
+                                                       const float* __restrict__ emb, float* __restrict__ grad_emb,
+                                                       uint32_t rows)
+{
+    constexpr uint32_t VPI = 64 / F;
+    const uint32_t r = blockIdx.x;
+    if (r >= rows) return;
+    const uint32_t lane = threadIdx.x, ch = lane % F, vs = lane / F;
+    const int32_t  s = seg[r], e = seg[r + 1];
+    float          acc = 0;
+    const bool     pos = (double)emb[(size_t)r * F + ch] > 0.9;
+    const uint32_t sel = pos ? 0u : 1u;
+    if (s != e) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const uint32_t* __restrict__ pbr = v3.pixels_by_row[a];
+            const float* __restrict__    G = v3.G[a];
+            float                        part = 0;
+            for (int32_t k = s + (int32_t)vs; k < e; k += (int32_t)(4 * VPI)) {
+                uint32_t px[4];
+                float    v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int32_t kk = k + u * (int32_t)VPI;
+                    px[u] = kk < e ? pbr[kk] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    v[u] = px[u] != 0xFFFFFFFFu ? G[((size_t)px[u] * F + ch) * 2 + sel] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 4; u++) part += v[u];
+            }
+#pragma unroll
+            for (uint32_t m = F; m < 64; m <<= 1) part += __shfl_xor(part, (int)m);
+            acc += pos ? part : -part;          // the three planes' gradients, added in plane order
+        }
+    }
+    if (vs == 0) grad_emb[(size_t)r * F + ch] = acc;
+}
+
 }  // namespace cnc
 
 using namespace cnc;
@@ -225,5 +274,21 @@ extern "C" int cnc_cnt_np_embed_planned_backward(const uint32_t* pixels_by_row, 
     CNC_VOTE_SWITCH(F, hipLaunchKernelGGL((k_cnt_votes_bwd<FF>), dim3(n_rows), dim3(64), 0, s,
                                           pixels_by_row, row_seg, embeddings_clip, grad_over_sum,
                                           grad_embeddings, n_rows));
+    return launch_status();
+}
+
+extern "C" int cnc_cnt_np_embed_planned_backward3(const uint32_t* pixels_by_row_xy, const uint32_t* pixels_by_row_xz,
+                                                  const uint32_t* pixels_by_row_yz, const int32_t* row_seg,
+                                                  const float* embeddings_clip, const float* grad_over_sum_xy,
+                                                  const float* grad_over_sum_xz, const float* grad_over_sum_yz,
+                                                  float* grad_embeddings, uint32_t n_rows, uint32_t F, void* stream)
+{
+    if (n_rows == 0) return CNC_OK;
+    if (!row_seg || !embeddings_clip || !grad_over_sum_xy || !grad_over_sum_xz || !grad_over_sum_yz || !grad_embeddings)
+        return CNC_ERR_INVALID_VALUE;
+    hipStream_t s = (hipStream_t)stream;
+    Votes3      v3{{pixels_by_row_xy, pixels_by_row_xz, pixels_by_row_yz}, {grad_over_sum_xy, grad_over_sum_xz, grad_over_sum_yz}};
+    CNC_VOTE_SWITCH(F, hipLaunchKernelGGL((k_cnt_votes_bwd3<FF>), dim3(n_rows), dim3(64), 0, s, v3, row_seg,
+                                          embeddings_clip, grad_embeddings, n_rows));
     return launch_status();
 }

@@ -183,6 +183,13 @@ int cnc_cnt_np_embed_planned_backward(const uint32_t* pixels_by_row, const int32
 /* The same forward counts in two steps, for callers that project one table onto several planes (the three calls
  * of utils_bpp_acc.py:590-600 vote on the same embeddings): masks[r] bit ch = (embeddings_clip[r][ch] > 0.9),
  * F <= 32, packed once; then a 4-byte gather per vertex instead of a 4 F byte row.  Counts are integers: equal. */
+/* Backward of the three projections (xy, xz, yz) of ONE table in one pass: grad_embeddings [n_rows, F] is WRITTEN
+ * (0 for rows without vertices) = the sum of the three cnc_cnt_np_embed_planned_backward results on a zeroed table. */
+int cnc_cnt_np_embed_planned_backward3(const uint32_t* pixels_by_row_xy, const uint32_t* pixels_by_row_xz,
+                                       const uint32_t* pixels_by_row_yz, const int32_t* row_seg,
+                                       const float* embeddings_clip, const float* grad_over_sum_xy,
+                                       const float* grad_over_sum_xz, const float* grad_over_sum_yz,
+                                       float* grad_embeddings, uint32_t n_rows, uint32_t F, void* stream);
 int cnc_cnt_vote_masks(const float* embeddings_clip, uint32_t n_rows, uint32_t F, uint32_t* masks, void* stream);
 int cnc_cnt_np_embed_planned_masked(const uint32_t* rows_by_pixel, const int32_t* pixel_seg, const uint32_t* masks,
                                     float* outputs, uint32_t n_pixels, uint32_t F, void* stream);
