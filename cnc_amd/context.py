@@ -678,18 +678,20 @@ class CNC_context_models(nn.Module):
             frac = _cnt_np_embed_planned.apply(plan, embeddings_3D_q, axis)
         else:
             frac = _cnt_np_embed.apply(idx_coords2, embeddings_3D_q, resolution, 2 ** self.log2_hashmap_size, axis)
-        frac = frac[..., 0].permute(2, 0, 1).unsqueeze(0).contiguous()      # [1, F, R-2, R-2]
-        frac = nnf.pad(frac, pad=[1, 1, 1, 1])                              # ring of zeros
-        return frac.squeeze(0).permute(1, 2, 0).contiguous().view(-1, self.n_features)
+        return self._ring_of_zeros(frac)
 
     def get_pn_embed_frac_planes(self, embeddings_3D_q, plan):
         """`get_pn_embed_frac` for the xy, xz and yz planes at once (one autograd node, see `_cnt_np_embed_planned3`)."""
         out = []
         for frac in _cnt_np_embed_planned3.apply(plan, embeddings_3D_q):
-            frac = frac[..., 0].permute(2, 0, 1).unsqueeze(0).contiguous()      # [1, F, R-2, R-2]
-            frac = nnf.pad(frac, pad=[1, 1, 1, 1])                              # ring of zeros
-            out.append(frac.squeeze(0).permute(1, 2, 0).contiguous().view(-1, self.n_features))
+            out.append(self._ring_of_zeros(frac))
         return out
+
+    def _ring_of_zeros(self, frac):
+        """[R-2, R-2, F, 2] vote fractions -> the [R * R, F] table of the +1 fractions with a ring of zero pixels.
+        The reference permutes to [1, F, R-2, R-2], pads the two spatial axes and permutes back
+        (utils_bpp_acc.py:520-526): the same values as padding the first two axes in place."""
+        return nnf.pad(frac[..., 0], pad=[0, 0, 1, 1, 1, 1]).reshape(-1, self.n_features)
 
     @staticmethod
     def _project(binary_vxl, axis):
