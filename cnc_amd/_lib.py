@@ -81,7 +81,7 @@ SIGNATURES = {
     "cnc_field_post": [_vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp],
     "cnc_field_post_backward": [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _vp],
     "cnc_ctx_mlp_forward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp, _vp],
-    "cnc_ctx_mlp_backward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp] * 10 + [_vp],
+    "cnc_ctx_mlp_backward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp] * 10 + [_u32, _u32, _vp],
     "cnc_ctx_window_gather": [_vp] * 8,
     "cnc_bernoulli_bits_partials": [C.c_uint64, _u32],
     "cnc_bernoulli_bits_forward": [_vp, _vp, _vp, C.c_uint64, _u32, _vp, _vp],
@@ -97,7 +97,7 @@ CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 17          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 18          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

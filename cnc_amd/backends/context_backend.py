@@ -18,6 +18,9 @@ def _f32c(t, name):
     return t
 
 
+_REPLICAS = 16        # zeroed copies of the weight-gradient buffer per backward call
+
+
 class ContextMLP(Function):
     """y = MLP([in_a | in_b | pg]) per row — `seq` is the reference's nn.Sequential: one Linear (the 2-D
     heads) or Linear-LeakyReLU-Linear-LeakyReLU-Linear (context_model_3D).  in_b / pg may be None."""
@@ -60,14 +63,21 @@ class ContextMLP(Function):
         g_b = torch.empty_like(in_b) if (in_b is not None and ctx.needs_input_grad[1]) else None
         g_pg = torch.zeros(pgv.numel(), dtype=torch.float32, device=dev) if pgv is not None else None
         # every weight / bias gradient in ONE zero-filled buffer (the kernel accumulates with atomics)
-        flat = torch.zeros(sum(w.numel() for w in ws if w is not None), dtype=torch.float32, device=dev)
+        # (_REPLICAS copies: the kernel's ~1000 workgroups spread their atomics over them, summed below)
+        total = sum(w.numel() for w in ws if w is not None)
+        copies = torch.zeros((_REPLICAS, total), dtype=torch.float32, device=dev)
+        first, at = [], 0
+        for w in ws:
+            first.append(None if w is None else copies[0, at:at + w.numel()])
+            at += 0 if w is None else w.numel()
+        check(_lib.lib().cnc_ctx_mlp_backward(ptr(in_a), Ca, Ca, ptr(in_b), Cb, Cb, ptr(pgv), ptr(pg_index), N, n_layers, F,
+                                              *[ptr(w) for w in ws], ptr(g), ptr(g_a), ptr(g_b), ptr(g_pg),
+                                              *[ptr(w) for w in first], _REPLICAS, total, stream(dev)), "ctx_mlp_backward")
+        flat = copies.sum(0) if _REPLICAS > 1 else copies[0]
         gws, at = [], 0
         for w in ws:
             gws.append(None if w is None else flat[at:at + w.numel()].view_as(w))
             at += 0 if w is None else w.numel()
-        check(_lib.lib().cnc_ctx_mlp_backward(ptr(in_a), Ca, Ca, ptr(in_b), Cb, Cb, ptr(pgv), ptr(pg_index), N, n_layers, F,
-                                              *[ptr(w) for w in ws], ptr(g), ptr(g_a), ptr(g_b), ptr(g_pg),
-                                              *[ptr(w) for w in gws], stream(dev)), "ctx_mlp_backward")
         return (g_a, g_b, None if g_pg is None else g_pg.reshape(pg_shape), *gws, None)
 
 

@@ -157,6 +157,7 @@ struct MlpGrads {
     const float* g_out;                       // [N, F]
     float *g_a, *g_b, *g_pg;                  // [N, Ca], [N, Cb] or null, scalar accumulator or null
     float *gW1, *gb1, *gW2, *gb2, *gW3, *gb3; // accumulated with atomicAdd: zeroed by the caller
+    uint32_t n_rep, rep_stride;               // block b adds into copy b % n_rep, rep_stride floats further on
 };
 
 // One wave reduces outer products over its 64 vertices: acc[k] += sum_v A[v][e / NB] * B[v][e % NB] for the
@@ -197,12 +198,17 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
     constexpr int H1 = NL == 1 ? F : kH;
     constexpr int kPitch = kMaxC + 1;                         // tile pitch (words); covers 32 + 1 and C + 1
     __shared__ float sW1t[kMaxC * H1], sb1[H1], sW2t[NL == 3 ? kH * kH : 1], sb2[kH], sW3t[NL == 3 ? kH * F : 1], sb3[F];
-    __shared__ float tiles[kBwdThreads / 64][2][64 * kPitch]; // per wave: tile A, tile B
+    // per wave: tile A (gradients at a layer's output: <= 32 columns, F for the single-Linear heads) and tile B (that
+    // layer's inputs: <= kMaxC columns).  The narrow tile A of NL == 1 takes 25.6 instead of 42 KB per block:
+    // 6 instead of 3 blocks per CU for the nine 2-D heads of a step.
+    constexpr int kPitchA = NL == 1 ? F + 1 : kPitch;
+    __shared__ float tilesA[kBwdThreads / 64][64 * kPitchA];
+    __shared__ float tilesB[kBwdThreads / 64][64 * kPitch];
     load_weights<NL, F>(a, sW1t, sb1, sW2t, sb2, sW3t, sb3);
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* tA = tiles[wave][0];
-    float* tB = tiles[wave][1];
+    float* tA = tilesA[wave];
+    float* tB = tilesB[wave];
     // weight-gradient elements owned by this lane (accumulated over every batch of the block)
     constexpr int K1 = (H1 * kMaxC + 63) / 64, K2 = NL == 3 ? kH * kH / 64 : 1, K3 = NL == 3 ? (F * kH + 63) / 64 : 1;
     float aW1[K1] = {}, aW2[K2] = {}, aW3[K3] = {}, ab1 = 0, ab2 = 0, ab3 = 0, apg = 0;
@@ -239,12 +245,12 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int f = 0; f < F; f++) tA[lane * kPitch + f] = d_o[f];
+            for (int f = 0; f < F; f++) tA[lane * kPitchA + f] = d_o[f];
             __syncthreads();
-            outer_acc<K3>(tA, kPitch, F, tB, kPitch, kH, lane, aW3);
+            outer_acc<K3>(tA, kPitchA, F, tB, kPitch, kH, lane, aW3);
             if (lane < F) {
                 float s = 0.0f;
-                for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitch + lane];
+                for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitchA + lane];
                 ab3 += s;
             }
             __syncthreads();
@@ -255,22 +261,22 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
 #pragma unroll
                 for (int j = 0; j < kH; j++) s = __builtin_fmaf(sW2t[i * kH + j], d2[j], s);
                 d1[i] = h1[i] > 0.0f ? s : kSlope * s;
-                tA[lane * kPitch + i] = d2[i];
+                tA[lane * kPitchA + i] = d2[i];
                 tB[lane * kPitch + i] = h1[i];
                 __builtin_amdgcn_sched_barrier(0);       // as in mlp_row: do not hoist the whole layer's weight reads
             }
             __syncthreads();
-            outer_acc<K2>(tA, kPitch, kH, tB, kPitch, kH, lane, aW2);
+            outer_acc<K2>(tA, kPitchA, kH, tB, kPitch, kH, lane, aW2);
             if (lane < kH) {
                 float s = 0.0f;
-                for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitch + lane];
+                for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitchA + lane];
                 ab2 += s;
             }
             __syncthreads();
         }
         // input gradient, and tiles A = d1 [64][H1], B = inputs [64][C] -> dW1
 #pragma unroll
-        for (int j = 0; j < H1; j++) tA[lane * kPitch + j] = d1[j];
+        for (int j = 0; j < H1; j++) tA[lane * kPitchA + j] = d1[j];
         float   s_pg = 0.0f;       // this row's gradient of the Pg column
         auto d_in = [&](uint32_t c) {      // d input[c] = sum_j W1[j][c] d1[j]
             float        s = 0.0f;
@@ -333,21 +339,24 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
             }
         }
         __syncthreads();
-        outer_acc<K1>(tA, kPitch, H1, tB, kPitch, a.C, lane, aW1);
+        outer_acc<K1>(tA, kPitchA, H1, tB, kPitch, a.C, lane, aW1);
         if (lane < H1) {
             float s = 0.0f;
-            for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitch + lane];
+            for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitchA + lane];
             ab1 += s;
         }
         __syncthreads();
     }
-    flush_acc<K1>(g.gW1, H1 * a.C, lane, aW1);
-    if (lane < H1) atomicAdd(g.gb1 + lane, ab1);
+    // ~1000 blocks adding into the same few hundred addresses serialise at the memory side (21 us of a 72 us
+    // single-Linear call): the caller hands n_rep zeroed copies of the weight-gradient buffer and sums them
+    const size_t rep = (size_t)(blockIdx.x % g.n_rep) * g.rep_stride;
+    flush_acc<K1>(g.gW1 + rep, H1 * a.C, lane, aW1);
+    if (lane < H1) atomicAdd(g.gb1 + rep + lane, ab1);
     if constexpr (NL == 3) {
-        flush_acc<K2>(g.gW2, kH * kH, lane, aW2);
-        flush_acc<K3>(g.gW3, F * kH, lane, aW3);
-        if (lane < kH) atomicAdd(g.gb2 + lane, ab2);
-        if (lane < F) atomicAdd(g.gb3 + lane, ab3);
+        flush_acc<K2>(g.gW2 + rep, kH * kH, lane, aW2);
+        flush_acc<K3>(g.gW3 + rep, F * kH, lane, aW3);
+        if (lane < kH) atomicAdd(g.gb2 + rep + lane, ab2);
+        if (lane < F) atomicAdd(g.gb3 + rep + lane, ab3);
     }
     if (g.g_pg && a.pg_index) {
         if (pg_at >= 0 && lane == 0) atomicAdd(g.g_pg + pg_at, apg);
@@ -476,14 +485,15 @@ extern "C" int cnc_ctx_mlp_backward(const float* in_a, uint32_t lda, uint32_t Ca
                                     const float* W1, const float* b1, const float* W2, const float* b2,
                                     const float* W3, const float* b3, const float* grad_out, float* grad_a,
                                     float* grad_b, float* grad_pg, float* gW1, float* gb1, float* gW2, float* gb2,
-                                    float* gW3, float* gb3, void* stream)
+                                    float* gW3, float* gb3, uint32_t n_replicas, uint32_t replica_stride, void* stream)
 {
     if (N == 0) return CNC_OK;
+    if (n_replicas == 0) n_replicas = 1;
     MlpArgs a{in_a, lda, Ca, in_b, ldb, in_b ? Cb : 0u, pg, pg ? pg_index : nullptr, N,
               Ca + (in_b ? Cb : 0u) + (pg ? 1u : 0u), W1, b1, W2, b2, W3, b3};
     if (!grad_out || !grad_a || !gW1 || !gb1 || !mlp_args_ok(a, n_layers)) return CNC_ERR_INVALID_VALUE;
     if (n_layers == 3 && (!gW2 || !gb2 || !gW3 || !gb3)) return CNC_ERR_INVALID_VALUE;
-    MlpGrads g{grad_out, grad_a, grad_b, pg ? grad_pg : nullptr, gW1, gb1, gW2, gb2, gW3, gb3};
+    MlpGrads g{grad_out, grad_a, grad_b, pg ? grad_pg : nullptr, gW1, gb1, gW2, gb2, gW3, gb3, n_replicas, replica_stride};
     return n_layers == 1 ? launch_mlp<1>(true, F, a, nullptr, g, (hipStream_t)stream)
                          : launch_mlp<3>(true, F, a, nullptr, g, (hipStream_t)stream);
 }

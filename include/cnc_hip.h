@@ -438,14 +438,17 @@ int cnc_ctx_mlp_forward(const float* in_a, uint32_t lda, uint32_t Ca, const floa
                         const float* W1, const float* b1, const float* W2, const float* b2,
                         const float* W3, const float* b3, float* out, void* stream);
 /* Backward: grad_a [N, Ca] written; grad_b [N, Cb] written when non-NULL; *grad_pg and every weight / bias
- * gradient ACCUMULATED with atomics (the caller zero-fills them).                                      */
+ * gradient ACCUMULATED with atomics (the caller zero-fills them).  n_replicas (>= 1) zero-filled copies of the
+ * weight / bias gradients, replica_stride floats apart (gW1 ... gb3 point into copy 0): workgroup b adds into copy
+ * b % n_replicas and the caller sums the copies — ~1000 workgroups adding into the same few hundred addresses
+ * serialise at the memory side.                                                                         */
 int cnc_ctx_mlp_backward(const float* in_a, uint32_t lda, uint32_t Ca, const float* in_b, uint32_t ldb,
                          uint32_t Cb, const float* pg, const int64_t* pg_index, uint32_t N, uint32_t n_layers,
                          uint32_t F,
                          const float* W1, const float* b1, const float* W2, const float* b2,
                          const float* W3, const float* b3, const float* grad_out, float* grad_a,
                          float* grad_b, float* grad_pg, float* gW1, float* gb1, float* gW2, float* gb2,
-                         float* gW3, float* gb3, void* stream);
+                         float* gW3, float* gb3, uint32_t n_replicas, uint32_t replica_stride, void* stream);
 /* The per-step sample of the 3-D context pass (utils_bpp_acc.py:619-667), all coded levels at once: level i
  * contributes the vertices pos[i][0 .. p_at[i+1]-p_at[i]) (int16 triples, already offset to the window start)
  * and the slots cnt[i] / val[i][0 .. v_at[i+1]-v_at[i]).  Written, concatenated over the levels: pts i16 [P,3],
