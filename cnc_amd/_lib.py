@@ -77,6 +77,8 @@ SIGNATURES = {
     "cnc_field_prepare": [_vp, _vp, _u32, _vp, _vp, _vp],
     "cnc_ste_binary_forward": [_vp, _vp, C.c_uint64, _vp],
     "cnc_ste_binary_backward": [_vp, _vp, _vp, C.c_uint64, _vp],
+    "cnc_relu_backward_bias_partials": [_u32],
+    "cnc_relu_backward_bias": [_vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "cnc_field_sinusoid": [_vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp],
     "cnc_field_post": [_vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp],
     "cnc_field_post_backward": [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _vp],
@@ -91,13 +93,14 @@ SIGNATURES = {
 }
 
 # entry points that return something other than a status code
-RESTYPES = {"cnc_grid_encode_backward_binned_workspace": C.c_uint64, "cnc_bernoulli_bits_partials": C.c_uint32}
+RESTYPES = {"cnc_grid_encode_backward_binned_workspace": C.c_uint64, "cnc_bernoulli_bits_partials": C.c_uint32,
+            "cnc_relu_backward_bias_partials": C.c_uint32}
 
 CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 18          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 19          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

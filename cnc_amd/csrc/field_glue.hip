@@ -92,6 +92,41 @@ __global__ __launch_bounds__(256) void k_ste_binary_bwd(const float* __restrict_
     }
 }
 
+// ReLU backward and the bias gradient of the layer in one pass: g = y > 0 ? grad_out : 0 (aten::threshold_backward),
+// partial[block][c] = sum of g[:, c] over the block's rows (summed by the caller: ~1000 blocks adding into C addresses
+// would serialise).  One lane per (row lane, 4 columns): a row is read and written as consecutive 16-byte pieces.
+__global__ __launch_bounds__(256) void k_relu_bwd_bias(const float* __restrict__ grad_out, const float* __restrict__ y,
+                                                       uint32_t N, uint32_t C, uint32_t rows_per_block,
+                                                       float* __restrict__ g, float* __restrict__ partial)
+{
+    __shared__ float s_part[256 * 4];
+    const uint32_t Q = C / 4, R = 256 / Q;                  // column quads, row lanes
+    const uint32_t q = threadIdx.x % Q, rl = threadIdx.x / Q;
+    const uint32_t r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    float4 acc = make_float4(0, 0, 0, 0);
+    if (rl < R) {
+        for (uint32_t r = r0 + rl; r < r1; r += R) {
+            const size_t at = (size_t)r * C + 4 * q;
+            const float4 go = *reinterpret_cast<const float4*>(grad_out + at), yy = *reinterpret_cast<const float4*>(y + at);
+            float4       v;
+            v.x = yy.x > 0.0f ? go.x : 0.0f;
+            v.y = yy.y > 0.0f ? go.y : 0.0f;
+            v.z = yy.z > 0.0f ? go.z : 0.0f;
+            v.w = yy.w > 0.0f ? go.w : 0.0f;
+            *reinterpret_cast<float4*>(g + at) = v;
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    *reinterpret_cast<float4*>(s_part + 4 * threadIdx.x) = acc;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        const uint32_t c = threadIdx.x;
+        float          s = 0.0f;
+        for (uint32_t k = 0; k < R; k++) s += s_part[4 * (k * Q + c / 4) + c % 4];
+        partial[(size_t)blockIdx.x * C + c] = s;
+    }
+}
+
 // real spherical harmonics up to degree 4 of d (field.SHEncoding, term by term)
 __device__ __forceinline__ void sh4(float x, float y, float z, float (&o)[16])
 {
@@ -219,6 +254,23 @@ extern "C" int cnc_ste_binary_backward(const float* x, const float* grad_out, fl
         return CNC_ERR_INVALID_VALUE;
     hipLaunchKernelGGL(k_ste_binary_bwd, dim3((uint32_t)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, x, grad_out,
                        grad_in, n);
+    return launch_status();
+}
+
+static uint32_t relu_bwd_blocks(uint32_t N) { return min(div_up(N, 256u), 1024u); }
+
+extern "C" uint32_t cnc_relu_backward_bias_partials(uint32_t N) { return N ? relu_bwd_blocks(N) : 0; }
+
+extern "C" int cnc_relu_backward_bias(const float* grad_out, const float* y, uint32_t N, uint32_t C, float* grad_in,
+                                      float* partial, void* stream)
+{
+    if (N == 0) return CNC_OK;
+    if (!grad_out || !y || !grad_in || !partial || C == 0 || C % 4 || C > 256 ||
+        ((uintptr_t)grad_out | (uintptr_t)y | (uintptr_t)grad_in) % 16)
+        return CNC_ERR_INVALID_VALUE;
+    const uint32_t blocks = relu_bwd_blocks(N);
+    hipLaunchKernelGGL(k_relu_bwd_bias, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grad_out, y, N, C,
+                       div_up(N, blocks), grad_in, partial);
     return launch_status();
 }
 

@@ -73,8 +73,21 @@ class _LinearReLUSplitK(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         x, weight, y = ctx.saved_tensors
-        g = torch.ops.aten.threshold_backward(grad_out.contiguous(), y, 0.0)      # ReLU's backward as one kernel (gt + where were two)
         grad_x = grad_w = grad_b = None
+        grad_out = grad_out.contiguous()
+        C = y.shape[1]
+        if (ctx.needs_input_grad[2] and y.dtype == torch.float32 and grad_out.dtype == torch.float32 and C % 4 == 0
+                and C <= 256 and y.is_contiguous()):
+            # ReLU's backward and the column sums for the bias gradient in one pass over the gradient
+            from . import _lib
+            L, n = _lib.lib(), y.shape[0]
+            g = torch.empty_like(y)
+            partial = torch.empty((int(L.cnc_relu_backward_bias_partials(n)), C), dtype=torch.float32, device=y.device)
+            _lib.check(L.cnc_relu_backward_bias(grad_out.data_ptr(), y.data_ptr(), n, C, g.data_ptr(), partial.data_ptr(),
+                                                _lib.stream(y.device)), "relu_backward_bias")
+            grad_b = partial.sum(0)
+        else:
+            g = torch.ops.aten.threshold_backward(grad_out, y, 0.0)      # nn.ReLU's own backward kernel
         if ctx.needs_input_grad[0]:
             grad_x = g @ weight
         if ctx.needs_input_grad[1]:
@@ -88,7 +101,7 @@ class _LinearReLUSplitK(torch.autograd.Function):
                 grad_w = torch.bmm(g[:head].view(s, m, -1).transpose(1, 2), x[:head].view(s, m, -1)).sum(0)
                 if head < n:
                     grad_w = grad_w + g[head:].t() @ x[head:]
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[2] and grad_b is None:
             grad_b = g.sum(0)
         return grad_x, grad_w, grad_b
 

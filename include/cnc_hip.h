@@ -528,6 +528,14 @@ int cnc_field_post(const float* base_out, uint32_t ld_base, uint32_t geo_feat_di
 int cnc_ste_binary_forward(const float* x, float* out, uint64_t n, void* stream);
 int cnc_ste_binary_backward(const float* x, const float* grad_out, float* grad_in, uint64_t n, void* stream);
 
+/* Backward of y = relu(...) [N, C] (C a multiple of 4, <= 256; contiguous, 16-byte aligned) and the bias gradient of
+ * the Linear in front of it, in one pass: grad_in = y > 0 ? grad_out : 0 (aten::threshold_backward, nn.ReLU's own);
+ * partial [cnc_relu_backward_bias_partials(N), C] receives per-workgroup column sums of grad_in — their sum over the
+ * first axis is the bias gradient (replaces threshold_backward + sum(0): one read of the gradient less).        */
+uint32_t cnc_relu_backward_bias_partials(uint32_t N);
+int cnc_relu_backward_bias(const float* grad_out, const float* y, uint32_t N, uint32_t C, float* grad_in,
+                           float* partial, void* stream);
+
 /* out[i, col:ld] = [x_i (3) | sin(freqs[k] x_i) (3), cos(freqs[k] x_i) (3) for k < n_freqs | zeros]: the Embedder
  * of ngp.py:583-599 (include_input, periodic_fns = [sin, cos]) written into the base MLP's input matrix
  * (row stride ld, first column col; everything from col to ld is written).  x [N,3], freqs [n_freqs] on the

@@ -107,3 +107,25 @@ def test_field_glue_kernels_equal_the_op_chain(cuda):
     assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-7) and torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-6)
     for ga, gb in zip(a[4], b[4]):
         assert float((ga - gb).abs().max()) <= 2e-4 * max(float(ga.abs().max()), 1e-12)
+
+
+@pytest.mark.parametrize("N,C", [(1, 4), (777, 80), (100003, 160), (5000, 256)])
+def test_relu_backward_with_bias_sums(cuda, N, C):
+    """cnc_relu_backward_bias through `_LinearReLUSplitK`: the masked gradient equals aten::threshold_backward bit for
+    bit; the bias gradient equals the column sums within float32 summation error; dX / dW as the op chain."""
+    from cnc_amd.mlp import _LinearReLUSplitK
+    g = torch.Generator(device="cpu").manual_seed(N + C)
+    x = torch.randn(N, 24, generator=g).to(cuda).requires_grad_()
+    w = (torch.randn(C, 24, generator=g) * 0.3).to(cuda).requires_grad_()
+    b = torch.randn(C, generator=g).to(cuda).requires_grad_()
+    go = torch.randn(N, C, generator=g).to(cuda)
+    y = _LinearReLUSplitK.apply(x, w, b)
+    y.backward(go)
+    x2, w2, b2 = (t.detach().clone().requires_grad_() for t in (x, w, b))
+    y2 = torch.relu(torch.nn.functional.linear(x2, w2, b2))
+    y2.backward(go)
+    mask = torch.ops.aten.threshold_backward(go, y.detach(), 0.0)
+    want_b = mask.double().sum(0)
+    assert torch.allclose(b.grad.double(), want_b, rtol=1e-5, atol=1e-5 * float(mask.abs().sum(0).max()) + 1e-6)
+    assert torch.allclose(x.grad, x2.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(w.grad, w2.grad, rtol=1e-3, atol=1e-3 * float(w2.grad.abs().max()))
