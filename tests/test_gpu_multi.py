@@ -42,6 +42,26 @@ def test_bench_spawns_two_ranks_and_allreduces(cuda):
     assert "[bench rank 1]" in r.stderr and "[bench rank 0]" in r.stderr
 
 
+def test_bench_under_the_drivers_launcher(cuda):
+    """The driver's own command line for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (here both ranks on cuda:0 over gloo)."""
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-train-step"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=_clean_env(CNC_BENCH_ONE_DEVICE="1", CNC_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and [x["world_size"] for x in out["ranks"]] == [2, 2]
+
+
 def test_bench_refuses_a_world_that_contradicts_gpus(cuda):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1"], cwd=ROOT,
                        capture_output=True, text=True, timeout=300,
