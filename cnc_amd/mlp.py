@@ -122,11 +122,12 @@ def linear_fn(x, weight, bias):
     return F.linear(x, weight, bias)
 
 
-def run_layers(layers, h, first_weight=None):
+def run_layers(layers, h, first_weight=None, last_rows=None):
     """`nn.Sequential(*layers)(h)`, with every Linear -> ReLU pair as ONE hipBLASLt GEMM with bias +
     ReLU in the epilogue (`torch._addmm_activation`) instead of a GEMM and a separate pass over the
     activations; under autograd through `_LinearReLUSplitK`.
-    `first_weight` replaces the first Linear's weight (zero-padded input columns)."""
+    `first_weight` replaces the first Linear's weight (zero-padded input columns); `last_rows` = k keeps only the
+    first k output units of the LAST Linear (a caller that reads nothing else: the density query)."""
     layers = list(layers)
     fuse = h.is_cuda and h.dim() == 2
     i = 0
@@ -134,6 +135,10 @@ def run_layers(layers, h, first_weight=None):
         m = layers[i]
         if isinstance(m, nn.Linear):
             w = first_weight if (i == 0 and first_weight is not None) else m.weight
+            if last_rows is not None and i == len(layers) - 1:
+                h = linear_fn(h, w[:last_rows], None if m.bias is None else m.bias[:last_rows])
+                i += 1
+                continue
             if fuse and m.bias is not None and i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU):
                 if torch.is_grad_enabled() and (h.requires_grad or w.requires_grad):
                     h = _LinearReLUSplitK.apply(h, w, m.bias)

@@ -160,3 +160,22 @@ def test_no_grad_field_uses_fused_epilogue_and_matches(cuda):
     ya.backward(g); yb.backward(g)
     for pa, pb in zip(f.mlp_base.network.parameters(), ref_base.parameters()):
         assert (pa.grad - pb.grad).abs().max() <= 1e-4 * (1 + pb.grad.abs().max())
+
+
+def test_density_only_query_matches_the_full_head(cuda):
+    """`query_density` without gradients evaluates unit 0 of the base MLP's last layer only (the sampler's visibility
+    pass is 6-8x the samples of the gradient pass): same densities as the full 1 + geo_feat_dim outputs."""
+    from cnc_amd.field import NGPRadianceField_mygrid_2D3D
+    torch.manual_seed(11)
+    f = NGPRadianceField_mygrid_2D3D(aabb=[-1.5] * 3 + [1.5] * 3, n_features_per_level=8, n_neurons=160).to(cuda)
+    with torch.no_grad():
+        for p in f.parameters():
+            if p.dim() == 2 and p.shape[1] == 8:
+                p.uniform_(-1, 1)
+    x = (torch.rand(200000, 3, device=cuda) * 3.4 - 1.7)          # some outside the box: selector
+    with torch.no_grad():
+        only = f.query_density(x)
+        full, _ = f.query_density(x, return_feat=True)
+    assert only.shape == full.shape == (200000, 1)
+    assert torch.allclose(only, full, rtol=2e-5, atol=1e-7)
+    assert bool((only[(x.abs() > 1.5).any(-1)] == 0).all())
