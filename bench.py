@@ -218,12 +218,13 @@ def train_step_entry(dev):
     from cnc_amd.trainer import TrainConfig, Trainer
     cfg = TrainConfig(n_features=8, sample_num=150000, image_size=400, out_dir="/tmp/cnc_bench_bits")
     tr = Trainer(cfg, device=dev)
-    for step in range(80):                  # occupancy warm-up + adaptive ray budget settle
+    warm = 240       # occupancy warm-up, adaptive ray budget settled, surfaces formed: from here on the march hands the
+    for step in range(warm):                # sampler 6-8x the samples that survive it, as for the rest of a 30k-step run
         tr.train_step(step, want_stats=False)
     torch.cuda.synchronize()
     n_steps, samples, rays = 60, 0, 0
     t0 = time.perf_counter()
-    for step in range(80, 80 + n_steps):
+    for step in range(warm, warm + n_steps):
         s = tr.train_step(step, want_stats=False)       # loss scalars are read back on log steps only (as train:368)
         if s is not None:
             samples += s["n_rendering_samples"]
@@ -233,7 +234,7 @@ def train_step_entry(dev):
     return {"ms_per_step": dt / n_steps * 1e3, "rendered_samples_per_s": samples / dt, "rays_per_s": rays / dt,
             "samples_per_step": samples / n_steps, "steps": n_steps, "timed_region": False,
             "config": "full model, F=8, 12x3D(2^19)+3x4x2D(2^17), sample_num=150000, lmbda=2e-3, procedural ball "
-                      "scene, target 2^18 samples/step (includes the occupancy refresh every 16 steps)"}
+                      "scene, target 2^18 samples/step, steps 240-299 (includes the occupancy refresh every 16 steps)"}
 
 
 def main():

@@ -70,6 +70,8 @@ SIGNATURES = {
     "cnc_volrend_backward": [_vp] * 19 + [_u32, _u32, _vp],
     "cnc_render_visibility": [_vp] * 5 + [_i32, _f32, _f32, _vp, _vp, _vp, _u32, _vp],
     "cnc_compact_samples": [_vp] * 9 + [_u32, _vp],
+    "cnc_ray_window_samples": [_vp] * 10 + [_u32, _vp],
+    "cnc_ray_transmittance": [_vp] * 6 + [_u32, _vp],
     "cnc_interval_edges_to_samples": [_vp] * 9 + [_u32, _vp],
     "cnc_pack_bounds": [_vp, _i64, _vp, _vp, _i64, _vp],
     "cnc_level_stats_forward": [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
@@ -100,7 +102,7 @@ CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 19          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 20          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

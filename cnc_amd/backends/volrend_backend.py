@@ -143,6 +143,31 @@ def compact_samples(starts, counts, mask, kept, t_starts, t_ends) -> Tuple[torch
     return o_r, o_s, o_e, new_starts, kept
 
 
+def window_samples(starts, first, cnts, t_starts, t_ends, total):
+    """(ray_indices, t_starts, t_ends, source_index) of samples [first[r], first[r] + cnts[r]) of every ray; `total` =
+    cnts.sum() (the caller read it back together with whatever else it needed)."""
+    n_rays, dev = starts.shape[0], t_starts.device
+    out_starts = torch.cumsum(cnts, 0) - cnts
+    o_s = torch.empty(total, dtype=torch.float32, device=dev)
+    o_e = torch.empty(total, dtype=torch.float32, device=dev)
+    o_r = torch.empty(total, dtype=torch.int64, device=dev)
+    o_i = torch.empty(total, dtype=torch.int64, device=dev)
+    if total:
+        check(_lib.lib().cnc_ray_window_samples(ptr(starts), ptr(first), ptr(cnts), ptr(out_starts), ptr(t_starts),
+                                                ptr(t_ends), ptr(o_s), ptr(o_e), ptr(o_r), ptr(o_i), n_rays, stream(dev)),
+              "ray_window_samples")
+    return o_r, o_s, o_e, o_i
+
+
+def ray_transmittance(starts, cnts, t_starts, t_ends, sigmas):
+    """exp(-sum sigma dt) over the first cnts[r] samples of every ray: float32 [n_rays]."""
+    n_rays = starts.shape[0]
+    out = torch.empty(n_rays, dtype=torch.float32, device=sigmas.device)
+    check(_lib.lib().cnc_ray_transmittance(ptr(starts), ptr(cnts), _p(t_starts), _p(t_ends), _p(sigmas), ptr(out), n_rays,
+                                           stream(sigmas.device)), "ray_transmittance")
+    return out
+
+
 def samples_from_intervals(intervals, sample_counts, total: Optional[int] = None):
     """(ray_indices, t_starts, t_ends, starts) of the samples a traverse_grids call produced, from its
     interval edges — `intervals` is the RaySegmentsSpec the extension returned (two-pass or over-allocated

@@ -302,6 +302,43 @@ __global__ __launch_bounds__(256) void k_compact(
     }
 }
 
+// Depth window of every ray: samples [win_lo[r], win_lo[r] + win_n[r]) of ray r go to out_starts[r] + k, with the
+// position they came from — the sampler evaluates the density window by window and stops behind opaque surfaces.
+__global__ __launch_bounds__(256) void k_window_samples(
+    const int64_t* __restrict__ starts, const int64_t* __restrict__ win_lo, const int64_t* __restrict__ win_n,
+    const int64_t* __restrict__ out_starts, const float* __restrict__ t_starts, const float* __restrict__ t_ends,
+    float* __restrict__ o_starts, float* __restrict__ o_ends, int64_t* __restrict__ o_ray, int64_t* __restrict__ o_src,
+    uint32_t n_rays)
+{
+    const uint32_t j = threadIdx.x & 31;
+    const uint32_t ray = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (ray >= n_rays) return;
+    const int64_t n = win_n[ray];
+    if (n <= 0) return;
+    const int64_t s0 = starts[ray] + win_lo[ray], o0 = out_starts[ray];
+    for (int64_t k = j; k < n; k += 32) {
+        o_starts[o0 + k] = t_starts[s0 + k];
+        o_ends[o0 + k] = t_ends[s0 + k];
+        o_ray[o0 + k] = (int64_t)ray;
+        o_src[o0 + k] = s0 + k;
+    }
+}
+
+// exp(-sum of sigma dt over the first cnts[r] samples of ray r): what is left of the ray after them
+__global__ __launch_bounds__(256) void k_ray_transmittance(
+    const int64_t* __restrict__ starts, const int64_t* __restrict__ cnts, const float* __restrict__ t_starts,
+    const float* __restrict__ t_ends, const float* __restrict__ sigmas, float* __restrict__ trans, uint32_t n_rays)
+{
+    const uint32_t j = threadIdx.x & 31;
+    const uint32_t ray = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const bool     live = ray < n_rays;
+    const int64_t  s0 = live ? starts[ray] : 0, n = live ? cnts[ray] : 0;
+    float          acc = 0.0f;
+    for (int64_t k = j; k < n; k += 32) acc += sigmas[s0 + k] * (t_ends[s0 + k] - t_starts[s0 + k]);
+    acc = half_wave_sum(acc);
+    if (live && j == 0) trans[ray] = expf(-acc);
+}
+
 // t_starts = intervals.vals[is_left], t_ends = intervals.vals[is_right] (occ_grid.py:176-177,
 // utils.py:408-409) and the samples' ray ids, without boolean indexing: the k-th left (right) edge of a ray
 // is the start (end) of its k-th sample.  iv_starts may describe the over-allocated layout.
@@ -423,6 +460,32 @@ extern "C" int cnc_compact_samples(const int64_t* chunk_starts, const int64_t* c
         return CNC_ERR_INVALID_VALUE;
     hipLaunchKernelGGL(k_compact, ray_grid(n_rays), dim3(256), 0, (hipStream_t)stream, chunk_starts, chunk_cnts,
                        out_starts, mask, t_starts, t_ends, out_t_starts, out_t_ends, out_ray_indices, n_rays);
+    return launch_status();
+}
+
+extern "C" int cnc_ray_window_samples(const int64_t* chunk_starts, const int64_t* window_first, const int64_t* window_cnts,
+                                      const int64_t* out_starts, const float* t_starts, const float* t_ends,
+                                      float* out_t_starts, float* out_t_ends, int64_t* out_ray_indices,
+                                      int64_t* out_source_index, uint32_t n_rays, void* stream)
+{
+    if (n_rays == 0) return CNC_OK;
+    if (!chunk_starts || !window_first || !window_cnts || !out_starts || !t_starts || !t_ends || !out_t_starts ||
+        !out_t_ends || !out_ray_indices || !out_source_index)
+        return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_window_samples, ray_grid(n_rays), dim3(256), 0, (hipStream_t)stream, chunk_starts, window_first,
+                       window_cnts, out_starts, t_starts, t_ends, out_t_starts, out_t_ends, out_ray_indices,
+                       out_source_index, n_rays);
+    return launch_status();
+}
+
+extern "C" int cnc_ray_transmittance(const int64_t* chunk_starts, const int64_t* chunk_cnts, const float* t_starts,
+                                     const float* t_ends, const float* sigmas, float* transmittance, uint32_t n_rays,
+                                     void* stream)
+{
+    if (n_rays == 0) return CNC_OK;
+    if (!chunk_starts || !chunk_cnts || !t_starts || !t_ends || !sigmas || !transmittance) return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_ray_transmittance, ray_grid(n_rays), dim3(256), 0, (hipStream_t)stream, chunk_starts, chunk_cnts,
+                       t_starts, t_ends, sigmas, transmittance, n_rays);
     return launch_status();
 }
 

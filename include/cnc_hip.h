@@ -407,6 +407,18 @@ int cnc_render_visibility(const int64_t* chunk_starts, const int64_t* chunk_cnts
 int cnc_compact_samples(const int64_t* chunk_starts, const int64_t* chunk_cnts, const int64_t* out_starts,
                         const uint8_t* mask, const float* t_starts, const float* t_ends, float* out_t_starts,
                         float* out_t_ends, int64_t* out_ray_indices, uint32_t n_rays, void* stream);
+/* (extension) Depth windows for a sampler that evaluates the density front to back and stops behind opaque surfaces
+ * (same survivors as evaluating every marched sample, volrend.py:425-475: a sample behind transmittance <
+ * early_stop_eps is dropped whatever its density).
+ *   cnc_ray_window_samples: samples [window_first[r], window_first[r] + window_cnts[r]) of ray r -> out_starts[r] + k
+ *     (out_starts = exclusive cumsum of window_cnts), with out_source_index = their positions in the marched arrays;
+ *   cnc_ray_transmittance : transmittance[r] = exp(-sum sigma dt) over the first chunk_cnts[r] samples of ray r.     */
+int cnc_ray_window_samples(const int64_t* chunk_starts, const int64_t* window_first, const int64_t* window_cnts,
+                           const int64_t* out_starts, const float* t_starts, const float* t_ends, float* out_t_starts,
+                           float* out_t_ends, int64_t* out_ray_indices, int64_t* out_source_index, uint32_t n_rays,
+                           void* stream);
+int cnc_ray_transmittance(const int64_t* chunk_starts, const int64_t* chunk_cnts, const float* t_starts,
+                          const float* t_ends, const float* sigmas, float* transmittance, uint32_t n_rays, void* stream);
 /* intervals.vals[is_left], intervals.vals[is_right], samples.ray_indices[is_valid] (occ_grid.py:176-178,
  * utils.py:408-410): the k-th left / right edge of a ray opens / closes its k-th sample.  iv_chunk_starts may be
  * the over-allocated layout of traverse_grids; out_starts [n_rays] = packed sample starts.                  */

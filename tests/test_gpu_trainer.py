@@ -179,3 +179,44 @@ def test_density_only_query_matches_the_full_head(cuda):
     assert only.shape == full.shape == (200000, 1)
     assert torch.allclose(only, full, rtol=2e-5, atol=1e-7)
     assert bool((only[(x.abs() > 1.5).any(-1)] == 0).all())
+
+
+def test_front_to_back_density_gives_the_same_samples(cuda, tmp_path):
+    """The sampler's depth-window evaluation of the density (a ray leaves once its transmittance is below
+    early_stop_eps) returns the samples of the one-shot evaluation, and evaluates far fewer."""
+    from cnc_amd.nerfacc.estimators.occ_grid import OccGridEstimator
+    from cnc_amd.render import _FieldOnRays
+    from cnc_amd.trainer import Trainer
+    tr = Trainer(_cfg(tmp_path, lmbda=0.0), device=cuda)
+    tr.train(steps=150, log=None)                      # a surface has formed
+    tr.field.eval(); tr.estimator.eval()
+    view = tr.dataset.view(0)
+    o, d = view["rays"].origins.reshape(-1, 3), view["rays"].viewdirs.reshape(-1, 3)
+    seen = []
+
+    class Counting(_FieldOnRays):
+        def density(self, t_starts, t_ends, ray_indices):
+            seen.append(t_starts.shape[0])
+            return super().density(t_starts, t_ends, ray_indices)
+    fn = Counting(tr.field, o, d, with_positions=False)
+    kw = dict(sigma_fn=fn.density, near_plane=tr.cfg.near_plane, render_step_size=tr.cfg.render_step_size,
+              stratified=False, cone_angle=tr.cfg.cone_angle, alpha_thre=tr.cfg.alpha_thre)
+    pays = OccGridEstimator._front_to_back_pays
+    outs = []
+    try:
+        for mode in (False, True):
+            OccGridEstimator._front_to_back_pays = lambda self, n, m=mode: m
+            seen.clear()
+            with torch.no_grad():
+                ri, ts, te = tr.estimator.sampling(o, d, **kw)
+            outs.append((ri.clone(), ts.clone(), te.clone(), sum(seen), len(seen)))
+    finally:
+        OccGridEstimator._front_to_back_pays = pays
+    (ri_a, ts_a, te_a, n_a, calls_a), (ri_b, ts_b, te_b, n_b, calls_b) = outs
+    assert calls_a == 1 and 1 < calls_b <= 3
+    assert n_b < 0.7 * n_a                              # most of the marched samples are never evaluated
+    # a GEMM row may round differently in a different batch: allow a handful of samples at the threshold to differ
+    assert abs(ts_a.shape[0] - ts_b.shape[0]) <= 1e-4 * ts_a.shape[0] + 2
+    if ts_a.shape[0] == ts_b.shape[0]:
+        same = (ri_a == ri_b) & (ts_a == ts_b) & (te_a == te_b)
+        assert float(same.float().mean()) > 0.9999
