@@ -141,11 +141,12 @@ def traverse_grids(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
 
 
 def march_samples(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
-                  step_size, cone_angle, traverse_steps_limit=-1, want_terminate_planes=False):
+                  step_size, cone_angle, traverse_steps_limit=-1, want_terminate_planes=False, clamped_total=None):
     """(extension) The march as the renderer consumes it — see cnc_march_samples in include/cnc_hip.h.
     Returns (ray_indices i64 [S], t_starts [S], t_ends [S], chunk_starts [n_rays], chunk_cnts [n_rays],
     terminate_planes or None).  Count pass, exclusive cumsum + ONE host sync (the sample total sizes the
-    result, as in data_spec.hpp:86-96), fill pass."""
+    result, as in data_spec.hpp:86-96), fill pass.  `clamped_total` = {"at": w}: the same sync also brings
+    sum(min(count, w)) back, under the key "total" (a caller that is about to take the first w samples of every ray)."""
     for name, t in (("rays_o", rays_o), ("rays_d", rays_d), ("binaries", binaries), ("aabbs", aabbs),
                     ("t_sorted", t_sorted), ("t_indices", t_indices), ("hits", hits),
                     ("near_planes", near_planes), ("far_planes", far_planes)):
@@ -167,7 +168,10 @@ def march_samples(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indice
 
     launch(None, None, None, None, term)
     ends = torch.cumsum(counts, 0)
-    total = int(ends[-1].item()) if n_rays else 0
+    if clamped_total is not None and n_rays:
+        total, clamped_total["total"] = torch.stack([ends[-1], counts.clamp(max=int(clamped_total["at"])).sum()]).tolist()
+    else:
+        total = int(ends[-1].item()) if n_rays else 0
     starts = ends - counts
     t_starts = torch.empty(total, dtype=torch.float32, device=dev)
     t_ends = torch.empty(total, dtype=torch.float32, device=dev)

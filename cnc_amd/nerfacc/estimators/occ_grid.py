@@ -80,9 +80,11 @@ class OccGridEstimator(AbstractEstimator):
             crossings, order = torch.sort(crossings, dim=-1)
         else:                           # one box: (entry, exit) is already sorted
             order = torch.arange(2, device=rays_o.device, dtype=torch.int64).expand(rays_o.shape[0], 2)
+        first = {"at": self._WINDOWS[0]} if self._WINDOWS else None
         ray_indices, t_starts, t_ends, starts, counts, _ = _C.march_samples(
             rays_o, rays_d, None, self.binaries.contiguous(), boxes, crossings.contiguous(), order.contiguous(),
-            hit.contiguous(), near_planes.contiguous(), far_planes.contiguous(), step, cone_angle)
+            hit.contiguous(), near_planes.contiguous(), far_planes.contiguous(), step, cone_angle, clamped_total=first)
+        self._first_window_total = None if first is None else first.get("total")
         return ray_indices, t_starts, t_ends, starts, counts
 
     @torch.no_grad()
@@ -146,10 +148,15 @@ class OccGridEstimator(AbstractEstimator):
         sigmas = torch.zeros_like(t_starts)
         done = torch.zeros_like(counts)
         alive = counts > 0
+        done_any = False
         for w in self._WINDOWS + (None,):
             left = counts - done
             take = torch.where(alive, left if w is None else left.clamp(max=w), torch.zeros_like(left))
-            total = int(take.sum().item())
+            if w is self._WINDOWS[0] and done_any is False and self._first_window_total is not None:
+                total = int(self._first_window_total)          # came back with the march's own sample total
+            else:
+                total = int(take.sum().item())
+            done_any = True
             if total == 0:
                 break
             ri_w, ts_w, te_w, src = _K.window_samples(starts, done, take, t_starts, t_ends, total)
