@@ -573,6 +573,7 @@ class CNC_context_models(nn.Module):
         self.idx_coords2_tmp = None
         self.vote_plan = None
         self.batched_inputs_list = None
+        self._rows_2D_cat = [None, None, None]
 
     # ------------------------------------------------------------------------------- helpers
     def _sample_allocation(self, sample_num):
@@ -859,15 +860,28 @@ class CNC_context_models(nn.Module):
             batches = iter(self.batched_inputs_list[k])
             with _range("ctx/level_Pg"):
                 Pg_all, bits_all = self.level_stats(p_q, self._off2_host)
+            # the coded levels of a plane share one rate kernel (their rows are distinct table rows, the bits add up):
+            # one gather / one table-sized gradient per plane instead of one per level
+            one_rate = self.fused_heads and p_q.is_cuda
+            rows_of, means_of = [], []
             for n in range(self.n_levels_2D):
                 Pg_n, bits_n = Pg_all[n], bits_all[n]
                 if self._coded_2D(n):
                     points_n, order, rows, unique_cnt, cum = next(batches)
                     with _range("ctx/2D_mean"):
                         mean = self._mean_2D(Ec, n, points_n, Pg_n, binary_2D[k], pn_frac, order, unique_cnt, cum=cum)
+                    if one_rate:
+                        rows_of.append(rows)
+                        means_of.append(mean)
+                        continue
                     with _range("ctx/2D_entropy"):
                         bits_n = self._bits(p_q, rows, mean)
                 ttl_bit_sum = ttl_bit_sum + bits_n
+            if rows_of:
+                with _range("ctx/2D_entropy"):
+                    if refresh or self._rows_2D_cat[k] is None:
+                        self._rows_2D_cat[k] = torch.cat(rows_of)          # fixed until the next refresh
+                    ttl_bit_sum = ttl_bit_sum + self._bits(p_q, self._rows_2D_cat[k], torch.cat(means_of))
             ttl_num_sum += p_q.numel()
 
         # 3-D: a random contiguous window of hash slots per level (:619-634)
