@@ -35,6 +35,11 @@ SIGNATURES = {
     "cnc_grid_encode_backward_binned_workspace": [_u32, _u32, _u32],
     "cnc_grid_encode_backward_binned": [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32,
                                         _u32, _u32, _vp, C.c_uint64, _vp],
+    "cnc_backward_plan_create": [C.POINTER(_vp)],
+    "cnc_backward_plan_destroy": [_vp],
+    "cnc_grid_encode_backward_overlapped_workspace": [_u32, _u32, _u32],
+    "cnc_grid_encode_backward_overlapped": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _u32, _u32,
+                                            _u32, _u32, _vp, C.c_uint64, _vp],
     "cnc_pack_sign_bits": [_vp, _vp, C.c_uint64, _u32, _vp, _vp],
     "cnc_grid_encode_forward_bits": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_mlp_forward32": [_vp, _u32, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _u32, _u32, _vp],
@@ -95,14 +100,15 @@ SIGNATURES = {
 }
 
 # entry points that return something other than a status code
-RESTYPES = {"cnc_grid_encode_backward_binned_workspace": C.c_uint64, "cnc_bernoulli_bits_partials": C.c_uint32,
+RESTYPES = {"cnc_grid_encode_backward_binned_workspace": C.c_uint64,
+            "cnc_grid_encode_backward_overlapped_workspace": C.c_uint64, "cnc_bernoulli_bits_partials": C.c_uint32,
             "cnc_relu_backward_bias_partials": C.c_uint32}
 
 CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 20          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 21          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

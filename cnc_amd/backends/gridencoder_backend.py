@@ -121,53 +121,18 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         L = _lib.lib()
         nbytes = int(L.cnc_grid_encode_backward_binned_workspace(int(N), n_binned, level_rows))
         flags = _lib.CNC_FLAG_STE_BINARY if ste_binary else 0
-        k = int(n_levels) - n_binned          # coarse levels: atomic kernel; the rest: bin + owner passes
-        if k > 0 and n_binned > 0 and N >= _OVERLAP_MIN_POINTS and overlap_streams and _OVERLAP_ENABLED:
-            # The two halves write disjoint table rows and lean on different units (memory-side
-            # atomics vs. HBM reads / writes): they run on two streams, forked from and joined to the
-            # caller's stream with events.  The bin + owner passes are the long pole, so they are issued
-            # FIRST (on the side stream) and the coarse kernel fills in next to them: 1.016 ms back to
-            # back, 0.963 with the coarse call first, 0.904 this way (per 2^20 samples).
-            cur = torch.cuda.current_stream(grad.device)
-            fork = torch.cuda.Event()
-            fork.record(cur)
-            lm = grad_ld == 0                  # level-major [L, N, F]: slice; point-major: shift the column
-            # with 4+ binned levels they go out as two groups on two side streams (the bin pass of one
-            # next to the owner pass of the other: stores vs. gathers): 0.960 -> 0.919 ms on the probe
-            h = n_binned // 2 if n_binned >= 4 and _SPLIT_FINE else n_binned
-            groups = [(k, k + h), (k + h, int(n_levels))] if h < n_binned else [(k, int(n_levels))]
-            joins, rc = [], 0
-            for gi, (l0, l1) in enumerate(groups):
-                nb = l1 - l0
-                # side streams and scratch are per (device, caller stream, group): two caller streams
-                # (or threads) never share a scratch buffer that is still in flight
-                side = _side_stream(grad.device, (cur.cuda_stream, gi))
-                wsg = _workspace(grad.device, int(L.cnc_grid_encode_backward_binned_workspace(int(N), nb, level_rows)),
-                                 (cur.cuda_stream, gi))
-                g_f = grad[l0:l1] if lm else grad
-                if _RECORD_STREAM:
-                    for t_ in (grad, inputs, embeddings, grad_embeddings, wsg):
-                        t_.record_stream(side)   # the caching allocator must not recycle them under the side stream
-                with torch.cuda.stream(side):
-                    side.wait_event(fork)
-                    rcg = L.cnc_grid_encode_backward_binned(
-                        ptr(g_f), ptr(inputs), ptr(embeddings), ptr(offsets_list[l0:]), ptr(resolutions_list[l0:]),
-                        ptr(grad_embeddings), int(N), int(num_dim), int(n_features), nb, flags,
-                        ptr(ste_clip_count), int(grad_ld), int(grad_col) + (0 if lm else l0 * int(n_features)),
-                        nb, level_rows, ptr(wsg), wsg.numel(), stream(grad.device))
-                    rc = rc or rcg
-                    join = torch.cuda.Event()
-                    join.record(side)
-                    joins.append(join)
-            rc0 = L.cnc_grid_encode_backward(
-                ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
-                ptr(grad_embeddings), int(N), int(num_dim), int(n_features), k, int(Rb), None, None, None,
-                None, flags | _lib.CNC_FLAG_LEVELS_FINEST_FIRST, ptr(ste_clip_count), None, int(grad_ld),
-                int(grad_col), stream(grad.device))
-            for join in joins:
-                cur.wait_event(join)
-            check(rc0, "grid_encode_backward")
-            check(rc, "grid_encode_backward_binned")
+        if overlap_streams and _OVERLAP_ENABLED:
+            # coarse levels on the caller's stream, the finest ones on side streams the library owns through a plan
+            # object: fork, join and the split into groups live behind the C ABI (grid_encode_overlap.hip)
+            cur = torch.cuda.current_stream(grad.device).cuda_stream
+            nbytes = int(L.cnc_grid_encode_backward_overlapped_workspace(int(N), n_binned, level_rows))
+            ws = _workspace(grad.device, nbytes, (cur, 0))
+            rc = L.cnc_grid_encode_backward_overlapped(
+                _plan(grad.device, cur), ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
+                ptr(grad_embeddings), int(N), int(num_dim), int(n_features), int(n_levels), flags, ptr(ste_clip_count),
+                int(grad_ld), int(grad_col), n_binned, level_rows, ptr(ws),
+                ws.numel(), stream(grad.device))
+            check(rc, "grid_encode_backward_overlapped")
             return
         ws = _workspace(grad.device, nbytes, (torch.cuda.current_stream(grad.device).cuda_stream, 0))
         rc = L.cnc_grid_encode_backward_binned(
@@ -188,21 +153,21 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
 
 
 _WORKSPACES = {}
-_SIDE_STREAMS = {}
-_OVERLAP_MIN_POINTS = 1 << 16      # = the smallest binned call; 2^16..2^18 points gain 10-16 %, 2^20 points 4-6 %
-_SPLIT_FINE = os.environ.get("CNC_BWD_SPLIT_FINE", "1") != "0"
-_RECORD_STREAM = os.environ.get("CNC_BWD_RECORD_STREAM", "1") != "0"
-_SIDE_PRIORITY = int(os.environ.get("CNC_BWD_SIDE_PRIORITY", "0"))     # measurement switch: -1 = high
+_PLANS = {}
 _OVERLAP_ENABLED = os.environ.get("CNC_BWD_OVERLAP", "1") != "0"   # measurement switch (profiles/)
 
 
-def _side_stream(device, which=0):
-    key = (device.type, device.index, which)
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        st = torch.cuda.Stream(device=device, priority=_SIDE_PRIORITY)
-        _SIDE_STREAMS[key] = st
-    return st
+def _plan(device, caller_stream):
+    """One cnc_backward_plan (two side streams + events, owned by the library) per (device, caller stream)."""
+    import ctypes as C
+    key = (device.type, device.index, caller_stream)
+    h = _PLANS.get(key)
+    if h is None:
+        out = C.c_void_p()
+        with torch.cuda.device(device):
+            check(_lib.lib().cnc_backward_plan_create(C.byref(out)), "backward_plan_create")
+        h = _PLANS[key] = out
+    return h
 
 
 def _workspace(device, nbytes, which=0):

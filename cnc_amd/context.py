@@ -36,24 +36,7 @@ from .backends import pack_and_align
 from .gridencoder import STE_binary, STE_multistep
 from .mlp import Linear
 
-_codec = None
-
-
-def _codec_lib():
-    global _codec
-    if _codec is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcnc_codec.so")
-        if not os.path.exists(path):
-            raise RuntimeError(f"{path} not found: build it with `python -m cnc_amd.build`")
-        L = C.CDLL(path)
-        L.cnc_rc_bound.restype = C.c_int64
-        L.cnc_rc_bound.argtypes = [C.c_int64]
-        L.cnc_rc_encode_pm1.restype = C.c_int64
-        L.cnc_rc_encode_pm1.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
-        L.cnc_rc_decode_pm1.restype = C.c_int
-        L.cnc_rc_decode_pm1.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
-        _codec = L
-    return _codec
+from ._codec import lib as _codec_lib  # noqa: E402  (libcnc_codec.so, include/cnc_codec.h)
 
 
 def get_grid_index(hashmap_size, resolution, pos_grid):

@@ -944,4 +944,4 @@ extern "C" const char* cnc_error_string(int code)
     }
 }
 
-extern "C" int cnc_abi_version(void) { return 20; }
+extern "C" int cnc_abi_version(void) { return 21; }

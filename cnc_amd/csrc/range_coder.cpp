@@ -147,6 +147,83 @@ extern "C" int64_t cnc_rc_encode_pm1(const float* p_one, const float* x_pm1, int
     return sink.finish();
 }
 
+// ---- general alphabets: torchac's `encode_int16_normalized_cdf` / `decode_int16_normalized_cdf` ----------------
+// cdf: [n, Lp] 16-bit integers, cdf[i][0] = 0 <= cdf[i][1] <= ... ; the last entry stands for 2^16 whatever it
+// holds (torchac stores 65536 wrapped to 0 there); symbols 0 .. Lp-2.
+extern "C" int64_t cnc_rc_encode_cdf16(const uint16_t* cdf, const int16_t* sym, int64_t n, int32_t Lp,
+                                       uint8_t* out, int64_t cap)
+{
+    if (Lp < 2) return -2;
+    BitSink  sink(out, cap);
+    Interval iv;
+    uint64_t pending = 0;
+    const int32_t last = Lp - 2;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t s = sym[i];
+        if (s < 0 || s > last) return -2;
+        const uint16_t* c = cdf + i * Lp;
+        iv.narrow(c[s], s == last ? 0x10000u : static_cast<uint32_t>(c[s + 1]));
+        for (;;) {
+            if (iv.high < kTop) {
+                sink.bit_then_pending(0, pending);
+            } else if (iv.low >= kTop) {
+                sink.bit_then_pending(1, pending);
+            } else if (iv.low >= kQ1 && iv.high < kQ3) {
+                ++pending;
+                iv.low &= ~kQ1;
+                iv.high |= kQ1;
+            } else {
+                break;
+            }
+            iv.low <<= 1;
+            iv.high = (iv.high << 1) | 1u;
+        }
+    }
+    ++pending;
+    sink.bit_then_pending(iv.low < kQ1 ? 0u : 1u, pending);
+    return sink.finish();
+}
+
+extern "C" int cnc_rc_decode_cdf16(const uint16_t* cdf, int64_t n, int32_t Lp, const uint8_t* in, int64_t len,
+                                   int16_t* sym)
+{
+    if (Lp < 2) return -2;
+    BitSource src(in, len);
+    Interval  iv;
+    uint32_t  value = 0;
+    const int32_t last = Lp - 2;
+    for (int i = 0; i < 32; ++i) value = (value << 1) | src.next();
+    for (int64_t i = 0; i < n; ++i) {
+        const uint64_t span = static_cast<uint64_t>(iv.high) - iv.low + 1;
+        const uint32_t count = static_cast<uint32_t>(
+            (((static_cast<uint64_t>(value) - iv.low + 1) << 16) - 1) / span) & 0xFFFFu;
+        const uint16_t* c = cdf + i * Lp;
+        // the largest s in [0, last] with c[s] <= count (c[0] = 0): bisection over the row
+        int32_t lo = 0, hi = last;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if (c[mid] <= count) lo = mid; else hi = mid - 1;
+        }
+        sym[i] = static_cast<int16_t>(lo);
+        if (i == n - 1) break;
+        iv.narrow(c[lo], lo == last ? 0x10000u : static_cast<uint32_t>(c[lo + 1]));
+        for (;;) {
+            if (iv.low >= kTop || iv.high < kTop) {
+            } else if (iv.low >= kQ1 && iv.high < kQ3) {
+                iv.low &= ~kQ1;
+                iv.high |= kQ1;
+                value -= kQ1;
+            } else {
+                break;
+            }
+            iv.low <<= 1;
+            iv.high = (iv.high << 1) | 1u;
+            value = (value << 1) | src.next();
+        }
+    }
+    return 0;
+}
+
 extern "C" int cnc_rc_decode_pm1(const float* p_one, int64_t n, const uint8_t* in, int64_t len,
                                  float* x_pm1)
 {

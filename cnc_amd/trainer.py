@@ -218,30 +218,14 @@ class Trainer:
             resolutions_list=c.resolutions_list, log2_hashmap_size=c.log2_hashmap_size,
             resolutions_list_2D=c.resolutions_list_2D, log2_hashmap_size_2D=c.log2_hashmap_size_2D,
             ste_binary=True, Q=10, fused_features=c.fused_features).to(self.device)
-        self.context = CNC_context_models(
-            num_dim=3, resolutions_list=c.resolutions_list, resolutions_list_2D=c.resolutions_list_2D,
-            log2_hashmap_size=c.log2_hashmap_size, log2_hashmap_size_2D=c.log2_hashmap_size_2D,
-            n_features=c.n_features, sample_num=c.sample_num, max_context_layer_num=c.max_context_layer_num,
-            ste_binary=True, Q=10, Pg_level=c.Pg_level, Pg_level_2D=c.Pg_level_2D, Rb=c.grid_resolution,
-            step_update=c.step_update, skip_levels_3D=c.skip_levels_3D, skip_levels_2D=c.skip_levels_2D,
-            device=self.device,
-            dimension_wise_resolution=c.dimension_wise_resolution or c.resolutions_list[-1])
+        self.context = self.build_context()
         # `dataset`: anything with fetch() / view(i) / update_num_rays(n) (LoaderDataset for real scenes); the
         # procedural scene otherwise (no dataset ships with the repository)
         self.dataset = dataset if dataset is not None else \
             SyntheticBallDataset(c.image_size, device=self.device, seed=c.seed + 1000 * self.rank)
         self.dataset.update_num_rays(c.init_batch_size)
 
-        # one kernel per parameter list instead of the ~9 passes of the foreach implementation (0.8 -> 0.2 ms per step)
-        one_pass = self.device.type == "cuda" and os.environ.get("CNC_FUSED_ADAM", "1") == "1"
-        self.opt = torch.optim.Adam(self.field.parameters(), lr=c.lr, eps=1e-15, weight_decay=c.weight_decay, fused=one_pass)
-        self.opt2 = torch.optim.Adam(self.context.parameters(), lr=c.lr, eps=1e-15, fused=one_pass)
-
-        def sched(o):
-            return torch.optim.lr_scheduler.ChainedScheduler([
-                torch.optim.lr_scheduler.LinearLR(o, start_factor=0.01, total_iters=c.warmup_iters),
-                torch.optim.lr_scheduler.MultiStepLR(o, milestones=list(c.milestones), gamma=0.33)])
-        self.sched, self.sched2 = sched(self.opt), sched(self.opt2)
+        self.build_optimizers()
         self.loss_scale = 2.0 ** 10          # GradScaler(2**10), never unscaled (train:211,361-362)
 
         self.bucket = None
@@ -256,6 +240,34 @@ class Trainer:
                 torch.distributed.broadcast(r, 0)
                 return r
             self.context.rand_like = synced_rand_like
+
+    def build_context(self):
+        """The context models of this configuration (train:221-241).  Their vertex tables draw from the CPU
+        generator (randperm of the dense levels, utils_bpp_acc.py:312), so a caller that wants a particular
+        draw seeds, calls this and assigns the result to `self.context` (then `build_optimizers()`)."""
+        c = self.cfg
+        return CNC_context_models(
+            num_dim=3, resolutions_list=c.resolutions_list, resolutions_list_2D=c.resolutions_list_2D,
+            log2_hashmap_size=c.log2_hashmap_size, log2_hashmap_size_2D=c.log2_hashmap_size_2D,
+            n_features=c.n_features, sample_num=c.sample_num, max_context_layer_num=c.max_context_layer_num,
+            ste_binary=True, Q=10, Pg_level=c.Pg_level, Pg_level_2D=c.Pg_level_2D, Rb=c.grid_resolution,
+            step_update=c.step_update, skip_levels_3D=c.skip_levels_3D, skip_levels_2D=c.skip_levels_2D,
+            device=self.device,
+            dimension_wise_resolution=c.dimension_wise_resolution or c.resolutions_list[-1])
+
+    def build_optimizers(self):
+        """Both Adam groups and their chained schedules (train:257-297)."""
+        c = self.cfg
+        # one kernel per parameter list instead of the ~9 passes of the foreach implementation (0.8 -> 0.2 ms per step)
+        one_pass = self.device.type == "cuda" and os.environ.get("CNC_FUSED_ADAM", "1") == "1"
+        self.opt = torch.optim.Adam(self.field.parameters(), lr=c.lr, eps=1e-15, weight_decay=c.weight_decay, fused=one_pass)
+        self.opt2 = torch.optim.Adam(self.context.parameters(), lr=c.lr, eps=1e-15, fused=one_pass)
+
+        def sched(o):
+            return torch.optim.lr_scheduler.ChainedScheduler([
+                torch.optim.lr_scheduler.LinearLR(o, start_factor=0.01, total_iters=c.warmup_iters),
+                torch.optim.lr_scheduler.MultiStepLR(o, milestones=list(c.milestones), gamma=0.33)])
+        self.sched, self.sched2 = sched(self.opt), sched(self.opt2)
 
     # -------------------------------------------------------------------------------- training
     def train_step(self, step: int, want_stats: bool = True) -> Optional[Dict[str, float]]:

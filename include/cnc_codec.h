@@ -32,6 +32,17 @@ int64_t cnc_rc_encode_pm1(const float* p_one, const float* x_pm1, int64_t n, uin
 int cnc_rc_decode_pm1(const float* p_one, int64_t n, const uint8_t* in, int64_t len,
                       float* x_pm1);
 
+/* General alphabets — what `torchac.encode_int16_normalized_cdf(cdf_int, sym)` / `decode_int16_normalized_cdf`
+ * bind (and, after the float -> 16-bit conversion done by the Python shim cnc_amd/backends/torchac.py exactly as
+ * torchac's `_convert_to_int_and_normalize` publishes it, `encode_float_cdf` / `decode_float_cdf`, the two calls of
+ * examples/utils_bpp_acc.py:87,108).  cdf: [n, Lp] uint16 rows, row[0] = 0, non-decreasing, the LAST entry stands
+ * for 2^16 whatever it holds (torchac stores 65536 wrapped to 0); sym[i] in [0, Lp-2].
+ * encode: bytes written, -1 if cap < cnc_rc_bound(n), -2 for a symbol outside the alphabet.  decode: 0 / -2. */
+int64_t cnc_rc_encode_cdf16(const uint16_t* cdf, const int16_t* sym, int64_t n, int32_t Lp, uint8_t* out,
+                            int64_t cap);
+int cnc_rc_decode_cdf16(const uint16_t* cdf, int64_t n, int32_t Lp, const uint8_t* in, int64_t len,
+                        int16_t* sym);
+
 #ifdef __cplusplus
 }
 #endif

@@ -303,3 +303,59 @@ def test_bench_chunk_backward_against_oracle(cuda, oracle, overlap, which):
     assert np.all(got[abs64 == 0] == 0)
     # and globally far tighter than the worst case (errors do not line up)
     assert err.max() <= 1e-5 * np.abs(acc64).max()
+
+
+def test_overlapped_entry_straight_through_the_c_abi(cuda):
+    """cnc_grid_encode_backward_overlapped as a C host would call it (ABI v21): create a plan, one call on a
+    non-default stream with the caller's own scratch, destroy the plan.  Same gradient as the serial binned entry;
+    the work is ordered on the caller's stream when the call returns (no synchronisation in between)."""
+    import ctypes as C
+
+    from cnc_amd import _lib
+    from cnc_amd.backends import gridencoder_backend as be
+    from cnc_amd.synthetic import RES_16L, level_offsets
+    F, L, N = 8, 16, (1 << 18) + 77
+    offs = level_offsets(RES_16L, 19, 3)
+    o_t, r_t = torch.as_tensor(offs, device=cuda), torch.tensor(RES_16L, dtype=torch.int32, device=cuda)
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    emb = torch.sign(torch.rand((int(offs[-1]), F), generator=gen) * 2 - 1).to(cuda)
+    x = torch.rand((N, 3), generator=gen).to(cuda)
+    g = torch.randn((L, N, F), generator=gen).to(cuda)
+    n_binned, level_rows = be.plan_binned_levels(RES_16L, [int(v) for v in offs], 3, F, N)
+    lib = _lib.lib()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    want = torch.zeros_like(emb)
+    ws0 = torch.empty(int(lib.cnc_grid_encode_backward_binned_workspace(N, n_binned, level_rows)), dtype=torch.uint8, device=cuda)
+    rc = lib.cnc_grid_encode_backward_binned(p(g), p(x), p(emb), p(o_t), p(r_t), p(want), N, 3, F, L, _lib.CNC_FLAG_STE_BINARY, None,
+                                             0, 0, n_binned, level_rows, p(ws0), ws0.numel(), _lib.stream(cuda))
+    assert rc == 0
+    torch.cuda.synchronize()
+    plan = C.c_void_p()
+    assert lib.cnc_backward_plan_create(C.byref(plan)) == 0 and plan.value
+    nbytes = int(lib.cnc_grid_encode_backward_overlapped_workspace(N, n_binned, level_rows))
+    assert nbytes >= ws0.numel()
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=cuda)
+    side = torch.cuda.Stream(device=cuda)
+    got = torch.empty_like(emb)
+    with torch.cuda.stream(side):
+        got.zero_()                                  # queued on the caller's stream right before
+        for _ in range(2):                           # a plan is reusable call after call
+            got.zero_()
+            rc = lib.cnc_grid_encode_backward_overlapped(plan, p(g), p(x), p(emb), p(o_t), p(r_t), p(got), N, 3, F, L,
+                                                         _lib.CNC_FLAG_STE_BINARY, None, 0, 0, n_binned, level_rows, p(ws),
+                                                         ws.numel(), C.c_void_p(side.cuda_stream))
+            assert rc == 0
+        snap = got.clone()                           # queued right after: must see both halves
+    side.synchronize()
+    assert lib.cnc_backward_plan_destroy(plan) == 0
+    scale = float(want.abs().max())
+    assert float((snap - want).abs().max()) <= 1e-5 * scale
+    assert float(snap[: int(offs[1])].abs().max()) > 0 and float(snap[int(offs[-2]):].abs().max()) > 0
+    # NULL plan / tiny N: the serial path, same entry
+    got2 = torch.zeros_like(emb)
+    rc = lib.cnc_grid_encode_backward_overlapped(None, p(g), p(x), p(emb), p(o_t), p(r_t), p(got2), N, 3, F, L,
+                                                 _lib.CNC_FLAG_STE_BINARY, None, 0, 0, n_binned, level_rows, p(ws), ws.numel(),
+                                                 _lib.stream(cuda))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert float((got2 - want).abs().max()) <= 1e-5 * scale
