@@ -211,18 +211,25 @@ def spawn_ranks(args) -> int:
     return rc
 
 
-def train_step_entry(dev):
-    """The WHOLE model in the loop (configs[1]/[2]): 12x3-D (T=2^19) + 3x4 2-D (T=2^17) levels at F=8,
-    sample_num=150000, occupancy marcher, radiance-field MLPs, volume rendering, context models + entropy
-    loss, Adam — `cnc_amd.trainer.Trainer.train_step` on the procedural scene, 2^18 target samples per step."""
+def train_step_entry(dev, world=1, rank=0):
+    """The WHOLE model in the loop (configs[1]/[2]; configs[3] at world > 1): 12x3-D (T=2^19) + 3x4 2-D (T=2^17) levels
+    at F=8, sample_num=150000, occupancy marcher, radiance-field MLPs, volume rendering, context models + entropy
+    loss, Adam — `cnc_amd.trainer.Trainer.train_step` on the procedural scene, 2^18 target samples per step and rank.
+    At world > 1 every rank renders its own rays; the ray-loss gradient (one flat 161 MB bucket) is all-reduced
+    asynchronously while the context backward runs (trainer.py).  Reported: the whole job's rendered samples / s
+    (all ranks' samples over the slowest rank's time), the all-reduce alone, and how much of it the step still
+    waits for."""
     from cnc_amd.trainer import TrainConfig, Trainer
     cfg = TrainConfig(n_features=8, sample_num=150000, image_size=400, out_dir="/tmp/cnc_bench_bits")
     tr = Trainer(cfg, device=dev)
-    warm = 240       # occupancy warm-up, adaptive ray budget settled, surfaces formed: from here on the march hands the
+    warm = int(os.environ.get("CNC_BENCH_TRAIN_WARM", "240"))       # occupancy warm-up, adaptive ray budget settled, surfaces formed: from here on the march hands the
     for step in range(warm):                # sampler 6-8x the samples that survive it, as for the rest of a 30k-step run
         tr.train_step(step, want_stats=False)
     torch.cuda.synchronize()
-    n_steps, samples, rays = 60, 0, 0
+    if world > 1:
+        torch.distributed.barrier()
+        tr.time_comm = True
+    n_steps, samples, rays = int(os.environ.get("CNC_BENCH_TRAIN_STEPS", "60")), 0, 0     # (test hooks: shorter runs)
     t0 = time.perf_counter()
     for step in range(warm, warm + n_steps):
         s = tr.train_step(step, want_stats=False)       # loss scalars are read back on log steps only (as train:368)
@@ -231,10 +238,38 @@ def train_step_entry(dev):
             rays += s["num_rays"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"ms_per_step": dt / n_steps * 1e3, "rendered_samples_per_s": samples / dt, "rays_per_s": rays / dt,
-            "samples_per_step": samples / n_steps, "steps": n_steps, "timed_region": False,
-            "config": "full model, F=8, 12x3D(2^19)+3x4x2D(2^17), sample_num=150000, lmbda=2e-3, procedural ball "
-                      "scene, target 2^18 samples/step, steps 240-299 (includes the occupancy refresh every 16 steps)"}
+    out = {"ms_per_step": dt / n_steps * 1e3, "rendered_samples_per_s": samples / dt, "rays_per_s": rays / dt,
+           "samples_per_step": samples / n_steps, "steps": n_steps, "timed_region": False, "world_size": world,
+           "config": "full model, F=8, 12x3D(2^19)+3x4x2D(2^17), sample_num=150000, lmbda=2e-3, procedural ball "
+                     "scene, target 2^18 samples/step" + ("/rank" if world > 1 else "") +
+                     f", steps {warm}-{warm + n_steps - 1} (includes the occupancy refresh every 16 steps)"}
+    if world > 1:
+        exposed = sum(a.elapsed_time(b) for a, b in tr._comm_events) / max(len(tr._comm_events), 1)
+        tr.time_comm = False
+        flat = tr.bucket.flat
+        alone = []
+        for _ in range(6):                 # the same bucket, nothing else on the GPU
+            torch.cuda.synchronize()
+            torch.distributed.barrier()
+            t1 = time.perf_counter()
+            torch.distributed.all_reduce(flat)
+            torch.cuda.synchronize()
+            alone.append((time.perf_counter() - t1) * 1e3)
+        alone_ms = sorted(alone[1:])[len(alone[1:]) // 2]
+        tot = torch.tensor([float(samples), float(rays), dt, exposed, alone_ms], dtype=torch.float64, device=dev)
+        mx = tot.clone()
+        torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
+        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
+        dt_max = float(mx[2])
+        out.update({"ms_per_step": dt_max / n_steps * 1e3, "rendered_samples_per_s": float(tot[0]) / dt_max,
+                    "rays_per_s": float(tot[1]) / dt_max, "samples_per_step": float(tot[0]) / n_steps,
+                    "allreduce_bytes": int(flat.numel() * flat.element_size()),
+                    "allreduce_alone_ms": float(mx[4]), "allreduce_exposed_ms_per_step": float(mx[3]),
+                    "allreduce_hidden_frac": max(0.0, 1.0 - float(mx[3]) / max(float(mx[4]), 1e-9)),
+                    "allreduce_note": "alone = blocking all-reduce of the same flat gradient bucket on an idle GPU (median "
+                                      "of 5, slowest rank); exposed = HIP-event time the compute stream waits for the "
+                                      "asynchronous all-reduce after the context backward (mean per step, slowest rank)"})
+    return out
 
 
 def main():
@@ -260,6 +295,7 @@ def main():
     # single-GPU box (tests/test_gpu_bench_multi.py)
     if os.environ.get("CNC_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+        os.environ["CNC_DIST_ONE_DEVICE"] = "1"       # the Trainer's own device pick follows (cnc_amd.dist)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = "none"
@@ -338,6 +374,11 @@ def main():
                     overlap_streams=False))
         torch.cuda.synchronize()
         extra.collect()
+
+    # the DP training step (configs[3]) runs on EVERY rank; rank 0 reports the aggregate
+    ts_multi = None
+    if world > 1 and not args.no_train_step:
+        ts_multi = train_step_entry(dev, world, rank)
 
     tot = torch.tensor([float(samples), elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -433,8 +474,8 @@ def main():
             "ranks": ranks,
             "roofline": roofline, "roofline_forward": other, "kernels": kernels,
         }
-        if not args.no_train_step and world == 1:
-            ts = train_step_entry(dev)
+        if not args.no_train_step:
+            ts = train_step_entry(dev) if world == 1 else ts_multi
             out["train_step"] = ts
             kernels["train_step(full model: march+field+render+context+adam)"] = {
                 "launches": ts["steps"], "avg_ms": ts["ms_per_step"], "units_per_s": ts["rendered_samples_per_s"],

@@ -61,21 +61,28 @@ class _PosedImages(torch.utils.data.Dataset):
     def update_num_rays(self, num_rays):
         self.num_rays = num_rays
 
+    def seed_sampling(self, seed: int):
+        """(extension) draw training images / pixels / random backgrounds from a generator of this loader's own
+        instead of the global one — one seed per data-parallel rank."""
+        self._gen = torch.Generator(device=self.images.device).manual_seed(int(seed))
+
     def _pixels_to_sample(self, index, dev):
         """(image ids, x, y, output shape): `num_rays` random pixels when training, else every pixel of image
         `index` in row-major order."""
         if self.training:
             n = self.num_rays
-            ids = (torch.randint(0, len(self), (n,), device=dev) if self.batch_over_images
+            g = getattr(self, "_gen", None)
+            ids = (torch.randint(0, len(self), (n,), device=dev, generator=g) if self.batch_over_images
                    else torch.full((n,), index, device=dev))
-            return ids, torch.randint(0, self.WIDTH, (n,), device=dev), torch.randint(0, self.HEIGHT, (n,), device=dev), (n,)
+            return (ids, torch.randint(0, self.WIDTH, (n,), device=dev, generator=g),
+                    torch.randint(0, self.HEIGHT, (n,), device=dev, generator=g), (n,))
         cols, rows = torch.meshgrid(torch.arange(self.WIDTH, device=dev), torch.arange(self.HEIGHT, device=dev),
                                     indexing="xy")
         return torch.tensor([index], device=dev), cols.reshape(-1), rows.reshape(-1), (self.HEIGHT, self.WIDTH)
 
     def _background(self, dev):
         if self.training and self.color_bkgd_aug == "random":
-            return torch.rand(3, device=dev)
+            return torch.rand(3, device=dev, generator=getattr(self, "_gen", None))
         level = _BKGD.get(self.color_bkgd_aug, 1.0) if self.training else 1.0     # evaluation is always on white
         return torch.full((3,), level, device=dev)
 

@@ -52,7 +52,7 @@ def build_parser():
     return ap
 
 
-def make_config_and_data(args, device):
+def make_config_and_data(args, device, rank=0, world=1):
     kind = args.dataset
     if kind is None:
         root_has_scene = os.path.isdir(os.path.join(args.data_root, args.scene))
@@ -79,9 +79,14 @@ def make_config_and_data(args, device):
         from .datasets import SubjectLoader_Tanks
         train = SubjectLoader_Tanks(subject_id=scene, root_fp=args.data_root, split="train", num_rays=1024, device=device)
         test = SubjectLoader_Tanks(subject_id=scene, root_fp=args.data_root, split="test", num_rays=None, device=device)
-        kw.update(aabb=tuple(float(v) for v in train.aabb.tolist()), render_step_size=train.render_step_size,
-                  near_plane=0.01)
+        # near_plane stays 0.0: the reference driver never hands the loader's NEAR to the sampler
+        # (train_CNC_tank_temples.py:176)
+        kw.update(aabb=tuple(float(v) for v in train.aabb.tolist()), render_step_size=train.render_step_size)
         dataset = LoaderDataset(train, test)
+    if dataset is not None and world > 1:
+        # data parallelism: every rank draws its OWN images / pixels (the all-reduce then averages world different
+        # batches); replica-identical draws (occupancy cells, context windows) stay on the global generators
+        dataset.seed_sampling(42 + 1000 * rank)
     n_test = len(dataset) if dataset is not None else 4
     kw["test_views"] = n_test if args.test_views is None else min(args.test_views, n_test)
     return kind, TrainConfig(**kw), dataset
@@ -106,16 +111,25 @@ def evaluate(tr: Trainer, n_views: int):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    device = torch.device("cuda", 0) if torch.cuda.is_available() else None
-    if device is None:
+    if not torch.cuda.is_available():
         raise SystemExit("cnc_amd.train needs an MI355X (the HIP extension has no CPU fallback)")
-    kind, cfg, dataset = make_config_and_data(args, device)
+    # under `torchrun --nproc-per-node N`: join the group first, so that the loaders are built on THIS rank's GPU
+    from . import dist as cdist
+    rank, _, world = cdist.init()
+    device = torch.device("cuda", cdist.local_device_index() if world > 1 else 0)
+    kind, cfg, dataset = make_config_and_data(args, device, rank, world)
     tr = Trainer(cfg, device=device, dataset=dataset)
     r4 = lambda v: str(np.round(v, decimals=4))
 
     tic = time.time()
     tr.train(steps=cfg.max_steps)
     elapsed = time.time() - tic
+    if world > 1:
+        # the replicas are identical after training: evaluation, the codec round trip (it writes and re-reads
+        # ./bitstreams/<scene>/*.b) and the results line are rank 0's; the others wait here and leave
+        if rank != 0:
+            torch.distributed.barrier()
+            return None
     psnr_avg, lpips_avg, ssim_avg = evaluate(tr, cfg.test_views)
     print(f"evaluation: psnr_avg={psnr_avg}, lpips_avg={lpips_avg}, ssim_avg={ssim_avg}")
 
@@ -152,6 +166,8 @@ def main(argv=None):
     with open(out, "a") as fw:
         fw.write("\t".join(cols) + "\n")
     print(f"results line appended to {out}")
+    if world > 1:
+        torch.distributed.barrier()
     return cols
 
 

@@ -187,12 +187,20 @@ class LoaderDataset:
 
     def __init__(self, train_loader, test_loader):
         self.train, self.test = train_loader, test_loader
+        self._gen = None
+
+    def seed_sampling(self, seed: int):
+        """Per-rank stream for the image index drawn here and for the loader's pixel draws (data parallelism:
+        without it every rank would render the same batch and the all-reduce would average N copies of one
+        gradient)."""
+        self._gen = torch.Generator().manual_seed(int(seed))
+        self.train.seed_sampling(int(seed) + 1)
 
     def update_num_rays(self, n):
         self.train.update_num_rays(int(n))
 
     def fetch(self):
-        return self.train[int(torch.randint(0, len(self.train), (1,)).item())]
+        return self.train[int(torch.randint(0, len(self.train), (1,), generator=self._gen).item())]
 
     def view(self, i):
         return self.test[i % len(self.test)]
@@ -229,6 +237,8 @@ class Trainer:
         self.loss_scale = 2.0 ** 10          # GradScaler(2**10), never unscaled (train:211,361-362)
 
         self.bucket = None
+        self.time_comm = False          # bench hook: HIP events around the wait for the gradient all-reduce
+        self._comm_events = []
         if self.world > 1:
             plist = list(self.field.parameters()) + list(self.context.parameters())
             self.bucket = cdist.GradBucket(plist)          # ray-loss gradients (all-reduced)
@@ -316,14 +326,22 @@ class Trainer:
             A, B = self.bucket, self.bucket_ctx
             A.zero()
             A.bind(force=True)
-            (mse * self.loss_scale).backward()
+            if mse.requires_grad:          # a rank whose rays met no sample has nothing to add (its peers do): the
+                (mse * self.loss_scale).backward()     # collective below must still be entered by everyone
             work = A.allreduce(average=False, async_op=True)
             if c.lmbda > 0:
                 B.zero()
                 B.bind(force=True)
                 (c.lmbda * bpp * self.loss_scale).backward()
             if work is not None:
+                if self.time_comm:      # how long the compute stream stalls for the collective (what was NOT hidden
+                    e0 = torch.cuda.Event(enable_timing=True)        # behind the context backward)
+                    e0.record()
                 work.wait()
+                if self.time_comm:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    self._comm_events.append((e0, e1))
             A.flat.div_(self.world)
             if c.lmbda > 0:
                 A.flat.add_(B.flat)

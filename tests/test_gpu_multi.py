@@ -42,6 +42,24 @@ def test_bench_spawns_two_ranks_and_allreduces(cuda):
     assert "[bench rank 1]" in r.stderr and "[bench rank 0]" in r.stderr
 
 
+def test_bench_reports_the_data_parallel_training_step(cuda):
+    """At N > 1 the line carries a `train_step` block measured on every rank (the whole model, ray-loss gradient
+    all-reduced while the context backward runs): aggregate samples / s, the all-reduce alone and what of it the
+    step still waits for."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=1500,
+                       env=_clean_env(CNC_BENCH_ONE_DEVICE="1", CNC_BENCH_BACKEND="gloo", CNC_BENCH_TRAIN_WARM="20",
+                                      CNC_BENCH_TRAIN_STEPS="6"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    ts = out["train_step"]
+    assert ts["world_size"] == 2 and ts["steps"] == 6
+    assert ts["allreduce_bytes"] > 150e6                      # the flat bucket: tables + MLPs + context models at F=8
+    assert ts["allreduce_alone_ms"] > 0 and ts["allreduce_exposed_ms_per_step"] >= 0
+    assert 0.0 <= ts["allreduce_hidden_frac"] <= 1.0
+    assert ts["rendered_samples_per_s"] > 0 and ts["samples_per_step"] > 1e5     # both ranks' samples
+
+
 def test_bench_under_the_drivers_launcher(cuda):
     """The driver's own command line for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (here both ranks on cuda:0 over gloo)."""
