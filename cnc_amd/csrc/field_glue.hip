@@ -209,20 +209,21 @@ __global__ __launch_bounds__(256) void k_field_post_bwd(const float* __restrict_
                                                         const float* __restrict__ g_head, uint32_t ld_head, uint32_t N,
                                                         float* __restrict__ g_base)
 {
+    // grad_base_out has the row stride of base_out (ld_base >= 1 + geo); columns past 1 + geo get zeros
     const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t cols = 1 + geo;
-    if (e >= (uint64_t)N * cols) return;
-    const uint32_t i = (uint32_t)(e / cols), c = (uint32_t)(e % cols);
+    if (e >= (uint64_t)N * ld_base) return;
+    const uint32_t i = (uint32_t)(e / ld_base), c = (uint32_t)(e % ld_base);
     float v = 0.0f;
     if (c == 0) {
         if (g_density) {
             const float s = selector ? (float)selector[i] : 1.0f;
             v = (g_density[i] * s) * expf(fminf(base[(size_t)i * ld_base] - 1.0f, 15.0f));
         }
-    } else if (g_head) {
+    } else if (c < cols && g_head) {
         v = g_head[(size_t)i * ld_head + 16 + (c - 1)];
     }
-    g_base[(size_t)i * cols + c] = v;
+    g_base[(size_t)i * ld_base + c] = v;
 }
 
 }  // namespace cnc
@@ -306,7 +307,7 @@ extern "C" int cnc_field_post_backward(const float* base_out, uint32_t ld_base, 
     if (N == 0) return CNC_OK;
     if (!base_out || !grad_base_out || ld_base < 1 + geo_feat_dim) return CNC_ERR_INVALID_VALUE;
     if (grad_head_in && ld_head < 16 + geo_feat_dim) return CNC_ERR_INVALID_VALUE;
-    const uint64_t n = (uint64_t)N * (1 + geo_feat_dim);
+    const uint64_t n = (uint64_t)N * ld_base;
     hipLaunchKernelGGL(k_field_post_bwd, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base_out,
                        ld_base, geo_feat_dim, selector, grad_density, grad_head_in, ld_head, N, grad_base_out);
     return launch_status();

@@ -76,10 +76,10 @@ __device__ __forceinline__ float excl_step(float v, uint32_t j, float& total)
 __global__ __launch_bounds__(256) void k_volrend_fwd(
     const int64_t* __restrict__ starts, const int64_t* __restrict__ cnts,
     const float* __restrict__ t_starts, const float* __restrict__ t_ends, const float* __restrict__ sigmas,
-    const float* __restrict__ rgbs, const float* __restrict__ opacity_in, const float* __restrict__ prefix_trans,
+    const float* __restrict__ rgbs, const float* opacity_in /* may alias `opacity` (iterative render) */, const float* __restrict__ prefix_trans,
     const float* __restrict__ bkgd,
     float* __restrict__ weights, float* __restrict__ trans_out, float* __restrict__ alphas,
-    float* __restrict__ colors, float* __restrict__ opacity, float* __restrict__ depth,
+    float* __restrict__ colors, float* opacity /* may alias `opacity_in` */, float* __restrict__ depth,
     uint32_t n_rays, uint32_t flags)
 {
     const uint32_t j = threadIdx.x & 31;

@@ -577,7 +577,8 @@ int cnc_relu_backward_bias(const float* grad_out, const float* y, uint32_t N, ui
 int cnc_field_sinusoid(const float* x, const float* freqs, uint32_t n_freqs, uint32_t N, float* out, uint32_t ld,
                        uint32_t col, void* stream);
 
-/* grad_base_out [N, 1 + geo] from grad_density [N] (nullable) and grad_head_in [N, ld_head] (nullable):
+/* grad_base_out [N, ld_base] (the row stride of base_out; columns past 1 + geo are zero-filled) from
+ * grad_density [N] (nullable) and grad_head_in [N, ld_head] (nullable):
  * column 0 = grad_density * selector * exp(min(density_raw - 1, 15)) (trunc_exp's clamped gradient,
  * ngp.py:318-334), columns 1.. = grad_head_in[:, 16:16+geo].                                          */
 int cnc_field_post_backward(const float* base_out, uint32_t ld_base, uint32_t geo_feat_dim,

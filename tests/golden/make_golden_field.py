@@ -446,7 +446,7 @@ def gen_train(ngp, ex_utils, ub, nerfacc, Rays, tag, steps, warmup_iters):
     out = run_trajectory(ngp, ex_utils, ub, nerfacc, Rays, tag, steps, warmup_iters, noise_seed=None)
     for k in (1, 2):
         noisy = run_trajectory(ngp, ex_utils, ub, nerfacc, Rays, f"{tag}+noise{k}", steps, warmup_iters, noise_seed=100 + k)
-        for name in ("mse", "bpp", "mb", "n_samples", "num_rays", "occupied", "final_sign_xyz", "final_w0_norm"):
+        for name in ("mse", "bpp", "mb", "n_samples", "num_rays", "occupied", "final_sign_xyz", "final_w0_norm", "signs", "norms"):
             out[f"noise{k}_{name}"] = noisy[name]
     np.savez_compressed(os.path.join(HERE, f"train_toy_{tag}.npz"), steps=np.int64(steps), warmup_iters=np.int64(warmup_iters), **out)
 
@@ -478,6 +478,15 @@ def run_trajectory(ngp, ex_utils, ub, nerfacc, Rays, tag, steps, warmup_iters, n
         if k.endswith(".params"):
             filled[k] = filled[k] * (1e-4 / 1.3)
     f.load_state_dict(filled, strict=True)
+    if noise_seed is not None:
+        # a perturbation of a few ulps (2^-22 relative) of every dense weight: from there on every activation, every
+        # gradient and every Adam ratio differs from the unperturbed run in its last bits, the way two correct
+        # float32 implementations with different summation orders differ
+        rng = np.random.default_rng(noise_seed + 7)
+        with torch.no_grad():
+            for name, p_ in list(f.named_parameters()) + list(ctx.named_parameters()):
+                if not name.endswith(".params"):
+                    p_.mul_(torch.from_numpy((1.0 + 2.0 ** -22 * rng.standard_normal(tuple(p_.shape))).astype(np.float32)))
 
     opt = torch.optim.Adam([{"params": f.parameters()}], lr=c["lr"], eps=1e-15, weight_decay=c["weight_decay"])
     opt2 = torch.optim.Adam([{"params": ctx.parameters()}], lr=c["lr"], eps=1e-15)
@@ -490,6 +499,7 @@ def run_trajectory(ngp, ex_utils, ub, nerfacc, Rays, tag, steps, warmup_iters, n
     scaler = _LossScale()
     num_rays = c["init_batch_size"]
     rec = {k: [] for k in ("mse", "bpp", "mb", "n_samples", "num_rays", "occupied", "lr")}
+    signs, norms = [], []
     torch.manual_seed(29)
     with RandTape() as tape, (SummationNoise(noise_seed) if noise_seed is not None else _NoNoise()):
         for step in range(steps):
@@ -514,12 +524,20 @@ def run_trajectory(ngp, ex_utils, ub, nerfacc, Rays, tag, steps, warmup_iters, n
             opt.step(); opt2.step(); s1.step(); s2.step()
             rec["mse"].append(mse.item()); rec["bpp"].append(bpp.item()); rec["mb"].append(float(mb)); rec["n_samples"].append(n)
             rec["occupied"].append(int(est.binaries.sum()))
+            # state after the step: the signs of every table entry (what the binarised model IS) and norms of the dense parts
+            e = f.mlp_base
+            signs.append(np.packbits(np.concatenate([(t.params.detach().numpy() >= 0).reshape(-1) for t in
+                                                     (e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz)])))
+            norms.append([float(p.detach().double().norm()) for p in list(f.parameters())[4:]] +
+                         [float(p.detach().double().norm()) for p in ctx.parameters()])
             if step == 0:
                 out["step0_rgb"] = rgb.detach().numpy(); out["step0_opacity"] = acc.detach().numpy()
                 out["step0_binaries"] = est.binaries.numpy().copy()
     out["rand_like_shapes"] = np.array([",".join(str(s) for s in sh) for sh in tape.shapes])
     for k, v in rec.items():
         out[k] = np.asarray(v, np.float64)
+    out["signs"] = np.stack(signs)
+    out["norms"] = np.asarray(norms)
     out["final_sign_xyz"] = (f.mlp_base.encoding_xyz.params.detach().numpy() >= 0)
     out["final_w0_norm"] = np.float64(f.mlp_base.network[0].weight.detach().norm().item())
     out["final_ctx3d_w0"] = ctx.context_model_3D[0].weight.detach().numpy().copy()

@@ -277,11 +277,9 @@ class _NumpyBall:
 @pytest.mark.parametrize("tag", ["ref", "fast"])
 def test_training_trajectory(cuda, tag, fused, tmp_path):
     """The reference's loop body (train:302-366) on its own classes vs `Trainer.train_step`, same batches, same
-    random stream, same initial state.  Step 0 (nothing has been optimised yet): everything to 1e-4 and the
-    sample count exactly.  Later steps: binarised tables flip individual signs on float noise (the tables start
-    at |x| <= 1e-4 and Adam moves them by lr per step), so the band is: per-step mse within 3 %, bpp within
-    1.5 %, rendered samples within 2 %, occupied cells within 2 cells, learning rate exact, and at the end
-    at most 2 % of the 3-D table's signs differ."""
+    random stream, same initial state.  As long as every table entry has the reference's sign (the first 4-8
+    steps) everything agrees to 1e-4 / exactly; after that the band is the reference's own spread under a few-ulp
+    perturbation (see below and make_golden_field.py)."""
     from cnc_amd.trainer import TrainConfig, Trainer
     g = np.load(os.path.join(GOLD, f"train_toy_{tag}.npz"))
     c = TRAIN
@@ -309,6 +307,7 @@ def test_training_trajectory(cuda, tag, fused, tmp_path):
             filled[k] = filled[k] * (1e-4 / 1.3)
     tr.field.load_state_dict(filled, strict=True)
     rec = {k: [] for k in ("mse", "bpp", "mb", "n_samples", "num_rays", "occupied", "lr")}
+    signs, norms, values = [], [], []
     torch.manual_seed(29)
     with cpu_rand_like() as tape:
         for step in range(steps):
@@ -318,6 +317,13 @@ def test_training_trajectory(cuda, tag, fused, tmp_path):
             assert s is not None
             rec["mse"].append(s["mse"]); rec["bpp"].append(s["bpp"]); rec["mb"].append(s["embed_bits_MB"])
             rec["n_samples"].append(s["n_rendering_samples"]); rec["occupied"].append(int(tr.estimator.binaries.sum()))
+            e = tr.field.mlp_base
+            tabs = (e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz)
+            flat = torch.cat([t.params.detach().reshape(-1) for t in tabs])
+            signs.append(np.packbits((flat >= 0).cpu().numpy()))
+            values.append(flat.cpu().numpy())
+            norms.append([float(p.detach().double().norm()) for p in list(tr.field.parameters())[4:]] +
+                         [float(p.detach().double().norm()) for p in tr.context.parameters()])
             if step == 0:
                 assert np.array_equal(tr.estimator.binaries.cpu().numpy(), g["step0_binaries"])
     want_shapes = [tuple(int(v) for v in s.split(",")) for s in g["rand_like_shapes"]]
@@ -325,26 +331,56 @@ def test_training_trajectory(cuda, tag, fused, tmp_path):
     assert len(tape.shapes) == len(want_shapes)
     assert [s for s in tape.shapes if len(s) != 1 or s[0] < 16] == [s for s in want_shapes if len(s) != 1 or s[0] < 16]
     r = {k: np.asarray(v, np.float64) for k, v in rec.items()}
+    n_bits = values[0].shape[0]
+    differ = [int(np.unpackbits(a ^ b)[:n_bits].sum()) for a, b in zip(signs, g["signs"])]
+    norm_dev = np.abs(np.asarray(norms) / g["norms"] - 1).max(axis=1)
     if os.environ.get("CNC_TRAJ_PRINT"):
+        print("table signs that differ from the reference after each step:", differ)
+        print("largest relative deviation of a dense parameter's norm after each step:", np.array2string(norm_dev, precision=2))
+        first = next((k for k, d in enumerate(differ) if d), None)
+        if first is not None:
+            idx = np.nonzero(np.unpackbits(signs[first] ^ g["signs"][first])[:n_bits])[0]
+            F_ = c["F"]
+            n3 = tr.field.mlp_base.encoding_xyz.params.numel()
+            print("first step with a differing sign:", first, "entries", idx[:10], "of", n_bits, "(3-D table holds", n3, ")")
+            for j in idx[:6]:
+                hist = [float(v[j]) for v in values[max(0, first - 3): first + 1]]
+                print("   entry", int(j), "row", int(j) // F_, "feature", int(j) % F_, "my values over the last steps:", hist)
         for k in ("mse", "bpp", "n_samples", "num_rays", "occupied"):
             print(k, "got ", np.array2string(r[k], precision=5, max_line_width=250))
             print(k, "want", np.array2string(g[k], precision=5, max_line_width=250))
-    # step 0
-    assert r["n_samples"][0] == g["n_samples"][0] and r["num_rays"][0] == g["num_rays"][0]
-    assert abs(r["mse"][0] - g["mse"][0]) <= 1e-4 * g["mse"][0]
-    assert abs(r["bpp"][0] - g["bpp"][0]) <= 1e-4 * g["bpp"][0]
-    assert abs(r["mb"][0] - g["mb"][0]) <= 1e-4 * g["mb"][0]
-    # the band
+    # ---- while no table entry has a different sign: the same model, so the same numbers (at least the first 4 steps)
+    agree = next((k for k, d in enumerate(differ) if d), steps)
+    assert agree >= 4, differ
+    for k in range(agree):
+        assert r["n_samples"][k] == g["n_samples"][k] and r["num_rays"][k] == g["num_rays"][k], k
+        assert r["occupied"][k] == g["occupied"][k], k
+        for name in ("mse", "bpp", "mb"):
+            assert abs(r[name][k] - g[name][k]) <= 1e-4 * g[name][k], (name, k, r[name][k], g[name][k])
+        assert norm_dev[k] <= 1e-5, (k, norm_dev[k])              # every MLP tensor of the field and the context models
     assert np.allclose(r["lr"], g["lr"], rtol=1e-12, atol=0)
+    # ---- afterwards: binarised tables + Adam are a chaotic system (an entry that lands within rounding of zero takes the
+    # other sign, the next steps amplify it).  The golden holds the reference's OWN spread: two more runs of the
+    # reference whose dense weights were perturbed by 2^-22 relative (a few ulps) at the start.  The run under test
+    # must stay at least as close to the unperturbed reference as those do (x1.5 slack, +2 entries / cells).
+    spread_signs = np.max([[int(np.unpackbits(a ^ b)[:n_bits].sum()) for a, b in zip(g["signs"], g[f"noise{k}_signs"])]
+                           for k in (1, 2)], axis=0)
+    assert all(d <= 1.5 * sp + 2 for d, sp in zip(differ, np.maximum.accumulate(spread_signs))), (differ, spread_signs.tolist())
+    first_noise = min(next((k for k, d in enumerate(np.unpackbits(g["signs"] ^ g[f"noise{q}_signs"], axis=1)[:, :n_bits].sum(1)) if d), steps)
+                      for q in (1, 2))
+    assert agree >= first_noise, (agree, first_noise)
     dev = {k: float(np.abs(r[k] / g[k] - 1).max()) for k in ("mse", "bpp", "mb", "n_samples", "num_rays")}
-    print(tag, "fused" if fused else "unfused", "max relative deviation per series:", dev,
-          "occupied diff", float(np.abs(r["occupied"] - g["occupied"]).max()))
-    assert dev["mse"] <= 0.03 and dev["bpp"] <= 0.015 and dev["mb"] <= 0.015, dev
-    assert dev["n_samples"] <= 0.02 and dev["num_rays"] <= 0.02, dev
-    assert np.abs(r["occupied"] - g["occupied"]).max() <= 2
-    sign = (tr.field.mlp_base.encoding_xyz.params.detach().cpu().numpy() >= 0)
-    flipped = float((sign != g["final_sign_xyz"]).mean())
-    print("signs that differ at the end:", flipped)
-    assert flipped <= 0.02
-    w0 = float(tr.field.mlp_base.network[0].weight.detach().norm().item())
-    assert abs(w0 - float(g["final_w0_norm"])) <= 1e-3 * float(g["final_w0_norm"])
+    ref_dev = {k: max(float(np.abs(g[f"noise{q}_{k}"] / g[k] - 1).max()) for q in (1, 2)) for k in dev}
+    print(tag, "fused" if fused else "unfused", "first differing sign at step", agree, "(perturbed reference:", first_noise, ")",
+          "max relative deviation per series:", {k: round(v, 4) for k, v in dev.items()}, "reference's own spread:",
+          {k: round(v, 4) for k, v in ref_dev.items()}, "signs differing at the end:", differ[-1], "vs", int(spread_signs[-1]))
+    for k in dev:
+        assert dev[k] <= 1.5 * ref_dev[k] + 1e-3, (k, dev[k], ref_dev[k])
+    occ_dev = max(float(np.abs(g[f"noise{q}_occupied"] - g["occupied"]).max()) for q in (1, 2))
+    assert np.abs(r["occupied"] - g["occupied"]).max() <= 1.5 * occ_dev + 2
+    # the smoothed end of the run: mean over the last 10 steps (two perturbed runs are a thin sample of the spread of
+    # a 10-step mean whose terms swing between 0.7 and 2.0 with the context window drawn: 10 % floor)
+    for k in ("mse", "bpp"):
+        mine, want = r[k][-10:].mean(), g[k][-10:].mean()
+        own = max(abs(g[f"noise{q}_{k}"][-10:].mean() / want - 1) for q in (1, 2))
+        assert abs(mine / want - 1) <= 1.5 * own + 0.10, (k, mine, want, own)
