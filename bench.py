@@ -183,6 +183,44 @@ def cpu_baseline(w):
     return port, torch_fallback
 
 
+def compulsory_backward_bytes(x, offsets_host):
+    """Bytes a backward call on these points cannot avoid: the points and every upstream gradient row once, every
+    touched table row read and written once.  The touched rows are counted with torch on the GPU (index arithmetic
+    of gridencoder.cu:45-87 in int64, uint32 wrap by masking), outside the timed region."""
+    n = x.shape[0]
+    touched = 0
+    primes = (1, 2654435761, 805459861)
+    for l, R in enumerate(synthetic.RES_16L):
+        rows = offsets_host[l + 1] - offsets_host[l]
+        p0 = torch.floor(x * float(R - 2) + 0.5).to(torch.int64)
+        dense = R ** 3 <= rows
+        keys = []
+        for corner in range(8):
+            c = p0 + torch.tensor([(corner >> 0) & 1, (corner >> 1) & 1, (corner >> 2) & 1], device=x.device)
+            if dense:
+                idx = c[:, 0] + c[:, 1] * R + c[:, 2] * R * R
+            else:
+                idx = ((c[:, 0] * primes[0]) ^ (c[:, 1] * primes[1]) ^ (c[:, 2] * primes[2])) & 0xFFFFFFFF
+            keys.append(idx % rows)
+        touched += int(torch.unique(torch.cat(keys)).numel())
+    return {"points": n * 4 * D, "gradient_rows": n * L * F * 4, "touched_table_rows": touched,
+            "table_rmw": 2 * touched * F * 4, "total": n * 4 * D + n * L * F * 4 + 2 * touched * F * 4}
+
+
+def kernel_source_hashes():
+    """git blob hashes of the kernel sources, as tools/summarise_pmc_r03.py stores them next to the measured traffic."""
+    import hashlib
+    out = {}
+    for rel in ("cnc_amd/csrc/grid_encode.hip", "cnc_amd/csrc/grid_encode_merge.hip", "cnc_amd/csrc/grid_encode_binned.hip",
+                "cnc_amd/csrc/grid_encode_overlap.hip", "cnc_amd/csrc/encoder_common.hpp", "cnc_amd/csrc/common.hpp",
+                "cnc_amd/csrc/march.hip"):
+        path = os.path.join(ROOT, rel)
+        if os.path.exists(path):
+            data = open(path, "rb").read()
+            out[rel] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    return out
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N copies of this script, one rank per GPU,
     with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); rank 0 prints the line."""
@@ -347,6 +385,18 @@ def main():
             extra.launch("grid_encode_forward_fp32_table(uniform pts)", n, lambda: enc.grid_encode_forward(
                 xs, w["table"], w["offsets"], w["resolutions"], w["out"], n, D, F, L, 0, 128, 0.0, None, None, None,
                 ste_binary=True))
+        if w.get("probe_chunk") is not None and w["probe_chunk"].shape[0] == CHUNK:
+            # the forward as the product's field issues it: point-major rows straight into a 256-wide MLP input
+            # (out_ld / out_col, cnc_amd/field.py) instead of the [L, N, F] array of the drop-in entry
+            feat = torch.empty((CHUNK, 256), device=dev)
+            for it in range(7):
+                if it == 2:
+                    torch.cuda.synchronize()
+                    extra.pending = [p_ for p_ in extra.pending if not p_[0].startswith("grid_encode_forward(point-major")]
+                extra.launch("grid_encode_forward(point-major into a [N,256] MLP input)", CHUNK, lambda: enc.grid_encode_forward_bits(
+                    w["probe_chunk"], w["bits"], w["offsets"], w["resolutions"], feat, CHUNK, D, F, L, 128, None, None, None,
+                    out_ld=256, out_col=0))
+            del feat
         ngrid.traverse_grids(w["rays_o"], w["rays_d"], w["binaries"], w["aabbs"], step_size=STEP_SIZE, cone_angle=0.0)
         for _ in range(3):      # the `nerfacc.csrc` drop-in entry (intervals + samples, 27 B / sample), for the record
             extra.launch("traverse_grids drop-in (ray_aabb+traverse x2+cumsum)", w["rays_o"].shape[0],
@@ -413,22 +463,59 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             tj = json.load(open(tp))
-        traffic = tj.get(dom_name)
-        measured = traffic / launch_s if traffic else None
+        # the byte counts are tied to the kernels they were measured on: a kernel source that changed since
+        # (git blob hash) marks them stale
+        measured_on = tj.get("_sources", {})
+        now = kernel_source_hashes()
+        stale = sorted(k for k in now if measured_on.get(k) != now[k]) if measured_on else ["(no source hashes in traffic.json)"]
+        req_peak = float(tj.get("_fabric_request_rate_peak_G_per_s", 50.0)) * 1e9
+
+        def entry_of(name):
+            e = tj.get(name)
+            return e if isinstance(e, dict) else None
+
+        def rates(e, dur):
+            """calibrated bytes / s, both bounds, and the L2 -> fabric request rate of one entry over `dur` seconds"""
+            if not e:
+                return {}
+            req = (e.get("read_requests") or 0) + (e.get("write_requests") or 0)
+            return {"traffic": e["bytes"], "achieved": e["bytes"] / dur / 1e9, "frac": e["bytes"] / dur / HBM_PEAK,
+                    "traffic_bounds": [e["bytes_min(read requests x 64 B)"], e["bytes_max(read requests x 128 B)"]],
+                    "frac_bounds": [e["bytes_min(read requests x 64 B)"] / dur / HBM_PEAK,
+                                    e["bytes_max(read requests x 128 B)"] / dur / HBM_PEAK],
+                    "fabric_requests": {"read": e.get("read_requests"), "write": e.get("write_requests"),
+                                        "achieved_G_per_s": req / dur / 1e9, "peak_G_per_s": req_peak / 1e9,
+                                        "frac": req / dur / req_peak}}
+
+        dom = entry_of(dom_name)
+        rr = rates(dom, launch_s)
         nb = (enc.plan_binned_levels(synthetic.RES_16L, w["offsets_host"], D, F, CHUNK) or (0, 0))[0]
-        desc = {"grid_encode_backward": f"one cnc_grid_encode_backward_binned call = k_grid_encode_bwd_merge ({L - nb} coarse "
+        desc = {"grid_encode_backward": f"one cnc_grid_encode_backward_overlapped call = k_grid_encode_bwd_merge ({L - nb} coarse "
                                         f"levels, runs merged across rays, atomics) + k_bwd_bin + k_bwd_owner ({nb} finest levels, LDS "
                                         "accumulation); avg_launch_ms is the whole call between two events on the "
-                                        "caller's stream (side streams joined before the closing event)",
+                                        "caller's stream (the library joins its side streams before returning)",
                 "grid_encode_forward": "k_grid_encode_fwd_bits"}
+        comp = None
+        if dom_name == "grid_encode_backward" and w.get("probe_chunk") is not None and w["probe_chunk"].shape[0] == CHUNK:
+            comp = compulsory_backward_bytes(w["probe_chunk"], w["offsets_host"])
         roofline = {"kernel": dom_name, "kernel_parts": desc[dom_name], "bound": "hbm",
-                    "achieved": None if measured is None else measured / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": None if measured is None else measured / HBM_PEAK, "traffic": traffic,
-                    "frac_basis": "measured HBM bytes per launch (profiles/traffic.json: 2*FETCH_SIZE + WRITE_SIZE, rocprofv3 "
-                                  "--pmc) / avg_launch_ms / 8 TB/s",
+                    "achieved": rr.get("achieved"), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                    "frac": rr.get("frac"), "traffic": rr.get("traffic"),
+                    "frac_basis": "HBM bytes per launch from rocprofv3 --pmc passes (profiles/traffic.json), corrected per access "
+                                  "class as calibrated in profiles/r03_counter_calibration.md — a streamed read request = 128 B "
+                                  "(FETCH_SIZE tallies 64), a gathered 32-byte row = one 64-byte request, WRITE_SIZE as reported — "
+                                  "over avg_launch_ms over 8 TB/s.  frac_bounds: every read request 64 B / 128 B.",
+                    "frac_bounds": rr.get("frac_bounds"), "traffic_bounds": rr.get("traffic_bounds"),
+                    "traffic_stale": bool(stale), "traffic_stale_sources": stale,
+                    "fabric_requests": rr.get("fabric_requests"),
+                    "fabric_requests_note": "the finest levels sit on the L2 -> fabric REQUEST rate, not on bytes: a gather of one "
+                                            "32-byte gradient row costs a whole request (tools/fetch_calib.hip: 51.5 G gathers/s "
+                                            "from 2 GiB, a 16 B/lane stream 46.9 G requests/s = 6.0 TB/s)",
                     "achieved_algorithmic": algorithmic / 1e9,
                     "algorithmic_over_peak": algorithmic / HBM_PEAK,
-                    "traffic_over_algorithmic": None if not traffic else traffic / (bytes_per * k[2] / k[1]),
+                    "traffic_over_algorithmic": None if not rr else rr["traffic"] / (bytes_per * k[2] / k[1]),
+                    "compulsory_bytes": None if comp is None else comp["total"], "compulsory_parts": comp,
+                    "traffic_over_compulsory": None if (comp is None or not rr) else rr["traffic"] / comp["total"],
                     "bytes_per_sample": bytes_per, "samples_per_launch": k[2] / k[1],
                     "avg_launch_ms": launch_s * 1e3}
         # each half of the backward call against the bound it actually sits on
@@ -437,29 +524,35 @@ def main():
         pf = extra.acc.get("bwd_finest_levels(k_bwd_bin+k_bwd_owner), alone")
         if pc:
             dur = pc[0] / pc[1]
-            req = tj.get("k_grid_encode_bwd_merge_atomic_requests")
+            e = entry_of("k_grid_encode_bwd_merge")
+            req = None if not e else e.get("atomic_requests")
             parts["k_grid_encode_bwd_merge"] = {
                 "avg_ms": dur * 1e3, "bound": "memory-side fp32 atomic requests (tools/atomic_probe.hip: 21 G requests/s)",
                 "note": "since the cells are merged across rays the kernel is vector-issue-bound, not request-bound: without "
                         "its atomics it runs 10 % faster, without the MFMA accumulation 35 % (DESIGN 4.2b, second pass)",
                 "atomic_requests_per_launch": req, "achieved_G_requests_per_s": None if not req else req / dur / 1e9,
                 "peak_G_requests_per_s": 21.0, "frac": None if not req else req / dur / 21e9}
+            parts["k_grid_encode_bwd_merge"].update({"hbm_" + k_: v for k_, v in rates(e, dur).items() if k_ in ("traffic", "frac")})
         if pf:
             dur = pf[0] / pf[1]
-            tb = tj.get("k_bwd_bin+k_bwd_owner")
-            parts["k_bwd_bin+k_bwd_owner"] = {
-                "avg_ms": dur * 1e3, "bound": "hbm", "traffic": tb,
-                "achieved_GBps": None if not tb else tb / dur / 1e9, "peak_GBps": HBM_PEAK / 1e9,
-                "frac": None if not tb else tb / dur / HBM_PEAK}
+            e = entry_of("k_bwd_bin+k_bwd_owner")
+            parts["k_bwd_bin+k_bwd_owner"] = dict({"avg_ms": dur * 1e3, "bound": "L2 -> fabric request rate (gathers); hbm bytes beside it",
+                                                   "peak_GBps": HBM_PEAK / 1e9}, **rates(e, dur))
         roofline["parts"] = parts
-        tf = tj.get("grid_encode_forward")
+        ef = entry_of("grid_encode_forward")
         fl = kf[0] / kf[1]
-        other = {"kernel": "grid_encode_forward", "bound": "L2->L1 line rate of the byte gathers (DESIGN 4.3); HBM only for "
-                                                           "the 512 B/sample output stream",
-                 "traffic": tf, "achieved": None if not tf else tf / fl / 1e9, "unit": "GB/s",
-                 "frac": None if not tf else tf / fl / HBM_PEAK,
-                 "achieved_algorithmic": BYTES_FWD * kf[2] / kf[0] / 1e9, "bytes_per_sample": BYTES_FWD,
-                 "avg_launch_ms": fl * 1e3}
+        other = dict({"kernel": "grid_encode_forward", "bound": "L2->L1 line rate of the byte gathers (DESIGN 4.3); HBM only for "
+                                                               "the 512 B/sample output stream", "unit": "GB/s",
+                      "achieved_algorithmic": BYTES_FWD * kf[2] / kf[0] / 1e9, "bytes_per_sample": BYTES_FWD,
+                      "avg_launch_ms": fl * 1e3}, **rates(ef, fl))
+        pm = extra.acc.get("grid_encode_forward(point-major into a [N,256] MLP input)")
+        if pm:
+            other["point_major_variant"] = {
+                "avg_launch_ms": pm[0] / pm[1] * 1e3, "samples_per_s": pm[2] / pm[0],
+                "note": "the same gather writing point-major rows into a [N, 256] feature matrix (out_ld=256), the form the "
+                        "product's field uses (no [L,N,F] array, no permute / cat afterwards); the 512 B/sample still have to "
+                        "reach HBM once — only a gather fused into the MLP kernel would remove them",
+                "output_bytes_per_sample": L * F * 4}
         out = {
             "metric": "ray-samples/s/GPU (16Lx2^19xF8 grid)", "value": samples_all / elapsed_max,
             "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): the judged bench line, rocprofv3 kernel stats of the same command, PMC passes
+# (FETCH_SIZE / WRITE_SIZE / raw L2->fabric request counters / TCC_ATOMIC_sum: separate runs, counters only, no trace
+# domains), the bench without the stream overlap, the counter calibration probe, and the kernel stats of the
+# full-size training step.  -> gpurun_out/r03/ ; tools/summarise_pmc_r03.py turns them into profiles/r03_* and
+# profiles/traffic.json (with the git blob hashes of the kernels it was measured on).
+set -u
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/r03
+rm -rf $OUT
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+WHAT=${1:-all}
+timeout 1200 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
+CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train-step"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $ROOT/bench.py --no-cpu-baseline --no-train-step > $OUT/stats.json 2> $OUT/stats.log
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $CMD > $OUT/pmc_fetch.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $CMD > $OUT/pmc_write.log 2>&1
+timeout 900 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT/pmc_req -o p -- $CMD > $OUT/pmc_req.log 2>&1
+timeout 900 rocprofv3 --pmc TCC_ATOMIC_sum --output-format csv -d $OUT/pmc_atomic -o p -- $CMD > $OUT/pmc_atomic.log 2>&1
+CNC_BWD_OVERLAP=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_no_overlap -o bench -- python $ROOT/bench.py --no-cpu-baseline --no-train-step > $OUT/bench_no_overlap.json 2> $OUT/stats_no_overlap.log
+if [ "$WHAT" = "all" ]; then
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_train -o train -- python $ROOT/tools/bench_train.py --no-profile > $OUT/train.log 2>&1
+  bash $ROOT/tools/collect_calib.sh > $OUT/calib.log 2>&1
+fi
+find $OUT -name "*kernel_trace.csv" -delete      # large; the stats csv is what is kept
+find $OUT -name "*.db" -delete
+ls -R $OUT | head -60
