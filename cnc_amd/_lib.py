@@ -106,6 +106,7 @@ RESTYPES = {"cnc_grid_encode_backward_binned_workspace": C.c_uint64,
 
 CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2
+CNC_FLAG_BIN_LANE_STORES = 4
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
 ABI_VERSION = 21          # cnc_abi_version() of the library this table was written for

@@ -120,7 +120,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         n_binned, level_rows = int(binned[0]), int(binned[1])
         L = _lib.lib()
         nbytes = int(L.cnc_grid_encode_backward_binned_workspace(int(N), n_binned, level_rows))
-        flags = _lib.CNC_FLAG_STE_BINARY if ste_binary else 0
+        flags = (_lib.CNC_FLAG_STE_BINARY if ste_binary else 0) | (_lib.CNC_FLAG_BIN_LANE_STORES if _BIN_LANE_STORES else 0)
         if overlap_streams and _OVERLAP_ENABLED:
             # coarse levels on the caller's stream, the finest ones on side streams the library owns through a plan
             # object: fork, join and the split into groups live behind the C ABI (grid_encode_overlap.hip)
@@ -155,6 +155,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
 _WORKSPACES = {}
 _PLANS = {}
 _OVERLAP_ENABLED = os.environ.get("CNC_BWD_OVERLAP", "1") != "0"   # measurement switch (profiles/)
+_BIN_LANE_STORES = os.environ.get("CNC_BWD_BIN_LANE_STORES", "0") == "1"   # measurement switch: the round-2 bin pass
 
 
 def _plan(device, caller_stream):

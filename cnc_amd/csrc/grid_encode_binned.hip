@@ -184,6 +184,198 @@ __global__ __launch_bounds__(1024) void k_bwd_bin(BinnedArgs a)
     }
 }
 
+// ---- pass 1, second form: the block's items leave in BIN ORDER ------------------------------------------------
+// k_bwd_bin above lets every lane store its own items: the 8 or so items a block adds to one bin are contiguous in
+// memory but written by different lanes of different waves at different times, and the L2 merges only part of them
+// into full sectors — rocprofv3 counts 9.6 M write requests per 7-level pass for 235 MB of items (1.5 items per
+// 64-byte request), and with everything else overlapped the whole backward call sits on the L2 -> fabric request
+// rate (53 M requests in 1.06 ms = 50 G/s, the ceiling of tools/fetch_calib.hip).  Here the block sorts the SOURCE
+// IDS of its items by bin in LDS (a 16-bit id per item: 40 KB where the 16-byte payloads would need 256 KB) and then
+// walks the sorted list: lane t rebuilds item t from its sample (the corner set-up again: vector ALU is what this
+// pass has to spare) and stores it, so that a wave-instruction writes 64 consecutive slots of the sorted order —
+// whole (block, bin) runs, 128 contiguous bytes on average.
+constexpr uint32_t kSortBins = 2048;                                  // three LDS arrays of that many words
+#ifndef CNC_SORT_SAMPLES_PER_THREAD
+#define CNC_SORT_SAMPLES_PER_THREAD 4
+#endif
+constexpr uint32_t kSortSamplesPerThread = CNC_SORT_SAMPLES_PER_THREAD;   // 4096 samples per block: runs of 8 items per bin
+constexpr uint32_t kSortItems = 1024 * kSortSamplesPerThread * 5;     // source ids per block (typically 4.2 per sample)
+
+// item of corner pair p (half 0: the x corner's bin, carrying both corners when they share it; half 1: the x+1
+// corner's bin when it differs) — exactly what k_bwd_bin emits
+__device__ __forceinline__ Item pair_item(const Corners<3, false>& c, uint32_t sample, uint32_t p, uint32_t half, uint32_t& bin,
+                                          uint32_t& mask)
+{
+    // p may be a run-time value: pick the pair with selects (indexing the corner arrays dynamically would send them
+    // to scratch memory)
+    bool     v0 = false, v1 = false;
+    uint32_t r0 = 0, r1 = 0;
+    float    w0 = 0, w1 = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        const bool hit = q == p;
+        v0 = hit ? c.valid[2 * q] : v0;
+        v1 = hit ? c.valid[2 * q + 1] : v1;
+        r0 = hit ? c.row[2 * q] : r0;
+        r1 = hit ? c.row[2 * q + 1] : r1;
+        w0 = hit ? c.w[2 * q] : w0;
+        w1 = hit ? c.w[2 * q + 1] : w1;
+    }
+    const uint32_t b0 = r0 >> kSlabLog2, b1 = r1 >> kSlabLog2;
+    const bool     together = v0 && v1 && b1 == b0;
+    Item           it;
+    it.sample = sample;
+    it.w0 = w0 * c.wn_re;
+    it.w1 = w1 * c.wn_re;
+    mask = half ? 2u : (together ? 3u : 1u);
+    bin = half ? b1 : b0;
+    it.rows = (r0 & (kSlab - 1)) | (r1 & (kSlab - 1)) << 12 | mask << 24;
+    return it;
+}
+
+template <uint32_t F, bool STE>
+__global__ __launch_bounds__(1024) void k_bwd_bin_sorted(BinnedArgs a)
+{
+    __shared__ uint32_t s_start[kSortBins];       // items of this block per bin, then their first position in s_src
+    __shared__ uint32_t s_base[kSortBins];        // first slot of the block's run inside the bin (global reservation)
+    __shared__ uint16_t s_src[kSortItems];        // source ids in bin order: sample-in-block | pair << 13 | half << 15
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_total;
+    const uint32_t slot = a.first_level + blockIdx.y;
+    const uint32_t off = (uint32_t)a.offsets[slot];
+    const uint32_t hs = (uint32_t)a.offsets[slot + 1] - off;
+    const uint32_t R = (uint32_t)a.resolutions[slot];
+    const bool     binnable = div_up(hs, kSlab) <= a.bins;
+    const bool     mask_on = STE && (a.clip_count == nullptr || *a.clip_count != 0);
+    uint32_t*      bin_count = a.bin_count + (size_t)blockIdx.y * a.bins;
+    Item*          items = a.items + (size_t)blockIdx.y * a.bins * a.cap;
+    const uint32_t base_i = blockIdx.x * 1024 * kSortSamplesPerThread;
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t V = F < 4 ? F : 4;
+
+    auto spill_corners = [&](const Corners<3, false>& c, uint32_t i, uint32_t corners) {
+        float        g[F];
+        const float* gp = a.grad + feat_index(a.lay, slot, a.N, i, F);
+#pragma unroll
+        for (uint32_t q = 0; q < F; q += V) {
+            float gv[V];
+            load_vec<V>(gp + q, gv);
+#pragma unroll
+            for (uint32_t j = 0; j < V; j++) g[q + j] = gv[j];
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++)
+            if ((corners >> q) & 1u) atomic_row<F, STE>(a, mask_on, off + c.row[q], c.w[q] * c.wn_re, g);
+    };
+
+    if (!binnable) {      // a level with more rows than the bins were sized for: every corner goes to atomics
+#pragma unroll
+        for (uint32_t k = 0; k < kSortSamplesPerThread; k++) {
+            const uint32_t i = base_i + k * 1024 + tid;
+            float x[3];
+            if (!(i < a.N && load_point<3>(a.inputs, i, x))) continue;
+            Corners<3, false> c;
+            c.setup(x, R, hs, 0, nullptr);
+            uint32_t all = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) all |= (c.valid[q] ? 1u : 0u) << q;
+            if (all) spill_corners(c, i, all);
+        }
+        return;
+    }
+
+    for (uint32_t b = tid; b < kSortBins; b += 1024) s_start[b] = 0;
+    __syncthreads();
+    // ---- count: every item takes its rank inside its bin; (bin, rank) stay in registers ----
+    uint32_t key[kSortSamplesPerThread][8];
+#pragma unroll
+    for (uint32_t k = 0; k < kSortSamplesPerThread; k++) {
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) key[k][q] = 0xFFFFFFFFu;
+        const uint32_t i = base_i + k * 1024 + tid;
+        float x[3];
+        if (i < a.N && load_point<3>(a.inputs, i, x)) {
+            Corners<3, false> c;
+            c.setup(x, R, hs, 0, nullptr);
+#pragma unroll
+            for (uint32_t p = 0; p < 4; p++) {
+                const bool     v0 = c.valid[2 * p], v1 = c.valid[2 * p + 1];
+                const uint32_t b0 = c.row[2 * p] >> kSlabLog2, b1 = c.row[2 * p + 1] >> kSlabLog2;
+                if (v0) key[k][2 * p] = b0 | atomicAdd(&s_start[b0], 1u) << 11;
+                if (v1 && !(v0 && b1 == b0)) key[k][2 * p + 1] = b1 | atomicAdd(&s_start[b1], 1u) << 11;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- reserve (one global atomic per non-empty bin of this block) and exclusive prefix over the bins ----
+    const uint32_t n0 = s_start[2 * tid], n1 = s_start[2 * tid + 1];
+    s_base[2 * tid] = (n0 && 2 * tid < a.bins) ? atomicAdd(&bin_count[2 * tid], n0) : 0u;
+    s_base[2 * tid + 1] = (n1 && 2 * tid + 1 < a.bins) ? atomicAdd(&bin_count[2 * tid + 1], n1) : 0u;
+    uint32_t incl = n0 + n1;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if ((tid & 63) >= d) incl += up;
+    }
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 16; w++) before += (w < (tid >> 6)) ? s_wave[w] : 0u;
+    const uint32_t excl = before + incl - (n0 + n1);
+    s_start[2 * tid] = excl;
+    s_start[2 * tid + 1] = excl + n0;
+    if (tid == 1023) s_total = before + incl;
+    __syncthreads();
+    const uint32_t total = s_total;
+    if (total > kSortItems) {
+        // more items than the id list holds (straddling pairs everywhere): this block stores lane by lane, as
+        // k_bwd_bin does
+#pragma unroll
+        for (uint32_t k = 0; k < kSortSamplesPerThread; k++) {
+            const uint32_t i = base_i + k * 1024 + tid;
+            float x[3];
+            if (!(i < a.N && load_point<3>(a.inputs, i, x))) continue;
+            Corners<3, false> c;
+            c.setup(x, R, hs, 0, nullptr);
+            uint32_t spill = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                if (key[k][q] == 0xFFFFFFFFu) continue;
+                uint32_t bin, mask;
+                const Item it = pair_item(c, i, q >> 1, q & 1u, bin, mask);
+                const uint32_t at = s_base[bin] + (key[k][q] >> 11);
+                if (at < a.cap) items[(size_t)bin * a.cap + at] = it;
+                else spill |= mask << (q & ~1u);
+            }
+            if (spill) spill_corners(c, i, spill);
+        }
+        return;
+    }
+    // ---- source ids into bin order ----
+#pragma unroll
+    for (uint32_t k = 0; k < kSortSamplesPerThread; k++)
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++)
+            if (key[k][q] != 0xFFFFFFFFu)
+                s_src[s_start[key[k][q] & 0x7FFu] + (key[k][q] >> 11)] = (uint16_t)((k * 1024 + tid) | (q >> 1) << 13 | (q & 1u) << 15);
+    __syncthreads();
+    // ---- walk the sorted list: consecutive lanes, consecutive slots ----
+    for (uint32_t pos = tid; pos < total; pos += 1024) {
+        const uint32_t src = s_src[pos];
+        const uint32_t i = base_i + (src & 0x1FFFu);
+        float x[3];
+        load_point<3>(a.inputs, i, x);
+        Corners<3, false> c;
+        c.setup(x, R, hs, 0, nullptr);
+        uint32_t bin, mask;
+        const Item it = pair_item(c, i, (src >> 13) & 3u, (src >> 15) & 1u, bin, mask);
+        const uint32_t at = s_base[bin] + (pos - s_start[bin]);
+        if (at < a.cap) items[(size_t)bin * a.cap + at] = it;
+        else spill_corners(c, i, mask << (2 * ((src >> 13) & 3u)));
+    }
+}
+
 // LDS accumulators are stored by 16-byte chunk: acc[chunk][row][4 floats].  With row-major
 // [row][F] a 16-byte access of random rows only ever touches every other 16-byte bank group (the
 // first halves of 32-byte rows), doubling the conflicts of the read-modify-write that bounds pass 2.
@@ -365,14 +557,18 @@ __global__ __launch_bounds__(64) void k_bwd_owner(BinnedArgs a)
 }
 
 template <uint32_t F>
-static void launch_binned(const BinnedArgs& a, uint32_t n_binned, bool ste, hipStream_t s)
+static void launch_binned(const BinnedArgs& a, uint32_t n_binned, bool ste, bool sorted, hipStream_t s)
 {
-    const dim3 g1(div_up(a.N, 1024 * kBinSamplesPerThread), n_binned), g2(a.bins * div_up(a.cap, a.part), n_binned);
+    sorted = sorted && a.bins <= kSortBins;
+    const dim3 g1(div_up(a.N, 1024 * (sorted ? kSortSamplesPerThread : kBinSamplesPerThread)), n_binned),
+        g2(a.bins * div_up(a.cap, a.part), n_binned);
     if (ste) {
-        hipLaunchKernelGGL((k_bwd_bin<F, true>), g1, dim3(1024), 0, s, a);
+        if (sorted) hipLaunchKernelGGL((k_bwd_bin_sorted<F, true>), g1, dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL((k_bwd_bin<F, true>), g1, dim3(1024), 0, s, a);
         hipLaunchKernelGGL((k_bwd_owner<F, true>), g2, dim3(64), 0, s, a);
     } else {
-        hipLaunchKernelGGL((k_bwd_bin<F, false>), g1, dim3(1024), 0, s, a);
+        if (sorted) hipLaunchKernelGGL((k_bwd_bin_sorted<F, false>), g1, dim3(1024), 0, s, a);
+        else hipLaunchKernelGGL((k_bwd_bin<F, false>), g1, dim3(1024), 0, s, a);
         hipLaunchKernelGGL((k_bwd_owner<F, false>), g2, dim3(64), 0, s, a);
     }
 }
@@ -457,10 +653,11 @@ extern "C" int cnc_grid_encode_backward_binned(const float* grad, const float* i
                  bins, (uint32_t)cap, owner_part(N, bins, cap), ws, (Item*)((char*)workspace + heads * kHeadBytes), ste_clip_count,
                  FeatLayout{grad_ld, grad_col}};
     const bool ste = (flags & CNC_FLAG_STE_BINARY) != 0;
+    const bool sorted = (flags & CNC_FLAG_BIN_LANE_STORES) == 0;
     switch (F) {
-    case 2: launch_binned<2>(a, n_binned, ste, s); break;
-    case 4: launch_binned<4>(a, n_binned, ste, s); break;
-    default: launch_binned<8>(a, n_binned, ste, s); break;
+    case 2: launch_binned<2>(a, n_binned, ste, sorted, s); break;
+    case 4: launch_binned<4>(a, n_binned, ste, sorted, s); break;
+    default: launch_binned<8>(a, n_binned, ste, sorted, s); break;
     }
     return launch_status();
 }

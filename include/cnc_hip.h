@@ -51,6 +51,9 @@ extern "C" {
                                             * levels (fewer same-row atomics in flight; 0.58 -> 0.50 ms on the 9
                                             * coarse levels of the 16-level bench grid).  With fine levels in
                                             * the call the interleaving costs cache locality: leave it unset. */
+#define CNC_FLAG_BIN_LANE_STORES 4u   /* measurement switch for cnc_grid_encode_backward_binned / _overlapped (same
+                                       * result): the round-2 bin pass, every lane storing its own items, instead of
+                                       * the default that writes a block's items in bin order (k_bwd_bin_sorted) */
 
 const char* cnc_error_string(int code);
 int         cnc_abi_version(void);              /* bumps when a signature below changes */
