@@ -529,7 +529,7 @@ def main():
             parts["k_grid_encode_bwd_merge"] = {
                 "avg_ms": dur * 1e3, "bound": "memory-side fp32 atomic requests (tools/atomic_probe.hip: 21 G requests/s)",
                 "note": "since the cells are merged across rays the kernel is vector-issue-bound, not request-bound: without "
-                        "its atomics it runs 10 % faster, without the MFMA accumulation 35 % (DESIGN 4.2b, second pass)",
+                        "its atomics it runs 10 % faster, without the MFMA accumulation 35 % (docs/engineering_log.md §4.2b, second pass)",
                 "atomic_requests_per_launch": req, "achieved_G_requests_per_s": None if not req else req / dur / 1e9,
                 "peak_G_requests_per_s": 21.0, "frac": None if not req else req / dur / 21e9}
             parts["k_grid_encode_bwd_merge"].update({"hbm_" + k_: v for k_, v in rates(e, dur).items() if k_ in ("traffic", "frac")})
@@ -541,7 +541,7 @@ def main():
         roofline["parts"] = parts
         ef = entry_of("grid_encode_forward")
         fl = kf[0] / kf[1]
-        other = dict({"kernel": "grid_encode_forward", "bound": "L2->L1 line rate of the byte gathers (DESIGN 4.3); HBM only for "
+        other = dict({"kernel": "grid_encode_forward", "bound": "L2->L1 line rate of the byte gathers (docs/engineering_log.md §4.3); HBM only for "
                                                                "the 512 B/sample output stream", "unit": "GB/s",
                       "achieved_algorithmic": BYTES_FWD * kf[2] / kf[0] / 1e9, "bytes_per_sample": BYTES_FWD,
                       "avg_launch_ms": fl * 1e3}, **rates(ef, fl))

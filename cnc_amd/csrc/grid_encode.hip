@@ -2,7 +2,7 @@
 //
 // Stands in for gridencoder/src/gridencoder.cu of the reference (kernel_grid :96-396,
 // kernel_grid_backward :399-585, cnt_np_embed{,_backward} :873-1087) behind the C ABI of
-// include/cnc_hip.h.  Design notes:
+// include/cnc_hip.h.  Design notes (docs/engineering_log.md §4.1-4.2):
 //   * A table row is F floats.  A row is fetched by G = F/V adjacent lanes, V = min(F,4) floats
 //     (<= 16 B, one global_load_dwordx4) per lane, so one wave-instruction touches 64/G rows and
 //     the G lanes of a row land in one 16B-aligned span of a single cache line.  No lane ever

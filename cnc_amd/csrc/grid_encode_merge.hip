@@ -6,7 +6,7 @@
 // (level 0) to 0.46 (resolution 214) open a cell no earlier run of the block visited; in 256 samples it is
 // 0.93-0.96.  This kernel takes kMB = 1024 samples per block, chains the runs of equal cells through a
 // small LDS hash table and sends ONE set of atomics per distinct cell — the coarse levels are bound by the
-// memory-side atomic units, so the number of atomic instructions is what their time was
+// memory-side atomic units (docs/engineering_log.md §4.2b), so the number of atomic instructions is what their time was
 // made of.
 //
 // How it got here (9 coarse levels of the bench grid, ms per 2^20 marched samples; k_grid_encode_bwd: 0.523):

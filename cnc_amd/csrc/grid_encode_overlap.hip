@@ -2,7 +2,7 @@
 //
 // The coarse levels (run-merging atomic kernel) and the finest levels (bin + owner passes, grid_encode_binned.hip)
 // write disjoint table rows and lean on different units (memory-side atomics vs. HBM reads / writes), so they
-// overlap: measured 1.12 -> 1.07 ms per 2^20 samples.  Until ABI v20 the fork / join lived in the
+// overlap: measured 1.12 -> 1.07 ms per 2^20 samples (docs/engineering_log.md §4.2b).  Until ABI v20 the fork / join lived in the
 // Python mirror; a C or C++ integrator calling cnc_grid_encode_backward_binned got the serial 1.12 ms.  Here the
 // streams and events belong to a plan object the caller creates once (no globals in the library), and one call
 // does:   fork event on `stream`  ->  finest levels in one or two groups on the plan's side streams

@@ -1,5 +1,5 @@
 """Marched vs surviving samples of the sampler over a full-size training run (the ratio that decides whether the
-front-to-back density evaluation pays)."""
+front-to-back density evaluation pays, docs/engineering_log.md §10)."""
 import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cnc_amd.trainer import TrainConfig, Trainer
