@@ -136,52 +136,63 @@ __device__ __forceinline__ uint32_t load_row_bits(const uint8_t* __restrict__ bi
     }
 }
 
+// P = level slots per lane.  Level-major output ([L, N, F], the drop-in layout): P = 1, a wave stores 64 consecutive
+// rows.  Point-major output (rows of a wider [N, ld] matrix, lay.ld != 0): a lane's F floats of ONE level are half
+// a 64-byte sector whose other half belongs to the next level — written by another block much later, the two halves
+// reach the fabric as two partial write requests (measured: 0.479 instead of 0.241 ms per 2^20 points at 16 levels).
+// With P * F = 16 floats a lane finishes whole 64-byte pieces of its row: 0.451 ms — the rest of the gap is the 1 KB
+// stride between the lanes' rows (a level-major wave writes 2 KB in one piece), which only an LDS transpose of
+// several levels per block would close.
 template <uint32_t D, uint32_t F, bool VXL>
 __global__ __launch_bounds__(256) void k_grid_encode_fwd_bits(
     const float* __restrict__ inputs, const uint8_t* __restrict__ bits,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
-    float* __restrict__ out, uint32_t N, uint32_t Rb, const uint8_t* __restrict__ vxl,
+    float* __restrict__ out, uint32_t N, uint32_t L, uint32_t P, uint32_t Rb, const uint8_t* __restrict__ vxl,
     const int32_t* __restrict__ min_level_id, const int32_t* __restrict__ sat, FeatLayout lay)
 {
     constexpr uint32_t C = 1u << D;
     constexpr uint32_t V = F < 4 ? F : 4;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= N) return;
-    const uint32_t slot = blockIdx.y;
-    const uint32_t level = slot + (min_level_id ? (uint32_t)min_level_id[b] : 0u);
-    float* o = out + feat_index(lay, slot, N, b, F);
-    float  acc[F];
+    float      x[D];
+    const bool inside = load_point<D>(inputs, b, x);
+    const uint32_t first = min_level_id ? (uint32_t)min_level_id[b] : 0u;
+    for (uint32_t pl = 0; pl < P; pl++) {
+        const uint32_t slot = blockIdx.y * P + pl;
+        if (slot >= L) break;
+        const uint32_t level = slot + first;
+        float* o = out + feat_index(lay, slot, N, b, F);
+        float  acc[F];
 #pragma unroll
-    for (uint32_t k = 0; k < F; k++) acc[k] = 0;
-
-    float x[D];
-    if (load_point<D>(inputs, b, x)) {
-        const uint32_t off = (uint32_t)offsets[level];
-        const uint32_t hs = (uint32_t)offsets[level + 1] - off;
-        const uint32_t R = (uint32_t)resolutions[level];
-        Corners<D, VXL> c;
-        c.setup(x, R, hs, Rb, vxl, sat);
-        uint32_t rb[C];
+        for (uint32_t k = 0; k < F; k++) acc[k] = 0;
+        if (inside) {
+            const uint32_t off = (uint32_t)offsets[level];
+            const uint32_t hs = (uint32_t)offsets[level + 1] - off;
+            const uint32_t R = (uint32_t)resolutions[level];
+            Corners<D, VXL> c;
+            c.setup(x, R, hs, Rb, vxl, sat);
+            uint32_t rb[C];
 #pragma unroll
-        for (uint32_t i = 0; i < C; i++)
-            rb[i] = c.valid[i] ? load_row_bits<F>(bits, (uint64_t)off + c.row[i]) : 0u;
+            for (uint32_t i = 0; i < C; i++)
+                rb[i] = c.valid[i] ? load_row_bits<F>(bits, (uint64_t)off + c.row[i]) : 0u;
 #pragma unroll
-        for (uint32_t i = 0; i < C; i++) {
-            // an invalid corner gets weight +0: fmaf(+0, +-1, acc) == acc, no per-feature select
-            const float tw = c.valid[i] ? c.w[i] * c.wn_re : 0.0f;
+            for (uint32_t i = 0; i < C; i++) {
+                // an invalid corner gets weight +0: fmaf(+0, +-1, acc) == acc, no per-feature select
+                const float tw = c.valid[i] ? c.w[i] * c.wn_re : 0.0f;
 #pragma unroll
-            for (uint32_t k = 0; k < F; k++) {
-                const float e = ((rb[i] >> k) & 1u) ? 1.0f : -1.0f;
-                acc[k] = __builtin_fmaf(tw, e, acc[k]);
+                for (uint32_t k = 0; k < F; k++) {
+                    const float e = ((rb[i] >> k) & 1u) ? 1.0f : -1.0f;
+                    acc[k] = __builtin_fmaf(tw, e, acc[k]);
+                }
             }
         }
-    }
 #pragma unroll
-    for (uint32_t k = 0; k < F; k += V) {
-        float v[V];
+        for (uint32_t k = 0; k < F; k += V) {
+            float v[V];
 #pragma unroll
-        for (uint32_t j = 0; j < V; j++) v[j] = acc[k + j];
-        store_vec<V>(o + k, v);
+            for (uint32_t j = 0; j < V; j++) v[j] = acc[k + j];
+            store_vec<V>(o + k, v);
+        }
     }
 }
 
@@ -901,9 +912,15 @@ static void launch_fwd_bits(const float* inputs, const uint8_t* bits, const int3
                             uint32_t Rb, const uint8_t* vxl, const int32_t* mli, const int32_t* sat,
                             FeatLayout lay, hipStream_t s)
 {
-    const dim3 grid(div_up(N, 256), L, 1);
-    if (vxl) hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, true>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, Rb, vxl, mli, sat, lay);
-    else hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, false>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, Rb, vxl, mli, nullptr, lay);
+    // point-major rows: several level slots per lane (see the kernel)
+    uint32_t P = 1;
+    if (lay.ld != 0 && L > 1) {
+        P = F >= 16 ? 1u : 16u / F;      // 16 floats = one 64-byte sector per lane (measured at F = 8, 16 levels, ms per 2^20
+        if (P > L) P = L;                // points: P = 1: 0.479, 2: 0.451, 4: 0.521, 8: 0.571, 16: 0.532; level-major 0.243)
+    }
+    const dim3 grid(div_up(N, 256), div_up(L, P), 1);
+    if (vxl) hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, true>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, L, P, Rb, vxl, mli, sat, lay);
+    else hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, false>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, L, P, Rb, vxl, mli, nullptr, lay);
 }
 
 extern "C" int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* bits,

