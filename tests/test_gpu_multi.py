@@ -136,3 +136,34 @@ def test_two_rank_trainer_replicas_stay_identical(cuda, tmp_path):
     assert a["binaries"] == b["binaries"] and a["rays"] == b["rays"]
     assert a["mse"] != b["mse"]                             # ... trained on different rays
     assert sum(a["absum"]) > 0
+
+
+def test_two_rank_cli_on_a_real_scene_layout(cuda, tmp_path):
+    """`torchrun`-style launch of `python -m cnc_amd.train` on an on-disk nerf_synthetic scene: the loaders live on each
+    rank's own device (here both on cuda:0), every rank trains on its own pixel stream, and only rank 0 evaluates,
+    encodes / decodes and writes the results line."""
+    from test_gpu_cli import _fabricate
+    _fabricate(tmp_path / "data", "lego")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    argv = ["--max_steps", "24", "--n_features", "2", "--sample_num", "20000", "--test_views", "1", "--log2_hashmap_size", "14",
+            "--log2_hashmap_size_2D", "12", "--results", str(tmp_path / "out.txt"), "--out_dir", str(tmp_path / "bits"),
+            "--data_root", str(tmp_path / "data"), "--scene", "lego"]
+    procs = []
+    for rank in range(2):
+        env = _clean_env(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                         CNC_DIST_ONE_DEVICE="1", CNC_DIST_BACKEND="gloo", PYTHONPATH=ROOT)
+        procs.append(subprocess.Popen([sys.executable, "-m", "cnc_amd.train"] + argv, env=env, cwd=str(tmp_path),
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=900)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(o)
+    lines = open(tmp_path / "out.txt").read().strip().splitlines()
+    assert len(lines) == 1 and lines[0].split("\t")[0] == "lego"          # ONE results line, rank 0's
+    assert sum("results line appended" in o for o in outs) == 1
+    assert sum("evaluation:" in o for o in outs) == 1
+    assert len([f for f in os.listdir(tmp_path / "bits") if f.endswith(".b")]) == 33

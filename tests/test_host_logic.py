@@ -343,3 +343,49 @@ def test_bench_refuses_a_world_that_contradicts_gpus():
         env.pop("WORLD_SIZE")
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py")], env=env, capture_output=True, text=True)
         assert r.returncode != 0 and "needs an MI355X" in r.stderr
+
+
+def test_per_rank_sampling_streams_of_the_real_scene_loaders(tmp_path):
+    """Data parallelism: `LoaderDataset.seed_sampling(seed + 1000 * rank)` gives every rank its own stream of images /
+    pixels / backgrounds (without it all ranks would draw the same batch from the identically seeded global
+    generators and the all-reduce would average N copies of one gradient), reproducibly, and leaves the global
+    generators — which the replica-identical draws use — untouched."""
+    import json
+    from PIL import Image
+    from cnc_amd.datasets import SubjectLoader
+    from cnc_amd.trainer import LoaderDataset
+    root = tmp_path / "nerf_synthetic" / "lego"
+    (root / "train").mkdir(parents=True)
+    rng = np.random.default_rng(0)
+    frames = []
+    for i in range(5):
+        Image.fromarray(rng.integers(0, 256, size=(16, 16, 4), dtype=np.uint8), "RGBA").save(root / "train" / f"r_{i}.png")
+        c2w = np.eye(4)
+        c2w[:3, 3] = [0.1 * i, 0.0, 4.0]
+        frames.append({"file_path": f"./train/r_{i}", "transform_matrix": c2w.tolist()})
+    for split in ("train", "test"):
+        json.dump({"camera_angle_x": 0.6911, "frames": frames}, open(root / f"transforms_{split}.json", "w"))
+
+    def dataset(rank):
+        tr = SubjectLoader("lego", str(tmp_path / "nerf_synthetic"), "train", num_rays=32, color_bkgd_aug="random")
+        te = SubjectLoader("lego", str(tmp_path / "nerf_synthetic"), "test")
+        ds = LoaderDataset(tr, te)
+        if rank is not None:
+            ds.seed_sampling(42 + 1000 * rank)
+        return ds
+
+    torch.manual_seed(7)
+    state = torch.get_rng_state()
+    a0, a1, b0 = dataset(0), dataset(1), dataset(0)
+    fa0, fa1, fb0 = a0.fetch(), a1.fetch(), b0.fetch()
+    assert torch.equal(torch.get_rng_state(), state)                       # the global generator was not consumed
+    assert torch.equal(fa0["pixels"], fb0["pixels"]) and torch.equal(fa0["rays"].origins, fb0["rays"].origins)
+    assert torch.equal(fa0["color_bkgd"], fb0["color_bkgd"])               # same rank, same stream
+    assert not torch.equal(fa0["pixels"], fa1["pixels"])                   # another rank, another batch
+    assert not torch.equal(fa0["color_bkgd"], fa1["color_bkgd"])
+    # without a per-rank seed the loaders follow the global generators, as the single-GPU reference does
+    torch.manual_seed(7)
+    g0 = dataset(None).fetch()
+    torch.manual_seed(7)
+    g1 = dataset(None).fetch()
+    assert torch.equal(g0["pixels"], g1["pixels"])
