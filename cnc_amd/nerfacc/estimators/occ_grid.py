@@ -92,12 +92,20 @@ class OccGridEstimator(AbstractEstimator):
                  alpha_fn: Optional[Callable] = None, near_plane: float = 0.0, far_plane: float = 1e10,
                  t_min: Optional[Tensor] = None, t_max: Optional[Tensor] = None, render_step_size: float = 1e-3,
                  early_stop_eps: float = 1e-4, alpha_thre: float = 0.0, stratified: bool = False,
-                 cone_angle: float = 0.0) -> Tuple[Tensor, Tensor, Tensor]:
+                 cone_angle: float = 0.0, front_to_back: Optional[bool] = None) -> Tuple[Tensor, Tensor, Tensor]:
         """Samples (ray_indices, t_starts, t_ends) along the rays: marched with `render_step_size` (growing
         with `cone_angle`) through occupied cells between the near / far planes (optionally per-ray `t_min` /
         `t_max`), jittered by up to one step when `stratified`; if a density (`sigma_fn`) or opacity
         (`alpha_fn`) callback is given, samples behind transmittance < `early_stop_eps` — and, for
-        `alpha_thre` > 0, samples more transparent than min(alpha_thre, mean occupancy) — are dropped."""
+        `alpha_thre` > 0, samples more transparent than min(alpha_thre, mean occupancy) — are dropped.
+
+        `front_to_back` (extension): evaluate `sigma_fn` in depth windows and stop a ray once what is left of it
+        is below `early_stop_eps` (see `_density_front_to_back`).  The callback is then called up to
+        len(CNC_SAMPLER_WINDOWS) + 1 times on SUBSETS of the samples (never on all of them at once) and samples that
+        are never evaluated count as sigma = 0, so it must be a stateless per-sample function returning non-negative
+        densities — true of the radiance field's `query_density`; the survivors are then the same as with one call.
+        None (default): on when the previous call marched at least 4x what it kept and this one marches >= 2^17
+        samples on a GPU; True / False force it."""
         from ...backends import volrend_backend as _K
         n_rays = rays_o.shape[0]
         near = torch.full((n_rays,), float(near_plane), dtype=rays_o.dtype, device=rays_o.device)
@@ -113,7 +121,8 @@ class OccGridEstimator(AbstractEstimator):
         field = sigma_fn if sigma_fn is not None else alpha_fn
         if field is not None and (alpha_thre > 0.0 or early_stop_eps > 0.0):
             n = t_starts.shape[0]
-            if n and sigma_fn is not None and early_stop_eps > 0.0 and self._front_to_back_pays(n):
+            windows = self._front_to_back_pays(n) if front_to_back is None else (bool(front_to_back) and bool(self._WINDOWS))
+            if n and sigma_fn is not None and early_stop_eps > 0.0 and windows:
                 values = self._density_front_to_back(sigma_fn, starts, counts, t_starts, t_ends, early_stop_eps)
             else:
                 values = field(t_starts, t_ends, ray_indices) if n else torch.empty((0,), device=t_starts.device)

@@ -201,17 +201,12 @@ def test_front_to_back_density_gives_the_same_samples(cuda, tmp_path):
     fn = Counting(tr.field, o, d, with_positions=False)
     kw = dict(sigma_fn=fn.density, near_plane=tr.cfg.near_plane, render_step_size=tr.cfg.render_step_size,
               stratified=False, cone_angle=tr.cfg.cone_angle, alpha_thre=tr.cfg.alpha_thre)
-    pays = OccGridEstimator._front_to_back_pays
     outs = []
-    try:
-        for mode in (False, True):
-            OccGridEstimator._front_to_back_pays = lambda self, n, m=mode: m
-            seen.clear()
-            with torch.no_grad():
-                ri, ts, te = tr.estimator.sampling(o, d, **kw)
-            outs.append((ri.clone(), ts.clone(), te.clone(), sum(seen), len(seen)))
-    finally:
-        OccGridEstimator._front_to_back_pays = pays
+    for mode in (False, True):                         # the public switch of `sampling`
+        seen.clear()
+        with torch.no_grad():
+            ri, ts, te = tr.estimator.sampling(o, d, front_to_back=mode, **kw)
+        outs.append((ri.clone(), ts.clone(), te.clone(), sum(seen), len(seen)))
     (ri_a, ts_a, te_a, n_a, calls_a), (ri_b, ts_b, te_b, n_b, calls_b) = outs
     assert calls_a == 1 and 1 < calls_b <= 3
     assert n_b < 0.7 * n_a                              # most of the marched samples are never evaluated
