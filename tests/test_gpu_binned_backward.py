@@ -359,3 +359,38 @@ def test_overlapped_entry_straight_through_the_c_abi(cuda):
     assert rc == 0
     torch.cuda.synchronize()
     assert float((got2 - want).abs().max()) <= 1e-5 * scale
+
+
+@pytest.mark.parametrize("lane_stores", [False, True])
+def test_sorted_bin_pass_overflow_and_round2_switch(cuda, oracle, lane_stores):
+    """k_bwd_bin_sorted keeps a 16-bit source id per item in LDS, 5 per sample; when a block has more (here: every
+    corner pair straddles a slab edge — all points sit in cell x = 255 of a resolution-300 level, so the x and the x+1
+    rows differ in bit 8 — 8 items per sample) it stores lane by lane like the round-2 kernel.  Same gradient, also
+    with the round-2 bin pass selected by CNC_FLAG_BIN_LANE_STORES, and for points that do not straddle."""
+    from cnc_amd import _lib
+    F = 8
+    res = [20, 300]
+    offs, resl, emb = make_grid(res, 12, 3, F, seed=61)
+    rng = np.random.default_rng(62)
+    N = 9000
+    x = rng.uniform(0.02, 0.98, size=(N, 3)).astype(np.float32)
+    x[:6000, 0] = (255.2 / 298.0)                       # floor(x * (R - 2) + 0.5) = 255 for R = 300
+    g = rng.normal(size=(len(res), N, F)).astype(np.float32)
+    want32, acc64 = oracle.grid_encode_backward(g, x, emb, offs, resl, ste_binary=True, want_acc64=True)
+    _, abs64 = oracle.grid_encode_backward(np.abs(g), x, emb, offs, resl, ste_binary=True, want_acc64=True)
+    t = lambda a: torch.as_tensor(a, device=cuda)
+    lib = _lib.lib()
+    ws_bytes = int(lib.cnc_grid_encode_backward_binned_workspace(N, 1, 4096))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=cuda)
+    ge = torch.zeros(emb.shape, dtype=torch.float32, device=cuda)
+    gd, xd, ed, od, rd = t(g), t(x), t(emb), t(offs), t(resl)
+    flags = _lib.CNC_FLAG_STE_BINARY | (_lib.CNC_FLAG_BIN_LANE_STORES if lane_stores else 0)
+    rc = lib.cnc_grid_encode_backward_binned(gd.data_ptr(), xd.data_ptr(), ed.data_ptr(), od.data_ptr(), rd.data_ptr(),
+                                             ge.data_ptr(), N, 3, F, 2, flags, None, 0, 0, 1, 4096, ws.data_ptr(), ws_bytes,
+                                             _lib.stream())
+    _lib.check(rc, "binned")
+    torch.cuda.synchronize()
+    _check_bwd(ge.cpu().numpy(), want32, acc64, abs64, n_terms_max=N * 8)
+    # the binned level really received its gradient through the bins: most items landed there
+    counts = ws[: 16 * 4].view(torch.int32).cpu().numpy()                   # the 16 bin counters lead the workspace
+    assert counts.sum() > 6000 * 7
