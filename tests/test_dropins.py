@@ -118,6 +118,18 @@ def test_torchac_standin_round_trip_and_binary_stream(dropins):
     assert len(st5) * 8 <= h * 1.01 + 64
     with pytest.raises(ValueError):
         torchac.encode_float_cdf(cdf5, s5 + 5)
+    # edges: nothing to code, a one-symbol alphabet, probabilities at and next to 0 / 1 (the +arange(Lp) of the 16-bit
+    # conversion keeps every symbol codable)
+    e = torchac.encode_float_cdf(torch.zeros(0, 3), torch.zeros(0, dtype=torch.int16))
+    assert torchac.decode_float_cdf(torch.zeros(0, 3), e).shape == (0,)
+    one = torch.tensor([[0.0, 1.0]] * 10)
+    z = torch.zeros(10, dtype=torch.int16)
+    assert torch.equal(torchac.decode_float_cdf(one, torchac.encode_float_cdf(one, z)), z)
+    pe = torch.tensor([1e-9, 1 - 1e-9, 0.5, 0.0, 1.0])
+    pu = (1 - pe).unsqueeze(-1)
+    ce = torch.cat([torch.zeros_like(pu), pu, torch.ones_like(pu)], -1)
+    se = torch.tensor([0, 1, 1, 0, 1], dtype=torch.int16)
+    assert torch.equal(torchac.decode_float_cdf(ce, torchac.encode_float_cdf(ce, se, check_input_bounds=True)), se)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree only exists in the build container")
