@@ -4,6 +4,7 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
+[ -x $ROOT/tools/cumask_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $ROOT/tools/cumask_probe $ROOT/tools/cumask_probe.hip
 $ROOT/tools/cumask_probe > $OUT/cumask.jsonl 2> $OUT/cumask.err
 rm -rf $OUT/mfma_r03
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma_r03 -o m -- python $ROOT/tools/mlp_pmc_r03.py > $OUT/mfma_r03.log 2>&1
