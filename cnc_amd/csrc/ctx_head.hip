@@ -160,34 +160,57 @@ struct MlpGrads {
     uint32_t n_rep, rep_stride;               // block b adds into copy b % n_rep, rep_stride floats further on
 };
 
-// One wave reduces outer products over its 64 vertices: acc[k] += sum_v A[v][e / NB] * B[v][e % NB] for the
-// elements e = lane + 64 k < NA * NB this lane owns.  A / B tiles live in the wave's LDS region, pitch +1.
-template <int MAXK>
-__device__ __forceinline__ void outer_acc(const float* tA, uint32_t pitchA, uint32_t NA, const float* tB,
-                                          uint32_t pitchB, uint32_t NB, uint32_t lane, float (&acc)[MAXK])
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One wave reduces outer products over its 64 vertices on the matrix cores:
+//     G[i][j] += sum_v P[v][i] * Q[v][j],   i < NA <= 16 TA,  j < NB <= 16 TB,
+// as 16 steps of v_mfma_f32_16x16x4_f32 per 16 x 16 tile of G (K = 4 vertices per step).  Lane l feeds vertex
+// 4 s + l / 16 with column l % 16 of P (operand A) and of Q (operand B): ONE LDS read per lane, operand and step —
+// 16 (TA + TB) reads per lane and batch where a lane-owns-elements loop read 2 x 64 words per owned element
+// (2048 reads per lane for the 32 x 32 layer: the whole kernel sat on the LDS pipe, 9-13 x its forward).
+// P / Q tiles live in the wave's LDS region ([64][pitch]); tile (ta, tb) of G ends up in acc[ta][tb]: element
+// (row, col) in lane col + 16 (row / 4), register row % 4.  `ntb` = column tiles in use (wave-uniform).
+template <int TA, int TB>
+__device__ __forceinline__ void outer_mfma(const float* tP, uint32_t pitchP, uint32_t NA, const float* tQ,
+                                           uint32_t pitchQ, uint32_t NB, uint32_t ntb, uint32_t lane,
+                                           f32x4 (&acc)[TA][TB])
 {
-    const uint32_t total = NA * NB;
+    const uint32_t c = lane & 15u, k = lane >> 4;
+#pragma unroll 4
+    for (uint32_t s = 0; s < 16; s++) {
+        const uint32_t v = 4u * s + k;
+        float a[TA], b[TB];
 #pragma unroll
-    for (int k = 0; k < MAXK; k++) {
-        const uint32_t e = lane + 64u * k;
-        if (e < total) {
-            const uint32_t ia = e / NB, ib = e % NB;
-            float s = 0.0f;
-#pragma unroll 8
-            for (uint32_t v = 0; v < 64; v++) s = __builtin_fmaf(tA[v * pitchA + ia], tB[v * pitchB + ib], s);
-            acc[k] += s;
+        for (int ta = 0; ta < TA; ta++) {
+            const uint32_t i = 16u * ta + c;
+            a[ta] = i < NA ? tP[v * pitchP + i] : 0.0f;
         }
+#pragma unroll
+        for (int tb = 0; tb < TB; tb++) {
+            const uint32_t j = 16u * tb + c;
+            b[tb] = j < NB ? tQ[v * pitchQ + j] : 0.0f;
+        }
+#pragma unroll
+        for (int ta = 0; ta < TA; ta++)
+#pragma unroll
+            for (int tb = 0; tb < TB; tb++)
+                if ((uint32_t)tb < ntb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
     }
 }
 
-template <int MAXK>
-__device__ __forceinline__ void flush_acc(float* g, uint32_t total, uint32_t lane, const float (&acc)[MAXK])
+// adds the accumulated tiles into g[NA][NB] (nn.Linear layout [out, in])
+template <int TA, int TB>
+__device__ __forceinline__ void flush_mfma(float* g, uint32_t NA, uint32_t NB, uint32_t lane, const f32x4 (&acc)[TA][TB])
 {
 #pragma unroll
-    for (int k = 0; k < MAXK; k++) {
-        const uint32_t e = lane + 64u * k;
-        if (e < total) atomicAdd(g + e, acc[k]);
-    }
+    for (int ta = 0; ta < TA; ta++)
+#pragma unroll
+        for (int tb = 0; tb < TB; tb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t i = 16u * ta + 4u * (lane >> 4) + r, j = 16u * tb + (lane & 15u);
+                if (i < NA && j < NB) atomicAdd(g + i * NB + j, acc[ta][tb][r]);
+            }
 }
 
 constexpr int kBwdThreads = 128;    // two waves per block: each needs two 64-row LDS tiles (2 x 10.5 KB)
@@ -209,9 +232,11 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* tA = tilesA[wave];
     float* tB = tilesB[wave];
-    // weight-gradient elements owned by this lane (accumulated over every batch of the block)
-    constexpr int K1 = (H1 * kMaxC + 63) / 64, K2 = NL == 3 ? kH * kH / 64 : 1, K3 = NL == 3 ? (F * kH + 63) / 64 : 1;
-    float aW1[K1] = {}, aW2[K2] = {}, aW3[K3] = {}, ab1 = 0, ab2 = 0, ab3 = 0, apg = 0;
+    // weight-gradient tiles of this wave (accumulated over every batch of the block, MFMA layout: outer_mfma)
+    constexpr int T1A = (H1 + 15) / 16, T1B = (kMaxC + 15) / 16, TH = kH / 16, TF = (F + 15) / 16;
+    f32x4 aW1[T1A][T1B] = {}, aW2[NL == 3 ? TH : 1][NL == 3 ? TH : 1] = {}, aW3[NL == 3 ? TF : 1][NL == 3 ? TH : 1] = {};
+    float ab1 = 0, ab2 = 0, ab3 = 0, apg = 0;
+    const uint32_t ntb1 = (a.C + 15u) / 16u;
     int64_t pg_at = -1;            // pg_index mode: the table entry this WAVE is accumulating for (wave-uniform)
 
     const uint32_t n_batches = (a.N + kBwdThreads - 1) / kBwdThreads;
@@ -247,7 +272,7 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
 #pragma unroll
             for (int f = 0; f < F; f++) tA[lane * kPitchA + f] = d_o[f];
             __syncthreads();
-            outer_acc<K3>(tA, kPitchA, F, tB, kPitch, kH, lane, aW3);
+            outer_mfma<TF, TH>(tA, kPitchA, F, tB, kPitch, kH, TH, lane, aW3);
             if (lane < F) {
                 float s = 0.0f;
                 for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitchA + lane];
@@ -266,7 +291,7 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
                 __builtin_amdgcn_sched_barrier(0);       // as in mlp_row: do not hoist the whole layer's weight reads
             }
             __syncthreads();
-            outer_acc<K2>(tA, kPitchA, kH, tB, kPitch, kH, lane, aW2);
+            outer_mfma<TH, TH>(tA, kPitchA, kH, tB, kPitch, kH, TH, lane, aW2);
             if (lane < kH) {
                 float s = 0.0f;
                 for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitchA + lane];
@@ -339,7 +364,7 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
             }
         }
         __syncthreads();
-        outer_acc<K1>(tA, kPitchA, H1, tB, kPitch, a.C, lane, aW1);
+        outer_mfma<T1A, T1B>(tA, kPitchA, H1, tB, kPitch, a.C, ntb1, lane, aW1);
         if (lane < H1) {
             float s = 0.0f;
             for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitchA + lane];
@@ -350,11 +375,11 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
     // ~1000 blocks adding into the same few hundred addresses serialise at the memory side (21 us of a 72 us
     // single-Linear call): the caller hands n_rep zeroed copies of the weight-gradient buffer and sums them
     const size_t rep = (size_t)(blockIdx.x % g.n_rep) * g.rep_stride;
-    flush_acc<K1>(g.gW1 + rep, H1 * a.C, lane, aW1);
+    flush_mfma<T1A, T1B>(g.gW1 + rep, H1, a.C, lane, aW1);
     if (lane < H1) atomicAdd(g.gb1 + rep + lane, ab1);
     if constexpr (NL == 3) {
-        flush_acc<K2>(g.gW2 + rep, kH * kH, lane, aW2);
-        flush_acc<K3>(g.gW3 + rep, F * kH, lane, aW3);
+        flush_mfma<TH, TH>(g.gW2 + rep, kH, kH, lane, aW2);
+        flush_mfma<TF, TH>(g.gW3 + rep, F, kH, lane, aW3);
         if (lane < kH) atomicAdd(g.gb2 + rep + lane, ab2);
         if (lane < F) atomicAdd(g.gb3 + rep + lane, ab3);
     }

@@ -137,12 +137,17 @@ class _FusedFeatures(Function):
     binarised with the fused STE and a bit plane."""
 
     @staticmethod
-    def forward(ctx, x, owner, *params):
+    def forward(ctx, x, owner, rows, *params):
+        """`rows` >= N: the matrix gets that many rows, those behind the N encoded ones are zero (a bucketed row
+        count for the GEMMs that follow: NGPRadianceField_mygrid_2D3D._bucket_rows); the backward reads the
+        gradient of the first N rows only."""
         from .backends import gridencoder_backend as be
         encs = owner._encoders()
         N = x.shape[0]
         ld, cols = owner._layout()
-        feat = torch.empty(N, ld, device=x.device, dtype=torch.float32)
+        feat = torch.empty(max(N, rows or 0), ld, device=x.device, dtype=torch.float32)
+        if feat.shape[0] > N:
+            feat[N:].zero_()
         # plane coordinates by slicing (an index list would cost a host->device copy and a sync each)
         xs = (x.contiguous(), x[:, :2].contiguous(), x[:, ::2].contiguous(), x[:, 1:].contiguous())
         saved = []
@@ -162,7 +167,7 @@ class _FusedFeatures(Function):
             _lib.check(_lib.lib().cnc_field_sinusoid(xs[0].data_ptr(), fr.data_ptr(), fr.numel(), N, feat.data_ptr(), ld,
                                                      c0, _lib.stream(x.device)), "field_sinusoid")
         elif c0 < ld:
-            feat[:, c0:].zero_()
+            feat[:N, c0:].zero_()
         ctx.save_for_backward(*xs, *params, *saved)
         ctx.owner = owner
         return feat
@@ -176,7 +181,7 @@ class _FusedFeatures(Function):
         xs, params, clips = t[0:4], t[4:8], t[8:12]
         ld, cols = owner._layout()
         grad = grad.contiguous()
-        N = grad.shape[0]
+        N = xs[0].shape[0]                 # rows of padding behind them (`rows`) carry no sample
         grads = []
         for enc, p, xi, clip, col in zip(encs, params, xs, clips, cols):
             g = torch.zeros_like(p)
@@ -185,7 +190,7 @@ class _FusedFeatures(Function):
                                     None, None, ste_binary=True, ste_clip_count=clip,
                                     grad_ld=ld, grad_col=col, binned=enc._binned_plan(N))
             grads.append(g)
-        return (None, None, *grads)
+        return (None, None, None, *grads)
 
 
 class compose_3D_2D_embed(nn.Module):
@@ -226,9 +231,9 @@ class compose_3D_2D_embed(nn.Module):
                 and isinstance(self.network[0], nn.Linear)
                 and all(e.ste_binary and e.fused_ste and e.bitplane for e in self._encoders()))
 
-    def features_fused(self, x):
-        """[N, ld] feature matrix; columns [width, ld) are zero."""
-        return _FusedFeatures.apply(x, self, *(e.params for e in self._encoders()))
+    def features_fused(self, x, rows=None):
+        """[N, ld] feature matrix; columns [width, ld) are zero.  `rows` > N appends zero rows (_FusedFeatures)."""
+        return _FusedFeatures.apply(x, self, rows, *(e.params for e in self._encoders()))
 
     def features(self, x):
         xs, ys, zs = torch.chunk(x, 3, dim=-1)
@@ -240,14 +245,17 @@ class compose_3D_2D_embed(nn.Module):
             parts.append(self.embed_fn(x))
         return torch.cat(parts, dim=-1)
 
-    def forward(self, x, last_rows=None):
-        """`last_rows` = k: only the first k outputs of the network are computed."""
+    def forward(self, x, last_rows=None, rows=None):
+        """`last_rows` = k: only the first k outputs of the network are computed.  `rows` > N (fused path only):
+        the network runs on that many rows, the ones behind the N samples being zero features."""
         if self._can_fuse(x):
-            feat = self.features_fused(x)
+            feat = self.features_fused(x, rows)
             first = self.network[0]
             pad = feat.shape[1] - first.in_features
             w = F.pad(first.weight, (0, pad)) if pad else first.weight
             return run_layers(self.network, feat, first_weight=w, last_rows=last_rows)
+        if rows is not None and rows > x.shape[0]:
+            raise ValueError("rows: only on the fused feature path")
         return run_layers(self.network, self.features(x), last_rows=last_rows)
 
 
@@ -317,6 +325,8 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         # normalise / selector, density activation, SH encoding and the head-input concat as single kernels
         self.fused_glue = fused_features and not sh_fp16_round and os.environ.get("CNC_FUSED_GLUE", "1") == "1"
         self._head_fused = None
+        # sample counts from here on run at a bucketed row count (`_bucket_rows`); CNC_ROW_BUCKET_MIN=0 pads every call
+        self.row_bucket_min = int(os.environ.get("CNC_ROW_BUCKET_MIN", "4096"))
         self._head_shape_ok = n_neurons == 160       # the 32-row kernel is instantiated for 160-wide layers
         self.resolutions_list_2D, self.log2_hashmap_size_2D = resolutions_list_2D, log2_hashmap_size_2D
 
@@ -356,29 +366,49 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         return (self.fused_glue and x.is_cuda and x.dtype == torch.float32 and not self.unbounded and self.num_dim == 3
                 and self.density_activation is _default_density_activation and 1 + self.geo_feat_dim <= 128)
 
+    def _bucket_rows(self, n: int) -> int:
+        """Row count the field's kernels and GEMMs run at for `n` samples: `n` rounded up to a multiple of ~3 % of
+        itself (2^(floor(log2 n) - 5)).  The sample count of a training step is new every step, and a hipBLASLt
+        GEMM whose row count the library has not seen yet costs 77-127 us of HOST time against 19-30 us for a known
+        one (tools/gemm_launch_probe.py) — ~20 GEMMs per step, in the part of the step that is launch-bound.  With
+        the rows bucketed a run meets a handful of distinct sizes.  The extra rows are zero feature rows with
+        selector 0 (zero density); their outputs are sliced away, so they receive zero gradient, and the encoders
+        neither compute nor back-propagate them (`_FusedFeatures`)."""
+        if n < self.row_bucket_min:
+            return n
+        g = 1 << max(6, n.bit_length() - 6)
+        return (n + g - 1) // g * g
+
     def _prepare(self, x):
-        """(unit-cube positions [N,3], selector u8 [N]) of world positions: one kernel."""
+        """(unit-cube positions [N,3], selector u8 [Np], Np) of N world positions: one kernel.  Np =
+        `_bucket_rows(N)` (when the base network can take extra rows); the selector of the rows of padding is 0."""
         from . import _lib
         p = x.reshape(-1, 3).contiguous()
         N = p.shape[0]
+        Np = self._bucket_rows(N) if self.mlp_base._can_fuse(p) else N
         x_unit = torch.empty_like(p)
-        selector = torch.empty(N, dtype=torch.uint8, device=p.device)
+        selector = torch.empty(Np, dtype=torch.uint8, device=p.device)
         _lib.check(_lib.lib().cnc_field_prepare(p.data_ptr(), self.aabb.contiguous().data_ptr(), N, x_unit.data_ptr(),
                                                 selector.data_ptr(), _lib.stream(p.device)), "field_prepare")
-        return x_unit, selector
+        if Np != N:
+            selector[N:].zero_()
+        return x_unit, selector, Np
 
     def query_density(self, x, return_feat: bool = False):
         if self._glue_ok(x):
             lead = list(x.shape[:-1])
-            x_unit, selector = self._prepare(x)
+            x_unit, selector, Np = self._prepare(x)
+            N = x_unit.shape[0]
             if not return_feat and not torch.is_grad_enabled():
                 # the sampler's visibility pass (6-8x the samples of the gradient pass once a surface has formed: 1.5-2 M
                 # against 2^18) reads the density only: unit 0 of the last layer instead of all 1 + geo_feat_dim
-                h = self.mlp_base(x_unit, last_rows=1)
+                h = self.mlp_base(x_unit, last_rows=1, rows=Np)
                 density, _ = _FieldPost.apply(h, selector, None, 0)
-                return density.view(lead + [1])
-            h = self.mlp_base(x_unit)
+                return (density if Np == N else density[:N]).view(lead + [1])
+            h = self.mlp_base(x_unit, rows=Np)
             density, _ = _FieldPost.apply(h, selector, None, self.geo_feat_dim)
+            if Np != N:
+                density, h = density[:N], h[:N]
             density = density.view(lead + [1])
             return (density, h[:, 1:].view(lead + [self.geo_feat_dim])) if return_feat else density
         if self.unbounded:
@@ -431,10 +461,16 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         if directions is not None and self.use_viewdirs and self.geo_feat_dim > 0 and self._glue_ok(positions) \
                 and directions.is_cuda and directions.dtype == torch.float32:
             lead = list(positions.shape[:-1])
-            x_unit, selector = self._prepare(positions)
-            h = self.mlp_base(x_unit)
-            density, head_in = _FieldPost.apply(h, selector, directions.reshape(-1, 3), self.geo_feat_dim)
+            x_unit, selector, Np = self._prepare(positions)
+            N = x_unit.shape[0]
+            dirs = directions.reshape(-1, 3)
+            if Np != N:          # rows of padding (`_bucket_rows`): any direction will do
+                dirs = torch.cat([dirs, dirs.new_zeros((Np - N, 3))])
+            h = self.mlp_base(x_unit, rows=Np)
+            density, head_in = _FieldPost.apply(h, selector, dirs, self.geo_feat_dim)
             rgb = torch.sigmoid(self._head(head_in))
+            if Np != N:
+                rgb, density = rgb[:N], density[:N]
             return rgb.view(lead + [3]), density.view(lead + [1])
         density, embedding = self.query_density(positions, return_feat=True)
         rgb = self._query_rgb(directions, embedding=embedding)

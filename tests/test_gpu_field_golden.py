@@ -116,10 +116,15 @@ def build_field(cuda, kw, fused, seed=17, density_bias=None, table_scale=None):
 
 
 # ------------------------------------------------------------------------------------------------------- field
+@pytest.mark.parametrize("bucket_min", [1 << 30, 0], ids=["exact_rows", "padded_rows"])
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
 @pytest.mark.parametrize("case", ["f8", "f2"])
-def test_field_matches_reference(cuda, case, fused):
+def test_field_matches_reference(cuda, case, fused, bucket_min):
+    """`padded_rows`: every call runs at a bucketed row count (field._bucket_rows: what the training step does
+    from 4096 samples on) — the reference's values must come out of the first N rows all the same."""
     from cnc_amd.field import NGPRadianceField_mygrid_2D3D
+    if bucket_min == 0 and not fused:
+        pytest.skip("rows are only bucketed on the fused path")
     g = np.load(os.path.join(GOLD, "field_toy.npz"))
     kw = FIELD_CASES[case]
     f = NGPRadianceField_mygrid_2D3D(aabb=torch.tensor(AABB), ste_binary=True, ste_multistep=False, add_noise=False, Q=10,
@@ -135,7 +140,11 @@ def test_field_matches_reference(cuda, case, fused):
     assert f.geo_feat_dim == int(g[f"{case}_geo_feat_dim"])
     f.load_state_dict(fill_state(sd, seed=17), strict=True)
     f = f.to(cuda)
+    f.row_bucket_min = bucket_min
     x = torch.from_numpy(g[f"{case}_pos"]).to(cuda)
+    if bucket_min == 0:
+        assert f._bucket_rows(1000) == 1024 and f._bucket_rows(260000) == 262144 and f._bucket_rows(64) == 64
+        f._bucket_rows = lambda n: (n + 64) // 64 * 64          # the fixture has 256 rows: always pad
     v = torch.from_numpy(g[f"{case}_dirs"]).to(cuda)
     # the base MLP's input as the reference composes it: [xyz levels | xy | xz | yz | x, sin, cos ...]
     with torch.no_grad():

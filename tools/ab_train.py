@@ -1,0 +1,34 @@
+"""Scratch: A/B of a Trainer switch inside ONE process (boxes differ by more than the effects measured here):
+alternating blocks of steps with the switch off / on, wall time per step of each block."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cnc_amd.trainer import TrainConfig, Trainer
+
+cfg = TrainConfig(n_features=8, sample_num=150000, max_steps=2000, image_size=400, out_dir="/tmp/bits")
+tr = Trainer(cfg, device=torch.device("cuda:0"))
+what = sys.argv[1] if len(sys.argv) > 1 else "bucket"
+
+def switch(on):
+    if what == "bucket":
+        tr.field.row_bucket_min = 4096 if on else 1 << 30
+    else:
+        os.environ[what] = "1" if on else "0"
+
+step = 0
+for _ in range(240):
+    tr.train_step(step, want_stats=False); step += 1
+res = {False: [], True: []}
+for rep in range(8):
+    for on in (False, True):
+        switch(on)
+        for _ in range(8):
+            tr.train_step(step, want_stats=False); step += 1
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(40):
+            tr.train_step(step, want_stats=False); step += 1
+        torch.cuda.synchronize()
+        res[on].append((time.perf_counter() - t0) / 40 * 1e3)
+for on in (False, True):
+    r = sorted(res[on])
+    print(f"{what} {'on ' if on else 'off'}: median {r[len(r)//2]:.2f} ms  min {r[0]:.2f}  max {r[-1]:.2f}   {['%.2f' % x for x in res[on]]}")

@@ -57,6 +57,11 @@ int main()
     run<1>(t, rows, stride, 1, "workgroup scope, per-XCD copies", dsum);
     run<2>(t, rows, stride, 1, "wavefront scope, per-XCD copies", dsum);
     run<1>(t, rows, stride, 0, "workgroup scope, shared (UNSAFE)", dsum);
+    // per-XCD PARTITIONS that fit the XCD's 4 MiB L2: 2^16 rows = 2 MiB, 2^15 rows = 1 MiB per XCD
+    run<0>(t, 1u << 16, stride, 1, "agent scope, 2 MiB per-XCD partitions", dsum);
+    run<1>(t, 1u << 16, stride, 1, "workgroup scope, 2 MiB per-XCD partitions", dsum);
+    run<1>(t, 1u << 15, stride, 1, "workgroup scope, 1 MiB per-XCD partitions", dsum);
+    run<1>(t, 1u << 17, stride, 1, "workgroup scope, 4 MiB per-XCD partitions", dsum);
     const uint32_t rows2 = 1u << 22;              // 128 MiB per copy: far beyond L2
     float* t2; (void)hipMalloc(&t2, (size_t)rows2 * 8 * 8 * sizeof(float));
     run<0>(t2, rows2, (size_t)rows2 * 8, 0, "agent scope, shared table", dsum);
