@@ -55,6 +55,41 @@ def _check_sat(occ_sat, binary_vxl):
     return occ_sat
 
 
+def occupancy_vertex_bits(binary_vxl, occ_sat, resolutions, max_vertices=1 << 26):
+    """(extension) per-level vertex bit planes of the occupancy mask (cnc_grid_vertex_bits): for every level whose
+    R^D vertices number at most `max_vertices`, one bit per vertex = the per-corner box test of kernel_grid
+    (gridencoder.cu:221-276).  Returns (words int32 [W], offsets int32 [L]: first word of level l's plane, -1 = none)."""
+    D = binary_vxl.dim()
+    Rb = binary_vxl.shape[-1]
+    L = _lib.lib()
+    offs, total = [], 0
+    for R in resolutions:
+        R = int(R)
+        if R >= 3 and R ** D <= max_vertices:
+            offs.append(total)
+            total += int(L.cnc_grid_vertex_bits_words(D, R))
+        else:
+            offs.append(-1)
+    words = torch.empty(max(total, 2), dtype=torch.int32, device=binary_vxl.device)
+    sat = _check_sat(occ_sat, binary_vxl)
+    for R, o in zip(resolutions, offs):
+        if o >= 0:
+            check(L.cnc_grid_vertex_bits(ptr(sat), D, int(Rb), int(R), words.data_ptr() + 4 * o,
+                                         stream(binary_vxl.device)), "grid_vertex_bits")
+    return words, torch.tensor(offs, dtype=torch.int32, device=binary_vxl.device)
+
+
+def _vb(vertex_bits, binary_vxl, n_levels):
+    """(words pointer, offsets pointer) of an optional `vertex_bits` pair; the offsets must cover the call's levels."""
+    if vertex_bits is None or binary_vxl is None:
+        return None, None
+    words, offs = vertex_bits
+    if (words.dtype != torch.int32 or offs.dtype != torch.int32 or not words.is_cuda or not offs.is_cuda
+            or not words.is_contiguous() or not offs.is_contiguous() or offs.numel() < n_levels):
+        raise RuntimeError("vertex_bits must be (int32 CUDA words, int32 CUDA offsets [>= n_levels])")
+    return words.data_ptr(), offs.data_ptr()
+
+
 def _common_checks(named):
     for name, t in named:
         check_cuda(t, name)
@@ -64,7 +99,7 @@ def _common_checks(named):
 
 def grid_encode_forward(inputs, embeddings, offsets_list, resolutions_list, outputs, N, num_dim,
                         n_features, n_levels, max_level, Rb, PV, dy_dx=None, binary_vxl=None,
-                        min_level_id=None, *, ste_binary=False, occ_sat=None, out_ld=0, out_col=0):
+                        min_level_id=None, *, ste_binary=False, occ_sat=None, out_ld=0, out_col=0, vertex_bits=None):
     _common_checks([("inputs", inputs), ("embeddings", embeddings), ("offsets_list", offsets_list),
                     ("resolutions_list", resolutions_list), ("outputs", outputs)])
     _check_floating(inputs, "inputs")
@@ -84,7 +119,8 @@ def grid_encode_forward(inputs, embeddings, offsets_list, resolutions_list, outp
         ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list), ptr(outputs),
         int(N), int(num_dim), int(n_features), int(n_levels), int(Rb), float(PV), ptr(dy_dx),
         ptr(binary_vxl), ptr(min_level_id), _lib.CNC_FLAG_STE_BINARY if ste_binary else 0,
-        ptr(_check_sat(occ_sat, binary_vxl)), int(out_ld), int(out_col), stream(inputs.device))
+        ptr(_check_sat(occ_sat, binary_vxl)), *_vb(vertex_bits, binary_vxl, 0 if min_level_id is not None else n_levels),
+        int(out_ld), int(out_col), stream(inputs.device))
     check(rc, "grid_encode_forward")
 
 
@@ -92,7 +128,7 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
                          N, num_dim, n_features, n_levels, max_level, Rb, dy_dx=None,
                          grad_inputs=None, binary_vxl=None, min_level_id=None, *, ste_binary=False,
                          ste_clip_count=None, occ_sat=None, grad_ld=0, grad_col=0, binned=None,
-                         interleave_levels=False, overlap_streams=True):
+                         interleave_levels=False, overlap_streams=True, vertex_bits=None):
     """gridencoder.h:24-36.  `binned` (extension) = (n_binned, level_rows) from `plan_binned_levels`:
     take that many finest levels off the global-atomic path (cnc_grid_encode_backward_binned).
     `interleave_levels` (extension, same result): CNC_FLAG_LEVELS_FINEST_FIRST for the plain entry —
@@ -148,7 +184,8 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         ptr(dy_dx), ptr(grad_inputs), ptr(binary_vxl), ptr(min_level_id),
         (_lib.CNC_FLAG_STE_BINARY if ste_binary else 0)
         | (_lib.CNC_FLAG_LEVELS_FINEST_FIRST if interleave_levels else 0), ptr(ste_clip_count),
-        ptr(_check_sat(occ_sat, binary_vxl)), int(grad_ld), int(grad_col), stream(grad.device))
+        ptr(_check_sat(occ_sat, binary_vxl)), *_vb(vertex_bits, binary_vxl, 0 if min_level_id is not None else n_levels),
+        int(grad_ld), int(grad_col), stream(grad.device))
     check(rc, "grid_encode_backward")
 
 
@@ -224,7 +261,7 @@ def pack_sign_bits(embeddings, bits=None, clip_count=None):
 
 def grid_encode_forward_bits(inputs, bits, offsets_list, resolutions_list, outputs, N, num_dim,
                              n_features, n_levels, Rb, binary_vxl=None, min_level_id=None, occ_sat=None,
-                             out_ld=0, out_col=0):
+                             out_ld=0, out_col=0, vertex_bits=None):
     """(extension) grid_encode_forward on the bit plane of a binarised table; same outputs as
     grid_encode_forward(..., ste_binary=True) on the fp32 table."""
     _common_checks([("inputs", inputs), ("bits", bits), ("offsets_list", offsets_list),
@@ -244,7 +281,8 @@ def grid_encode_forward_bits(inputs, bits, offsets_list, resolutions_list, outpu
     rc = _lib.lib().cnc_grid_encode_forward_bits(
         ptr(inputs), ptr(bits), ptr(offsets_list), ptr(resolutions_list), ptr(outputs), int(N),
         int(num_dim), int(n_features), int(n_levels), int(Rb), ptr(binary_vxl), ptr(min_level_id),
-        ptr(_check_sat(occ_sat, binary_vxl)), int(out_ld), int(out_col), stream(inputs.device))
+        ptr(_check_sat(occ_sat, binary_vxl)), *_vb(vertex_bits, binary_vxl, 0 if min_level_id is not None else n_levels),
+        int(out_ld), int(out_col), stream(inputs.device))
     check(rc, "grid_encode_forward_bits")
 
 
@@ -311,22 +349,23 @@ class VotePlan:
         for axis in range(3):
             p = pix[axis]
             if bool((p[1:] >= p[:-1]).all()) if p.numel() > 1 else True:
-                rows_sorted = rows                      # the xy plane of an (x, y, z)-sorted list
+                rows_sorted, p_sorted = rows, p         # the xy plane of an (x, y, z)-sorted list
             else:
-                rows_sorted = rows[torch.sort(p, stable=True)[1]]
+                p_sorted, order = torch.sort(p, stable=True)
+                rows_sorted = rows[order]
             self.rows_by_pixel.append(rows_sorted.contiguous())
-            self.pixel_seg.append(self._segments(p, self.n_pixels))
+            self.pixel_seg.append(self._segments(p_sorted, self.n_pixels))
         # backward: pixels ordered by row (one order for the three planes)
-        order = torch.sort(rows, stable=True)[1]
+        rows_sorted, order = torch.sort(rows, stable=True)
         self.pixels_by_row = [p[order].contiguous() for p in pix]
-        self.row_seg = self._segments(rows, self.hashmap_size)
+        self.row_seg = self._segments(rows_sorted, self.hashmap_size)
 
     @staticmethod
-    def _segments(keys, n):
-        counts = torch.bincount(keys, minlength=n)
-        seg = torch.zeros(n + 1, dtype=torch.int32, device=keys.device)
-        seg[1:] = torch.cumsum(counts, 0).to(torch.int32)
-        return seg
+    def _segments(sorted_keys, n):
+        """seg[k] = number of keys < k for k = 0 .. n (int32), from the SORTED key list: a binary search per
+        boundary instead of a histogram of 10^7 keys with atomics (0.5 ms each, four per occupancy refresh)."""
+        bounds = torch.arange(n + 1, dtype=sorted_keys.dtype, device=sorted_keys.device)
+        return torch.searchsorted(sorted_keys, bounds, right=False).to(torch.int32)
 
 
 def cnt_np_embed_planned(plan, embeddings_clip, outputs, n_features, axis):

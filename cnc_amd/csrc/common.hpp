@@ -30,7 +30,19 @@ struct FeatLayout {
     uint32_t col;
     uint32_t finest_first = 0;   // backward only: walk the level slots from the last one down
     uint32_t n_slots = 0;        // backward only: 1-D grid, block id = chunk * n_slots + level slot
+    // optional per-level vertex bit planes of the occupancy mask (cnc_grid_vertex_bits): bit q0 + R (q1 + R q2) of
+    // the level's plane = box_any(q); vboff[level] = first 32-bit word of the plane, < 0 = the level has none
+    const uint32_t* vbits = nullptr;
+    const int32_t*  vboff = nullptr;
+    uint32_t        nt = 0;      // forward: streaming (non-temporal) stores of the outputs
 };
+
+__device__ __forceinline__ const uint32_t* vertex_plane(const FeatLayout& lay, uint32_t level)
+{
+    if (lay.vbits == nullptr) return nullptr;
+    const int32_t w = lay.vboff[level];
+    return w < 0 ? nullptr : lay.vbits + w;
+}
 
 __device__ __forceinline__ size_t feat_index(FeatLayout lay, uint32_t slot, uint32_t N, uint32_t b,
                                              uint32_t F)

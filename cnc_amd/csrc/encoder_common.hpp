@@ -32,6 +32,24 @@ __device__ __forceinline__ void store_vec(float* __restrict__ p, const float (&v
     *reinterpret_cast<T*>(p) = t;
 }
 
+// Streaming store: the line is not kept in the L2 (the encoder's output is read back much later by another kernel; the
+// bit plane / table it gathers from should keep the cache).
+template <uint32_t V>
+__device__ __forceinline__ void store_vec_nt(float* __restrict__ p, const float (&v)[V])
+{
+    if constexpr (V == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 t = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<f4*>(p));
+    } else if constexpr (V == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 t = {v[0], v[1]};
+        __builtin_nontemporal_store(t, reinterpret_cast<f2*>(p));
+    } else {
+        __builtin_nontemporal_store(v[0], p);
+    }
+}
+
 // Corner set-up for one (point, level): weights, validity and row indices.
 // Mirrors gridencoder.cu:166-291 (forward) / :443-562 (backward).
 template <uint32_t D, bool VXL>
@@ -46,7 +64,8 @@ struct Corners {
 
     __device__ __forceinline__ void setup(const float (&x)[D], uint32_t R, uint32_t hs,
                                           uint32_t Rb, const uint8_t* __restrict__ vxl,
-                                          const int32_t* __restrict__ sat = nullptr)
+                                          const int32_t* __restrict__ sat = nullptr,
+                                          const uint32_t* __restrict__ vplane = nullptr)
     {
         float    pos[D];
         uint32_t g[D];
@@ -82,6 +101,18 @@ struct Corners {
 #pragma unroll
             for (uint32_t b = 0; b < 2; b++) part[d][b] = d == 0 ? (hashed ? qa[d][b] : qa[d][b] * m) : qa[d][b] * m;
         }
+        // dense vertex index per axis value for the vertex bit plane (x fastest: the two x-neighbours of a corner
+        // pair share a word)
+        uint32_t vpart[D][2];
+        if constexpr (VXL) {
+            uint32_t vs = 1;
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) {
+                vpart[d][0] = qa[d][0] * vs;
+                vpart[d][1] = qa[d][1] * vs;
+                vs *= R;
+            }
+        }
         const bool pow2 = (hs & (hs - 1)) == 0;
         float wn = 0;
 #pragma unroll
@@ -102,7 +133,18 @@ struct Corners {
             if constexpr (VXL) {
                 // the reference evaluates the box for every corner; its result only matters
                 // for non-border ones, so skip the (expensive) scan otherwise
-                if (ok) ok = sat ? box_any_sat<D>(q, R, Rb, sat) : box_any<D>(q, R, Rb, vxl);
+                // (a level with a vertex bit plane — the same predicate evaluated once per vertex and occupancy
+                // update — reads ONE bit here instead of 2^D table entries)
+                if (ok) {
+                    if (vplane) {
+                        uint32_t vi = 0;
+#pragma unroll
+                        for (uint32_t d = 0; d < D; d++) vi += vpart[d][(i >> d) & 1u];
+                        ok = (vplane[vi >> 5] >> (vi & 31u)) & 1u;
+                    } else {
+                        ok = sat ? box_any_sat<D>(q, R, Rb, sat) : box_any<D>(q, R, Rb, vxl);
+                    }
+                }
             }
             if (pow2) index &= hs - 1;
             else if (index >= hs) index %= hs;

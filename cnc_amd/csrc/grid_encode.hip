@@ -17,6 +17,8 @@
 //   * Optional STE fusion (CNC_FLAG_STE_BINARY): sign() is applied to the gathered values, which
 //     removes the reference's separate full-table STE_binary passes (ngp.py:22-39,244-245).
 #include "common.hpp"
+#include <cstdlib>
+
 #include "encoder_common.hpp"
 
 namespace cnc {
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd(
     const float* table = emb + (size_t)off * F + h * V;
 
     Corners<D, VXL> c;
-    c.setup(x, R, hs, Rb, vxl, sat);
+    c.setup(x, R, hs, Rb, vxl, sat, vertex_plane(lay, level));
 
     float v[C][V];
 #pragma unroll
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd_bits(
             const uint32_t hs = (uint32_t)offsets[level + 1] - off;
             const uint32_t R = (uint32_t)resolutions[level];
             Corners<D, VXL> c;
-            c.setup(x, R, hs, Rb, vxl, sat);
+            c.setup(x, R, hs, Rb, vxl, sat, vertex_plane(lay, level));
             uint32_t rb[C];
 #pragma unroll
             for (uint32_t i = 0; i < C; i++)
@@ -191,7 +193,8 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd_bits(
             float v[V];
 #pragma unroll
             for (uint32_t j = 0; j < V; j++) v[j] = acc[k + j];
-            store_vec<V>(o + k, v);
+            if (lay.nt) store_vec_nt<V>(o + k, v);
+            else store_vec<V>(o + k, v);
         }
     }
 }
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd_simple(
     const size_t base = (size_t)off * F + h * V;
 
     Corners<D, VXL> c;
-    c.setup(x, R, hs, Rb, vxl, sat);
+    c.setup(x, R, hs, Rb, vxl, sat, vertex_plane(lay, level));
 
 #pragma unroll
     for (uint32_t i = 0; i < C; i++) {
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
             const uint32_t hs = (uint32_t)offsets[level + 1] - off;
             const uint32_t R = (uint32_t)resolutions[level];
             Corners<D, VXL> c;
-            c.setup(x, R, hs, Rb, vxl, sat);
+            c.setup(x, R, hs, Rb, vxl, sat, vertex_plane(lay, level));
             uint64_t cell = 0;   // integer cell coordinates, 16 bits per axis (R <= 65535)
 #pragma unroll
             for (uint32_t d = D; d-- > 0;) {
@@ -808,8 +811,9 @@ extern "C" int cnc_grid_encode_forward(const float* inputs, const float* embeddi
                                        float* outputs, uint32_t N, uint32_t D, uint32_t F,
                                        uint32_t L, uint32_t Rb, float PV, float* dy_dx,
                                        const uint8_t* binary_vxl, const int32_t* min_level_id,
-                                       uint32_t flags, const int32_t* occ_sat, uint32_t out_ld,
-                                       uint32_t out_col, void* stream)
+                                       uint32_t flags, const int32_t* occ_sat,
+                                       const uint32_t* vertex_bits, const int32_t* vertex_bit_offsets,
+                                       uint32_t out_ld, uint32_t out_col, void* stream)
 {
     (void)PV;
     if (N == 0 || L == 0) return CNC_OK;
@@ -818,6 +822,7 @@ extern "C" int cnc_grid_encode_forward(const float* inputs, const float* embeddi
               binary_vxl, min_level_id, (hipStream_t)stream, nullptr, binary_vxl ? occ_sat : nullptr,
               FeatLayout{out_ld, out_col}};
     if (!layout_ok(a.lay, F, L)) return CNC_ERR_INVALID_VALUE;
+    if (binary_vxl && vertex_bits && vertex_bit_offsets) { a.lay.vbits = vertex_bits; a.lay.vboff = vertex_bit_offsets; }
     int rc = dispatch_D<false>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
     if (rc == CNC_OK && dy_dx)   // the dy_dx branch of kernel_grid, as its own launch (not a hot path)
         rc = launch_dy_dx(inputs, embeddings, offsets, resolutions, dy_dx, N, D, F, L, min_level_id,
@@ -832,7 +837,8 @@ extern "C" int cnc_grid_encode_backward(const float* grad, const float* inputs,
                                         uint32_t Rb, const float* dy_dx, float* grad_inputs,
                                         const uint8_t* binary_vxl, const int32_t* min_level_id,
                                         uint32_t flags, const uint32_t* ste_clip_count,
-                                        const int32_t* occ_sat, uint32_t grad_ld,
+                                        const int32_t* occ_sat, const uint32_t* vertex_bits,
+                                        const int32_t* vertex_bit_offsets, uint32_t grad_ld,
                                         uint32_t grad_col, void* stream)
 {
     if ((dy_dx == nullptr) != (grad_inputs == nullptr)) return CNC_ERR_INVALID_VALUE;   // both or neither
@@ -844,6 +850,7 @@ extern "C" int cnc_grid_encode_backward(const float* grad, const float* inputs,
               binary_vxl ? occ_sat : nullptr,
               FeatLayout{grad_ld, grad_col, (flags & CNC_FLAG_LEVELS_FINEST_FIRST) ? 1u : 0u}};
     if (!layout_ok(a.lay, F, L)) return CNC_ERR_INVALID_VALUE;
+    if (binary_vxl && vertex_bits && vertex_bit_offsets) { a.lay.vbits = vertex_bits; a.lay.vboff = vertex_bit_offsets; }
     int rc = dispatch_D<true>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
     if (rc == CNC_OK && dy_dx)   // kernel_input_backward (gridencoder.cu:588-614)
         rc = launch_input_backward(grad, dy_dx, grad_inputs, N, D, F, L, FeatLayout{grad_ld, grad_col},
@@ -918,6 +925,9 @@ static void launch_fwd_bits(const float* inputs, const uint8_t* bits, const int3
         P = F >= 16 ? 1u : 16u / F;      // 16 floats = one 64-byte sector per lane (measured at F = 8, 16 levels, ms per 2^20
         if (P > L) P = L;                // points: P = 1: 0.479, 2: 0.451, 4: 0.521, 8: 0.571, 16: 0.532; level-major 0.243)
     }
+    // streaming stores of the outputs: -2.4 % on the call, the bit plane keeps the L2 (CNC_FWD_NT=0: measurement switch)
+    static const int nt_mode = getenv("CNC_FWD_NT") ? atoi(getenv("CNC_FWD_NT")) : 1;
+    lay.nt = nt_mode ? 1u : 0u;
     const dim3 grid(div_up(N, 256), div_up(L, P), 1);
     if (vxl) hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, true>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, L, P, Rb, vxl, mli, sat, lay);
     else hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, false>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, L, P, Rb, vxl, mli, nullptr, lay);
@@ -928,12 +938,14 @@ extern "C" int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* 
                                             float* outputs, uint32_t N, uint32_t D, uint32_t F,
                                             uint32_t L, uint32_t Rb, const uint8_t* binary_vxl,
                                             const int32_t* min_level_id, const int32_t* occ_sat,
+                                            const uint32_t* vertex_bits, const int32_t* vertex_bit_offsets,
                                             uint32_t out_ld, uint32_t out_col, void* stream)
 {
     if (N == 0 || L == 0) return CNC_OK;
     if (!inputs || !bits || !offsets || !resolutions || !outputs) return CNC_ERR_INVALID_VALUE;
-    const FeatLayout lay{out_ld, out_col};
+    FeatLayout lay{out_ld, out_col};
     if (!layout_ok(lay, F, L)) return CNC_ERR_INVALID_VALUE;
+    if (binary_vxl && vertex_bits && vertex_bit_offsets) { lay.vbits = vertex_bits; lay.vboff = vertex_bit_offsets; }
     hipStream_t s = (hipStream_t)stream;
 #define CNC_BITS_D(DD)                                                                              \
     CNC_F_SWITCH(F, (launch_fwd_bits<DD, FF>(inputs, bits, offsets, resolutions, outputs, N, L, Rb, \
@@ -945,6 +957,57 @@ extern "C" int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* 
     default: return CNC_ERR_INVALID_VALUE;
     }
 #undef CNC_BITS_D
+    return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vertex bit plane of one level: bit q0 + R (q1 + R q2) = box_any(q) (gridencoder.cu:221-276) for EVERY vertex of
+// the level, from the summed-volume table.  The masked kernels then read one bit per corner instead of 2^D table
+// entries (192 loads per vertex of a 3-level context window: 0.69 ms forward / 1.15 ms backward per training step).
+// Depends on (occupancy, R, Rb) only: rebuilt when the occupancy grid changes.
+// ---------------------------------------------------------------------------------------------
+namespace cnc {
+template <uint32_t D>
+__global__ __launch_bounds__(256) void k_vertex_bits(const int32_t* __restrict__ sat, uint32_t R, uint32_t Rb,
+                                                     uint64_t n_vertices, uint32_t* __restrict__ words)
+{
+    const uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    bool bit = false;
+    if (v < n_vertices) {
+        uint32_t q[D];
+        uint64_t r = v;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) { q[d] = (uint32_t)(r % R); r /= R; }
+        bit = box_any_sat<D>(q, R, Rb, sat);
+    }
+    const uint64_t m = __ballot(bit);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (lane == 0) words[v >> 5] = (uint32_t)m;                       // v is a multiple of 64 here
+    else if (lane == 32) words[v >> 5] = (uint32_t)(m >> 32);
+}
+}  // namespace cnc
+
+extern "C" uint64_t cnc_grid_vertex_bits_words(uint32_t D, uint32_t R)
+{
+    uint64_t n = 1;
+    for (uint32_t d = 0; d < D; d++) n *= R;
+    return (n + 63) / 64 * 2;
+}
+
+extern "C" int cnc_grid_vertex_bits(const int32_t* occ_sat, uint32_t D, uint32_t Rb, uint32_t R, uint32_t* words,
+                                    void* stream)
+{
+    if (!occ_sat || !words || R < 3 || D < 1 || D > 3) return CNC_ERR_INVALID_VALUE;
+    uint64_t n = 1;
+    for (uint32_t d = 0; d < D; d++) n *= R;
+    const uint64_t blocks = (n + 255) / 256;
+    if (blocks >= (1ull << 31)) return CNC_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    switch (D) {
+    case 1: hipLaunchKernelGGL((k_vertex_bits<1>), dim3((uint32_t)blocks), dim3(256), 0, s, occ_sat, R, Rb, n, words); break;
+    case 2: hipLaunchKernelGGL((k_vertex_bits<2>), dim3((uint32_t)blocks), dim3(256), 0, s, occ_sat, R, Rb, n, words); break;
+    default: hipLaunchKernelGGL((k_vertex_bits<3>), dim3((uint32_t)blocks), dim3(256), 0, s, occ_sat, R, Rb, n, words); break;
+    }
     return launch_status();
 }
 
@@ -961,4 +1024,4 @@ extern "C" const char* cnc_error_string(int code)
     }
 }
 
-extern "C" int cnc_abi_version(void) { return 21; }
+extern "C" int cnc_abi_version(void) { return 22; }

@@ -626,7 +626,7 @@ extern "C" int cnc_grid_encode_backward_binned(const float* grad, const float* i
                                                 grad_embeddings, N, D, F, L - n_binned, 0, nullptr,
                                                 nullptr, nullptr, nullptr,
                                                 flags | CNC_FLAG_LEVELS_FINEST_FIRST, ste_clip_count,
-                                                nullptr, grad_ld, grad_col, stream);
+                                                nullptr, nullptr, nullptr, grad_ld, grad_col, stream);
         if (rc != CNC_OK) return rc;
     }
     if (n_binned == 0) return CNC_OK;

@@ -126,7 +126,7 @@ extern "C" int cnc_grid_encode_backward_overlapped(cnc_backward_plan* plan, cons
     // the coarse levels fill in next to the (longer) bin + owner passes, on the caller's stream
     const int rc0 = cnc_grid_encode_backward(grad, inputs, embeddings, offsets, resolutions, grad_embeddings, N, D, F, coarse,
                                              0, nullptr, nullptr, nullptr, nullptr, flags | CNC_FLAG_LEVELS_FINEST_FIRST,
-                                             ste_clip_count, nullptr, grad_ld, grad_col, stream);
+                                             ste_clip_count, nullptr, nullptr, nullptr, grad_ld, grad_col, stream);
     for (int g = 0; g < groups; ++g)
         if (hipStreamWaitEvent(s, plan->join[g], 0) != hipSuccess) return CNC_ERR_LAUNCH;
     return rc0 != CNC_OK ? rc0 : rc;

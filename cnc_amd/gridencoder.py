@@ -19,6 +19,8 @@ op-by-op dataflow.
 from __future__ import annotations
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -81,7 +83,7 @@ class _grid_encode(Function):
     @staticmethod
     def forward(ctx, inputs, embeddings, offsets_list, resolutions_list, calc_grad_inputs=False,
                 min_level_id=None, n_levels_calc=1, binary_vxl=None, PV=0, ste=False, bits=None,
-                clip_count=None, occ_sat=None, binned=None):
+                clip_count=None, occ_sat=None, binned=None, vertex_bits=None):
         inputs = inputs.contiguous()
         if calc_grad_inputs:
             # dead in the reference too (ngp.py:58-60)
@@ -108,23 +110,27 @@ class _grid_encode(Function):
             mli = None
         else:
             offs, ress, mli = offsets_list, resolutions_list, min_level_id
+        vb_words, vb_offs = vertex_bits if (vertex_bits is not None and binary_vxl is not None) else (None, None)
+        if vb_offs is not None and scalar_window:
+            vb_offs = vb_offs[min_level_id:max_level_id]
+        vb = None if vb_words is None else (vb_words, vb_offs)
         if bits is not None and ste:
             # binarised table gathered from its bit plane (same values, 32x less table traffic)
             _backend.grid_encode_forward_bits(inputs, bits, offs, ress, outputs, N, num_dim,
                                               n_features, n_levels_calc, Rb, binary_vxl, mli, occ_sat,
-                                              out_ld=ld, out_col=0)
+                                              out_ld=ld, out_col=0, vertex_bits=vb)
         else:
             _backend.grid_encode_forward(inputs, embeddings, offs, ress, outputs, N, num_dim,
                                          n_features, n_levels_calc, 0, Rb, PV, None, binary_vxl, mli,
-                                         ste_binary=ste, occ_sat=occ_sat, out_ld=ld, out_col=0)
-        ctx.save_for_backward(inputs, embeddings, offs, ress, binary_vxl, mli, clip_count, occ_sat)
+                                         ste_binary=ste, occ_sat=occ_sat, out_ld=ld, out_col=0, vertex_bits=vb)
+        ctx.save_for_backward(inputs, embeddings, offs, ress, binary_vxl, mli, clip_count, occ_sat, vb_words, vb_offs)
         ctx.dims = (N, num_dim, n_features, n_levels_calc, Rb, ste)
         ctx.binned = binned if (binary_vxl is None and mli is None) else None
         return outputs
 
     @staticmethod
     def backward(ctx, grad):
-        inputs, embeddings, offs, ress, binary_vxl, mli, clip_count, occ_sat = ctx.saved_tensors
+        inputs, embeddings, offs, ress, binary_vxl, mli, clip_count, occ_sat, vb_words, vb_offs = ctx.saved_tensors
         N, num_dim, n_features, n_levels_calc, Rb, ste = ctx.dims
         grad = grad.contiguous()                       # [N, L*F], read in place (grad_ld)
         grad_embeddings = torch.zeros_like(embeddings)
@@ -132,8 +138,9 @@ class _grid_encode(Function):
                                       num_dim, n_features, n_levels_calc, 0, Rb, None, None,
                                       binary_vxl, mli, ste_binary=ste, ste_clip_count=clip_count,
                                       occ_sat=occ_sat, binned=ctx.binned,
-                                      grad_ld=n_levels_calc * n_features, grad_col=0)
-        return (None, grad_embeddings) + (None,) * 12
+                                      grad_ld=n_levels_calc * n_features, grad_col=0,
+                                      vertex_bits=None if vb_words is None else (vb_words, vb_offs))
+        return (None, grad_embeddings) + (None,) * 13
 
 
 grid_encode = _grid_encode.apply
@@ -160,12 +167,16 @@ class GridEncoder(nn.Module):
         # bit-plane gather for binarised tables (needs the fused STE path); the packed plane is
         # cached until the table is modified in place (optimizer step bumps Tensor._version)
         self.bitplane = bitplane and fused_ste
+        # masked calls (binary_vxl): per-level vertex bit planes of the occupancy test (extension, same results)
+        self.vertex_bits = os.environ.get("CNC_VERTEX_BITS", "1") == "1"
         self._bits = None
         self._bits_key = None
         self._bits_src = None
         self._clip_count = None
         self._sat = None
         self._sat_key = None
+        self._vbits = None
+        self._vbits_key = None
 
         # rows per level = min(2^log2T, R^D) rounded up to a multiple of 8 (ngp.py:197-210)
         self.max_params = 2 ** log2_hashmap_size
@@ -237,6 +248,20 @@ class GridEncoder(nn.Module):
             self._sat_src = (binary_vxl,)   # keep the storage alive so data_ptr stays unique
         return self._sat
 
+    def _occ_vertex_bits(self, binary_vxl):
+        """Per-level vertex bit planes of the occupancy mask for THIS encoder's resolutions (levels of at most
+        2^26 vertices), rebuilt with the summed-volume table when the grid tensor changes: the masked kernels read
+        one bit per corner instead of 2^D table entries (`gridencoder_backend.occupancy_vertex_bits`)."""
+        if binary_vxl is None or not self.vertex_bits:
+            return None
+        key = (binary_vxl.data_ptr(), binary_vxl._version, tuple(binary_vxl.shape))
+        if self._vbits is None or self._vbits_key != key:
+            with torch.no_grad():
+                self._vbits = _backend.occupancy_vertex_bits(binary_vxl.contiguous(), self._occ_sat(binary_vxl),
+                                                             self._res_host)
+            self._vbits_key = key
+        return self._vbits
+
     # -- embeddings as the kernels should see them --------------------------------------------
     def _embeddings(self, params, test_phase):
         """Returns (table, ste_flag)."""
@@ -264,7 +289,8 @@ class GridEncoder(nn.Module):
         outputs = grid_encode(inputs, embeddings, self.offsets_list, self.resolutions_list, False,
                               min_level_id, n_levels_calc, binary_vxl, PV, ste, bits, clip,
                               self._occ_sat(binary_vxl),
-                              self._binned_plan(inputs.shape[0], min_level_id, max_level_id, binary_vxl))
+                              self._binned_plan(inputs.shape[0], min_level_id, max_level_id, binary_vxl),
+                              self._occ_vertex_bits(binary_vxl))
         return outputs.view(prefix_shape + [n_levels_calc * self.n_features])
 
     def forward_diff_levels(self, inputs, min_level_id_list=None, n_levels_calc=1, test_phase=False,
@@ -277,7 +303,7 @@ class GridEncoder(nn.Module):
         bits, clip = self._bit_plane(params) if (ste and self.bitplane) else (None, None)
         outputs = grid_encode(inputs, embeddings, self.offsets_list, self.resolutions_list, False,
                               min_level_id_list.contiguous(), n_levels_calc, binary_vxl, PV, ste, bits, clip,
-                              self._occ_sat(binary_vxl))
+                              self._occ_sat(binary_vxl), None, self._occ_vertex_bits(binary_vxl))
         return outputs.view(prefix_shape + [n_levels_calc * self.n_features])
 
     def forward_given_params(self, inputs, offsets_list, resolutions_list, outspace_params=None,

@@ -236,6 +236,12 @@ class Trainer:
         self.build_optimizers()
         self.loss_scale = 2.0 ** 10          # GradScaler(2**10), never unscaled (train:211,361-362)
 
+        # The context pass runs on its own stream: its backward (autograd replays every node on its forward's stream)
+        # then runs NEXT TO the render backward instead of after it — ~60 small latency-bound kernels beside the
+        # field's GEMMs (single process only: the data-parallel step orders its buckets on one stream).
+        self.ctx_stream = None
+        if self.device.type == "cuda" and os.environ.get("CNC_CTX_STREAM", "1") == "1":
+            self.ctx_stream = torch.cuda.Stream(device=self.device)
         self.bucket = None
         self.time_comm = False          # bench hook: HIP events around the wait for the gradient all-reduce
         self._comm_events = []
@@ -308,15 +314,37 @@ class Trainer:
         bpp, mb = 0.0, 0.0
         if c.lmbda > 0:
             e = self.field.mlp_base
-            bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(
-                e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
-                sample_num=None, step=step, sync_MB=False)
+            side = self.ctx_stream if self.bucket is None else None
+            if side is not None:
+                main = torch.cuda.current_stream(self.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(
+                        e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
+                        sample_num=None, step=step, sync_MB=False)
+                main.wait_stream(side)
+                for t in (bits_per_param, mb):      # allocated on the side stream, read on the main one from here on
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(main)
+            else:
+                bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(
+                    e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
+                    sample_num=None, step=step, sync_MB=False)
             loss = loss + c.lmbda * bits_per_param
             bpp = bits_per_param
         self.opt.zero_grad(set_to_none=self.bucket is None)
         self.opt2.zero_grad(set_to_none=self.bucket is None)
         if self.bucket is None:
-            (loss * self.loss_scale).backward()
+            if self.ctx_stream is not None and c.lmbda > 0 and os.environ.get("CNC_CTX_TWO_BACKWARDS", "1") == "1":
+                # two calls, the second one issued FROM the side stream: the root gradient of a backward call is
+                # created on the ambient stream, and every node waits for it — created on the main stream it would
+                # sit behind the whole render backward
+                (mse * self.loss_scale).backward()
+                with torch.cuda.stream(self.ctx_stream):
+                    (c.lmbda * bpp * self.loss_scale).backward()
+                torch.cuda.current_stream(self.device).wait_stream(self.ctx_stream)
+            else:
+                (loss * self.loss_scale).backward()
         else:
             # Data-parallel step.  The ray loss differs per rank, the entropy loss does not (same tables, same
             # window draw on every rank): so only the ray-loss gradient is exchanged, and its all-reduce runs

@@ -79,6 +79,7 @@ int cnc_grid_encode_forward(const float* inputs, const float* embeddings,
                             uint32_t Rb, float PV,
                             float* dy_dx, const uint8_t* binary_vxl, const int32_t* min_level_id,
                             uint32_t flags, const int32_t* occ_sat,
+                            const uint32_t* vertex_bits, const int32_t* vertex_bit_offsets,
                             uint32_t out_ld, uint32_t out_col, void* stream);
 /*   out_ld / out_col: 0 / 0 = the reference's level-major outputs [L, N, F].  out_ld != 0: write
  *   point-major into a wider feature matrix, outputs[b * out_ld + out_col + l * F + f], so several
@@ -87,7 +88,18 @@ int cnc_grid_encode_forward(const float* inputs, const float* embeddings,
 /*   occ_sat (may be NULL; only read when binary_vxl != NULL): summed-volume table of binary_vxl,
  *   int32 [(Rb+1)^D], sat[a][b][c] = #set cells with indices < (a,b,c).  With it the per-corner
  *   occupancy test costs 2^D loads instead of a scan of the whole +-1 vertex box; the result is
- *   identical (integer arithmetic).  The host mirror builds it with three cumsums per grid update. */
+ *   identical (integer arithmetic).  The host mirror builds it with three cumsums per grid update.
+ *   vertex_bits / vertex_bit_offsets (may be NULL; only read when binary_vxl != NULL): per-level bit planes of the
+ *   same predicate, built once per grid update by cnc_grid_vertex_bits — bit q0 + R (q1 + R q2) of level l's plane,
+ *   which starts at 32-bit word vertex_bit_offsets[l] of vertex_bits (i32 [L], indexed like `resolutions`; < 0 =
+ *   no plane for that level, the test falls back to occ_sat / the scan).  One bit read per corner instead of 2^D
+ *   table entries; identical results.                                                                        */
+
+/* Vertex bit plane of ONE level of resolution R (ABI v22): words[cnc_grid_vertex_bits_words(D, R)] u32, bit
+ * q0 + R (q1 + R q2) = 1 iff the +-1-vertex box of vertex q holds a set occupancy cell (gridencoder.cu:221-276,
+ * the per-corner test of kernel_grid evaluated for every vertex).  occ_sat as above.                        */
+uint64_t cnc_grid_vertex_bits_words(uint32_t D, uint32_t R);
+int cnc_grid_vertex_bits(const int32_t* occ_sat, uint32_t D, uint32_t Rb, uint32_t R, uint32_t* words, void* stream);
 
 /* grid_encode_backward (gridencoder.h:24-36, gridencoder.cu:808-866; kernel_grid_backward :399-585).
  *   grad [L, N, F] f32;  grad_embeddings [rows, F] f32, ACCUMULATED into (caller zero-fills,
@@ -100,7 +112,9 @@ int cnc_grid_encode_backward(const float* grad, const float* inputs, const float
                              const float* dy_dx, float* grad_inputs,
                              const uint8_t* binary_vxl, const int32_t* min_level_id,
                              uint32_t flags, const uint32_t* ste_clip_count,
-                             const int32_t* occ_sat, uint32_t grad_ld, uint32_t grad_col,
+                             const int32_t* occ_sat,
+                             const uint32_t* vertex_bits, const int32_t* vertex_bit_offsets,
+                             uint32_t grad_ld, uint32_t grad_col,
                              void* stream);   /* grad_ld/grad_col: layout of `grad`, as out_ld/out_col */
 /*   ste_clip_count (device pointer, may be NULL): with CNC_FLAG_STE_BINARY, the number of table
  *   entries with |v| > 1 as counted by cnc_pack_sign_bits.  When it reads 0 the STE mask is the
@@ -121,8 +135,10 @@ int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* bits,
                                  float* outputs,
                                  uint32_t N, uint32_t D, uint32_t F, uint32_t L, uint32_t Rb,
                                  const uint8_t* binary_vxl, const int32_t* min_level_id,
-                                 const int32_t* occ_sat, uint32_t out_ld, uint32_t out_col,
-                                 void* stream);   /* out_ld/out_col as cnc_grid_encode_forward */
+                                 const int32_t* occ_sat,
+                                 const uint32_t* vertex_bits, const int32_t* vertex_bit_offsets,
+                                 uint32_t out_ld, uint32_t out_col,
+                                 void* stream);   /* out_ld/out_col, vertex_bits as cnc_grid_encode_forward */
 
 /* Same gradient as cnc_grid_encode_backward (no binary_vxl / min_level_id), with the n_binned FINEST
  * levels taken off the global-atomic path (D = 3, F in {2,4,8}): their (sample, corner-pair)

@@ -27,28 +27,41 @@ def _points(N, D, seed):
     return x
 
 
-def _fwd_gpu(dev, x, emb, offs, res, L, vxl=None, mli=None, ste=False):
+def _vertex_bits(dev, vxl, res, use):
+    """(sat, (words, offsets)) of an occupancy grid for the levels `res`: the per-corner box test read from one bit
+    per vertex (cnc_grid_vertex_bits) instead of the scan / the summed-volume table."""
+    if not use or vxl is None:
+        return None, None
+    from cnc_amd.backends import gridencoder_backend as be
+    v = torch.as_tensor(vxl, device=dev)
+    sat = be.occupancy_sat(v)
+    return sat, be.occupancy_vertex_bits(v, sat, [int(r) for r in res])
+
+
+def _fwd_gpu(dev, x, emb, offs, res, L, vxl=None, mli=None, ste=False, vbits=False):
     from cnc_amd.backends import gridencoder_backend as be
     t = lambda a, dt=None: None if a is None else torch.as_tensor(a, device=dev)
     N, D = x.shape
     F = emb.shape[1]
     out = torch.empty((L, N, F), dtype=torch.float32, device=dev)
     Rb = 128 if vxl is None else vxl.shape[-1]
+    sat, vb = _vertex_bits(dev, vxl, res, vbits)
     be.grid_encode_forward(t(x), t(emb), t(offs), t(res), out, N, D, F, L, 0, Rb, 0.0, None,
-                           t(vxl), t(mli), ste_binary=ste)
+                           t(vxl), t(mli), ste_binary=ste, occ_sat=sat, vertex_bits=vb)
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
 
-def _bwd_gpu(dev, g, x, emb, offs, res, vxl=None, mli=None, ste=False):
+def _bwd_gpu(dev, g, x, emb, offs, res, vxl=None, mli=None, ste=False, vbits=False):
     from cnc_amd.backends import gridencoder_backend as be
     t = lambda a: None if a is None else torch.as_tensor(a, device=dev)
     L, N, F = g.shape
     D = x.shape[1]
     ge = torch.zeros(emb.shape, dtype=torch.float32, device=dev)
     Rb = 128 if vxl is None else vxl.shape[-1]
+    sat, vb = _vertex_bits(dev, vxl, res, vbits)
     be.grid_encode_backward(t(g), t(x), t(emb), t(offs), t(res), ge, N, D, F, L, 0, Rb, None, None,
-                            t(vxl), t(mli), ste_binary=ste)
+                            t(vxl), t(mli), ste_binary=ste, occ_sat=sat, vertex_bits=vb)
     torch.cuda.synchronize()
     return ge.cpu().numpy()
 
@@ -66,33 +79,69 @@ def test_forward_bit_exact(cuda, oracle, D, F):
     assert np.all(got[:, 2] == 0) and np.all(got[:, 3] == 0)   # OOB points
 
 
+VBITS = pytest.mark.parametrize("vbits", [False, True], ids=["box_scan", "vertex_bits"])
+
+
+@VBITS
 @pytest.mark.parametrize("D", [2, 3])
 @pytest.mark.parametrize("ste", [False, True])
-def test_forward_with_occupancy_mask(cuda, oracle, D, ste):
+def test_forward_with_occupancy_mask(cuda, oracle, D, ste, vbits):
     res = RES3 if D == 3 else RES2
     offs, resl, emb = make_grid(res, 10, D, 8, seed=3)
     vxl = ball_occupancy(16 if D == 3 else 32, D)
     x = _points(2500, D, seed=5)
     want = oracle.grid_encode_forward(x, emb, offs, resl, binary_vxl=vxl, ste_binary=ste)
-    got = _fwd_gpu(cuda, x, emb, offs, resl, len(res), vxl=vxl, ste=ste)
+    got = _fwd_gpu(cuda, x, emb, offs, resl, len(res), vxl=vxl, ste=ste, vbits=vbits)
     assert np.array_equal(got, want)
 
 
-def test_forward_level_window_slice_and_per_point_levels(cuda, oracle):
+@VBITS
+def test_forward_level_window_slice_and_per_point_levels(cuda, oracle, vbits):
     offs, resl, emb = make_grid(RES3, 10, 3, 4, seed=7)
     vxl = ball_occupancy(16, 3)
     x = _points(1777, 3, seed=8)
     # scalar window: the reference slices the tables in Python (ngp.py:90-91)
     lo, hi = 2, 5
     want = oracle.grid_encode_forward(x, emb, offs[lo:hi + 1], resl[lo:hi], binary_vxl=vxl)
-    got = _fwd_gpu(cuda, x, emb, offs[lo:hi + 1].copy(), resl[lo:hi].copy(), hi - lo, vxl=vxl)
+    got = _fwd_gpu(cuda, x, emb, offs[lo:hi + 1].copy(), resl[lo:hi].copy(), hi - lo, vxl=vxl, vbits=vbits)
     assert np.array_equal(got, want)
     # per-point window (forward_diff_levels, ngp.py:265-297)
     rng = np.random.default_rng(1)
     mli = rng.integers(0, len(RES3) - 3 + 1, size=x.shape[0]).astype(np.int32)
     want = oracle.grid_encode_forward(x, emb, offs, resl, n_levels_calc=3, binary_vxl=vxl, min_level_id=mli)
-    got = _fwd_gpu(cuda, x, emb, offs, resl, 3, vxl=vxl, mli=mli)
+    got = _fwd_gpu(cuda, x, emb, offs, resl, 3, vxl=vxl, mli=mli, vbits=vbits)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_vertex_bits_equal_the_box_test_of_every_vertex(cuda, oracle, D):
+    """cnc_grid_vertex_bits against the oracle: a vertex q of level R sits exactly on the point (q - 0.5) / (R - 2)
+    of that level, where corner 0 has weight 1 — encoding a table of ones there returns 1 iff the oracle's
+    per-corner box test (gridencoder.cu:221-276) passes for q.  Also: a level above the size cap gets no plane."""
+    from cnc_amd.backends import gridencoder_backend as be
+    res = [5, 9, 14] if D == 3 else [6, 19, 40]
+    Rb = 16 if D == 3 else 32
+    vxl = (np.random.default_rng(D).uniform(size=(Rb,) * D) < 0.02).astype(np.uint8)    # sparse: both answers occur
+    v = torch.as_tensor(vxl, device=cuda).to(torch.bool)
+    sat = be.occupancy_sat(v)
+    words, offs = be.occupancy_vertex_bits(v, sat, res, max_vertices=res[1] ** D)
+    offs = offs.cpu().numpy()
+    assert offs[0] == 0 and offs[1] > 0 and offs[2] == -1
+    words = words.cpu().numpy().view(np.uint32)
+    for l in (0, 1):
+        R = res[l]
+        q = np.stack(np.meshgrid(*[np.arange(1, R - 1)] * D, indexing="ij"), -1).reshape(-1, D)   # inner vertices
+        x = ((q.astype(np.float32) - np.float32(0.5)) / np.float32(R - 2)).astype(np.float32)
+        offs_l = np.array([0, R ** D + 8], dtype=np.int32)
+        emb = np.ones((R ** D + 8, 1), dtype=np.float32)
+        want = oracle.grid_encode_forward(x, emb, offs_l, np.array([R], dtype=np.int32), binary_vxl=vxl)[0, :, 0]
+        idx = sum(q[:, d].astype(np.int64) * R ** d for d in range(D))
+        got = (words[offs[l] + idx // 32] >> (idx % 32).astype(np.uint32)) & 1
+        # with a single valid corner of weight 1 the renormalised output is 1; 0 when the corner is masked out
+        # (other corners have weight 0: they add nothing either way)
+        assert np.array_equal(got.astype(np.float32), (want > 0.5).astype(np.float32))
+        if l == 1:
+            assert got.min() == 0 and got.max() == 1
 
 
 @pytest.mark.parametrize("N", [0, 1, 63, 64, 65, 257])
@@ -133,7 +182,8 @@ def test_backward_against_float64_shadow(cuda, oracle, D, F, ste):
         assert np.all(got[np.abs(emb) > 1] == 0)
 
 
-def test_backward_with_mask_and_per_point_levels(cuda, oracle):
+@VBITS
+def test_backward_with_mask_and_per_point_levels(cuda, oracle, vbits):
     offs, resl, emb = make_grid(RES3, 10, 3, 8, seed=21)
     vxl = ball_occupancy(16, 3)
     x = _points(1500, 3, seed=22)
@@ -142,7 +192,7 @@ def test_backward_with_mask_and_per_point_levels(cuda, oracle):
     g = rng.normal(size=(3, x.shape[0], 8)).astype(np.float32)
     want32, acc64 = oracle.grid_encode_backward(g, x, emb, offs, resl, binary_vxl=vxl, min_level_id=mli, want_acc64=True)
     _, abs64 = oracle.grid_encode_backward(np.abs(g), x, emb, offs, resl, binary_vxl=vxl, min_level_id=mli, want_acc64=True)
-    got = _bwd_gpu(cuda, g, x, emb, offs, resl, vxl=vxl, mli=mli)
+    got = _bwd_gpu(cuda, g, x, emb, offs, resl, vxl=vxl, mli=mli, vbits=vbits)
     _check_bwd(got, want32, acc64, abs64, n_terms_max=x.shape[0] * 8)
 
 
