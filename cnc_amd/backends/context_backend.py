@@ -61,11 +61,13 @@ class ContextMLP(Function):
         dev = in_a.device
         g_a = torch.empty_like(in_a)
         g_b = torch.empty_like(in_b) if (in_b is not None and ctx.needs_input_grad[1]) else None
-        g_pg = torch.zeros(pgv.numel(), dtype=torch.float32, device=dev) if pgv is not None else None
-        # every weight / bias gradient in ONE zero-filled buffer (the kernel accumulates with atomics)
-        # (_REPLICAS copies: the kernel's ~1000 workgroups spread their atomics over them, summed below)
+        # every weight / bias gradient (and the Pg gradient behind them) in ONE zero-filled buffer (the kernel
+        # accumulates with atomics; _REPLICAS copies: its ~1000 workgroups spread their atomics over them, summed below)
         total = sum(w.numel() for w in ws if w is not None)
-        copies = torch.zeros((_REPLICAS, total), dtype=torch.float32, device=dev)
+        n_pg = 0 if pgv is None else pgv.numel()
+        zeroed = torch.zeros(_REPLICAS * total + n_pg, dtype=torch.float32, device=dev)
+        copies = zeroed[:_REPLICAS * total].view(_REPLICAS, total)
+        g_pg = zeroed[_REPLICAS * total:] if pgv is not None else None
         first, at = [], 0
         for w in ws:
             first.append(None if w is None else copies[0, at:at + w.numel()])

@@ -456,6 +456,7 @@ class CNC_context_models(nn.Module):
         self.skip_levels_3D = skip_levels_3D
         self.skip_levels_2D = skip_levels_2D
         self.sample_num = sample_num
+        self._noncoded_3D = None
         self.max_context_layer_num = max_context_layer_num
 
         def offsets(res, T, D):
@@ -861,6 +862,9 @@ class CNC_context_models(nn.Module):
             batches = iter(self.batched_inputs_list[k])
             with _range("ctx/level_Pg"):
                 Pg_all, bits_all = self.level_stats(p_q, self._off2_host)
+                # one unbind each instead of a select per level: a select's backward is a zero-filled [L] vector plus
+                # a copy — 43 five-microsecond kernels per step for the 27 selects of the four tables
+                Pg_all, bits_all = Pg_all.unbind(0), bits_all.unbind(0)
             # the coded levels of a plane share one rate kernel (their rows are distinct table rows, the bits add up):
             # one gather / one table-sized gradient per plane instead of one per level
             one_rate = self.fused_heads and p_q.is_cuda
@@ -901,9 +905,11 @@ class CNC_context_models(nn.Module):
         # the window bounds of every level in ONE device->host copy
         v0s, v1s, p0s, p1s = torch.stack([v0s, v1s, p0s, p1s]).tolist()
         coded = [n for n in range(self.n_levels) if self._coded_3D(n)]
-        for n in range(self.n_levels):
-            if n not in coded:
-                ttl_bit_sum = ttl_bit_sum + bits_all[n]
+        if len(coded) < self.n_levels:
+            if self._noncoded_3D is None or self._noncoded_3D.device != bits_all.device:
+                self._noncoded_3D = torch.tensor([0.0 if n in coded else 1.0 for n in range(self.n_levels)],
+                                                 dtype=bits_all.dtype, device=bits_all.device)
+            ttl_bit_sum = ttl_bit_sum + torch.dot(bits_all, self._noncoded_3D)      # the zero-order levels, one op
         fused = self.fused_heads and params_q_xyz.is_cuda and len(coded) <= 16
         L = self.max_context_layer_num
         if coded and fused:
