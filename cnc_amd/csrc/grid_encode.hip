@@ -925,9 +925,11 @@ static void launch_fwd_bits(const float* inputs, const uint8_t* bits, const int3
         P = F >= 16 ? 1u : 16u / F;      // 16 floats = one 64-byte sector per lane (measured at F = 8, 16 levels, ms per 2^20
         if (P > L) P = L;                // points: P = 1: 0.479, 2: 0.451, 4: 0.521, 8: 0.571, 16: 0.532; level-major 0.243)
     }
-    // streaming stores of the outputs: -2.4 % on the call, the bit plane keeps the L2 (CNC_FWD_NT=0: measurement switch)
+    // streaming stores of the level-major outputs (a wave writes 2 KB in one piece): -2.4 % on the call, the bit plane
+    // keeps the L2 (CNC_FWD_NT=0: measurement switch).  NOT for point-major rows: their 32-byte pieces need the L2 to
+    // merge into whole sectors — streamed they cost 3.7x (0.078 -> 0.29 ms per 2^18 points at 12 levels).
     static const int nt_mode = getenv("CNC_FWD_NT") ? atoi(getenv("CNC_FWD_NT")) : 1;
-    lay.nt = nt_mode ? 1u : 0u;
+    lay.nt = (nt_mode && lay.ld == 0) ? 1u : 0u;
     const dim3 grid(div_up(N, 256), div_up(L, P), 1);
     if (vxl) hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, true>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, L, P, Rb, vxl, mli, sat, lay);
     else hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, false>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, L, P, Rb, vxl, mli, nullptr, lay);

@@ -160,6 +160,9 @@ __device__ __forceinline__ void flush_pairs(const Stage& st, float* __restrict__
 // rows with coalesced stores (flush_stage), and the lane continues exactly where it stopped
 // (same registers, same cell), so values and order equal the one-sweep march of grid.cu:68-318.
 // MODE 0: count only.  MODE 1: fill the reference's RaySegmentsSpec pair (intervals + samples).
+// MODE 3 (extension, small batches of cnc_march_samples): MODE 2's outputs stored by each lane as it goes — no LDS, no
+// pause / resume, full waves: for a training batch (~37 k rays, 260 k samples) the pass is a serial march per ray and
+// the staging only adds latency (0.66 -> the count pass's 0.35 ms); the big frames keep the coalesced flushes.
 // MODE 2 (extension, cnc_march_samples): fill (t_start, t_end, ray) per sample and nothing else — what the
 // renderer consumes (occ_grid.py:176-178 derives exactly these from the edge flags) — 16 instead of 27 bytes
 // per sample, 32-entry staging rows and a flush that only touches rows that have something to write.
@@ -174,7 +177,8 @@ __global__ __launch_bounds__(64) void k_traverse(
     Seg iv, Seg sm, float* __restrict__ terminate_planes, int32_t rpb)
 {
     extern __shared__ float s_dyn[];
-    constexpr bool FILL = MODE != 0;
+    constexpr bool DIRECT = MODE == 3;                  // fill without staging: every lane stores its own samples
+    constexpr bool FILL = MODE != 0 && !DIRECT;         // "FILL" below = the staged (resumable) fill passes
     constexpr bool PAIRS = MODE == 2;
     constexpr int  kRow = PAIRS ? PROW : kStage;        // staged entries per lane
     constexpr int  kPP = PROW + 1;
@@ -202,8 +206,11 @@ __global__ __launch_bounds__(64) void k_traverse(
         if (live && has_iv && iv.chunk_cnts[tid] == 0) live = false;
         if (live && has_sm && sm.chunk_cnts[tid] == 0) live = false;
     }
+    if constexpr (DIRECT) {
+        if (live && sm.chunk_cnts[tid] == 0) live = false;
+    }
     int64_t cs_iv = 0, cs_sm = 0;
-    if (FILL && live) {
+    if ((FILL || DIRECT) && live) {
         if (has_iv) cs_iv = iv.chunk_starts[tid];
         if (has_sm) cs_sm = sm.chunk_starts[tid];
     }
@@ -335,7 +342,12 @@ __global__ __launch_bounds__(64) void k_traverse(
                                     n_iv += 1;
                                 }
                             }
-                            if constexpr (PAIRS) {
+                            if constexpr (DIRECT) {
+                                const int64_t k = cs_sm + n_sm;
+                                sm.vals[k] = t_last;
+                                iv.vals[k] = t_next;
+                                sm.ray_indices[k] = tid;
+                            } else if constexpr (PAIRS) {
                                 st.sm[lane * kPP + st_sm] = t_last;
                                 st.iv[lane * kPP + st_sm] = t_next;
                                 st_sm++;
@@ -518,7 +530,10 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
         return CNC_ERR_INVALID_VALUE;
     // the fill pass of a small batch runs 16 rays per 64-lane block (measured on 27 k rays: 0.86 -> 0.67 ms; 8 / 32 rays:
     // 0.80 / 0.75; the count pass, which stages nothing in LDS, prefers full waves: 0.33 vs 0.36)
-    const int32_t  rpb = (chunk_starts && n_rays < (1 << 17)) ? 16 : 64;
+    const char*    dm = getenv("CNC_MARCH_DIRECT_MAX");        // measurement / test switch (0: always stage)
+    const int      direct_max = dm ? atoi(dm) : (1 << 17);
+    const bool     direct = chunk_starts && n_rays < direct_max;
+    const int32_t  rpb = (chunk_starts && !direct && n_rays < (1 << 17)) ? 16 : 64;
     const uint32_t blocks = div_up((uint32_t)n_rays, (uint32_t)rpb);
     Seg none{}, sm{};
     sm.chunk_cnts = chunk_cnts;
@@ -535,6 +550,12 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
     sm.vals = t_starts;
     sm.ray_indices = ray_indices;
     ends.vals = t_ends;
+    if (direct) {
+        hipLaunchKernelGGL((k_traverse<3>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
+                           n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices, near_planes,
+                           far_planes, step_size, cone_angle, traverse_steps_limit, ends, sm, terminate_planes, rpb);
+        return launch_status();
+    }
     // staging row length, measured on the 800x800 bench frame (count + fill, ms): 8 -> 3.53, 16 -> 2.55,
     // 32 -> 2.32, 64 -> 2.89 (LDS then limits the waves per CU)
     static const int row = getenv("CNC_PAIR_STAGE") ? atoi(getenv("CNC_PAIR_STAGE")) : 32;
