@@ -236,12 +236,16 @@ class Trainer:
         self.build_optimizers()
         self.loss_scale = 2.0 ** 10          # GradScaler(2**10), never unscaled (train:211,361-362)
 
-        # The context pass runs on its own stream: its backward (autograd replays every node on its forward's stream)
-        # then runs NEXT TO the render backward instead of after it — ~60 small latency-bound kernels beside the
-        # field's GEMMs (single process only: the data-parallel step orders its buckets on one stream).
+        # The context pass (forward and backward) runs on its own stream next to the render backward — see train_step
+        # (single process only: the data-parallel step orders its buckets on one stream).
         self.ctx_stream = None
         if self.device.type == "cuda" and os.environ.get("CNC_CTX_STREAM", "1") == "1":
             self.ctx_stream = torch.cuda.Stream(device=self.device)
+        # ... and from its own host thread, started before the render pass (`_context_pass`): the two passes are ~300
+        # launches each and the step is otherwise bound by the host issuing them one after the other.  Off = the
+        # sequential schedule, which keeps the reference's order of random draws (the trajectory goldens need it).
+        self.ctx_thread = self.ctx_stream is not None and os.environ.get("CNC_CTX_THREAD", "1") == "1"
+        self._pool = None
         self.bucket = None
         self.time_comm = False          # bench hook: HIP events around the wait for the gradient all-reduce
         self._comm_events = []
@@ -286,6 +290,23 @@ class Trainer:
         self.sched, self.sched2 = sched(self.opt), sched(self.opt2)
 
     # -------------------------------------------------------------------------------- training
+    def _context_pass(self, step: int, fork):
+        """Entropy loss forward + backward on the side stream (from whichever host thread calls it), ordered after the
+        event `fork` of the main stream.  Returns (bits_per_param, estimated MB, event that marks its end)."""
+        c, side = self.cfg, self.ctx_stream
+        torch.cuda.set_device(self.device)
+        e = self.field.mlp_base
+        side.wait_event(fork)
+        with torch.cuda.stream(side):
+            bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(
+                e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
+                sample_num=None, step=step, sync_MB=False)
+            # issued from the side stream: the root gradient of a backward call is created on the ambient stream and
+            # every node waits for it
+            (c.lmbda * bits_per_param * self.loss_scale).backward()
+            done = side.record_event()
+        return bits_per_param, mb, done
+
     def train_step(self, step: int, want_stats: bool = True) -> Optional[Dict[str, float]]:
         """One optimisation step.  `want_stats=False` leaves mse / psnr / bpp / embed_bits_MB out of the result
         (reading them back is a device->host sync per step; the reference only looks at them every 200 steps,
@@ -299,6 +320,22 @@ class Trainer:
             occ_thre=1e-2, n=c.step_update)
         if self.world > 1 and step % c.step_update == 0:
             cdist.broadcast_module_buffers(self.estimator, ["occs", "binaries"])
+        ctx_future = None
+        if self.ctx_thread and self.ctx_stream is not None and self.bucket is None and c.lmbda > 0:
+            # Single process: the ray loss and the entropy loss share nothing but the parameters and the occupancy
+            # grid (just updated above).  The entropy pass starts NOW, on the side stream and from a second host
+            # thread, next to the whole render pass.  What both passes read through a cache — the sign bit planes of
+            # the tables — is made current on the main stream first; gradients are cleared before either backward.
+            for enc in self.field.mlp_base._encoders():
+                if enc.ste_binary and enc.bitplane:
+                    enc._bit_plane(enc.params)
+            self.opt.zero_grad(set_to_none=True)
+            self.opt2.zero_grad(set_to_none=True)
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cnc-context")
+            ctx_future = self._pool.submit(self._context_pass, step,
+                                           torch.cuda.current_stream(self.device).record_event())
         rgb, acc, depth, n_samples, extra = render_image_with_occgrid(
             self.field, self.estimator, rays, near_plane=c.near_plane, render_step_size=c.render_step_size,
             render_bkgd=bkgd, cone_angle=c.cone_angle, alpha_thre=c.alpha_thre, return_extra=True)
@@ -306,45 +343,56 @@ class Trainer:
         if self.world > 1:   # every rank must take the same branch and keep the same ray budget
             n_all = int(cdist.sum_over_ranks(float(n_samples), self.device) / self.world)
         if n_all == 0:
+            if ctx_future is not None:
+                torch.cuda.current_stream(self.device).wait_event(ctx_future.result()[2])
             return None
         if c.target_sample_batch_size > 0:
             self.dataset.update_num_rays(int(len(pixels) * (c.target_sample_batch_size / float(n_all))))
         mse = F.mse_loss(rgb, pixels)
         loss = mse
         bpp, mb = 0.0, 0.0
-        if c.lmbda > 0:
-            e = self.field.mlp_base
-            side = self.ctx_stream if self.bucket is None else None
-            if side is not None:
-                main = torch.cuda.current_stream(self.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(
-                        e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
-                        sample_num=None, step=step, sync_MB=False)
-                main.wait_stream(side)
-                for t in (bits_per_param, mb):      # allocated on the side stream, read on the main one from here on
-                    if isinstance(t, torch.Tensor):
-                        t.record_stream(main)
-            else:
-                bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(
-                    e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
-                    sample_num=None, step=step, sync_MB=False)
-            loss = loss + c.lmbda * bits_per_param
+        e = self.field.mlp_base
+        ctx_args = (e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries)
+        side = self.ctx_stream if (self.bucket is None and c.lmbda > 0 and mse.requires_grad) else None
+        if ctx_future is not None:
+            (mse * self.loss_scale).backward()
+            bits_per_param, mb, done = ctx_future.result()
+            main = torch.cuda.current_stream(self.device)
+            main.wait_event(done)
+            for t in (bits_per_param, mb):      # allocated on the side stream, read on the main one from here on
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
             bpp = bits_per_param
-        self.opt.zero_grad(set_to_none=self.bucket is None)
-        self.opt2.zero_grad(set_to_none=self.bucket is None)
-        if self.bucket is None:
-            if self.ctx_stream is not None and c.lmbda > 0 and os.environ.get("CNC_CTX_TWO_BACKWARDS", "1") == "1":
-                # two calls, the second one issued FROM the side stream: the root gradient of a backward call is
-                # created on the ambient stream, and every node waits for it — created on the main stream it would
-                # sit behind the whole render backward
-                (mse * self.loss_scale).backward()
-                with torch.cuda.stream(self.ctx_stream):
-                    (c.lmbda * bpp * self.loss_scale).backward()
-                torch.cuda.current_stream(self.device).wait_stream(self.ctx_stream)
-            else:
-                (loss * self.loss_scale).backward()
+            side = True
+        elif side is not None:
+            # The sequential schedule of the same idea (one host thread; the reference's order of random draws):
+            #   render backward (main stream: few launches, GPU-heavy)
+            #   || context forward + context backward (side stream: ~250 launches, host-bound forward)
+            # The side stream forks BEFORE the render backward is enqueued; its host-side syncs (window bounds,
+            # nonzero) wait for the side stream only.
+            self.opt.zero_grad(set_to_none=True)
+            self.opt2.zero_grad(set_to_none=True)
+            main = torch.cuda.current_stream(self.device)
+            fork = main.record_event()
+            (mse * self.loss_scale).backward()
+            bits_per_param, mb, done = self._context_pass(step, fork)
+            main.wait_event(done)
+            for t in (bits_per_param, mb):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
+            bpp = bits_per_param
+        else:
+            if c.lmbda > 0:
+                bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(*ctx_args, sample_num=None, step=step,
+                                                                               sync_MB=False)
+                loss = loss + c.lmbda * bits_per_param
+                bpp = bits_per_param
+            self.opt.zero_grad(set_to_none=self.bucket is None)
+            self.opt2.zero_grad(set_to_none=self.bucket is None)
+        if side is not None:
+            pass
+        elif self.bucket is None:
+            (loss * self.loss_scale).backward()
         else:
             # Data-parallel step.  The ray loss differs per rank, the entropy loss does not (same tables, same
             # window draw on every rank): so only the ray-loss gradient is exchanged, and its all-reduce runs

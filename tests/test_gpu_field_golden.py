@@ -302,6 +302,7 @@ def test_training_trajectory(cuda, tag, fused, tmp_path):
                       milestones=tuple(c["milestones"]), warmup_iters=int(g["warmup_iters"]),
                       dimension_wise_resolution=c["fine"], out_dir=str(tmp_path))
     tr = Trainer(cfg, device=cuda, dataset=_NumpyBall(cuda))
+    tr.ctx_thread = False          # one host thread: the reference's ORDER of random draws (render pass, then context pass)
     torch.manual_seed(11)                              # the context tables' CPU draws, as the golden run
     tr.context = tr.build_context()
     tr.context.MAX_POINTS_NUM_TO_OOM = c["max_pts"]

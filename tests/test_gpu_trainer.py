@@ -215,3 +215,37 @@ def test_front_to_back_density_gives_the_same_samples(cuda, tmp_path):
     if ts_a.shape[0] == ts_b.shape[0]:
         same = (ri_a == ri_b) & (ts_a == ts_b) & (te_a == te_b)
         assert float(same.float().mean()) > 0.9999
+
+
+def test_threaded_context_pass_equals_the_sequential_schedule(cuda, tmp_path):
+    """The default single-process schedule (context forward + backward on a side stream, issued from a second host
+    thread next to the render pass) against the sequential one and against one stream / one thread: same loss, same
+    rate, same sample counts, same parameters after several steps — up to the order of float atomics.  The context
+    pass draws from its own generator here, so the values do not depend on which thread draws first."""
+    from cnc_amd.trainer import Trainer
+
+    def run(mode):
+        tr = Trainer(_cfg(tmp_path, seed=3), device=cuda)
+        g = torch.Generator(device=cuda)
+        g.manual_seed(77)
+        tr.context.rand_like = lambda t: torch.rand(t.shape, generator=g, device=t.device, dtype=t.dtype)
+        if mode == "plain":
+            tr.ctx_stream, tr.ctx_thread = None, False
+        elif mode == "stream":
+            tr.ctx_thread = False
+        else:
+            assert tr.ctx_thread and tr.ctx_stream is not None            # the default
+        out = [tr.train_step(s) for s in range(20)]
+        torch.cuda.synchronize()
+        return out, [p.detach().clone() for p in list(tr.field.parameters()) + list(tr.context.parameters())]
+
+    ref, ref_p = run("plain")
+    for mode in ("stream", "thread"):
+        got, got_p = run(mode)
+        for a, b in zip(ref[:4], got[:4]):             # before the chaotic regime of binarised tables (see DESIGN §6)
+            assert a["n_rendering_samples"] == b["n_rendering_samples"] and a["num_rays"] == b["num_rays"]
+            assert abs(a["mse"] - b["mse"]) <= 1e-5 * max(a["mse"], 1e-6) + 1e-9, mode
+            assert abs(a["bpp"] - b["bpp"]) <= 1e-5 * a["bpp"], mode
+        assert abs(ref[-1]["bpp"] - got[-1]["bpp"]) <= 0.05 * ref[-1]["bpp"], mode
+        assert abs(ref[-1]["mse"] - got[-1]["mse"]) <= 0.2 * ref[-1]["mse"], mode
+        assert all(torch.isfinite(p).all() for p in got_p)

@@ -12,10 +12,13 @@ what = sys.argv[1] if len(sys.argv) > 1 else "bucket"
 def switch(on):
     if what == "bucket":
         tr.field.row_bucket_min = 4096 if on else 1 << 30
+    elif what == "ctxthread":
+        tr.ctx_thread = on
     elif what == "ctxstream":
         if not hasattr(tr, "_cs"):
             tr._cs = tr.ctx_stream
         tr.ctx_stream = tr._cs if on else None
+        tr.ctx_thread = False
     elif what == "vbits":
         for e in tr.field.mlp_base._encoders():
             e.vertex_bits = on
