@@ -32,7 +32,7 @@ from cnc_amd.backends import nerfacc_cuda as ngrid_cuda  # noqa: E402
 
 F, L, D = 8, 16, 3
 LOG2_T = 19
-CHUNK = 1 << 20
+CHUNK = int(os.environ.get("CNC_BENCH_CHUNK", 1 << 20))      # samples per encoder call
 STEP_SIZE = 5e-3
 AABB = (-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)
 HBM_PEAK = 8.0e12
