@@ -236,8 +236,7 @@ class Trainer:
         self.build_optimizers()
         self.loss_scale = 2.0 ** 10          # GradScaler(2**10), never unscaled (train:211,361-362)
 
-        # The context pass (forward and backward) runs on its own stream next to the render backward — see train_step
-        # (single process only: the data-parallel step orders its buckets on one stream).
+        # The entropy pass (context forward and backward) runs on its own stream next to the render pass — see train_step
         self.ctx_stream = None
         if self.device.type == "cuda" and os.environ.get("CNC_CTX_STREAM", "1") == "1":
             self.ctx_stream = torch.cuda.Stream(device=self.device)
@@ -256,9 +255,15 @@ class Trainer:
             base = self.context.rand_like
 
             def synced_rand_like(t):
+                # the threaded schedule draws (and broadcasts) on the MAIN thread before it forks: collectives of one
+                # communicator must be issued in the same order on every rank, so the worker thread issues none
+                if self._ctx_rand is not None:
+                    r, self._ctx_rand = self._ctx_rand, None
+                    return r
                 r = base(t)
                 torch.distributed.broadcast(r, 0)
                 return r
+            self._ctx_rand = None
             self.context.rand_like = synced_rand_like
 
     def build_context(self):
@@ -290,9 +295,12 @@ class Trainer:
         self.sched, self.sched2 = sched(self.opt), sched(self.opt2)
 
     # -------------------------------------------------------------------------------- training
-    def _context_pass(self, step: int, fork):
+    def _context_pass(self, step: int, fork, params=None):
         """Entropy loss forward + backward on the side stream (from whichever host thread calls it), ordered after the
-        event `fork` of the main stream.  Returns (bits_per_param, estimated MB, event that marks its end)."""
+        event `fork` of the main stream.  `params` = None: the gradient is accumulated into `.grad`; a parameter list:
+        it is RETURNED (torch.autograd.grad, None for parameters the entropy loss does not reach) and `.grad` is left
+        alone — the data-parallel step keeps the ray-loss gradient there for its all-reduce.
+        Returns (bits_per_param, estimated MB, event that marks the end of the pass, gradients or None)."""
         c, side = self.cfg, self.ctx_stream
         torch.cuda.set_device(self.device)
         e = self.field.mlp_base
@@ -303,9 +311,14 @@ class Trainer:
                 sample_num=None, step=step, sync_MB=False)
             # issued from the side stream: the root gradient of a backward call is created on the ambient stream and
             # every node waits for it
-            (c.lmbda * bits_per_param * self.loss_scale).backward()
+            root = c.lmbda * bits_per_param * self.loss_scale
+            grads = None
+            if params is None:
+                root.backward()
+            else:
+                grads = torch.autograd.grad(root, params, allow_unused=True)
             done = side.record_event()
-        return bits_per_param, mb, done
+        return bits_per_param, mb, done, grads
 
     def train_step(self, step: int, want_stats: bool = True) -> Optional[Dict[str, float]]:
         """One optimisation step.  `want_stats=False` leaves mse / psnr / bpp / embed_bits_MB out of the result
@@ -321,21 +334,31 @@ class Trainer:
         if self.world > 1 and step % c.step_update == 0:
             cdist.broadcast_module_buffers(self.estimator, ["occs", "binaries"])
         ctx_future = None
-        if self.ctx_thread and self.ctx_stream is not None and self.bucket is None and c.lmbda > 0:
-            # Single process: the ray loss and the entropy loss share nothing but the parameters and the occupancy
-            # grid (just updated above).  The entropy pass starts NOW, on the side stream and from a second host
-            # thread, next to the whole render pass.  What both passes read through a cache — the sign bit planes of
-            # the tables — is made current on the main stream first; gradients are cleared before either backward.
+        if self.ctx_thread and self.ctx_stream is not None and c.lmbda > 0:
+            # The ray loss and the entropy loss share nothing but the parameters and the occupancy grid (just updated
+            # above).  The entropy pass starts NOW, on the side stream and from a second host thread, next to the whole
+            # render pass.  What both passes read through a cache — the sign bit planes of the tables — is made
+            # current on the main stream first; gradients are cleared before either backward.  Data parallel: the
+            # worker returns its gradient instead of accumulating it (`.grad` = the bucket that is all-reduced), and
+            # the window draw that every rank must share is made and broadcast here, on the main thread.
             for enc in self.field.mlp_base._encoders():
                 if enc.ste_binary and enc.bitplane:
                     enc._bit_plane(enc.params)
-            self.opt.zero_grad(set_to_none=True)
-            self.opt2.zero_grad(set_to_none=True)
+            if self.bucket is None:
+                self.opt.zero_grad(set_to_none=True)
+                self.opt2.zero_grad(set_to_none=True)
+            else:
+                self.bucket.zero()
+                self.bucket.bind(force=True)
+                self._ctx_rand = None
+                self._ctx_rand = self.context.rand_like(self.context.utils_rand)
+                self._ctx_rand.record_stream(self.ctx_stream)      # allocated here, read by the side stream
             if self._pool is None:
                 from concurrent.futures import ThreadPoolExecutor
                 self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cnc-context")
             ctx_future = self._pool.submit(self._context_pass, step,
-                                           torch.cuda.current_stream(self.device).record_event())
+                                           torch.cuda.current_stream(self.device).record_event(),
+                                           None if self.bucket is None else self.bucket.params)
         rgb, acc, depth, n_samples, extra = render_image_with_occgrid(
             self.field, self.estimator, rays, near_plane=c.near_plane, render_step_size=c.render_step_size,
             render_bkgd=bkgd, cone_angle=c.cone_angle, alpha_thre=c.alpha_thre, return_extra=True)
@@ -349,69 +372,70 @@ class Trainer:
         if c.target_sample_batch_size > 0:
             self.dataset.update_num_rays(int(len(pixels) * (c.target_sample_batch_size / float(n_all))))
         mse = F.mse_loss(rgb, pixels)
-        loss = mse
         bpp, mb = 0.0, 0.0
         e = self.field.mlp_base
         ctx_args = (e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries)
-        side = self.ctx_stream if (self.bucket is None and c.lmbda > 0 and mse.requires_grad) else None
-        if ctx_future is not None:
-            (mse * self.loss_scale).backward()
-            bits_per_param, mb, done = ctx_future.result()
-            main = torch.cuda.current_stream(self.device)
+        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+
+        def join(result):
+            """Order the main stream after the entropy pass; its outputs were allocated on the side stream."""
+            bits_per_param, mb_, done, grads = result
             main.wait_event(done)
-            for t in (bits_per_param, mb):      # allocated on the side stream, read on the main one from here on
+            for t in (bits_per_param, mb_) + tuple(g for g in (grads or ()) if g is not None):
                 if isinstance(t, torch.Tensor):
                     t.record_stream(main)
-            bpp = bits_per_param
-            side = True
-        elif side is not None:
-            # The sequential schedule of the same idea (one host thread; the reference's order of random draws):
-            #   render backward (main stream: few launches, GPU-heavy)
-            #   || context forward + context backward (side stream: ~250 launches, host-bound forward)
-            # The side stream forks BEFORE the render backward is enqueued; its host-side syncs (window bounds,
-            # nonzero) wait for the side stream only.
-            self.opt.zero_grad(set_to_none=True)
-            self.opt2.zero_grad(set_to_none=True)
-            main = torch.cuda.current_stream(self.device)
-            fork = main.record_event()
-            (mse * self.loss_scale).backward()
-            bits_per_param, mb, done = self._context_pass(step, fork)
-            main.wait_event(done)
-            for t in (bits_per_param, mb):
-                if isinstance(t, torch.Tensor):
-                    t.record_stream(main)
-            bpp = bits_per_param
-        else:
-            if c.lmbda > 0:
-                bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(*ctx_args, sample_num=None, step=step,
-                                                                               sync_MB=False)
-                loss = loss + c.lmbda * bits_per_param
-                bpp = bits_per_param
-            self.opt.zero_grad(set_to_none=self.bucket is None)
-            self.opt2.zero_grad(set_to_none=self.bucket is None)
-        if side is not None:
-            pass
-        elif self.bucket is None:
-            (loss * self.loss_scale).backward()
+            return bits_per_param, mb_, grads
+
+        if self.bucket is None:
+            if ctx_future is not None:
+                (mse * self.loss_scale).backward()
+                bpp, mb, _ = join(ctx_future.result())
+            elif self.ctx_stream is not None and c.lmbda > 0 and mse.requires_grad:
+                # The sequential schedule of the same idea (one host thread; the reference's order of random draws):
+                #   render backward (main stream: few launches, GPU-heavy)
+                #   || context forward + context backward (side stream: ~250 launches, host-bound forward)
+                # The side stream forks BEFORE the render backward is enqueued; its host-side syncs (window bounds,
+                # nonzero) wait for the side stream only.
+                self.opt.zero_grad(set_to_none=True)
+                self.opt2.zero_grad(set_to_none=True)
+                fork = main.record_event()
+                (mse * self.loss_scale).backward()
+                bpp, mb, _ = join(self._context_pass(step, fork))
+            else:
+                loss = mse
+                if c.lmbda > 0:
+                    bpp, mb = self.context.forward_binary_vxl_mixPg_3D2D(*ctx_args, sample_num=None, step=step,
+                                                                         sync_MB=False)
+                    loss = loss + c.lmbda * bpp
+                self.opt.zero_grad(set_to_none=True)
+                self.opt2.zero_grad(set_to_none=True)
+                (loss * self.loss_scale).backward()
         else:
             # Data-parallel step.  The ray loss differs per rank, the entropy loss does not (same tables, same
             # window draw on every rank): so only the ray-loss gradient is exchanged, and its all-reduce runs
-            # on the communicator's stream WHILE the context-model backward fills a second bucket.  The
-            # entropy gradient is equal across ranks only up to the order of its float atomics (~1e-9
-            # relative), so the replicas are re-aligned to rank 0 at every occupancy refresh (below).
+            # on the communicator's stream WHILE the entropy pass is still under way.  The entropy gradient is equal
+            # across ranks only up to the order of its float atomics (~1e-9 relative), so the replicas are
+            # re-aligned to rank 0 at every occupancy refresh (below).
             A, B = self.bucket, self.bucket_ctx
-            A.zero()
-            A.bind(force=True)
+            if ctx_future is None:
+                if c.lmbda > 0:
+                    bpp, mb = self.context.forward_binary_vxl_mixPg_3D2D(*ctx_args, sample_num=None, step=step,
+                                                                         sync_MB=False)
+                A.zero()
+                A.bind(force=True)
             if mse.requires_grad:          # a rank whose rays met no sample has nothing to add (its peers do): the
                 (mse * self.loss_scale).backward()     # collective below must still be entered by everyone
             work = A.allreduce(average=False, async_op=True)
-            if c.lmbda > 0:
+            ctx_grads = None
+            if ctx_future is not None:
+                bpp, mb, ctx_grads = join(ctx_future.result())
+            elif c.lmbda > 0:
                 B.zero()
                 B.bind(force=True)
                 (c.lmbda * bpp * self.loss_scale).backward()
             if work is not None:
                 if self.time_comm:      # how long the compute stream stalls for the collective (what was NOT hidden
-                    e0 = torch.cuda.Event(enable_timing=True)        # behind the context backward)
+                    e0 = torch.cuda.Event(enable_timing=True)        # behind the entropy pass)
                     e0.record()
                 work.wait()
                 if self.time_comm:
@@ -419,7 +443,10 @@ class Trainer:
                     e1.record()
                     self._comm_events.append((e0, e1))
             A.flat.div_(self.world)
-            if c.lmbda > 0:
+            if ctx_grads is not None:
+                pairs = [(v, g) for v, g in zip(A.views, ctx_grads) if g is not None]
+                torch._foreach_add_([v for v, _ in pairs], [g for _, g in pairs])
+            elif c.lmbda > 0:
                 A.flat.add_(B.flat)
             A.bind(force=True)
         self.opt.step()
