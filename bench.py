@@ -119,6 +119,7 @@ def step(w, timed, world):
     x = ngrid_cuda.sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends, w["aabbs"][0])
 
     gt = w["grad_table"]
+    finish_exchange(w, timed, world)                   # the previous frame's gradient exchange ran next to this march
     gt.zero_()                                         # zeros_like(embeddings), ngp.py:129
     out = w["out"]
     # STE_binary(params) of the reference (ngp.py:244-245) = one pass that writes the sign bit plane
@@ -137,9 +138,23 @@ def step(w, timed, world):
     mid = (S // CHUNK // 2) * CHUNK              # a chunk from the middle of the frame (the first one is atypical:
     w["probe_chunk"] = x[mid:mid + min(CHUNK, S)]    # 36k grazing rays of ~30 samples, 2.1 ms against 1.1-1.16)
     if world > 1:
-        # the only exchange of the path: one flat-bucket all-reduce of the table gradient
-        timed.launch("allreduce(grad_table)", gt.numel() * 4, lambda: w["bucket"].allreduce(average=True))
+        # the only exchange of the path: one flat-bucket all-reduce of the table gradient, asynchronous on the
+        # communicator's stream.  What the next frame does before it needs the table or its gradient again — the march
+        # (occupancy grid and rays only) — runs next to it; `finish_exchange` is where the compute stream joins.
+        w["exchange"] = w["bucket"].allreduce(average=False, async_op=True)
     return S
+
+
+def finish_exchange(w, timed, world):
+    """Wait for the pending all-reduce of the table gradient (if any) and turn the sum into the mean."""
+    work = w.pop("exchange", None)
+    if work is None:
+        return
+
+    def join():
+        work.wait()
+        w["bucket"].flat.div_(world)
+    timed.launch("allreduce(grad_table): wait + mean, after the next march", w["bucket"].flat.numel() * 4, join)
 
 
 def cpu_baseline(w):
@@ -363,12 +378,14 @@ def main():
 
     for _ in range(args.warmup):
         step(w, timed, world)
+    finish_exchange(w, timed, world)
     barrier()
     timed.pending, timed.acc = [], {}
     t0 = time.perf_counter()
     samples = 0
     for _ in range(args.steps):
         samples += step(w, timed, world)
+    finish_exchange(w, timed, world)          # the last frame's exchange ends inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     timed.collect()

@@ -35,7 +35,10 @@ def test_bench_spawns_two_ranks_and_allreduces(cuda):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     assert [x["rank"] for x in out["ranks"]] == [0, 1] and all(x["world_size"] == 2 for x in out["ranks"])
-    assert "allreduce(grad_table)" in out["kernels"] and out["kernels"]["allreduce(grad_table)"]["launches"] == 1
+    # one exchange per timed frame: issued asynchronously at the end of the frame, joined after the next march (or at the
+    # end of the timed region)
+    ar = [k for k in out["kernels"] if k.startswith("allreduce(grad_table)")]
+    assert len(ar) == 1 and out["kernels"][ar[0]]["launches"] == 1
     # whole-job value: both ranks' samples over the slowest rank's time
     assert out["value"] > 0 and out["config"]["samples_per_step_rank0"] > 6e7
     assert out["value"] * out["ms_per_step"] * 1e-3 > 1.5 * out["config"]["samples_per_step_rank0"]
