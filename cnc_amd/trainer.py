@@ -240,6 +240,10 @@ class Trainer:
         self.ctx_stream = None
         if self.device.type == "cuda" and os.environ.get("CNC_CTX_STREAM", "1") == "1":
             self.ctx_stream = torch.cuda.Stream(device=self.device)
+            # leaves are accumulated on the main stream, the entropy pass produces its gradients on the side stream: intended
+            _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if _quiet is not None:
+                _quiet(False)
         # ... and from its own host thread, started before the render pass (`_context_pass`): the two passes are ~300
         # launches each and the step is otherwise bound by the host issuing them one after the other.  Off = the
         # sequential schedule, which keeps the reference's order of random draws (the trajectory goldens need it).

@@ -250,7 +250,7 @@ def test_two_stream_split_equals_single_call(cuda, point_major):
 
 @pytest.mark.parametrize("overlap,which", [(False, "middle"), (True, "middle"), (True, "first")])
 def test_bench_chunk_backward_against_oracle(cuda, oracle, overlap, which):
-    """THE call bench.py times, oracle-checked at bench size: one 2^20-sample chunk from the middle of
+    """THE call bench.py times, oracle-checked at bench size: one chunk (bench.CHUNK samples) from the middle of
     bench.py's own marched 800x800 frame (and the FIRST chunk: 36k rays grazing the top of the ball, a thin
     slice of space whose rows hash unevenly onto the owner slabs — bins up to 7.7x the mean, shared by several
     owner waves), 16L x 2^19 x F8, raw U(-1e-4, 1e-4) table with ste_binary, the
@@ -271,7 +271,7 @@ def test_bench_chunk_backward_against_oracle(cuda, oracle, overlap, which):
                                    w["t_order"], hit, w["near"], w["far"], bench.STEP_SIZE, 0.0)[:3]
     x = ncu.sample_positions(w["rays_o"], w["rays_d"], ri, ts, te, w["aabbs"][0])
     S, N, L, F = x.shape[0], bench.CHUNK, bench.L, bench.F
-    assert S > 40 * N
+    assert S > 8 * N            # (CNC_BENCH_CHUNK may enlarge the call)
     c = (S // N) // 2 if which == "middle" else 0
     xs = x[c * N:(c + 1) * N].contiguous()
     be.pack_sign_bits(w["table"], w["bits"], w["clip"])

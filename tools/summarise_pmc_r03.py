@@ -56,7 +56,15 @@ with open(os.path.join(P, "r03_pmc_hbm_traffic.csv"), "w") as fh:
     for n in names:
         fh.write(f'"{n}",{get(fetch, n):.1f},{get(write, n):.1f},{get(rdreq, n):.0f},{get(wrreq, n):.0f},{get(atom, n):.0f},{cnt[n]}\n')
 
-N_CHUNK, L, F, L_BINNED = 1 << 20, 16, 8, 7
+L, F, L_BINNED = 16, 8, 7
+# samples per encoder call, averaged over the frame's calls like the counters below (the last call of a frame is partial)
+N_CHUNK = 1 << 20
+_bj = os.path.join(src, "bench.json")
+if os.path.exists(_bj) and os.path.getsize(_bj) > 0:
+    try:
+        N_CHUNK = int(round(json.loads([l for l in open(_bj) if l.startswith("{")][0])["roofline"]["samples_per_launch"]))
+    except Exception:
+        pass
 
 
 def call_total(d, pat, calls):
@@ -101,7 +109,8 @@ traffic = {
                                        2 * 640000 * 24, "per 640k-ray frame"),
     "_sources": {p: blob_hash(os.path.join(ROOT, p)) for p in KERNEL_SOURCES if os.path.exists(os.path.join(ROOT, p))},
     "_fabric_request_rate_peak_G_per_s": 50.0,
-    "_note": "per call on a 2^20-sample chunk of the bench frame; separate rocprofv3 --pmc passes of `python bench.py --steps 2 "
+    "_samples_per_call": N_CHUNK,
+    "_note": "per encoder call of the bench frame (_samples_per_call samples on average); separate rocprofv3 --pmc passes of `python bench.py --steps 2 "
              "--warmup 1 --no-cpu-baseline --no-train-step` (tools/collect_profiles_r03.sh, profiles/r03_pmc_hbm_traffic.csv); counter "
              "arithmetic per profiles/r03_counter_calibration.md: FETCH_SIZE = read requests x 64 B, a streamed request carries 128 B, a "
              "gathered 32-byte row is one request; the fabric sustains ~50 G requests/s (streaming 46.9, gathers 51.5: "
