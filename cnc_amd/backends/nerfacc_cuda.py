@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import torch
 
 from .. import _lib
@@ -157,13 +159,17 @@ def march_samples(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indice
     counts = torch.zeros(n_rays, dtype=torch.int64, device=dev)       # masked-out rays stay at 0
     term = torch.empty(n_rays, dtype=rays_o.dtype, device=dev) if want_terminate_planes else None
     L = _lib.lib()
+    # where each ray's first sample was produced: left by the count pass, picked up by the fill pass, which then marches
+    # only the span between a ray's first and last sample (CNC_MARCH_RESUME=0: both passes march the whole ray)
+    resume = torch.empty((n_rays, 8), dtype=torch.int32, device=dev) if os.environ.get("CNC_MARCH_RESUME", "1") == "1" \
+        else None
 
     def launch(starts, t0, t1, ri, tp):
         rc = L.cnc_march_samples(ptr(rays_o), ptr(rays_d), ptr(rays_mask), n_rays, ptr(binaries), binaries.shape[0],
                                  binaries.shape[1], binaries.shape[2], binaries.shape[3], ptr(aabbs), ptr(hits),
                                  ptr(t_sorted), ptr(t_indices), ptr(near_planes), ptr(far_planes), float(step_size),
                                  float(cone_angle), int(traverse_steps_limit), ptr(counts), ptr(starts), ptr(t0),
-                                 ptr(t1), ptr(ri), ptr(tp), stream(dev))
+                                 ptr(t1), ptr(ri), ptr(tp), ptr(resume), stream(dev))
         check(rc, "march_samples")
 
     launch(None, None, None, None, term)

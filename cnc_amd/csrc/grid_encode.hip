@@ -1026,4 +1026,4 @@ extern "C" const char* cnc_error_string(int code)
     }
 }
 
-extern "C" int cnc_abi_version(void) { return 22; }
+extern "C" int cnc_abi_version(void) { return 23; }

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64) void k_traverse(
     const uint8_t* __restrict__ hits, const float* __restrict__ t_sorted,
     const int64_t* __restrict__ t_indices, const float* __restrict__ near_planes,
     const float* __restrict__ far_planes, float step_size, float cone_angle, int32_t limit,
-    Seg iv, Seg sm, float* __restrict__ terminate_planes, int32_t rpb)
+    Seg iv, Seg sm, float* __restrict__ terminate_planes, int32_t rpb, uint32_t* __restrict__ rstate = nullptr)
 {
     extern __shared__ float s_dyn[];
     constexpr bool DIRECT = MODE == 3;                  // fill without staging: every lane stores its own samples
@@ -214,6 +214,27 @@ __global__ __launch_bounds__(64) void k_traverse(
         if (has_iv) cs_iv = iv.chunk_starts[tid];
         if (has_sm) cs_sm = sm.chunk_starts[tid];
     }
+    // Resume state (cnc_march_samples, rstate != nullptr).  The COUNT pass leaves, per ray, where its first sample was
+    // produced — the grid segment i, the cell, the three next-crossing distances and t_last — and the fill pass starts
+    // there and stops after the ray's last sample (it knows the count): it replays only the span between a ray's first
+    // and last sample, with the very same fp32 operations, not the empty space before and after it.
+    constexpr bool SAVE = MODE == 0;
+    constexpr bool RESTORE = MODE == 2 || MODE == 3;
+    bool    restore = false;
+    int64_t n_total = 0;
+    int32_t r_i = 0, r_cur[3] = {0, 0, 0};
+    float   r_t = 0, r_td[3] = {0, 0, 0};
+    if constexpr (RESTORE) {
+        if (rstate != nullptr && live) {
+            const uint32_t* r = rstate + (size_t)tid * 8;
+            r_i = (int32_t)r[0];
+            r_cur[0] = (int32_t)r[1]; r_cur[1] = (int32_t)r[2]; r_cur[2] = (int32_t)r[3];
+            r_t = __uint_as_float(r[4]);
+            r_td[0] = __uint_as_float(r[5]); r_td[1] = __uint_as_float(r[6]); r_td[2] = __uint_as_float(r[7]);
+            n_total = sm.chunk_cnts[tid];
+            restore = true;
+        }
+    }
     float near_plane = 0, far_plane = 0, o[3] = {0, 0, 0}, dir[3] = {1, 1, 1};
     if (live) {
         near_plane = near_planes[tid];
@@ -232,8 +253,8 @@ __global__ __launch_bounds__(64) void k_traverse(
     int64_t n_iv = 0, n_sm = 0;
     float   t_last = near_plane;
     bool    continuous = false;
-    int32_t i = base_t;
-    bool    resume = false, finished = !live;
+    int32_t i = restore ? r_i : base_t;
+    bool    resume = false, finished = !live, stop = false;
     int64_t level = 0;
     float   this_tmax = 0;
     float   tdist[3] = {0, 0, 0}, delta[3] = {0, 0, 0};
@@ -287,6 +308,14 @@ __global__ __launch_bounds__(64) void k_traverse(
                         delta[a] = flat ? this_tmax : voxel * inv[a] * sf;
                         over[a] = fin + step_i[a];
                     }
+                    if constexpr (RESTORE) {
+                        if (restore) {      // this segment's set-up is done: continue from the first sample's cell
+#pragma unroll
+                            for (int a = 0; a < 3; a++) { cur[a] = r_cur[a]; tdist[a] = r_td[a]; }
+                            t_last = r_t;
+                            restore = false;
+                        }
+                    }
                 }
                 resume = false;
 
@@ -319,6 +348,16 @@ __global__ __launch_bounds__(64) void k_traverse(
                                 const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
                                 if (t_last + dt * 0.5f >= t_trav) break;
                                 t_next = t_last + dt;
+                            }
+                            if constexpr (SAVE) {
+                                if (rstate != nullptr && n_sm == 0) {
+                                    uint32_t* r = rstate + (size_t)tid * 8;
+                                    r[0] = (uint32_t)i;
+                                    r[1] = (uint32_t)cur[0]; r[2] = (uint32_t)cur[1]; r[3] = (uint32_t)cur[2];
+                                    r[4] = __float_as_uint(t_last);
+                                    r[5] = __float_as_uint(tdist[0]); r[6] = __float_as_uint(tdist[1]);
+                                    r[7] = __float_as_uint(tdist[2]);
+                                }
                             }
                             if (has_iv) {
                                 if (!continuous) {
@@ -360,9 +399,12 @@ __global__ __launch_bounds__(64) void k_traverse(
                             n_sm++;
                             continuous = true;
                             t_last = t_next;
+                            if constexpr (RESTORE) {
+                                if (n_total > 0 && n_sm >= n_total) { stop = true; break; }     // the ray's last sample
+                            }
                             if (t_next >= t_trav) break;
                         }
-                        if (paused) break;
+                        if (paused || stop) break;
                     }
                     // single_traversal, utils_grid.cuh:121-149 (strict '<' tie-break x, y, then z)
                     const int ax = (tdist[0] < tdist[1] && tdist[0] < tdist[2]) ? 0
@@ -377,6 +419,7 @@ __global__ __launch_bounds__(64) void k_traverse(
                     resume = true;
                     break;
                 }
+                if (stop) break;
             }
             if (!paused) finished = true;
         }
@@ -522,7 +565,7 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
                                  const int64_t* t_indices, const float* near_planes, const float* far_planes,
                                  float step_size, float cone_angle, int32_t traverse_steps_limit,
                                  int64_t* chunk_cnts, const int64_t* chunk_starts, float* t_starts, float* t_ends,
-                                 int64_t* ray_indices, float* terminate_planes, void* stream)
+                                 int64_t* ray_indices, float* terminate_planes, uint32_t* resume_state, void* stream)
 {
     if (n_rays <= 0) return CNC_OK;
     if (!rays_o || !rays_d || !binaries || !aabbs || !hits || !t_sorted || !t_indices || !near_planes ||
@@ -541,7 +584,7 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
         hipLaunchKernelGGL(k_traverse<0>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
                            n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices,
                            near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, none, sm,
-                           terminate_planes, rpb);
+                           terminate_planes, rpb, resume_state);
         return launch_status();
     }
     if (!t_starts || !t_ends || !ray_indices) return CNC_ERR_INVALID_VALUE;
@@ -553,7 +596,8 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
     if (direct) {
         hipLaunchKernelGGL((k_traverse<3>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
                            n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices, near_planes,
-                           far_planes, step_size, cone_angle, traverse_steps_limit, ends, sm, terminate_planes, rpb);
+                           far_planes, step_size, cone_angle, traverse_steps_limit, ends, sm, terminate_planes, rpb,
+                           resume_state);
         return launch_status();
     }
     // staging row length, measured on the 800x800 bench frame (count + fill, ms): 8 -> 3.53, 16 -> 2.55,
@@ -563,7 +607,7 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
     hipLaunchKernelGGL((k_traverse<2, R>), dim3(blocks), dim3(64), 2 * 64 * (R + 1) * sizeof(float),              \
                        (hipStream_t)stream, rays_o, rays_d, rays_mask, n_rays, binaries, n_grids, resx, resy, resz, \
                        aabbs, hits, t_sorted, t_indices, near_planes, far_planes, step_size, cone_angle,            \
-                       traverse_steps_limit, ends, sm, terminate_planes, rpb)
+                       traverse_steps_limit, ends, sm, terminate_planes, rpb, resume_state)
     if (row == 8) CNC_LAUNCH_PAIRS(8);
     else if (row == 16) CNC_LAUNCH_PAIRS(16);
     else if (row == 64) CNC_LAUNCH_PAIRS(64);

@@ -354,14 +354,18 @@ int cnc_traverse_grids(const float* rays_o, const float* rays_d, const uint8_t* 
  *                          chunk_starts[ray] (the caller's exclusive cumsum of chunk_cnts); rays whose
  *                          chunk_cnts is 0 are skipped.  With rays_mask + traverse_steps_limit the same
  *                          two calls give the iterative evaluation render its packed samples directly.
- * terminate_planes (nullable) [n_rays]: where each marched ray stopped.                             */
+ * terminate_planes (nullable) [n_rays]: where each marched ray stopped (ask for it in the COUNT call).
+ * resume_state (nullable, ABI v23) u32 [n_rays, 8]: scratch the count call fills with where each ray produced its
+ *   first sample (grid segment, cell, the three next-crossing distances, t) and the fill call — given the same buffer —
+ *   starts from; the fill call then also stops at the ray's last sample.  Same samples, same values: only the span
+ *   between a ray's first and last sample is marched twice, not the empty space around it.                 */
 int cnc_march_samples(const float* rays_o, const float* rays_d, const uint8_t* rays_mask, int32_t n_rays,
                       const uint8_t* binaries, int32_t n_grids, int32_t resx, int32_t resy, int32_t resz,
                       const float* aabbs, const uint8_t* hits, const float* t_sorted,
                       const int64_t* t_indices, const float* near_planes, const float* far_planes,
                       float step_size, float cone_angle, int32_t traverse_steps_limit,
                       int64_t* chunk_cnts, const int64_t* chunk_starts, float* t_starts, float* t_ends,
-                      int64_t* ray_indices, float* terminate_planes, void* stream);
+                      int64_t* ray_indices, float* terminate_planes, uint32_t* resume_state, void* stream);
 
 /* (extension) Sample positions for the field in one pass: positions[s] = o[ray] + d[ray] * t_a[s], or
  * o + (d * (t_a[s] + t_b[s])) / 2 when t_b != NULL (rgb_sigma_fn, examples/utils.py:251-262, same

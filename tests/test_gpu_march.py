@@ -286,16 +286,19 @@ def test_hip_marcher_against_the_reference_lookup_golden(cuda, k):
                                    ref_occ, b.shape[-1])
 
 
+@pytest.mark.parametrize("resume", ["whole_ray", "resume_at_first_sample"])
 @pytest.mark.parametrize("fill", ["staged", "direct"])
 @pytest.mark.parametrize("limit,masked", [(-1, False), (9, True)])
 @pytest.mark.parametrize("res,step", [(32, 2e-2), (128, 5e-3)])
-def test_march_samples_equals_the_interval_edges(cuda, oracle, res, step, limit, masked, fill, monkeypatch):
+def test_march_samples_equals_the_interval_edges(cuda, oracle, res, step, limit, masked, fill, resume, monkeypatch):
     """cnc_march_samples (extension: (ray, t_start, t_end) per sample straight from the march) against the
     oracle's traverse_grids: t_starts == intervals.vals[is_left], t_ends == intervals.vals[is_right], same
     rays, counts and termination planes — unlimited two-pass and step-limited with dead rays.  `fill`: the LDS-staged
     fill pass of the big frames and the direct-store one small batches take (same march, same values)."""
     from cnc_amd import synthetic
     monkeypatch.setenv("CNC_MARCH_DIRECT_MAX", "0" if fill == "staged" else str(1 << 17))
+    # the fill pass continuing from the state the count pass left at each ray's first sample, and stopping at its last
+    monkeypatch.setenv("CNC_MARCH_RESUME", "0" if resume == "whole_ray" else "1")
     from cnc_amd.backends import nerfacc_cuda as C
     o, d = synthetic.pinhole_rays(36, 36, 0.6911, 4.0, 0.3, 0.4)
     binaries = synthetic.ball_binaries(res, radius=1.0)
