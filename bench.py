@@ -33,7 +33,7 @@ from cnc_amd.backends import nerfacc_cuda as ngrid_cuda  # noqa: E402
 F, L, D = 8, 16, 3
 LOG2_T = 19
 # samples per encoder call (CNC_BENCH_CHUNK overrides).  Larger calls change little: every backward call reads and
-# writes the table slabs of the 7 binned levels once (224 MB) whatever its size, and at 2^22 samples per call the frame
+# writes the table slabs of the binned levels once (~200 MB) whatever its size, and at 2^22 samples per call the frame
 # takes 83.9 instead of 85.2 ms (the backward 1.007 instead of 1.014 ms per 2^20 samples; 2^24 overflows the bins).
 CHUNK = int(os.environ.get("CNC_BENCH_CHUNK", 1 << 20))
 STEP_SIZE = 5e-3

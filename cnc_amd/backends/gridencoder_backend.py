@@ -219,17 +219,21 @@ def _workspace(device, nbytes, which=0):
     return ws
 
 
-def plan_binned_levels(resolutions, offsets, num_dim, n_features, n_points, min_resolution=288,
+def plan_binned_levels(resolutions, offsets, num_dim, n_features, n_points, min_resolution=400,
                        min_points=1 << 16):
     """Which finest levels the binned backward should take: (n_binned, level_rows) or None.
 
     `resolutions` / `offsets` are HOST sequences (the library never reads device tables on the host).
     A level qualifies when its cells are finer than typical sample spacing (resolution >=
-    min_resolution: below that, consecutive ray samples share cells and the run-merging atomic
-    kernel is the cheaper one) and its table has at least 2^16 rows; the qualifying levels must be
-    the last ones."""
+    min_resolution: below that, consecutive ray samples and the samples of neighbouring rays share cells and
+    the run-merging atomic kernel is the cheaper one) and its table has at least 2^16 rows; the qualifying
+    levels must be the last ones.  min_resolution: 288 until round 3 (7 binned levels of the 16-level bench grid);
+    with the sorted bin pass and the overlapped call the R = 296 level is cheaper on the merge kernel
+    (bench call 1.008 -> 0.980 ms per 2^20 samples; 200 / 288 / 400 / 560: 1.082 / 1.012 / 0.989 / 1.093 ms)."""
     if num_dim != 3 or n_features not in (2, 4, 8) or n_points < min_points or n_points >= 1 << 24:
         return None
+    if "CNC_BIN_MIN_RES" in os.environ:          # measurement switch
+        min_resolution = int(os.environ["CNC_BIN_MIN_RES"])
     res = [int(r) for r in resolutions]
     off = [int(o) for o in offsets]
     n, rows = 0, 0

@@ -105,7 +105,7 @@ def test_plan_and_mirror_route(cuda):
     from cnc_amd.backends import gridencoder_backend as be
     from cnc_amd.synthetic import RES_16L, level_offsets
     offs16 = level_offsets(RES_16L, 19, 3)
-    assert be.plan_binned_levels(RES_16L, offs16, 3, 8, 1 << 20) == (7, 1 << 19)
+    assert be.plan_binned_levels(RES_16L, offs16, 3, 8, 1 << 20) == (6, 1 << 19)
     assert be.plan_binned_levels(RES_16L, offs16, 3, 8, 1000) is None
     assert be.plan_binned_levels(RES_16L, offs16, 2, 8, 1 << 20) is None
     res = [20, 40, 90, 200]

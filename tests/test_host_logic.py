@@ -204,18 +204,18 @@ def test_nerf_synthetic_loader_on_a_fabricated_scene(tmp_path):
 
 def test_plan_binned_levels_host_only():
     """The level plan of the binned backward is made from HOST lists (no device reads): finest levels
-    with resolution >= 288 and >= 2^16 rows, as a suffix of the level list."""
+    with resolution >= 400 and >= 2^16 rows, as a suffix of the level list."""
     from cnc_amd.backends.gridencoder_backend import plan_binned_levels
     from cnc_amd.synthetic import RES_16L, RES_3D_REF, level_offsets
     off16 = level_offsets(RES_16L, 19, 3)
-    assert plan_binned_levels(RES_16L, off16, 3, 8, 1 << 20) == (7, 1 << 19)
+    assert plan_binned_levels(RES_16L, off16, 3, 8, 1 << 20) == (6, 1 << 19)
     assert plan_binned_levels(RES_16L, off16, 3, 8, 1 << 20, min_resolution=1000) == (3, 1 << 19)
     assert plan_binned_levels(RES_16L, off16, 3, 8, 1 << 15) is None          # too few points to pay
     assert plan_binned_levels(RES_16L, off16, 3, 16, 1 << 20) is None         # F = 16: atomic kernel only
     assert plan_binned_levels(RES_16L, off16, 2, 8, 1 << 20) is None          # planes stay on atomics
     off12 = level_offsets(RES_3D_REF, 19, 3)
     n, rows = plan_binned_levels(RES_3D_REF, off12, 3, 8, 1 << 18)
-    assert rows == 1 << 19 and n == sum(1 for r in RES_3D_REF if r >= 288)
+    assert rows == 1 << 19 and n == sum(1 for r in RES_3D_REF if r >= 400)
     # a coarse level after a fine one breaks the suffix
     assert plan_binned_levels([600, 20], [0, 1 << 19, (1 << 19) + 8000], 3, 8, 1 << 20) is None
 

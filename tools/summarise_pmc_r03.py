@@ -56,7 +56,7 @@ with open(os.path.join(P, "r03_pmc_hbm_traffic.csv"), "w") as fh:
     for n in names:
         fh.write(f'"{n}",{get(fetch, n):.1f},{get(write, n):.1f},{get(rdreq, n):.0f},{get(wrreq, n):.0f},{get(atom, n):.0f},{cnt[n]}\n')
 
-L, F, L_BINNED = 16, 8, 7
+L, F, L_BINNED = 16, 8, 6        # levels of the bench grid on the binned path (gridencoder_backend.plan_binned_levels)
 # samples per encoder call, averaged over the frame's calls like the counters below (the last call of a frame is partial)
 N_CHUNK = 1 << 20
 _bj = os.path.join(src, "bench.json")
