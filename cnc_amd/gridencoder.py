@@ -260,6 +260,7 @@ class GridEncoder(nn.Module):
                 self._vbits = _backend.occupancy_vertex_bits(binary_vxl.contiguous(), self._occ_sat(binary_vxl),
                                                              self._res_host)
             self._vbits_key = key
+            self._vbits_src = (binary_vxl,)   # keep the storage alive so data_ptr stays unique (as `_occ_sat` does)
         return self._vbits
 
     # -- embeddings as the kernels should see them --------------------------------------------
