@@ -23,6 +23,8 @@
 // D = 3, F = 8 (one cell per wave at a time: 64 lanes = 8 corners x 8 features), no occupancy mask, no
 // per-point level window: the coarse half of a binned backward call.  Everything else stays on
 // k_grid_encode_bwd.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "encoder_common.hpp"
 
@@ -248,8 +250,11 @@ void launch_bwd_merge(const float* grad, const float* inputs, const float* emb, 
 {
     lay.n_slots = L;
     const dim3 grid(div_up(N, kMB) * L);
-    if (ste) hipLaunchKernelGGL((k_grid_encode_bwd_merge<true>), grid, dim3(kMB), 0, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
-    else hipLaunchKernelGGL((k_grid_encode_bwd_merge<false>), grid, dim3(kMB), 0, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
+    // measurement switch: bytes of unused dynamic LDS per block (> 10 KB leaves ONE block per CU, i.e. half the wave slots
+    // and ~85 KB of LDS free for the owner waves of the binned levels running next to this kernel)
+    static const uint32_t pad = getenv("CNC_MERGE_PAD_LDS") ? (uint32_t)atoi(getenv("CNC_MERGE_PAD_LDS")) : 0u;
+    if (ste) hipLaunchKernelGGL((k_grid_encode_bwd_merge<true>), grid, dim3(kMB), pad, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
+    else hipLaunchKernelGGL((k_grid_encode_bwd_merge<false>), grid, dim3(kMB), pad, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
 }
 
 }  // namespace cnc
