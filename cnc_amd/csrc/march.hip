@@ -160,13 +160,15 @@ __device__ __forceinline__ void flush_pairs(const Stage& st, float* __restrict__
 // rows with coalesced stores (flush_stage), and the lane continues exactly where it stopped
 // (same registers, same cell), so values and order equal the one-sweep march of grid.cu:68-318.
 // MODE 0: count only.  MODE 1: fill the reference's RaySegmentsSpec pair (intervals + samples).
+// CONE0: cone_angle == 0 with step_size > 0 (every CNC configuration): dt = clamp(t * 0, step, 1e10) = step for every finite t,
+// so the three instructions per marching step that recompute it are dropped (same values).
 // MODE 3 (extension, small batches of cnc_march_samples): MODE 2's outputs stored by each lane as it goes — no LDS, no
 // pause / resume, full waves: for a training batch (~37 k rays, 260 k samples) the pass is a serial march per ray and
 // the staging only adds latency (0.66 -> the count pass's 0.35 ms); the big frames keep the coalesced flushes.
 // MODE 2 (extension, cnc_march_samples): fill (t_start, t_end, ray) per sample and nothing else — what the
 // renderer consumes (occ_grid.py:176-178 derives exactly these from the edge flags) — 16 instead of 27 bytes
 // per sample, 32-entry staging rows and a flush that only touches rows that have something to write.
-template <int MODE, int PROW = 32>
+template <int MODE, int PROW = 32, bool CONE0 = false>
 __global__ __launch_bounds__(64) void k_traverse(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const uint8_t* __restrict__ rays_mask, int32_t n_rays, const uint8_t* __restrict__ binaries,
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(64) void k_traverse(
                         if (step_size <= 0.0f) {
                             t_last = this_tmin;
                         } else {
-                            const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                            const float dt = CONE0 ? step_size : calc_dt(t_last, cone_angle, step_size, 1e10f);
                             while (!(t_last + dt * 0.5f >= this_tmin)) t_last += dt;
                         }
                     }
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(64) void k_traverse(
                         if (step_size <= 0.0f) {
                             t_last = t_trav;
                         } else {
-                            const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                            const float dt = CONE0 ? step_size : calc_dt(t_last, cone_angle, step_size, 1e10f);
                             while (!(t_last + dt * 0.5f >= t_trav)) t_last += dt;
                         }
                         continuous = false;
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(64) void k_traverse(
                             if (step_size <= 0.0f) {
                                 t_next = t_trav;
                             } else {
-                                const float dt = calc_dt(t_last, cone_angle, step_size, 1e10f);
+                                const float dt = CONE0 ? step_size : calc_dt(t_last, cone_angle, step_size, 1e10f);
                                 if (t_last + dt * 0.5f >= t_trav) break;
                                 t_next = t_last + dt;
                             }
@@ -573,6 +575,7 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
         return CNC_ERR_INVALID_VALUE;
     // the fill pass of a small batch runs 16 rays per 64-lane block (measured on 27 k rays: 0.86 -> 0.67 ms; 8 / 32 rays:
     // 0.80 / 0.75; the count pass, which stages nothing in LDS, prefers full waves: 0.33 vs 0.36)
+    const bool     cone0 = cone_angle == 0.0f && step_size > 0.0f;      // dt is the constant step (k_traverse CONE0)
     const char*    dm = getenv("CNC_MARCH_DIRECT_MAX");        // measurement / test switch (0: always stage)
     const int      direct_max = dm ? atoi(dm) : (1 << 17);
     const bool     direct = chunk_starts && n_rays < direct_max;
@@ -581,7 +584,11 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
     Seg none{}, sm{};
     sm.chunk_cnts = chunk_cnts;
     if (!chunk_starts) {        // pass 1: counts only
-        hipLaunchKernelGGL(k_traverse<0>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
+        if (cone0) hipLaunchKernelGGL((k_traverse<0, 32, true>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
+                           n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices,
+                           near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, none, sm,
+                           terminate_planes, rpb, resume_state);
+        else hipLaunchKernelGGL(k_traverse<0>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
                            n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices,
                            near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, none, sm,
                            terminate_planes, rpb, resume_state);
@@ -594,25 +601,37 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
     sm.ray_indices = ray_indices;
     ends.vals = t_ends;
     if (direct) {
-        hipLaunchKernelGGL((k_traverse<3>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
+        if (cone0) hipLaunchKernelGGL((k_traverse<3, 32, true>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
+                           n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices, near_planes,
+                           far_planes, step_size, cone_angle, traverse_steps_limit, ends, sm, terminate_planes, rpb,
+                           resume_state);
+        else hipLaunchKernelGGL((k_traverse<3>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
                            n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices, near_planes,
                            far_planes, step_size, cone_angle, traverse_steps_limit, ends, sm, terminate_planes, rpb,
                            resume_state);
         return launch_status();
     }
-    // staging row length, measured on the 800x800 bench frame (count + fill, ms): 8 -> 3.53, 16 -> 2.55,
-    // 32 -> 2.32, 64 -> 2.89 (LDS then limits the waves per CU)
-    static const int row = getenv("CNC_PAIR_STAGE") ? atoi(getenv("CNC_PAIR_STAGE")) : 32;
-#define CNC_LAUNCH_PAIRS(R)                                                                                         \
-    hipLaunchKernelGGL((k_traverse<2, R>), dim3(blocks), dim3(64), 2 * 64 * (R + 1) * sizeof(float),              \
+    // staging row length, measured on the 800x800 bench frame (count + fill, ms).  Marching whole rays: 8 -> 3.53,
+    // 16 -> 2.55, 32 -> 2.32, 64 -> 2.89 (LDS then limits the waves per CU).  With the fill pass resumed at the first
+    // sample (every step emits, rows fill evenly): 8 -> 2.27, 16 -> 2.04, 32 -> 2.15, 64 -> 2.54.
+    const char* ps = getenv("CNC_PAIR_STAGE");
+    const int   row = ps ? atoi(ps) : (resume_state ? 16 : 32);
+#define CNC_LAUNCH_PAIRS_(R, C0)                                                                                    \
+    hipLaunchKernelGGL((k_traverse<2, R, C0>), dim3(blocks), dim3(64), 2 * 64 * (R + 1) * sizeof(float),          \
                        (hipStream_t)stream, rays_o, rays_d, rays_mask, n_rays, binaries, n_grids, resx, resy, resz, \
                        aabbs, hits, t_sorted, t_indices, near_planes, far_planes, step_size, cone_angle,            \
                        traverse_steps_limit, ends, sm, terminate_planes, rpb, resume_state)
+#define CNC_LAUNCH_PAIRS(R)                   \
+    do {                                      \
+        if (cone0) CNC_LAUNCH_PAIRS_(R, true); \
+        else CNC_LAUNCH_PAIRS_(R, false);     \
+    } while (0)
     if (row == 8) CNC_LAUNCH_PAIRS(8);
     else if (row == 16) CNC_LAUNCH_PAIRS(16);
     else if (row == 64) CNC_LAUNCH_PAIRS(64);
     else CNC_LAUNCH_PAIRS(32);
 #undef CNC_LAUNCH_PAIRS
+#undef CNC_LAUNCH_PAIRS_
     return launch_status();
 }
 

@@ -286,11 +286,12 @@ def test_hip_marcher_against_the_reference_lookup_golden(cuda, k):
                                    ref_occ, b.shape[-1])
 
 
+@pytest.mark.parametrize("cone", [0.0, 4e-3], ids=["constant_step", "cone_step"])
 @pytest.mark.parametrize("resume", ["whole_ray", "resume_at_first_sample"])
 @pytest.mark.parametrize("fill", ["staged", "direct"])
 @pytest.mark.parametrize("limit,masked", [(-1, False), (9, True)])
 @pytest.mark.parametrize("res,step", [(32, 2e-2), (128, 5e-3)])
-def test_march_samples_equals_the_interval_edges(cuda, oracle, res, step, limit, masked, fill, resume, monkeypatch):
+def test_march_samples_equals_the_interval_edges(cuda, oracle, res, step, limit, masked, fill, resume, cone, monkeypatch):
     """cnc_march_samples (extension: (ray, t_start, t_end) per sample straight from the march) against the
     oracle's traverse_grids: t_starts == intervals.vals[is_left], t_ends == intervals.vals[is_right], same
     rays, counts and termination planes — unlimited two-pass and step-limited with dead rays.  `fill`: the LDS-staged
@@ -310,14 +311,15 @@ def test_march_samples_equals_the_interval_edges(cuda, oracle, res, step, limit,
     mask = torch.ones(n, dtype=torch.bool)
     if masked:
         mask[::4] = False
+    # `cone` = 0: the kernels specialised for a constant step (every CNC configuration); > 0: dt = clamp(t * cone, step, 1e10)
     oiv, osm, oterm = oracle.traverse_grids(o.numpy(), d.numpy(), binaries.numpy(), aabbs.numpy(), near.numpy(),
-                                            far.numpy(), step, 0.0, traverse_steps_limit=limit if limit > 0 else None,
+                                            far.numpy(), step, cone, traverse_steps_limit=limit if limit > 0 else None,
                                             over_allocate=limit > 0, rays_mask=mask.numpy())
     T = lambda a: a.to(cuda)
     t0, t1, hit = C.ray_aabb_intersect(T(o), T(d), T(aabbs), -float("inf"), float("inf"), float("inf"))
     order = torch.arange(2, device=cuda).expand(n, 2).contiguous()
     ri, ts, te, starts, counts, term = C.march_samples(T(o), T(d), T(mask) if masked else None, T(binaries), T(aabbs),
-                                                        torch.cat([t0, t1], -1), order, hit, T(near), T(far), step, 0.0,
+                                                        torch.cat([t0, t1], -1), order, hit, T(near), T(far), step, cone,
                                                         traverse_steps_limit=limit, want_terminate_planes=True)
     want_cnt = np.asarray(osm["chunk_cnts"])
     assert np.array_equal(counts.cpu().numpy(), want_cnt) and want_cnt.sum() > 2000
