@@ -389,3 +389,44 @@ def test_per_rank_sampling_streams_of_the_real_scene_loaders(tmp_path):
     torch.manual_seed(7)
     g1 = dataset(None).fetch()
     assert torch.equal(g0["pixels"], g1["pixels"])
+
+
+def test_field_row_buckets_and_vertex_set_host_logic():
+    """Host-side pieces of the round-3 training step that need no GPU: (i) the row count the field's GEMMs run at —
+    a multiple of 2^(floor(log2 n) - 5) at or above n, n itself below `row_bucket_min`, never more than ~3 % above n, and
+    only a handful of distinct values over the range a run's sample counts take; (ii) the vertex set of the vote plan
+    from shifted ORs equals the reference's candidates-then-unique construction (utils_bpp_acc.py:498-512)."""
+    from cnc_amd.field import NGPRadianceField_mygrid_2D3D
+    f = NGPRadianceField_mygrid_2D3D(aabb=[-1.5] * 3 + [1.5] * 3, n_features_per_level=2, n_neurons=32,
+                                     resolutions_list=(6, 9), log2_hashmap_size=8, resolutions_list_2D=(10,),
+                                     log2_hashmap_size_2D=8)
+    f.row_bucket_min = 4096
+    assert f._bucket_rows(100) == 100 and f._bucket_rows(4095) == 4095
+    assert f._bucket_rows(4096) == 4096 and f._bucket_rows(4097) == 4096 + 128
+    for n in (5000, 65537, 258446, 270000, 1500000):
+        b = f._bucket_rows(n)
+        g = 1 << (n.bit_length() - 6)
+        assert b >= n and b % g == 0 and b - n < g and b <= n * 1.032
+    assert len({f._bucket_rows(n) for n in range(240000, 280000, 37)}) <= 11
+    # (ii)
+    torch.manual_seed(0)
+    for Rb, t in ((8, 4), (6, 1), (5, 3)):
+        res = Rb * t + 2
+        occ = torch.rand(Rb, Rb, Rb) < 0.15
+        ar = torch.arange(-1, t + 1)
+        base = torch.stack(torch.meshgrid(ar, ar, ar, indexing="ij"), -1).unsqueeze(0)
+        cells = torch.stack(torch.meshgrid(*[torch.arange(Rb)] * 3, indexing="ij"), -1).view(-1, 1, 1, 1, 3)
+        coords = (cells[occ.reshape(-1)] * t + base).view(-1, 3) + 1
+        lin = torch.unique(coords[..., 0] * res * res + coords[..., 1] * res + coords[..., 2], dim=0)
+        want = torch.stack([lin // (res * res), (lin // res) % res, lin % res], -1)
+        m = occ
+        for axis in range(3):
+            up = m.repeat_interleave(t, dim=axis)
+            n = up.shape[axis]
+            shape = list(up.shape)
+            shape[axis] = n + 2
+            out = torch.zeros(shape, dtype=torch.bool)
+            for sft in range(3):
+                out.narrow(axis, sft, n).logical_or_(up)
+            m = out
+        assert torch.equal(torch.nonzero(m), want)
