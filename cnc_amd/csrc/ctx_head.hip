@@ -614,7 +614,15 @@ __global__ __launch_bounds__(256) void k_level_sums(const float* __restrict__ ta
             acc = 0.0;
         }
         float s = 0.0f;
-        for (uint32_t f = 0; f < F; f++) s += table[(size_t)r * F + f];
+        if ((F & 3u) == 0 && ((uintptr_t)table & 15u) == 0) {      // same order of additions, 16-byte loads
+            const float4* p = reinterpret_cast<const float4*>(table + (size_t)r * F);
+            for (uint32_t q = 0; q < F / 4; q++) {
+                const float4 v = p[q];
+                s += v.x; s += v.y; s += v.z; s += v.w;
+            }
+        } else {
+            for (uint32_t f = 0; f < F; f++) s += table[(size_t)r * F + f];
+        }
         acc += (double)s;
     }
     if (cur >= 0) atomicAdd(&s_acc[cur], acc);
@@ -657,10 +665,23 @@ __global__ __launch_bounds__(256) void k_level_stats_bwd(const double* __restric
         s_d[l] = (g_Pg ? g_Pg[l] * dp : 0.0f) + (g_bits ? g_bits[l] * dbits : 0.0f);
     }
     __syncthreads();
-    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total_rows * F) return;
-    const int64_t r = (int64_t)(e / F);
-    g_table[e] = (r >= lo.off[0] && r < lo.off[lo.n_levels]) ? s_d[level_of(lo, r)] : 0.0f;
+    // one 16-byte piece of a row per lane (the level is found once per piece, stores are whole float4s): the
+    // one-float-per-lane form ran at 1 TB/s (164 us for the 161 MB 3-D table of a training step)
+    if ((F & 3u) == 0 && ((uintptr_t)g_table & 15u) == 0) {
+        const uint32_t per_row = F / 4;
+        const uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+        if (q >= total_rows * per_row) return;
+        const int64_t r = (int64_t)(q / per_row);
+        const float   v = (r >= lo.off[0] && r < lo.off[lo.n_levels]) ? s_d[level_of(lo, r)] : 0.0f;
+        reinterpret_cast<float4*>(g_table)[q] = make_float4(v, v, v, v);
+        return;
+    }
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint64_t e = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4 + k;
+        if (e >= total_rows * F) return;
+        const int64_t r = (int64_t)(e / F);
+        g_table[e] = (r >= lo.off[0] && r < lo.off[lo.n_levels]) ? s_d[level_of(lo, r)] : 0.0f;
+    }
 }
 
 }  // namespace cnc
@@ -692,7 +713,8 @@ extern "C" int cnc_level_stats_backward(const double* sums, const int64_t* offse
     cnc::LevelOffsets lo{};
     lo.n_levels = (int32_t)n_levels;
     for (uint32_t i = 0; i <= n_levels; i++) lo.off[i] = offsets_host[i];
-    hipLaunchKernelGGL(cnc::k_level_stats_bwd, dim3((uint32_t)((total_rows * F + 255) / 256)), dim3(256), 0,
+    // a lane writes four floats (one float4 when the rows allow it)
+    hipLaunchKernelGGL(cnc::k_level_stats_bwd, dim3((uint32_t)(((total_rows * F + 3) / 4 + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, sums, lo, F, grad_Pg, grad_bits, total_rows, grad_table);
     return cnc::launch_status();
 }
