@@ -239,7 +239,7 @@ class Trainer:
         # The entropy pass (context forward and backward) runs on its own stream next to the render pass — see train_step
         self.ctx_stream = None
         if self.device.type == "cuda" and os.environ.get("CNC_CTX_STREAM", "1") == "1":
-            self.ctx_stream = torch.cuda.Stream(device=self.device)
+            self.ctx_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CNC_CTX_STREAM_PRIORITY", "0")))
             # leaves are accumulated on the main stream, the entropy pass produces its gradients on the side stream: intended
             _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
             if _quiet is not None:
