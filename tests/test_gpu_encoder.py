@@ -580,3 +580,48 @@ def test_ste_binary_kernels_equal_the_op_chain(cuda, n):
     assert torch.equal(y.detach().nan_to_num(nan=7.0), want.nan_to_num(nan=7.0))
     want_g = go * ((c == xd) + 0.0)
     assert torch.equal(x.grad, want_g)
+
+
+def test_vertex_bits_at_the_context_pass_size(cuda):
+    """Full-size check of the vertex bit planes (no oracle needed: the box scan / summed-volume path is oracle-pinned
+    above): the 12-level 3-D grid of the reference composition (R up to 514, T = 2^19, F = 8), a 128^3 ball occupancy
+    with speckle, 2^18 grid vertices as points with per-point level windows of 3 — what the context pass encodes.  The
+    masked bit-plane forward must return the SAME bits with the planes as with the summed-volume test, the finest
+    level (514^3 > 2^26 vertices) must have no plane and fall back, and the backward must agree to atomic order."""
+    from cnc_amd import synthetic
+    from cnc_amd.backends import gridencoder_backend as be
+    res, F, T = list(synthetic.RES_3D_REF), 8, 19
+    offs = synthetic.level_offsets(res, T, 3)
+    o_t = torch.as_tensor(offs, device=cuda)
+    r_t = torch.tensor(res, dtype=torch.int32, device=cuda)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    emb = torch.sign(torch.rand((int(offs[-1]), F), generator=g) * 2 - 1).to(cuda)
+    bits = be.pack_sign_bits(emb)
+    vxl = synthetic.ball_binaries(128, radius=1.0, device=cuda).squeeze(0)
+    vxl = vxl ^ (torch.rand(vxl.shape, generator=g) < 0.01).to(cuda)
+    sat = be.occupancy_sat(vxl)
+    words, voff = be.occupancy_vertex_bits(vxl, sat, res)
+    assert int(voff[-1]) == -1 and all(int(v) >= 0 for v in voff[:-1])
+    N, Lc = 1 << 18, 3
+    lvl = torch.randint(Lc, len(res), (N,), generator=g)                       # vertex level n, encoded at n-3 .. n-1
+    R = torch.tensor(res)[lvl]
+    q = (torch.rand((N, 3), generator=g) * (R[:, None] - 2).float()).floor() + 1     # inner vertices of level n
+    x = ((q - 0.5) / (R[:, None] - 2).float()).to(torch.float32).to(cuda).contiguous()
+    mli = (lvl - Lc).to(torch.int32).to(cuda)
+    outs = []
+    for vb in (None, (words, voff)):
+        out = torch.empty((N, Lc * F), dtype=torch.float32, device=cuda)
+        be.grid_encode_forward_bits(x, bits, o_t, r_t, out, N, 3, F, Lc, 128, vxl, mli, sat, out_ld=Lc * F, out_col=0,
+                                    vertex_bits=vb)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert float(outs[0].abs().sum()) > 0 and float((outs[0] == 0).float().mean()) > 0.01      # masked and unmasked corners
+    grad = torch.randn((N, Lc * F), generator=g).to(cuda)
+    gs = []
+    for vb in (None, (words, voff)):
+        ge = torch.zeros_like(emb)
+        be.grid_encode_backward(grad, x, emb, o_t, r_t, ge, N, 3, F, Lc, 0, 128, None, None, vxl, mli, ste_binary=True,
+                                occ_sat=sat, grad_ld=Lc * F, grad_col=0, vertex_bits=vb)
+        gs.append(ge)
+    scale = float(gs[0].abs().max())
+    assert scale > 0 and float((gs[0] - gs[1]).abs().max()) <= 2e-5 * scale
