@@ -332,3 +332,27 @@ def test_march_samples_equals_the_interval_edges(cuda, oracle, res, step, limit,
     assert np.array_equal(term.cpu().numpy()[live], np.asarray(oterm)[live])
     if masked:
         assert np.all(counts.cpu().numpy()[~mask.numpy()] == 0)
+
+
+def test_march_samples_resume_equals_whole_ray_march_on_the_bench_frame(cuda, monkeypatch):
+    """Full size, no oracle (the small cases above pin both forms to it): bench.py's own 800x800 frame, 640 k rays and
+    ~68 M samples.  The fill pass that resumes at each ray's first sample and stops at its last (constant-step kernels,
+    16-entry staging) must write exactly what the fill pass that marches every ray end to end writes."""
+    import bench
+    from cnc_amd.backends import nerfacc_cuda as C
+    w = bench.build_workload(cuda, 0)
+    t_lo, t_hi, hit = C.ray_aabb_intersect(w["rays_o"], w["rays_d"], w["aabbs"], -float("inf"), float("inf"), float("inf"))
+    outs = []
+    for resume in ("1", "0"):
+        monkeypatch.setenv("CNC_MARCH_RESUME", resume)
+        ri, ts, te, starts, counts, _ = C.march_samples(w["rays_o"], w["rays_d"], None, w["binaries"], w["aabbs"],
+                                                        torch.cat([t_lo, t_hi], -1), w["t_order"], hit, w["near"], w["far"],
+                                                        bench.STEP_SIZE, 0.0)
+        outs.append((ri, ts, te, starts, counts))
+    assert outs[0][1].shape[0] > 6e7
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # sortedness / packing: samples are grouped by ray in ray order, t ascending inside a ray
+    ri, ts, te, starts, counts = outs[0]
+    assert bool((ri[1:] >= ri[:-1]).all()) and bool((te > ts).all())
+    assert int(counts.sum()) == ts.shape[0] and bool((starts == torch.cumsum(counts, 0) - counts).all())
