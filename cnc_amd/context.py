@@ -641,6 +641,7 @@ class CNC_context_models(nn.Module):
     def init_binary_vxl_coords(self, scale=512):
         t = scale // self.binary_vxl_len
         resolution = scale + 2
+        self._idx_coord_t = t          # the cell-to-vertex factor the candidate lattice below was built for
         self.idx_coord_base = my_meshgrid3D(-1, t + 1, device=self.dev).unsqueeze(0)
         self.idx_coord_temp = my_meshgrid3D(0, self.binary_vxl_len, device=self.dev).view(-1, 1, 1, 1, 3)
         self.pn_frac_offsets_list = torch.tensor([0, resolution * resolution], device=self.dev, dtype=torch.int32)
@@ -650,6 +651,12 @@ class CNC_context_models(nn.Module):
         """Unique finest-level vertices inside / one ring around occupied cells (utils_bpp_acc.py:498-512)."""
         resolution = self.dimension_wise_resolution if resolution is None else resolution
         t = (resolution - 2) // self.binary_vxl_len
+        # The candidate lattice (`idx_coord_base`) is the one `init_binary_vxl_coords(scale)` built: the reference's
+        # expression only means something for resolution == scale + 2 (utils_bpp_acc.py:397-398,498-512), and the two
+        # branches below agree only then — so anything else is refused instead of answered two different ways.
+        if t != getattr(self, "_idx_coord_t", t):
+            raise ValueError(f"get_idx_coords2: resolution {resolution} does not match the lattice of "
+                             f"init_binary_vxl_coords (factor {self._idx_coord_t}, not {t})")
         occ = binary_vxl.squeeze(0)
         if self.fused_segments and occ.is_cuda and occ.dim() == 3 and t >= 1:
             # The same sorted set without materialising (t + 2)^3 candidates per occupied cell and sorting ~10^7 of
@@ -667,7 +674,7 @@ class CNC_context_models(nn.Module):
                 for sft in range(3):
                     out.narrow(axis, sft, n).logical_or_(up)
                 m = out
-            return torch.nonzero(m)
+            return torch.nonzero(m).to(self.idx_coord_base.dtype)      # int32, as the candidate-lattice branch returns
         sel = self.idx_coord_temp[occ.reshape(-1)]
         coords = (sel * t + self.idx_coord_base).view(-1, 3) + 1
         lin = coords[..., 0] * resolution * resolution + coords[..., 1] * resolution + coords[..., 2]

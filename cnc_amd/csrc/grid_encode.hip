@@ -984,8 +984,13 @@ __global__ __launch_bounds__(256) void k_vertex_bits(const int32_t* __restrict__
     }
     const uint64_t m = __ballot(bit);
     const uint32_t lane = threadIdx.x & 63u;
-    if (lane == 0) words[v >> 5] = (uint32_t)m;                       // v is a multiple of 64 here
-    else if (lane == 32) words[v >> 5] = (uint32_t)(m >> 32);
+    // the plane holds ceil(n / 64) * 2 words (cnc_grid_vertex_bits_words): the waves of the last block that lie
+    // wholly past the last vertex store nothing; lane 0 / 32 hold v = first vertex of their half-wave + 0 / 32 and
+    // the half-waves of the last PARTIAL wave both have a word (the plane is rounded up to whole 64-vertex pairs)
+    if (v - lane < n_vertices) {
+        if (lane == 0) words[v >> 5] = (uint32_t)m;                   // v is a multiple of 64 here
+        else if (lane == 32) words[v >> 5] = (uint32_t)(m >> 32);
+    }
 }
 }  // namespace cnc
 

@@ -69,12 +69,16 @@ class GradBucket:
     exchange is a single all-reduce.  `bind()` points each param.grad at its slice (autograd then
     accumulates in place), `allreduce()` sums across ranks and optionally averages."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], tail: int = 0):
+        """`tail`: extra fp32 slots behind the gradients that ride in the same all-reduce (`self.tail`): per-step
+        scalars every rank needs the sum of — the Trainer's sample count — without a collective of their own."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev, dt = self.params[0].device, self.params[0].dtype
         self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel, dtype=dt, device=dev)
+        self.flat = torch.zeros(self.numel + tail, dtype=dt, device=dev)
+        self.grads = self.flat[:self.numel]
+        self.tail = self.flat[self.numel:]
         self.views = []
         o = 0
         for p in self.params:
@@ -130,6 +134,38 @@ def broadcast_parameters(params: Iterable[torch.nn.Parameter], src: int = 0) -> 
             p.add_(0)            # in-place no-op that bumps p._version: caches keyed on it (sign plane) refresh
 
 
+def _checksums(params) -> torch.Tensor:
+    """Two wrapping int64 checksums of every tensor's BITS (sum and sum of squares of its int32 view): [P, 2]."""
+    out = []
+    for p in params:
+        v = p.detach().reshape(-1).view(torch.int32).to(torch.int64)
+        out.append(torch.stack([v.sum(), (v * v).sum()]))
+    return torch.stack(out)
+
+
+def resync_parameters(params, src: int = 0):
+    """Re-align replicas only where they differ: bit checksums of every parameter tensor are compared across the ranks
+    in ONE small collective (max of [c, -c]: max and min at once); the tensors whose checksums disagree on any rank
+    are overwritten with rank `src`'s.  Returns (tensors broadcast, bytes broadcast).  The decision is taken from the
+    all-reduced vector, so every rank broadcasts the same set."""
+    params = list(params)
+    if not _active() or not params:
+        return 0, 0
+    with torch.no_grad():
+        c = _checksums(params)
+        both = torch.cat([c, -c], dim=1)
+        dist.all_reduce(both, op=dist.ReduceOp.MAX)
+        differ = (both[:, :2] != -both[:, 2:]).any(dim=1).tolist()
+        n = nbytes = 0
+        for p, d in zip(params, differ):
+            if d:
+                dist.broadcast(p.data, src)
+                p.add_(0)        # bumps p._version: caches keyed on it (sign plane) refresh
+                n += 1
+                nbytes += p.numel() * p.element_size()
+    return n, nbytes
+
+
 def max_over_ranks(x: float, device) -> float:
     if not _active():
         return x
@@ -138,9 +174,11 @@ def max_over_ranks(x: float, device) -> float:
     return float(t.item())
 
 
-def sum_over_ranks(x: float, device) -> float:
+def sum_over_ranks(x, device):
+    """Sum of a float (or of every entry of a list of floats: ONE collective) over the ranks, as Python float(s)."""
+    many = isinstance(x, (list, tuple))
     if not _active():
-        return x
-    t = torch.tensor([x], dtype=torch.float64, device=device)
+        return list(x) if many else x
+    t = torch.tensor(list(x) if many else [x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t.item())
+    return t.tolist() if many else float(t.item())

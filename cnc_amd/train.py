@@ -94,19 +94,24 @@ def make_config_and_data(args, device, rank=0, world=1):
 
 @torch.no_grad()
 def evaluate(tr: Trainer, n_views: int):
-    """(psnr, lpips, -ssim) averaged over the test views, as train:384-431 (LPIPS unavailable: NaN)."""
+    """(psnr, lpips, -ssim) averaged over the test views, as train:384-431 (LPIPS unavailable: NaN).
+    world > 1: the views are sharded over the ranks (`cdist.shard_range`) and the two sums are
+    all-reduced — every rank calls this at the same point of the protocol and gets the same three numbers."""
+    from . import dist as cdist
     from .metrics import psnr, ssim
     c = tr.cfg
     tr.field.eval(); tr.estimator.eval()
-    ps, ss = [], []
-    for i in range(n_views):
+    lo, hi = cdist.shard_range(n_views, tr.rank, tr.world)
+    ps = ss = 0.0
+    for i in range(lo, hi):
         d = tr.dataset.view(i)
         rgb, _, _, _ = render_image_with_occgrid_test(1024, tr.field, tr.estimator, d["rays"], near_plane=c.near_plane,
                                                       render_step_size=c.render_step_size, render_bkgd=d["color_bkgd"],
                                                       cone_angle=c.cone_angle, alpha_thre=c.alpha_thre)
-        ps.append(psnr(rgb, d["pixels"]))
-        ss.append(-ssim(rgb.permute(2, 0, 1).unsqueeze(0), d["pixels"].permute(2, 0, 1).unsqueeze(0)))
-    return sum(ps) / len(ps), float("nan"), sum(ss) / len(ss)
+        ps += psnr(rgb, d["pixels"])
+        ss += -ssim(rgb.permute(2, 0, 1).unsqueeze(0), d["pixels"].permute(2, 0, 1).unsqueeze(0))
+    ps, ss = cdist.sum_over_ranks([ps, ss], tr.device)
+    return ps / max(n_views, 1), float("nan"), ss / max(n_views, 1)
 
 
 def main(argv=None):
@@ -124,24 +129,25 @@ def main(argv=None):
     tic = time.time()
     tr.train(steps=cfg.max_steps)
     elapsed = time.time() - tic
-    if world > 1:
-        # the replicas are identical after training: evaluation, the codec round trip (it writes and re-reads
-        # ./bitstreams/<scene>/*.b) and the results line are rank 0's; the others wait here and leave
-        if rank != 0:
-            torch.distributed.barrier()
-            return None
+    # world > 1: the replicas are identical after training.  Every rank runs the whole tail — its share of each
+    # evaluation (views sharded, sums all-reduced), and the codec round trip on files of its own (the coder is
+    # deterministic: same bytes on every rank; decode is sequential over levels, so it cannot be sharded) — so no
+    # rank waits in a barrier under the communicator's watchdog while another one works.  Rank 0's files are the
+    # ones under the canonical prefix, and rank 0 prints and writes the results line.
+    say = print if rank == 0 else (lambda *a, **k: None)
     psnr_avg, lpips_avg, ssim_avg = evaluate(tr, cfg.test_views)
-    print(f"evaluation: psnr_avg={psnr_avg}, lpips_avg={lpips_avg}, ssim_avg={ssim_avg}")
+    say(f"evaluation: psnr_avg={psnr_avg}, lpips_avg={lpips_avg}, ssim_avg={ssim_avg}")
 
     tic = time.time()
-    Pgs, embed_bits_MB, embed_bits_MB_codec, prefix = tr.encode()
+    Pgs, embed_bits_MB, embed_bits_MB_codec, prefix = tr.encode(
+        None if rank == 0 else os.path.join(cfg.out_dir, f".rank{rank}", "b"))
     encoding_time = time.time() - tic
-    print(f"encoded: estimated {embed_bits_MB} MB, coded {embed_bits_MB_codec} MB in {encoding_time:.1f} s")
+    say(f"encoded: estimated {embed_bits_MB} MB, coded {embed_bits_MB_codec} MB in {encoding_time:.1f} s")
     tic = time.time()
     tr.decode_into_field(Pgs, prefix)
     decoding_time = time.time() - tic
     psnr_c, lpips_c, ssim_c = evaluate(tr, cfg.test_views)
-    print(f"evaluation_decoded: psnr_avg_codec={psnr_c}, lpips_avg_codec={lpips_c}, ssim_avg_codec={ssim_c}, "
+    say(f"evaluation_decoded: psnr_avg_codec={psnr_c}, lpips_avg_codec={lpips_c}, ssim_avg_codec={ssim_c}, "
           f"size_codec={embed_bits_MB_codec}")
 
     sizes = tr.sizes_MB(embed_bits_MB_codec)
@@ -156,18 +162,20 @@ def main(argv=None):
         p_q, l_q, s_q = evaluate(tr, cfg.test_views)
         total = embed_bits_MB_codec + sizes["context_models"] + sizes["occupancy_grid"] + MBs
         per_digit += [str(digit), r4(MBs), r4(p_q), r4(l_q), r4(s_q), r4(total)]
-        print(f"{digit}-bit MLP: psnr={p_q}, total size {total * 1024:.1f} KB")
+        say(f"{digit}-bit MLP: psnr={p_q}, total size {total * 1024:.1f} KB")
     cols += [r4(MBs_orig), r4(sizes["context_models"]), r4(sizes["occupancy_grid"])] + per_digit
     cols += [r4(elapsed), r4(encoding_time), r4(decoding_time)]
 
+    if rank != 0:
+        import shutil
+        shutil.rmtree(os.path.join(cfg.out_dir, f".rank{rank}"), ignore_errors=True)
+        return cols
     folder = {"nerf_synthetic": "Synthetic-NeRF", "tanks": "TanksAndTemple", "procedural": "procedural"}[kind]
     out = args.results or os.path.join("./results", folder, "output.txt")
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     with open(out, "a") as fw:
         fw.write("\t".join(cols) + "\n")
     print(f"results line appended to {out}")
-    if world > 1:
-        torch.distributed.barrier()
     return cols
 
 

@@ -240,10 +240,10 @@ class Trainer:
         self.ctx_stream = None
         if self.device.type == "cuda" and os.environ.get("CNC_CTX_STREAM", "1") == "1":
             self.ctx_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CNC_CTX_STREAM_PRIORITY", "0")))
-            # leaves are accumulated on the main stream, the entropy pass produces its gradients on the side stream: intended
-            _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-            if _quiet is not None:
-                _quiet(False)
+        # leaves are accumulated on the main stream, the entropy pass produces its gradients on the side stream: intended.
+        # The switch is process-global, so it is held only for the duration of a train_step (see there).
+        self._warn_switch = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None) \
+            if self.ctx_stream is not None else None
         # ... and from its own host thread, started before the render pass (`_context_pass`): the two passes are ~300
         # launches each and the step is otherwise bound by the host issuing them one after the other.  Off = the
         # sequential schedule, which keeps the reference's order of random draws (the trajectory goldens need it).
@@ -254,8 +254,16 @@ class Trainer:
         self._comm_events = []
         if self.world > 1:
             plist = list(self.field.parameters()) + list(self.context.parameters())
-            self.bucket = cdist.GradBucket(plist)          # ray-loss gradients (all-reduced)
+            # ray-loss gradients (all-reduced) + ONE tail slot: this rank's sample count, so that the sum over the
+            # ranks arrives with the gradients instead of through a blocking collective in the middle of the step
+            self.bucket = cdist.GradBucket(plist, tail=1)
             self.bucket_ctx = cdist.GradBucket(plist)      # entropy-loss gradients (replica-identical)
+            self._count_host = torch.zeros(1, dtype=torch.float32)
+            if self.device.type == "cuda":
+                self._count_host = self._count_host.pin_memory()
+            self._count_pending = None                     # (event, num_rays of the step the count belongs to)
+            # how often the replicas had to be re-aligned (cdist.resync_parameters, every `step_update` steps)
+            self.resync = {"checks": 0, "fired": 0, "tensors": 0, "bytes": 0}
             base = self.context.rand_like
 
             def synced_rand_like(t):
@@ -299,6 +307,13 @@ class Trainer:
         self.sched, self.sched2 = sched(self.opt), sched(self.opt2)
 
     # -------------------------------------------------------------------------------- training
+    def _context_pass_worker(self, step, fork, params, grad_mode, autocast):
+        """`_context_pass` on the worker thread with the submitting thread's grad and autocast modes (both are
+        thread-local in PyTorch and a fresh thread starts from the defaults)."""
+        enabled, dtype = autocast
+        with torch.set_grad_enabled(grad_mode), torch.autocast(self.device.type, dtype=dtype, enabled=enabled):
+            return self._context_pass(step, fork, params)
+
     def _context_pass(self, step: int, fork, params=None):
         """Entropy loss forward + backward on the side stream (from whichever host thread calls it), ordered after the
         event `fork` of the main stream.  `params` = None: the gradient is accumulated into `.grad`; a parameter list:
@@ -331,50 +346,94 @@ class Trainer:
         c = self.cfg
         self.field.train(); self.estimator.train(); self.context.train()
         data = self.dataset.fetch()
-        rays, pixels, bkgd = data["rays"], data["pixels"], data["color_bkgd"]
         self.estimator.update_every_n_steps(
             step=step, occ_eval_fn=lambda x: self.field.query_density(x) * c.render_step_size,
             occ_thre=1e-2, n=c.step_update)
         if self.world > 1 and step % c.step_update == 0:
             cdist.broadcast_module_buffers(self.estimator, ["occs", "binaries"])
         ctx_future = None
-        if self.ctx_thread and self.ctx_stream is not None and c.lmbda > 0:
-            # The ray loss and the entropy loss share nothing but the parameters and the occupancy grid (just updated
-            # above).  The entropy pass starts NOW, on the side stream and from a second host thread, next to the whole
-            # render pass.  What both passes read through a cache — the sign bit planes of the tables — is made
-            # current on the main stream first; gradients are cleared before either backward.  Data parallel: the
-            # worker returns its gradient instead of accumulating it (`.grad` = the bucket that is all-reduced), and
-            # the window draw that every rank must share is made and broadcast here, on the main thread.
-            for enc in self.field.mlp_base._encoders():
-                if enc.ste_binary and enc.bitplane:
-                    enc._bit_plane(enc.params)
-            if self.bucket is None:
-                self.opt.zero_grad(set_to_none=True)
-                self.opt2.zero_grad(set_to_none=True)
-            else:
-                self.bucket.zero()
-                self.bucket.bind(force=True)
+        if self._warn_switch is not None:
+            self._warn_switch(False)
+        try:
+            if self.ctx_thread and self.ctx_stream is not None and c.lmbda > 0:
+                # The ray loss and the entropy loss share nothing but the parameters and the occupancy grid (just
+                # updated above).  The entropy pass starts NOW, on the side stream and from a second host thread, next
+                # to the whole render pass.  What both passes read through a cache — the sign bit planes of the tables
+                # — is made current on the main stream first; gradients are cleared before either backward.  Data
+                # parallel: the worker returns its gradient instead of accumulating it (`.grad` = the bucket that is
+                # all-reduced), and the window draw that every rank must share is made and broadcast here, on the main
+                # thread.
+                for enc in self.field.mlp_base._encoders():
+                    if enc.ste_binary and enc.bitplane:
+                        enc._bit_plane(enc.params)
+                if self.bucket is None:
+                    self.opt.zero_grad(set_to_none=True)
+                    self.opt2.zero_grad(set_to_none=True)
+                else:
+                    self.bucket.zero()
+                    self.bucket.bind(force=True)
+                    self._ctx_rand = None
+                    self._ctx_rand = self.context.rand_like(self.context.utils_rand)
+                    self._ctx_rand.record_stream(self.ctx_stream)      # allocated here, read by the side stream
+                if self._pool is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cnc-context")
+                autocast = (torch.is_autocast_enabled(self.device.type), torch.get_autocast_dtype(self.device.type))
+                ctx_future = self._pool.submit(self._context_pass_worker, step,
+                                               torch.cuda.current_stream(self.device).record_event(),
+                                               None if self.bucket is None else self.bucket.params,
+                                               torch.is_grad_enabled(), autocast)
+            return self._train_step_tail(step, want_stats, data, ctx_future)
+        except BaseException:
+            # Never leave the worker running behind an exception: it writes `.grad` and reads the tables.  Wait for it
+            # (its own error, if any, is secondary), order the main stream after whatever it enqueued, and drop the
+            # window draw that was made for it.
+            if ctx_future is not None:
+                try:
+                    ctx_future.result()
+                except BaseException:
+                    pass
+                torch.cuda.current_stream(self.device).wait_stream(self.ctx_stream)
+            if self.bucket is not None:
                 self._ctx_rand = None
-                self._ctx_rand = self.context.rand_like(self.context.utils_rand)
-                self._ctx_rand.record_stream(self.ctx_stream)      # allocated here, read by the side stream
-            if self._pool is None:
-                from concurrent.futures import ThreadPoolExecutor
-                self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cnc-context")
-            ctx_future = self._pool.submit(self._context_pass, step,
-                                           torch.cuda.current_stream(self.device).record_event(),
-                                           None if self.bucket is None else self.bucket.params)
+            raise
+        finally:
+            if self._warn_switch is not None:
+                self._warn_switch(True)
+
+    def _lagged_sample_count(self, num_rays_now: int, n_samples: int) -> None:
+        """Data-parallel ray budget without a collective of its own.  The reference resizes the next batch from this
+        step's sample count (train:340-344); with N ranks the count that matters is the mean over the ranks, and asking
+        for it here would put a blocking all-reduce + host sync between the render forward and its backward on every
+        rank.  Instead this rank's count rides in the tail slot of the gradient bucket; the sum comes back with the
+        gradients and is read at the NEXT step, right here — after the march has synchronised the host anyway — and
+        resizes the batch after that: num_rays[k+1] = num_rays[k-1] * target / mean_count[k-1].  Same fixed point
+        (target / samples-per-ray), one step later; every rank computes it from the same all-reduced number."""
+        c = self.cfg
+        if self._count_pending is not None:
+            ev, rays_then = self._count_pending
+            ev.synchronize()                        # long since complete: the step before this one
+            mean = float(self._count_host[0]) / self.world
+            if c.target_sample_batch_size > 0 and mean >= 1.0:
+                self.dataset.update_num_rays(int(rays_then * (c.target_sample_batch_size / mean)))
+        self._count_pending = None
+        self.bucket.tail.fill_(float(n_samples))    # enqueued before the backward; the bucket is zeroed before this
+
+    def _train_step_tail(self, step, want_stats, data, ctx_future):
+        c = self.cfg
+        rays, pixels, bkgd = data["rays"], data["pixels"], data["color_bkgd"]
         rgb, acc, depth, n_samples, extra = render_image_with_occgrid(
             self.field, self.estimator, rays, near_plane=c.near_plane, render_step_size=c.render_step_size,
             render_bkgd=bkgd, cone_angle=c.cone_angle, alpha_thre=c.alpha_thre, return_extra=True)
-        n_all = n_samples
-        if self.world > 1:   # every rank must take the same branch and keep the same ray budget
-            n_all = int(cdist.sum_over_ranks(float(n_samples), self.device) / self.world)
-        if n_all == 0:
-            if ctx_future is not None:
-                torch.cuda.current_stream(self.device).wait_event(ctx_future.result()[2])
-            return None
-        if c.target_sample_batch_size > 0:
-            self.dataset.update_num_rays(int(len(pixels) * (c.target_sample_batch_size / float(n_all))))
+        if self.world == 1:
+            if n_samples == 0:
+                if ctx_future is not None:
+                    torch.cuda.current_stream(self.device).wait_event(ctx_future.result()[2])
+                return None
+            if c.target_sample_batch_size > 0:
+                self.dataset.update_num_rays(int(len(pixels) * (c.target_sample_batch_size / float(n_samples))))
+        # world > 1: no rank leaves the step (the collective below must be entered by everyone; a rank without samples
+        # adds a zero ray gradient), and the ray budget follows the all-reduced count of the step before
         mse = F.mse_loss(rgb, pixels)
         bpp, mb = 0.0, 0.0
         e = self.field.mlp_base
@@ -419,7 +478,7 @@ class Trainer:
             # window draw on every rank): so only the ray-loss gradient is exchanged, and its all-reduce runs
             # on the communicator's stream WHILE the entropy pass is still under way.  The entropy gradient is equal
             # across ranks only up to the order of its float atomics (~1e-9 relative), so the replicas are
-            # re-aligned to rank 0 at every occupancy refresh (below).
+            # compared at every occupancy refresh and re-aligned to rank 0 where they differ (below).
             A, B = self.bucket, self.bucket_ctx
             if ctx_future is None:
                 if c.lmbda > 0:
@@ -427,6 +486,7 @@ class Trainer:
                                                                          sync_MB=False)
                 A.zero()
                 A.bind(force=True)
+            self._lagged_sample_count(len(pixels), n_samples)
             if mse.requires_grad:          # a rank whose rays met no sample has nothing to add (its peers do): the
                 (mse * self.loss_scale).backward()     # collective below must still be entered by everyone
             work = A.allreduce(average=False, async_op=True)
@@ -446,12 +506,17 @@ class Trainer:
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()
                     self._comm_events.append((e0, e1))
-            A.flat.div_(self.world)
+            # the summed sample count goes to the host behind the collective; nobody waits for it before the next step
+            self._count_host.copy_(A.tail, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._count_pending = (ev, len(pixels))
+            A.grads.div_(self.world)
             if ctx_grads is not None:
                 pairs = [(v, g) for v, g in zip(A.views, ctx_grads) if g is not None]
                 torch._foreach_add_([v for v, _ in pairs], [g for _, g in pairs])
             elif c.lmbda > 0:
-                A.flat.add_(B.flat)
+                A.grads.add_(B.flat)
             A.bind(force=True)
         self.opt.step()
         if c.lmbda > 0:
@@ -460,7 +525,14 @@ class Trainer:
         if c.lmbda > 0:
             self.sched2.step()
         if self.bucket is not None and (step + 1) % c.step_update == 0:
-            cdist.broadcast_parameters(self.bucket.params)        # 161 MB every `step_update` steps
+            # Only the entropy gradient can differ between replicas (float atomics in another order); the tensors it
+            # does not reach — the field's MLPs — stay bit-identical by construction.  Compare bit checksums (one
+            # small collective) and broadcast only what differs, instead of all 161 MB every time.
+            n, nbytes = cdist.resync_parameters(self.bucket.params)
+            self.resync["checks"] += 1
+            self.resync["fired"] += 1 if n else 0
+            self.resync["tensors"] += n
+            self.resync["bytes"] += nbytes
         if not want_stats:
             return {"n_rendering_samples": n_samples, "num_rays": len(pixels)}
         # the step's scalars in one device->host copy
@@ -509,6 +581,7 @@ class Trainer:
     def encode(self, prefix: Optional[str] = None):
         os.makedirs(self.cfg.out_dir, exist_ok=True)
         prefix = prefix or os.path.join(self.cfg.out_dir, "b")
+        os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
         e = self.field.mlp_base
         self.context.eval()
         return self.context.encode_binary_vxl_mixPg_3D2D(e.encoding_xyz, e.encoding_xy, e.encoding_xz,

@@ -91,3 +91,73 @@ def test_dist_helpers_refuse_an_uninitialised_world():
             "b.allreduce()") % ROOT
     r = __import__('subprocess').run([sys.executable, "-c", code], capture_output=True, text=True, env={k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')})
     assert r.returncode != 0 and "not initialised" in r.stderr
+
+
+def _worker_tail_resync(rank, world, port, q):
+    """What the data-parallel Trainer adds in round 4, at `world` ranks: the sample count riding in the gradient
+    bucket's tail slot, several scalars in one `sum_over_ranks`, and the checksum-triggered re-alignment."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from cnc_amd import dist as cd
+    cd.init("gloo")
+    torch.manual_seed(0)                      # identical replicas
+    table = torch.nn.Parameter(torch.randn(257, 8))
+    mlp = torch.nn.Linear(16, 4)
+    head = torch.nn.Linear(4, 4)
+    params = [table] + list(mlp.parameters()) + list(head.parameters())
+    bucket = cd.GradBucket(params, tail=1)
+    assert bucket.flat.numel() == bucket.numel + 1 and bucket.grads.numel() == bucket.numel
+    assert bucket.tail.data_ptr() == bucket.flat[bucket.numel:].data_ptr()
+    bucket.zero()
+    bucket.bind(force=True)
+    (table[rank] * float(rank + 1)).sum().backward()
+    bucket.tail.fill_(float(1000 + rank))                 # this rank's sample count
+    bucket.allreduce(average=False)
+    count = float(bucket.tail[0])
+    bucket.grads.div_(world)
+    rows = table.grad[:world, 0].clone()
+    two = cd.sum_over_ranks([float(rank), 1.0], "cpu")
+    # replicas identical: nothing to re-align
+    first = cd.resync_parameters(params)
+    # an ulp of drift in ONE tensor on ONE rank (what a float atomic in another order does): exactly that tensor
+    # is broadcast from rank 0, on every rank
+    if rank == world - 1:
+        with torch.no_grad():
+            v = mlp.weight.view(-1).view(torch.int32)
+            v[3] += 1
+    second = cd.resync_parameters(params)
+    third = cd.resync_parameters(params)
+    # +1 ulp and -1 ulp in two entries cancel in a plain bit sum; the second checksum (sum of squares) sees them
+    if rank == 1:
+        with torch.no_grad():
+            v = table.view(-1).view(torch.int32)
+            v[5] += 1
+            v[9] -= 1
+    fourth = cd.resync_parameters(params)
+    sums = [float(p.detach().double().sum()) for p in params]
+    q.put((rank, count, rows, two, first, second, third, fourth, sums))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bucket_tail_and_checksum_resync(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_tail_resync, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mlp_w_bytes, table_bytes = 4 * 16 * 4, 257 * 8 * 4
+    for rank, count, rows, two, first, second, third, fourth, sums in res:
+        assert count == sum(1000 + r for r in range(world))               # the tail slot came back summed
+        assert torch.allclose(rows, torch.arange(1, world + 1, dtype=torch.float32) / world)   # ... the gradients averaged
+        assert two == [sum(range(world)), float(world)]
+        assert first == (0, 0) and third == (0, 0)
+        assert second == (1, mlp_w_bytes) and fourth == (1, table_bytes)
+        assert sums == res[0][8]                                          # replicas identical again

@@ -150,6 +150,26 @@ def test_fused_segment_reduction_equals_packed_dataflow(setup):
         assert (a - b).abs().max() <= 1e-4 * b.abs().max()
 
 
+def test_vertex_set_fast_path_equals_the_candidate_lattice_branch(setup):
+    """get_idx_coords2: the shifted-OR construction (fused_segments, GPU) and the reference's candidates-then-unique
+    expression (utils_bpp_acc.py:498-512) return the same sorted vertex set in the same dtype; a resolution the
+    candidate lattice was not built for is refused by both."""
+    g, m, encs, binary = setup
+    out = {}
+    for fused in (True, False):
+        m.fused_segments = fused
+        out[fused] = m.get_idx_coords2(binary)
+    m.fused_segments = True
+    assert out[True].dtype == out[False].dtype == torch.int32
+    assert out[True].shape[0] > 0 and torch.equal(out[True], out[False])
+    other = m.dimension_wise_resolution + m.binary_vxl_len          # factor t + 1
+    for fused in (True, False):
+        m.fused_segments = fused
+        with pytest.raises(ValueError, match="does not match the lattice"):
+            m.get_idx_coords2(binary, resolution=other)
+    m.fused_segments = True
+
+
 def test_planned_votes_equal_atomic_votes(setup):
     """planned_votes=True (vertex list sorted once per refresh, segmented gathers) vs the atomic
     cnt_np_embed kernels: same entropy estimate, same gradients into the finest 3-D level and planes."""

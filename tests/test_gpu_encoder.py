@@ -144,6 +144,35 @@ def test_vertex_bits_equal_the_box_test_of_every_vertex(cuda, oracle, D):
             assert got.min() == 0 and got.max() == 1
 
 
+@pytest.mark.parametrize("D,R", [(2, 1026), (3, 5), (2, 9), (3, 22), (1, 70)])
+def test_vertex_bits_stay_inside_an_exact_size_plane(cuda, D, R):
+    """A C caller sizes the plane with cnc_grid_vertex_bits_words and nothing more: the waves of the last block that
+    lie past the last vertex must not store (R^D mod 256 in (0, 192] is the case that used to spill up to six zero
+    words; 1026^2, the default finest 2-D level, is one of them)."""
+    from cnc_amd import _lib
+    from cnc_amd.backends import gridencoder_backend as be
+    L = _lib.lib()
+    n = R ** D
+    assert 0 < n % 256 <= 192
+    Rb = 16
+    v = torch.ones((Rb,) * D, dtype=torch.bool, device=cuda)
+    sat = be.occupancy_sat(v)
+    nw = int(L.cnc_grid_vertex_bits_words(D, R))
+    assert nw == (n + 63) // 64 * 2
+    CANARY = 0x5A5A5A5A
+    buf = torch.full((nw + 16,), CANARY, dtype=torch.int32, device=cuda)
+    be.check(L.cnc_grid_vertex_bits(be.ptr(sat), D, Rb, R, buf.data_ptr(), be.stream(cuda)), "grid_vertex_bits")
+    torch.cuda.synchronize()
+    got = buf.cpu().numpy()
+    assert np.all(got[nw:] == CANARY), "cnc_grid_vertex_bits wrote past the plane"
+    words = got[:nw].view(np.uint32)
+    idx = np.arange(n)
+    bits = (words[idx // 32] >> (idx % 32).astype(np.uint32)) & 1
+    assert bits.max() == 1                                 # a full occupancy grid: inner vertices pass the box test
+    pad = np.arange(n, nw * 32)
+    assert np.all(((words[pad // 32] >> (pad % 32).astype(np.uint32)) & 1) == 0)   # padding bits are written zero
+
+
 @pytest.mark.parametrize("N", [0, 1, 63, 64, 65, 257])
 def test_forward_ragged_sizes(cuda, oracle, N):
     offs, resl, emb = make_grid(RES3, 10, 3, 8, seed=2)

@@ -162,6 +162,11 @@ def test_context_model_tables_toy():
     t = (34 - 2) // 8
     assert c.shape == ((t + 2) ** 3, 3)
     assert c.min(0).values.tolist() == [2 * t, 3 * t, 1 * t] and c.max(0).values.tolist() == [3 * t + 1, 4 * t + 1, 2 * t + 1]
+    assert c.dtype == torch.int32
+    # the candidate lattice was built for resolution 34 (factor 4): another resolution has no meaning here and is
+    # refused rather than answered differently by the two branches
+    with pytest.raises(ValueError, match="does not match the lattice"):
+        m.get_idx_coords2(bv, resolution=18)
 
 
 def test_nerf_synthetic_loader_on_a_fabricated_scene(tmp_path):
