@@ -82,6 +82,7 @@ def build_workload(dev, rank):
         table=table.to(dev),
         binaries=synthetic.ball_binaries(128, AABB, 1.0, device=dev),
         aabbs=torch.tensor([AABB], dtype=torch.float32, device=dev),
+        aabb0=torch.tensor(AABB, dtype=torch.float32, device=dev),
     )
     # one camera per rank on a circle (weak scaling: every GPU renders its own 800x800 view)
     o, d = synthetic.pinhole_rays(800, 800, 0.6911, 4.0, azimuth=0.7 + 0.785398 * rank, elevation=0.5)
@@ -111,15 +112,18 @@ def step(w, timed, world):
         # the march the renderer consumes (same t values and order as traverse_grids' interval edges)
         t_lo, t_hi, hit = ngrid_cuda.ray_aabb_intersect(rays_o, rays_d, w["aabbs"], -float("inf"), float("inf"),
                                                         float("inf"))
+        # The fill pass also emits each sample's position o + d (t_start + t_end) / 2 (rgb_sigma_fn,
+        # examples/utils.py:251-262) normalised to the unit cube (the radiance field's aabb mapping, ngp.py:518-519)
+        # — bit-equal to the separate cnc_sample_positions pass of rounds 1-3, which re-read (ray, t0, t1) per
+        # sample — and the ray id as int32 (int64 only at the nerfacc boundary).
+        box["ex"] = {"positions": True, "aabb": w["aabb0"], "ray_indices": "int32"}
         box["s"] = ngrid_cuda.march_samples(rays_o, rays_d, None, w["binaries"], w["aabbs"],
                                             torch.cat([t_lo, t_hi], -1), w["t_order"], hit, w["near"], w["far"],
-                                            STEP_SIZE, 0.0)
-    timed.launch("march(ray_aabb+count+cumsum+fill)", n_rays, march)
+                                            STEP_SIZE, 0.0, extras=box["ex"])
+    timed.launch("march(ray_aabb+count+cumsum+fill incl. positions)", n_rays, march)
     ray_indices, t_starts, t_ends = box["s"][:3]
     S = t_starts.shape[0]
-    # sample positions o + d (t_start + t_end) / 2 (rgb_sigma_fn, examples/utils.py:251-262), normalised to the
-    # unit cube (the radiance field's aabb mapping, ngp.py:518-519)
-    x = ngrid_cuda.sample_positions(rays_o, rays_d, ray_indices, t_starts, t_ends, w["aabbs"][0])
+    x = box["ex"]["positions"]
 
     gt = w["grad_table"]
     finish_exchange(w, timed, world)                   # the previous frame's gradient exchange ran next to this march

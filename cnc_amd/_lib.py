@@ -65,7 +65,7 @@ SIGNATURES = {
     "cnc_traverse_grids": [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                            _f32, _f32, _i32, _i32, C.POINTER(RaySegments), C.POINTER(RaySegments), _vp, _vp],
     "cnc_march_samples": [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
-                          _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+                          _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cnc_sample_positions": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "cnc_inclusive_sum": [_vp, _vp, _vp, _vp, _u32, _i64, _i32, _i32, _vp],
     "cnc_exclusive_sum": [_vp, _vp, _vp, _vp, _u32, _i64, _i32, _i32, _vp],
@@ -111,7 +111,7 @@ CNC_FLAG_LEVELS_FINEST_FIRST = 2
 CNC_FLAG_BIN_LANE_STORES = 4
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 23          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 24          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

@@ -143,12 +143,17 @@ def traverse_grids(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
 
 
 def march_samples(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
-                  step_size, cone_angle, traverse_steps_limit=-1, want_terminate_planes=False, clamped_total=None):
+                  step_size, cone_angle, traverse_steps_limit=-1, want_terminate_planes=False, clamped_total=None,
+                  extras=None):
     """(extension) The march as the renderer consumes it — see cnc_march_samples in include/cnc_hip.h.
     Returns (ray_indices i64 [S], t_starts [S], t_ends [S], chunk_starts [n_rays], chunk_cnts [n_rays],
     terminate_planes or None).  Count pass, exclusive cumsum + ONE host sync (the sample total sizes the
     result, as in data_spec.hpp:86-96), fill pass.  `clamped_total` = {"at": w}: the same sync also brings
-    sum(min(count, w)) back, under the key "total" (a caller that is about to take the first w samples of every ray)."""
+    sum(min(count, w)) back, under the key "total" (a caller that is about to take the first w samples of every ray).
+    `extras` (dict, filled in place): what the fill pass emits besides — "positions": True -> [S,3] sample positions
+    (o + d (t0 + t1) / 2, in the unit cube of extras["aabb"] (6 floats on the device) when given), "dirs": True ->
+    [S,3] ray directions, "ray_indices": "int32" | None -> the ray ids as int32 / not at all (the first return value
+    is then that tensor / None)."""
     for name, t in (("rays_o", rays_o), ("rays_d", rays_d), ("binaries", binaries), ("aabbs", aabbs),
                     ("t_sorted", t_sorted), ("t_indices", t_indices), ("hits", hits),
                     ("near_planes", near_planes), ("far_planes", far_planes)):
@@ -163,13 +168,25 @@ def march_samples(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indice
     # only the span between a ray's first and last sample (CNC_MARCH_RESUME=0: both passes march the whole ray)
     resume = torch.empty((n_rays, 8), dtype=torch.int32, device=dev) if os.environ.get("CNC_MARCH_RESUME", "1") == "1" \
         else None
+    ex = extras if extras is not None else {}
+    ri_kind = ex.get("ray_indices", "int64")
+    if ri_kind not in ("int64", "int32", None):
+        raise RuntimeError("march_samples: extras['ray_indices'] must be 'int64', 'int32' or None")
+    if ri_kind is None and not ex.get("positions"):
+        raise RuntimeError("march_samples: without ray indices the fill pass must at least emit positions")
+    box = ex.get("aabb")
+    if box is not None:
+        check_input(box, "extras['aabb']")
+        if box.dtype != torch.float32 or box.numel() != 6:
+            raise RuntimeError("march_samples: extras['aabb'] must be 6 float32 values on the device")
 
-    def launch(starts, t0, t1, ri, tp):
+    def launch(starts, t0, t1, ri, tp, pos=None, dirs=None, ri32=None):
         rc = L.cnc_march_samples(ptr(rays_o), ptr(rays_d), ptr(rays_mask), n_rays, ptr(binaries), binaries.shape[0],
                                  binaries.shape[1], binaries.shape[2], binaries.shape[3], ptr(aabbs), ptr(hits),
                                  ptr(t_sorted), ptr(t_indices), ptr(near_planes), ptr(far_planes), float(step_size),
                                  float(cone_angle), int(traverse_steps_limit), ptr(counts), ptr(starts), ptr(t0),
-                                 ptr(t1), ptr(ri), ptr(tp), ptr(resume), stream(dev))
+                                 ptr(t1), ptr(ri), ptr(tp), ptr(resume), ptr(pos), ptr(dirs), ptr(ri32), ptr(box),
+                                 stream(dev))
         check(rc, "march_samples")
 
     launch(None, None, None, None, term)
@@ -181,10 +198,18 @@ def march_samples(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indice
     starts = ends - counts
     t_starts = torch.empty(total, dtype=torch.float32, device=dev)
     t_ends = torch.empty(total, dtype=torch.float32, device=dev)
-    ray_indices = torch.empty(total, dtype=torch.int64, device=dev)
+    ray_indices = torch.empty(total, dtype=torch.int64, device=dev) if ri_kind == "int64" else None
+    ri32 = torch.empty(total, dtype=torch.int32, device=dev) if ri_kind == "int32" else None
+    pos = torch.empty((total, 3), dtype=torch.float32, device=dev) if ex.get("positions") else None
+    dirs = torch.empty((total, 3), dtype=torch.float32, device=dev) if ex.get("dirs") else None
     if total:
-        launch(starts, t_starts, t_ends, ray_indices, None)
-    return ray_indices, t_starts, t_ends, starts, counts, term
+        launch(starts, t_starts, t_ends, ray_indices, None, pos, dirs, ri32)
+    if extras is not None:
+        if ex.get("positions"):
+            extras["positions"] = pos
+        if ex.get("dirs"):
+            extras["dirs"] = dirs
+    return (ri32 if ri_kind == "int32" else ray_indices), t_starts, t_ends, starts, counts, term
 
 
 def sample_positions(rays_o, rays_d, ray_indices, t_a, t_b=None, aabb=None, want_dirs=False):

@@ -138,32 +138,43 @@ __device__ __forceinline__ uint32_t load_row_bits(const uint8_t* __restrict__ bi
     }
 }
 
-// P = level slots per lane.  Level-major output ([L, N, F], the drop-in layout): P = 1, a wave stores 64 consecutive
-// rows.  Point-major output (rows of a wider [N, ld] matrix, lay.ld != 0): a lane's F floats of ONE level are half
-// a 64-byte sector whose other half belongs to the next level — written by another block much later, the two halves
-// reach the fabric as two partial write requests (measured: 0.479 instead of 0.241 ms per 2^20 points at 16 levels).
-// With P * F = 16 floats a lane finishes whole 64-byte pieces of its row: 0.451 ms — the rest of the gap is the 1 KB
-// stride between the lanes' rows (a level-major wave writes 2 KB in one piece), which only an LDS transpose of
-// several levels per block would close.
-template <uint32_t D, uint32_t F, bool VXL>
+// P = level slots per lane.  Level-major output ([L, N, F], the drop-in layout): P = 1.  Point-major output (rows of
+// a wider [N, ld] matrix, lay.ld != 0): P * F = 16 floats, so that a point's piece of the row is a whole 64-byte line.
+//
+// Stores.  A lane owns a point, i.e. P*F*4 = 32 or 64 bytes of output; stored straight from its registers, a wave's
+// store instruction writes 16 bytes per lane at a 32 / 64-byte (level-major) or `ld`-float (point-major) stride: every
+// instruction touches a quarter or a half of each 64-byte line, the halves reach the fabric as separate partial write
+// requests (round 3: 11.7 M requests and WRITE_SIZE 735 MB for a 537 MB output; point-major 2x the level-major time).
+// TR = true: the wave transposes its 64 x (P*F) tile through LDS (swizzled at 16-byte granularity: conflict-free
+// ds_write_b128 / ds_read_b128), after which lane i of store s holds the 16-byte chunk s*64 + i of the tile in memory
+// order: level-major a wave's instruction writes 1 KB contiguous, point-major every instruction writes whole lines
+// (64 / Cp points x Cp*16 bytes).  The arithmetic is untouched (same corner order, same fmaf chain).
+template <uint32_t D, uint32_t F, bool VXL, bool TR>
 __global__ __launch_bounds__(256) void k_grid_encode_fwd_bits(
     const float* __restrict__ inputs, const uint8_t* __restrict__ bits,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
-    float* __restrict__ out, uint32_t N, uint32_t L, uint32_t P, uint32_t Rb, const uint8_t* __restrict__ vxl,
-    const int32_t* __restrict__ min_level_id, const int32_t* __restrict__ sat, FeatLayout lay)
+    float* __restrict__ out, uint32_t N, uint32_t L, uint32_t P, uint32_t cp_log2, uint32_t Rb,
+    const uint8_t* __restrict__ vxl, const int32_t* __restrict__ min_level_id, const int32_t* __restrict__ sat,
+    FeatLayout lay)
 {
     constexpr uint32_t C = 1u << D;
     constexpr uint32_t V = F < 4 ? F : 4;
+    extern __shared__ float s_tile[];            // TR only: [4 waves][64 points][Cp chunks of 4 floats], swizzled
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= N) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t Cp = 1u << cp_log2;           // 16-byte chunks per point and pass
+    float* tile = s_tile + (size_t)(threadIdx.x >> 6) * 64 * Cp * 4;
+    const uint32_t swz = (lane >> (3u - cp_log2)) & (Cp - 1u);
+    if constexpr (!TR) {
+        if (b >= N) return;
+    }
     float      x[D];
-    const bool inside = load_point<D>(inputs, b, x);
-    const uint32_t first = min_level_id ? (uint32_t)min_level_id[b] : 0u;
+    const bool inside = b < N && load_point<D>(inputs, b, x);
+    const uint32_t first = (min_level_id && b < N) ? (uint32_t)min_level_id[b] : 0u;
     for (uint32_t pl = 0; pl < P; pl++) {
         const uint32_t slot = blockIdx.y * P + pl;
         if (slot >= L) break;
         const uint32_t level = slot + first;
-        float* o = out + feat_index(lay, slot, N, b, F);
         float  acc[F];
 #pragma unroll
         for (uint32_t k = 0; k < F; k++) acc[k] = 0;
@@ -188,13 +199,38 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd_bits(
                 }
             }
         }
+        float* o = TR ? nullptr : out + feat_index(lay, slot, N, b, F);
 #pragma unroll
         for (uint32_t k = 0; k < F; k += V) {
             float v[V];
 #pragma unroll
             for (uint32_t j = 0; j < V; j++) v[j] = acc[k + j];
-            if (lay.nt) store_vec_nt<V>(o + k, v);
-            else store_vec<V>(o + k, v);
+            if constexpr (TR) {
+                const uint32_t f = pl * F + k;                      // float index inside the point's piece
+                store_vec<V>(tile + ((lane << cp_log2) + ((f >> 2) ^ swz)) * 4 + (f & 3u), v);
+            } else {
+                if (lay.nt) store_vec_nt<V>(o + k, v);
+                else store_vec<V>(o + k, v);
+            }
+        }
+    }
+    if constexpr (TR) {
+        __syncthreads();
+        const uint32_t slot0 = blockIdx.y * P;
+        const uint32_t n_floats = min(P, L - slot0) * F;           // of this pass, per point (a multiple of 4)
+        const uint32_t b0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u);    // the wave's first point
+        for (uint32_t s = 0; s < Cp; s++) {
+            const uint32_t g = s * 64 + lane;
+            const uint32_t pt = g >> cp_log2, c = g & (Cp - 1u);
+            const uint32_t bp = b0 + pt;
+            if (bp >= N || c * 4 >= n_floats) continue;
+            const uint32_t psw = (pt >> (3u - cp_log2)) & (Cp - 1u);
+            float v[4];
+            load_vec<4>(tile + ((pt << cp_log2) + (c ^ psw)) * 4, v);
+            float* o = lay.ld ? out + (size_t)bp * lay.ld + lay.col + slot0 * F + c * 4
+                              : out + ((size_t)slot0 * N + bp) * F + c * 4;
+            if (lay.nt) store_vec_nt<4>(o, v);
+            else store_vec<4>(o, v);
         }
     }
 }
@@ -922,17 +958,29 @@ static void launch_fwd_bits(const float* inputs, const uint8_t* bits, const int3
     // point-major rows: several level slots per lane (see the kernel)
     uint32_t P = 1;
     if (lay.ld != 0 && L > 1) {
-        P = F >= 16 ? 1u : 16u / F;      // 16 floats = one 64-byte sector per lane (measured at F = 8, 16 levels, ms per 2^20
-        if (P > L) P = L;                // points: P = 1: 0.479, 2: 0.451, 4: 0.521, 8: 0.571, 16: 0.532; level-major 0.243)
+        P = F >= 16 ? 1u : 16u / F;      // 16 floats = one 64-byte line per point and pass
+        if (P > L) P = L;
     }
-    // streaming stores of the level-major outputs (a wave writes 2 KB in one piece): -2.4 % on the call, the bit plane
-    // keeps the L2 (CNC_FWD_NT=0: measurement switch).  NOT for point-major rows: their 32-byte pieces need the L2 to
-    // merge into whole sectors — streamed they cost 3.7x (0.078 -> 0.29 ms per 2^18 points at 12 levels).
+    // wave-transposed stores (see the kernel): whenever a point's piece is 2, 4 or 8 whole 16-byte chunks in every
+    // pass and the rows keep them aligned (CNC_FWD_TR=0: measurement switch, the round-3 per-lane stores)
+    static const int tr_mode = getenv("CNC_FWD_TR") ? atoi(getenv("CNC_FWD_TR")) : 1;
+    const uint32_t W = P * F, tail = (L % P) * F;
+    const bool tr = tr_mode && (W == 8 || W == 16 || W == 32) && tail % 4 == 0 && lay.ld % 4 == 0 && lay.col % 4 == 0 &&
+                    (reinterpret_cast<uintptr_t>(outputs) & 15u) == 0;
+    const uint32_t cp_log2 = W == 8 ? 1u : (W == 16 ? 2u : 3u);
+    // streaming stores of the level-major outputs (a wave writes whole lines): the bit plane keeps the L2
+    // (CNC_FWD_NT=0: measurement switch).  Point-major rows: only with the transposed stores — a lane's own 16-byte
+    // pieces need the L2 to merge into lines (streamed they cost 3.7x).
     static const int nt_mode = getenv("CNC_FWD_NT") ? atoi(getenv("CNC_FWD_NT")) : 1;
-    lay.nt = (nt_mode && lay.ld == 0) ? 1u : 0u;
+    lay.nt = (nt_mode == 1 && lay.ld == 0) || (nt_mode == 2 && tr) ? 1u : 0u;
     const dim3 grid(div_up(N, 256), div_up(L, P), 1);
-    if (vxl) hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, true>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, L, P, Rb, vxl, mli, sat, lay);
-    else hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, false>), grid, dim3(256), 0, s, inputs, bits, offsets, resolutions, outputs, N, L, P, Rb, vxl, mli, nullptr, lay);
+    const size_t lds = tr ? (size_t)256 * W * sizeof(float) : 0;
+#define CNC_FWD_BITS(VX, TRV)                                                                                        \
+    hipLaunchKernelGGL((k_grid_encode_fwd_bits<D, F, VX, TRV>), grid, dim3(256), TRV ? lds : 0, s, inputs, bits, offsets, \
+                       resolutions, outputs, N, L, P, cp_log2, Rb, vxl, mli, VX ? sat : nullptr, lay)
+    if (vxl) { if (tr) CNC_FWD_BITS(true, true); else CNC_FWD_BITS(true, false); }
+    else     { if (tr) CNC_FWD_BITS(false, true); else CNC_FWD_BITS(false, false); }
+#undef CNC_FWD_BITS
 }
 
 extern "C" int cnc_grid_encode_forward_bits(const float* inputs, const uint8_t* bits,
@@ -1031,4 +1079,4 @@ extern "C" const char* cnc_error_string(int code)
     }
 }
 
-extern "C" int cnc_abi_version(void) { return 23; }
+extern "C" int cnc_abi_version(void) { return 24; }

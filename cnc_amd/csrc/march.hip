@@ -127,14 +127,35 @@ __device__ __forceinline__ void flush_stage(const Stage& st, const Seg& o, uint3
 // Flush of the (t_start, t_end) rows: only rows that hold something are visited (a wave pauses whenever ONE of
 // its rays has filled its row; the rays that are still far from full keep theirs), two rows per step, 32 lanes
 // each: a row leaves as 128 contiguous bytes per float array and 256 for the int64 ray ids.
+// What cnc_march_samples may emit per sample besides (t_start, t_end): the sample's position — the expression of the
+// reference's rgb_sigma_fn (examples/utils.py:251-262: o + d (t0 + t1) / 2), optionally mapped to the unit cube of
+// `aabb` as the field does first thing (ngp.py:518-519), same operations in the same order as k_sample_positions —
+// the ray direction, and the ray id as int32.  The marching lane has o and d in registers; a separate pass would
+// re-read (ray, t0, t1) for every sample (554 MB of fetches per 800x800 frame) to recompute them.
+struct SampleExtras {
+    float*       positions;      // [S, 3] or null
+    float*       dirs;           // [S, 3] or null
+    int32_t*     ray_indices32;  // [S] or null
+    const float* aabb;           // 6 floats or null: positions normalised to the box
+};
+
+__device__ __forceinline__ float sample_coord(float o, float d, float t0, float t1, const float* __restrict__ aabb, int a)
+{
+    float p = o + (d * (t0 + t1)) / 2.0f;
+    if (aabb) p = (p - aabb[a]) / (aabb[3 + a] - aabb[a]);
+    return p;
+}
+
 template <int PROW>
 __device__ __forceinline__ void flush_pairs(const Stage& st, float* __restrict__ t_starts,
                                             float* __restrict__ t_ends, int64_t* __restrict__ ray_indices,
-                                            uint32_t cnt, int64_t g, int32_t ray)
+                                            uint32_t cnt, int64_t g, int32_t ray, const SampleExtras& ex,
+                                            const float (&o)[3], const float (&dir)[3])
 {
     constexpr uint32_t G = 64 / PROW;                    // rows written per step, PROW lanes each
     constexpr int      kPP = PROW + 1;
     const uint32_t lane = threadIdx.x, grp = lane / PROW, e = lane % PROW;
+    const bool     want_od = ex.positions != nullptr || ex.dirs != nullptr;
     uint64_t todo = __ballot(cnt > 0);
     while (todo) {
         uint64_t m = todo;
@@ -144,11 +165,26 @@ __device__ __forceinline__ void flush_pairs(const Stage& st, float* __restrict__
         const uint32_t c = (uint32_t)__shfl((int)cnt, (int)src);
         const int64_t  gs = __shfl(g, (int)src);
         const int32_t  r = __shfl(ray, (int)src);
+        float so[3] = {0, 0, 0}, sd[3] = {0, 0, 0};
+        if (want_od) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) { so[a] = __shfl(o[a], (int)src); sd[a] = __shfl(dir[a], (int)src); }
+        }
         if (has && e < c) {
             const int64_t k = gs + e;
-            t_starts[k] = st.sm[src * kPP + e];
-            t_ends[k] = st.iv[src * kPP + e];
-            ray_indices[k] = r;
+            const float t0 = st.sm[src * kPP + e], t1 = st.iv[src * kPP + e];
+            t_starts[k] = t0;
+            t_ends[k] = t1;
+            if (ray_indices) ray_indices[k] = r;
+            if (ex.ray_indices32) ex.ray_indices32[k] = r;
+            if (ex.positions) {
+#pragma unroll
+                for (int a = 0; a < 3; a++) ex.positions[k * 3 + a] = sample_coord(so[a], sd[a], t0, t1, ex.aabb, a);
+            }
+            if (ex.dirs) {
+#pragma unroll
+                for (int a = 0; a < 3; a++) ex.dirs[k * 3 + a] = sd[a];
+            }
         }
 #pragma unroll
         for (uint32_t k = 0; k < G; k++) todo &= todo - 1;
@@ -176,7 +212,8 @@ __global__ __launch_bounds__(64) void k_traverse(
     const uint8_t* __restrict__ hits, const float* __restrict__ t_sorted,
     const int64_t* __restrict__ t_indices, const float* __restrict__ near_planes,
     const float* __restrict__ far_planes, float step_size, float cone_angle, int32_t limit,
-    Seg iv, Seg sm, float* __restrict__ terminate_planes, int32_t rpb, uint32_t* __restrict__ rstate = nullptr)
+    Seg iv, Seg sm, float* __restrict__ terminate_planes, int32_t rpb, uint32_t* __restrict__ rstate = nullptr,
+    SampleExtras ex = SampleExtras{nullptr, nullptr, nullptr, nullptr})
 {
     extern __shared__ float s_dyn[];
     constexpr bool DIRECT = MODE == 3;                  // fill without staging: every lane stores its own samples
@@ -387,7 +424,17 @@ __global__ __launch_bounds__(64) void k_traverse(
                                 const int64_t k = cs_sm + n_sm;
                                 sm.vals[k] = t_last;
                                 iv.vals[k] = t_next;
-                                sm.ray_indices[k] = tid;
+                                if (sm.ray_indices) sm.ray_indices[k] = tid;
+                                if (ex.ray_indices32) ex.ray_indices32[k] = tid;
+                                if (ex.positions) {
+#pragma unroll
+                                    for (int a = 0; a < 3; a++)
+                                        ex.positions[k * 3 + a] = sample_coord(o[a], dir[a], t_last, t_next, ex.aabb, a);
+                                }
+                                if (ex.dirs) {
+#pragma unroll
+                                    for (int a = 0; a < 3; a++) ex.dirs[k * 3 + a] = dir[a];
+                                }
                             } else if constexpr (PAIRS) {
                                 st.sm[lane * kPP + st_sm] = t_last;
                                 st.iv[lane * kPP + st_sm] = t_next;
@@ -428,7 +475,7 @@ __global__ __launch_bounds__(64) void k_traverse(
         if constexpr (!FILL) break;
         if constexpr (PAIRS) {
             __syncthreads();
-            flush_pairs<PROW>(st, sm.vals, iv.vals, sm.ray_indices, st_sm, cs_sm + fl_sm, tid);
+            flush_pairs<PROW>(st, sm.vals, iv.vals, sm.ray_indices, st_sm, cs_sm + fl_sm, tid, ex, o, dir);
             fl_sm += st_sm;
             st_sm = 0;
             __syncthreads();
@@ -567,7 +614,8 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
                                  const int64_t* t_indices, const float* near_planes, const float* far_planes,
                                  float step_size, float cone_angle, int32_t traverse_steps_limit,
                                  int64_t* chunk_cnts, const int64_t* chunk_starts, float* t_starts, float* t_ends,
-                                 int64_t* ray_indices, float* terminate_planes, uint32_t* resume_state, void* stream)
+                                 int64_t* ray_indices, float* terminate_planes, uint32_t* resume_state,
+                                 float* positions, float* dirs, int32_t* ray_indices32, const float* aabb, void* stream)
 {
     if (n_rays <= 0) return CNC_OK;
     if (!rays_o || !rays_d || !binaries || !aabbs || !hits || !t_sorted || !t_indices || !near_planes ||
@@ -594,7 +642,10 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
                            terminate_planes, rpb, resume_state);
         return launch_status();
     }
-    if (!t_starts || !t_ends || !ray_indices) return CNC_ERR_INVALID_VALUE;
+    // the ray of a sample: int64 (the nerfacc boundary), int32 (internal consumers), or neither when the caller only
+    // wants what the extras carry
+    if (!t_starts || !t_ends || (!ray_indices && !ray_indices32 && !positions)) return CNC_ERR_INVALID_VALUE;
+    const SampleExtras ex{positions, dirs, ray_indices32, aabb};
     Seg ends{};
     sm.chunk_starts = const_cast<int64_t*>(chunk_starts);
     sm.vals = t_starts;
@@ -604,11 +655,11 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
         if (cone0) hipLaunchKernelGGL((k_traverse<3, 32, true>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
                            n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices, near_planes,
                            far_planes, step_size, cone_angle, traverse_steps_limit, ends, sm, terminate_planes, rpb,
-                           resume_state);
+                           resume_state, ex);
         else hipLaunchKernelGGL((k_traverse<3>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
                            n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices, near_planes,
                            far_planes, step_size, cone_angle, traverse_steps_limit, ends, sm, terminate_planes, rpb,
-                           resume_state);
+                           resume_state, ex);
         return launch_status();
     }
     // staging row length, measured on the 800x800 bench frame (count + fill, ms).  Marching whole rays: 8 -> 3.53,
@@ -620,7 +671,7 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
     hipLaunchKernelGGL((k_traverse<2, R, C0>), dim3(blocks), dim3(64), 2 * 64 * (R + 1) * sizeof(float),          \
                        (hipStream_t)stream, rays_o, rays_d, rays_mask, n_rays, binaries, n_grids, resx, resy, resz, \
                        aabbs, hits, t_sorted, t_indices, near_planes, far_planes, step_size, cone_angle,            \
-                       traverse_steps_limit, ends, sm, terminate_planes, rpb, resume_state)
+                       traverse_steps_limit, ends, sm, terminate_planes, rpb, resume_state, ex)
 #define CNC_LAUNCH_PAIRS(R)                   \
     do {                                      \
         if (cone0) CNC_LAUNCH_PAIRS_(R, true); \

@@ -68,6 +68,10 @@ class _FieldOnRays:
 
     def colour_and_density(self, t_starts, t_ends, ray_indices):
         x, v = _mid_points(self.o, self.d, ray_indices, t_starts, t_ends)
+        return self.colour_and_density_at(x, v)
+
+    def colour_and_density_at(self, x, v):
+        """The same for sample positions / directions the caller already has (cnc_march_samples' extras)."""
         rgb, sigma = self.field(x, v)
         sigma = sigma.squeeze(-1)
         return (rgb, sigma, x) if self.with_positions else (rgb, sigma)
@@ -150,11 +154,15 @@ def render_image_with_occgrid_test(max_samples: int, radiance_field: torch.nn.Mo
             break
         steps = max(min(n // n_alive, 64), fewest)
         marched += steps
+        # the fill pass emits each sample's position and direction itself (the marching lane has o and d in registers:
+        # bit-equal to `_mid_points`, without the pass that re-reads (ray, t0, t1) per sample); the int64 ray ids are
+        # only written when something below indexes by them
+        ex = {"positions": True, "dirs": True, "ray_indices": "int64" if alpha_thre > 0 else None}
         ray_indices, t_starts, t_ends, starts, counts, resume_at = _C.march_samples(
             o, d, alive, grids, boxes, crossings, order, hit, resume_at, far, render_step_size, cone_angle,
-            traverse_steps_limit=steps, want_terminate_planes=True)
+            traverse_steps_limit=steps, want_terminate_planes=True, extras=ex)
         if t_starts.shape[0]:
-            rgbs, sigmas = fn.colour_and_density(t_starts, t_ends, ray_indices)
+            rgbs, sigmas = fn.colour_and_density_at(ex["positions"], ex["dirs"])
             rgbs, sigmas = rgbs.float().contiguous(), sigmas.float().contiguous()
             if alpha_thre > 0:
                 # transparent samples are left out of the sums (but still attenuate what lies behind them)

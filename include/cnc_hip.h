@@ -358,14 +358,22 @@ int cnc_traverse_grids(const float* rays_o, const float* rays_d, const uint8_t* 
  * resume_state (nullable, ABI v23) u32 [n_rays, 8]: scratch the count call fills with where each ray produced its
  *   first sample (grid segment, cell, the three next-crossing distances, t) and the fill call — given the same buffer —
  *   starts from; the fill call then also stops at the ray's last sample.  Same samples, same values: only the span
- *   between a ray's first and last sample is marched twice, not the empty space around it.                 */
+ *   between a ray's first and last sample is marched twice, not the empty space around it.
+ * Fill-pass extras (ABI v24, all nullable): the marching lane has its ray's o and d in registers, so it can emit what
+ *   the next pass would otherwise rebuild from (ray, t_start, t_end) per sample —
+ *   positions f32 [S,3]: o + (d (t_start + t_end)) / 2 (rgb_sigma_fn, examples/utils.py:251-262), mapped to the unit
+ *                       cube (p - min) / (max - min) of `aabb` (6 device floats, ngp.py:518-519) when aabb != NULL;
+ *                       same operations in the same order as cnc_sample_positions: bit-equal;
+ *   dirs f32 [S,3]: d of the sample's ray;  ray_indices32 i32 [S]: the ray id for internal consumers.
+ *   ray_indices (i64, the nerfacc boundary) may be NULL when ray_indices32 or positions is given.             */
 int cnc_march_samples(const float* rays_o, const float* rays_d, const uint8_t* rays_mask, int32_t n_rays,
                       const uint8_t* binaries, int32_t n_grids, int32_t resx, int32_t resy, int32_t resz,
                       const float* aabbs, const uint8_t* hits, const float* t_sorted,
                       const int64_t* t_indices, const float* near_planes, const float* far_planes,
                       float step_size, float cone_angle, int32_t traverse_steps_limit,
                       int64_t* chunk_cnts, const int64_t* chunk_starts, float* t_starts, float* t_ends,
-                      int64_t* ray_indices, float* terminate_planes, uint32_t* resume_state, void* stream);
+                      int64_t* ray_indices, float* terminate_planes, uint32_t* resume_state,
+                      float* positions, float* dirs, int32_t* ray_indices32, const float* aabb, void* stream);
 
 /* (extension) Sample positions for the field in one pass: positions[s] = o[ray] + d[ray] * t_a[s], or
  * o + (d * (t_a[s] + t_b[s])) / 2 when t_b != NULL (rgb_sigma_fn, examples/utils.py:251-262, same

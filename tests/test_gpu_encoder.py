@@ -343,6 +343,33 @@ def test_bit_plane_forward_equals_fp32_ste_forward(cuda, oracle, D, F):
         assert np.array_equal(out.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 255, 256, 257, 1000])
+@pytest.mark.parametrize("D,F,L", [(3, 8, 6), (3, 8, 5), (3, 8, 1), (3, 2, 6), (3, 2, 3), (3, 4, 5), (2, 8, 4), (2, 8, 3),
+                                   (3, 16, 3), (3, 32, 2), (3, 1, 6)])
+def test_bit_plane_forward_layouts_and_ragged_sizes(cuda, oracle, N, D, F, L):
+    """The wave-transposed stores of k_grid_encode_fwd_bits (round 4): level-major [L, N, F] and point-major rows inside
+    a wider [N, ld] matrix (out_ld / out_col), every point count around the wave and block sizes, level counts that
+    leave a short last pass (which falls back to per-lane stores when its piece is not whole 16-byte chunks) — all
+    bit-equal to the oracle, nothing written outside the encoder's columns."""
+    from cnc_amd.backends import gridencoder_backend as be
+    res = (RES3 if D == 3 else RES2)[:L]
+    offs, resl, emb = make_grid(res, 10, D, F, seed=60 + F)
+    x = _points(N, D, seed=61 + N)
+    t = lambda a: torch.as_tensor(a, device=cuda)
+    bits = be.pack_sign_bits(t(emb))
+    want = oracle.grid_encode_forward(x, emb, offs, resl, ste_binary=True)          # [L, N, F]
+    out = torch.full((L, N, F), 7.0, device=cuda)
+    be.grid_encode_forward_bits(t(x), bits, t(offs), t(resl), out, N, D, F, L, 128)
+    assert np.array_equal(out.cpu().numpy(), want)
+    for ld, col in ((L * F, 0), (L * F + 12, 4), (L * F + 8, 8)):
+        feat = torch.full((N, ld), 7.0, device=cuda)
+        be.grid_encode_forward_bits(t(x), bits, t(offs), t(resl), feat, N, D, F, L, 128, None, None, None,
+                                    out_ld=ld, out_col=col)
+        got = feat.cpu().numpy()
+        assert np.array_equal(got[:, col:col + L * F].reshape(N, L, F).transpose(1, 0, 2), want)
+        assert np.all(got[:, :col] == 7.0) and np.all(got[:, col + L * F:] == 7.0)     # the neighbours' columns
+
+
 def test_gridencoder_bit_plane_cache_tracks_in_place_updates(cuda):
     from cnc_amd.gridencoder import GridEncoder
     a = GridEncoder(3, 8, RES3, 10, ste_binary=True, bitplane=True).to(cuda)

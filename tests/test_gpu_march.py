@@ -332,6 +332,43 @@ def test_march_samples_equals_the_interval_edges(cuda, oracle, res, step, limit,
     assert np.array_equal(term.cpu().numpy()[live], np.asarray(oterm)[live])
     if masked:
         assert np.all(counts.cpu().numpy()[~mask.numpy()] == 0)
+    # fill-pass extras (ABI v24): positions / directions / int32 ray ids from the marching lane == the separate
+    # cnc_sample_positions pass on (ray, t_start, t_end), bit for bit, with and without the unit-cube mapping
+    for box in (None, torch.tensor([-1.5, -1.4, -1.3, 1.5, 1.6, 1.7], device=cuda)):
+        for kind in ("int32", None, "int64"):
+            ex = {"positions": True, "dirs": True, "ray_indices": kind, "aabb": box}
+            ri2, ts2, te2, starts2, counts2, _ = C.march_samples(
+                T(o), T(d), T(mask) if masked else None, T(binaries), T(aabbs), torch.cat([t0, t1], -1), order, hit,
+                T(near), T(far), step, cone, traverse_steps_limit=limit, extras=ex)
+            assert torch.equal(ts2, ts) and torch.equal(te2, te) and torch.equal(counts2, counts)
+            if kind is None:
+                assert ri2 is None
+            else:
+                assert ri2.dtype == (torch.int32 if kind == "int32" else torch.int64) and torch.equal(ri2.long(), ri)
+            pos, dirs = C.sample_positions(T(o), T(d), ri, ts, te, box, want_dirs=True)
+            assert torch.equal(ex["positions"], pos) and torch.equal(ex["dirs"], dirs)
+    with pytest.raises(RuntimeError, match="at least emit positions"):
+        C.march_samples(T(o), T(d), None, T(binaries), T(aabbs), torch.cat([t0, t1], -1), order, hit, T(near), T(far),
+                        step, cone, extras={"ray_indices": None})
+
+
+def test_march_positions_equal_the_separate_pass_on_the_bench_frame(cuda):
+    """bench.py's 800x800 frame (640 k rays, ~68 M samples, staged fill pass with 16-entry rows): the positions the
+    fill pass emits — unit-cube normalised, what the encoder is fed — equal cnc_sample_positions on the same samples."""
+    import bench
+    from cnc_amd.backends import nerfacc_cuda as C
+    w = bench.build_workload(cuda, 0)
+    t_lo, t_hi, hit = C.ray_aabb_intersect(w["rays_o"], w["rays_d"], w["aabbs"], -float("inf"), float("inf"), float("inf"))
+    args = (w["rays_o"], w["rays_d"], None, w["binaries"], w["aabbs"], torch.cat([t_lo, t_hi], -1), w["t_order"], hit,
+            w["near"], w["far"], bench.STEP_SIZE, 0.0)
+    ri, ts, te, starts, counts, _ = C.march_samples(*args)
+    ex = {"positions": True, "aabb": w["aabb0"], "ray_indices": "int32"}
+    ri32, ts2, te2, _, counts2, _ = C.march_samples(*args, extras=ex)
+    assert ts.shape[0] > 6e7 and torch.equal(ts, ts2) and torch.equal(te, te2) and torch.equal(counts, counts2)
+    assert ri32.dtype == torch.int32 and torch.equal(ri32.long(), ri)
+    want = C.sample_positions(w["rays_o"], w["rays_d"], ri, ts, te, w["aabb0"])
+    assert torch.equal(ex["positions"], want)
+    assert float(want.min()) >= 0.0 and float(want.max()) <= 1.0
 
 
 def test_march_samples_resume_equals_whole_ray_march_on_the_bench_frame(cuda, monkeypatch):
