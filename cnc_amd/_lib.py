@@ -89,7 +89,7 @@ SIGNATURES = {
     "cnc_relu_backward_bias_partials": [_u32],
     "cnc_relu_backward_bias": [_vp, _vp, _u32, _u32, _vp, _vp, _vp],
     "cnc_field_sinusoid": [_vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp],
-    "cnc_field_post": [_vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp],
+    "cnc_field_post": [_vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp],
     "cnc_field_post_backward": [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _vp],
     "cnc_ctx_mlp_forward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp, _vp],
     "cnc_ctx_mlp_backward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp] * 10 + [_u32, _u32, _vp],
@@ -109,6 +109,7 @@ RESTYPES = {"cnc_grid_encode_backward_binned_workspace": C.c_uint64,
 CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2
 CNC_FLAG_BIN_LANE_STORES = 4
+CNC_FIELD_SH_FP16 = 1
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
 ABI_VERSION = 24          # cnc_abi_version() of the library this table was written for

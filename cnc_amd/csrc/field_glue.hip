@@ -13,6 +13,7 @@
 // Same float operations in the same order as the op chain (the library is built with contraction off), so
 // the values are those of the unfused path.
 #include "common.hpp"
+#include <hip/hip_fp16.h>
 
 namespace cnc {
 
@@ -166,13 +167,15 @@ __device__ __forceinline__ float4 sh4_quad(uint32_t q, float x, float y, float z
     }
 }
 
+__device__ __forceinline__ float round_through_half(float v) { return __half2float(__float2half_rn(v)); }
+
 // one lane per (row, 4 columns of the head input): 16-byte stores, a row's lanes write its 4 * ld_head bytes back to
 // back; rows of `base` are [density_raw | geo features].  (One lane per column, each evaluating all 16 harmonics into
 // a runtime-indexed array, put that array into scratch memory: 218 us per 2^19 rows instead of ~25.)
 __global__ __launch_bounds__(256) void k_field_post(const float* __restrict__ base, uint32_t ld_base, uint32_t geo,
                                                     const uint8_t* __restrict__ selector, const float* __restrict__ dirs,
                                                     uint32_t N, float* __restrict__ density, float* __restrict__ head_in,
-                                                    uint32_t ld_head)
+                                                    uint32_t ld_head, uint32_t sh_fp16)
 {
     const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint32_t quads = head_in ? ld_head / 4 : 1;
@@ -190,6 +193,10 @@ __global__ __launch_bounds__(256) void k_field_post(const float* __restrict__ ba
 #pragma unroll
         for (int a = 0; a < 3; a++) d3[a] = ((dirs[(size_t)i * 3 + a] + 1.0f) / 2.0f) * 2.0f - 1.0f;
         v = sh4_quad(q, d3[0], d3[1], d3[2]);
+        if (sh_fp16) {      // tiny-cuda-nn stores the encoding as half; the reference's cat promotes it back
+            v.x = round_through_half(v.x); v.y = round_through_half(v.y);
+            v.z = round_through_half(v.z); v.w = round_through_half(v.w);
+        }
     } else {
         const float*   b = base + (size_t)i * ld_base + 1;
         const uint32_t k = 4 * q - 16;
@@ -289,14 +296,15 @@ extern "C" int cnc_field_sinusoid(const float* x, const float* freqs, uint32_t n
 
 extern "C" int cnc_field_post(const float* base_out, uint32_t ld_base, uint32_t geo_feat_dim, const uint8_t* selector,
                               const float* dirs, uint32_t N, float* density, float* head_in, uint32_t ld_head,
-                              void* stream)
+                              uint32_t flags, void* stream)
 {
     if (N == 0) return CNC_OK;
     if (!base_out || ld_base < 1 + geo_feat_dim || (!density && !head_in)) return CNC_ERR_INVALID_VALUE;
     if (head_in && (!dirs || ld_head < 16 + geo_feat_dim || ld_head % 4 || (uintptr_t)head_in % 16)) return CNC_ERR_INVALID_VALUE;
     const uint64_t n = (uint64_t)N * (head_in ? ld_head / 4 : 1);
     hipLaunchKernelGGL(k_field_post, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, base_out,
-                       ld_base, geo_feat_dim, selector, dirs, N, density, head_in, ld_head);
+                       ld_base, geo_feat_dim, selector, dirs, N, density, head_in, ld_head,
+                       (flags & CNC_FIELD_SH_FP16) ? 1u : 0u);
     return launch_status();
 }
 

@@ -269,7 +269,7 @@ class _FieldPost(Function):
     multiply / SH encoding (~45 elementwise launches) / cat of ngp.py:527-547."""
 
     @staticmethod
-    def forward(ctx, base_out, selector, dirs, geo):
+    def forward(ctx, base_out, selector, dirs, geo, sh_fp16=False):
         from . import _lib
         ctx.set_materialize_grads(False)
         base_out = base_out.contiguous()
@@ -281,7 +281,8 @@ class _FieldPost(Function):
         if dirs is not None:
             dirs = dirs.contiguous()
         _lib.check(_lib.lib().cnc_field_post(base_out.data_ptr(), ldb, geo, _lib.ptr(selector), _lib.ptr(dirs), N,
-                                             density.data_ptr(), _lib.ptr(head_in), ld, _lib.stream(dev)), "field_post")
+                                             density.data_ptr(), _lib.ptr(head_in), ld,
+                                             _lib.CNC_FIELD_SH_FP16 if sh_fp16 else 0, _lib.stream(dev)), "field_post")
         ctx.save_for_backward(base_out, selector)
         ctx.dims = (N, ldb, geo, ld)
         if head_in is None:
@@ -299,7 +300,7 @@ class _FieldPost(Function):
         _lib.check(_lib.lib().cnc_field_post_backward(base_out.data_ptr(), ldb, geo, _lib.ptr(selector), _lib.ptr(gd),
                                                       _lib.ptr(gh), ld, N, g_base.data_ptr(),
                                                       _lib.stream(base_out.device)), "field_post_backward")
-        return g_base, None, None, None
+        return g_base, None, None, None, None
 
 
 class NGPRadianceField_mygrid_2D3D(nn.Module):
@@ -309,8 +310,12 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
                  resolutions_list=(16, 22, 31, 42, 57, 78, 106, 146, 199, 273, 374, 512),
                  log2_hashmap_size: int = 19, resolutions_list_2D=(64, 128, 256, 512, 1024),
                  log2_hashmap_size_2D=17, n_features_per_level=2, n_neurons=64, ste_binary=True,
-                 ste_multistep=False, add_noise=False, Q=10, sh_fp16_round=False, fused_ste=True,
+                 ste_multistep=False, add_noise=False, Q=10, sh_fp16_round=True, fused_ste=True,
                  fused_features=True) -> None:
+        """`sh_fp16_round` (default True): the direction encoding's 16 values are rounded through half precision, as the
+        reference's CUDA path sees them — tiny-cuda-nn writes its encoding to a half tensor unless told otherwise
+        (ngp.py:412-425 passes no dtype) and `torch.cat` promotes it back (ngp.py:540-547).  False = full float32
+        harmonics (the closed-form stand-in the round-3 goldens were made with)."""
         super().__init__()
         if not isinstance(aabb, torch.Tensor):
             aabb = torch.tensor(aabb, dtype=torch.float32)
@@ -323,7 +328,8 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         self.resolutions_list, self.log2_hashmap_size = resolutions_list, log2_hashmap_size
         self.fused_head = os.environ.get("CNC_FUSED_HEAD", "1") == "1"
         # normalise / selector, density activation, SH encoding and the head-input concat as single kernels
-        self.fused_glue = fused_features and not sh_fp16_round and os.environ.get("CNC_FUSED_GLUE", "1") == "1"
+        self.fused_glue = fused_features and os.environ.get("CNC_FUSED_GLUE", "1") == "1"
+        self.sh_fp16_round = bool(sh_fp16_round)
         self._head_fused = None
         # sample counts from here on run at a bucketed row count (`_bucket_rows`); CNC_ROW_BUCKET_MIN=0 pads every call
         self.row_bucket_min = int(os.environ.get("CNC_ROW_BUCKET_MIN", "4096"))
@@ -467,7 +473,7 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
             if Np != N:          # rows of padding (`_bucket_rows`): any direction will do
                 dirs = torch.cat([dirs, dirs.new_zeros((Np - N, 3))])
             h = self.mlp_base(x_unit, rows=Np)
-            density, head_in = _FieldPost.apply(h, selector, dirs, self.geo_feat_dim)
+            density, head_in = _FieldPost.apply(h, selector, dirs, self.geo_feat_dim, self.sh_fp16_round)
             rgb = torch.sigmoid(self._head(head_in))
             if Np != N:
                 rgb, density = rgb[:N], density[:N]

@@ -43,6 +43,7 @@ class TrainConfig:
     max_context_layer_num: int = 3
     n_features: int = 4
     fused_features: bool = True      # encoders write straight into the base MLP's input matrix
+    sh_fp16_round: bool = True       # direction encoding rounded through half, as tiny-cuda-nn hands it to the reference
     # hard-coded in the reference (:135-186)
     n_neurons: int = 160
     resolutions_list: Tuple[int, ...] = (18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514)
@@ -225,7 +226,7 @@ class Trainer:
             aabb=self.estimator.aabbs[-1], n_features_per_level=c.n_features, n_neurons=c.n_neurons,
             resolutions_list=c.resolutions_list, log2_hashmap_size=c.log2_hashmap_size,
             resolutions_list_2D=c.resolutions_list_2D, log2_hashmap_size_2D=c.log2_hashmap_size_2D,
-            ste_binary=True, Q=10, fused_features=c.fused_features).to(self.device)
+            ste_binary=True, Q=10, fused_features=c.fused_features, sh_fp16_round=c.sh_fp16_round).to(self.device)
         self.context = self.build_context()
         # `dataset`: anything with fetch() / view(i) / update_num_rays(n) (LoaderDataset for real scenes); the
         # procedural scene otherwise (no dataset ships with the repository)

@@ -583,10 +583,15 @@ int cnc_field_prepare(const float* positions, const float* aabb, uint32_t N, flo
  *   head_in [N, ld_head] = [SH degree-4 (16) of dirs | geo features | zeros]       (ngp.py:540-547; nullable)
  * dirs [N,3] are the raw view directions (the (dir + 1) / 2 and its inverse are applied inside, as the
  * reference and tiny-cuda-nn do between them).  selector nullable (= all ones).  ld_head a multiple of 4
- * and head_in 16-byte aligned (rows are written with 16-byte stores).                                  */
+ * and head_in 16-byte aligned (rows are written with 16-byte stores).
+ * flags (ABI v24): CNC_FIELD_SH_FP16 rounds each of the 16 harmonics through IEEE half (round to nearest even)
+ * before it is stored as float — tiny-cuda-nn's encoding writes a HALF tensor unless asked otherwise and the
+ * reference asks for nothing (ngp.py:412-425), so the head MLP of the CUDA reference sees fp16-rounded inputs that
+ * `cat` promoted back to float (ngp.py:540-547).  The directions carry no gradient: the backward is unchanged.  */
+#define CNC_FIELD_SH_FP16 1u
 int cnc_field_post(const float* base_out, uint32_t ld_base, uint32_t geo_feat_dim, const uint8_t* selector,
                    const float* dirs, uint32_t N, float* density, float* head_in, uint32_t ld_head,
-                   void* stream);
+                   uint32_t flags, void* stream);
 /* STE_binary of ngp.py:22-39 over n floats (16-byte aligned buffers), one pass each way:
  *   forward : out = (c >= 0) * 1 + (c < 0) * -1 with c = clamp(x, -1, 1)   (+1 / -1; NaN -> 0)
  *   backward: grad_in = grad_out * (clamp(x, -1, 1) == x)                                                     */

@@ -3,7 +3,8 @@ the REFERENCE's own Python running in this container on CPU (the build container
 not exist on the GPU box).  Nothing of the reference's source is stored — only seeded inputs, key names and
 the numbers its functions returned.
 
-    python tests/golden/make_golden_field.py            # writes field_toy.npz, render_toy.npz, train_toy.npz
+    python tests/golden/make_golden_field.py            # writes field_toy{,_sh16}.npz, render_toy.npz, train_toy.npz
+    python tests/golden/make_golden_field.py field_sh16  # one of: field, field_sh16, render, train
 
 What runs:
   * `radiance_fields.ngp.NGPRadianceField_mygrid_2D3D` (ngp.py:365-566: feature order of
@@ -147,7 +148,18 @@ class _SHStub(torch.nn.Module):
         assert len(nested) == 1 and nested[0]["otype"] == "SphericalHarmonics" and nested[0]["degree"] == 4
         self.n_input_dims, self.n_output_dims = n_input_dims, 16
 
+    # tcnn's output precision: None = the float32 stand-in of rounds 1-3 (float64 polynomial rounded once);
+    # torch.float16 = what tiny-cuda-nn does on a GPU with fp16 support and the reference's defaults — the published
+    # polynomial evaluated in float32 and stored to a HALF tensor (ngp.py:412-425 asks for no dtype; :540-547 then
+    # `cat`s it with float32 features, which promotes the rounded values back)
+    output_dtype = None
+
     def forward(self, x):
+        if _SHStub.output_dtype is torch.float16:
+            d = x.detach().float().numpy() * np.float32(2.0) - np.float32(1.0)
+            v = _sh4_closed_form(d)
+            assert v.dtype == np.float32
+            return torch.from_numpy(v.astype(np.float16))
         d = x.detach().double().numpy() * 2.0 - 1.0
         return torch.from_numpy(_sh4_closed_form(d).astype(np.float32))
 
@@ -270,8 +282,10 @@ class RandTape:
 
 
 # ------------------------------------------------------------------------------------------------------- field
-def gen_field(ngp):
+def gen_field(ngp, sh16=False):
+    """sh16: the same cases with `tinycudann.Encoding` returning half precision (field_toy_sh16.npz)."""
     out = {}
+    _SHStub.output_dtype = torch.float16 if sh16 else None
     for name, kw in FIELD_CASES.items():
         torch.manual_seed(3)
         f = ngp.NGPRadianceField_mygrid_2D3D(aabb=torch.tensor(AABB), ste_binary=True, ste_multistep=False, add_noise=False,
@@ -313,7 +327,8 @@ def gen_field(ngp):
                                  mb.encoding_yz(torch.cat([ys, zs], -1)), mb.embed_fn(xu)], -1)
         out[f"{name}_mlp_in"] = feat_in.numpy()[:64]
         print(name, "keys", len(sd), "mlp_in", tuple(feat_in.shape), "geo", f.geo_feat_dim, "loss", loss.item())
-    np.savez_compressed(os.path.join(HERE, "field_toy.npz"), **out)
+    _SHStub.output_dtype = None
+    np.savez_compressed(os.path.join(HERE, "field_toy_sh16.npz" if sh16 else "field_toy.npz"), **out)
 
 
 # ------------------------------------------------------------------------------------------------------ render
@@ -555,6 +570,8 @@ def main():
     which = sys.argv[1:] or ["field", "render", "train"]
     if "field" in which:
         gen_field(ngp)
+    if "field_sh16" in which or "field" in which:
+        gen_field(ngp, sh16=True)
     if "render" in which:
         gen_render(ngp, ex_utils, nerfacc, Rays)
     if "train" in which:

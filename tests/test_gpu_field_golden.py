@@ -102,8 +102,9 @@ class cpu_rand_like:
 
 def build_field(cuda, kw, fused, seed=17, density_bias=None, table_scale=None):
     from cnc_amd.field import NGPRadianceField_mygrid_2D3D
+    # sh_fp16_round=False: the render / training goldens were made with the float32 stand-in for tiny-cuda-nn's encoding
     f = NGPRadianceField_mygrid_2D3D(aabb=torch.tensor(AABB), ste_binary=True, ste_multistep=False, add_noise=False, Q=10,
-                                     fused_features=fused, **kw)
+                                     fused_features=fused, sh_fp16_round=False, **kw)
     sd = fill_state(f.state_dict(), seed)
     if density_bias is not None:
         sd["mlp_base.network.2.bias"][0] = density_bias
@@ -118,17 +119,23 @@ def build_field(cuda, kw, fused, seed=17, density_bias=None, table_scale=None):
 # ------------------------------------------------------------------------------------------------------- field
 @pytest.mark.parametrize("bucket_min", [1 << 30, 0], ids=["exact_rows", "padded_rows"])
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
+@pytest.mark.parametrize("sh", ["sh_half", "sh_float"])
 @pytest.mark.parametrize("case", ["f8", "f2"])
-def test_field_matches_reference(cuda, case, fused, bucket_min):
+def test_field_matches_reference(cuda, case, fused, bucket_min, sh):
     """`padded_rows`: every call runs at a bucketed row count (field._bucket_rows: what the training step does
-    from 4096 samples on) — the reference's values must come out of the first N rows all the same."""
+    from 4096 samples on) — the reference's values must come out of the first N rows all the same.
+    `sh_half` (the product's default): the reference class with `tinycudann.Encoding` returning a HALF tensor, as
+    tiny-cuda-nn does on the reference's CUDA path (field_toy_sh16.npz); `sh_float`: the float32 stand-in of rounds
+    1-3 (field_toy.npz).  The weight gradient of the head's first layer tells the two apart (2.5 %)."""
     from cnc_amd.field import NGPRadianceField_mygrid_2D3D
     if bucket_min == 0 and not fused:
         pytest.skip("rows are only bucketed on the fused path")
-    g = np.load(os.path.join(GOLD, "field_toy.npz"))
+    g = np.load(os.path.join(GOLD, "field_toy_sh16.npz" if sh == "sh_half" else "field_toy.npz"))
     kw = FIELD_CASES[case]
     f = NGPRadianceField_mygrid_2D3D(aabb=torch.tensor(AABB), ste_binary=True, ste_multistep=False, add_noise=False, Q=10,
-                                     fused_features=fused, **kw)
+                                     fused_features=fused, **({} if sh == "sh_half" else {"sh_fp16_round": False}), **kw)
+    assert f.sh_fp16_round == (sh == "sh_half") and f.direction_encoding.fp16_round == f.sh_fp16_round
+    assert f.fused_glue == fused            # the half rounding no longer turns the fused glue kernels off
     sd = f.state_dict()
     # the reference's state dict: same keys in the same order, same shapes, same small buffers
     assert list(sd.keys()) == [str(k) for k in g[f"{case}_keys"]]
@@ -175,6 +182,12 @@ def test_field_matches_reference(cuda, case, fused, bucket_min):
     loss.backward()
     for k, p in f.named_parameters():
         close(p.grad, g[f"{case}_grad_{k}"], 2e-4, "grad " + k)
+    # ... and the other setting's golden is NOT matched (the two differ where the harmonics enter)
+    other = np.load(os.path.join(GOLD, "field_toy.npz" if sh == "sh_half" else "field_toy_sh16.npz"))
+    k = "mlp_head.0.weight"
+    want = other[f"{case}_grad_{k}"]
+    err = np.abs(dict(f.named_parameters())[k].grad.cpu().numpy() - want).max()
+    assert err > 2e-3 * np.abs(want).max(), "the half / float harmonics are indistinguishable: the golden pins nothing"
 
 
 def test_sh_convention_is_real_spherical_harmonics(cuda):
@@ -300,7 +313,8 @@ def test_training_trajectory(cuda, tag, fused, tmp_path):
                       init_batch_size=c["init_batch_size"], target_sample_batch_size=c["target"], weight_decay=c["weight_decay"],
                       grid_resolution=c["Rb"], render_step_size=c["render_step_size"], lr=c["lr"],
                       milestones=tuple(c["milestones"]), warmup_iters=int(g["warmup_iters"]),
-                      dimension_wise_resolution=c["fine"], out_dir=str(tmp_path))
+                      dimension_wise_resolution=c["fine"], out_dir=str(tmp_path),
+                      sh_fp16_round=False)          # the golden run's tinycudann stand-in returned float32
     tr = Trainer(cfg, device=cuda, dataset=_NumpyBall(cuda))
     tr.ctx_thread = False          # one host thread: the reference's ORDER of random draws (render pass, then context pass)
     torch.manual_seed(11)                              # the context tables' CPU draws, as the golden run
