@@ -243,6 +243,60 @@ def kernel_source_hashes():
     return out
 
 
+def field_entries(dev):
+    """The gradient-free radiance field on the reference composition (12 x 3-D T=2^19 + 3 x 4 planes T=2^17, F = 8,
+    H = 160) at N = 2^20 samples: ONE fused kernel (positions -> density, positions + directions -> rgb + density,
+    cnc_field_fused_forward) against the chain it replaces (four encoder launches into a [N, 256] matrix in HBM,
+    hipBLASLt GEMMs, glue kernels).  HIP events on the current stream, median of 7 after 3 warm-up calls."""
+    from cnc_amd.field import NGPRadianceField_mygrid_2D3D
+    torch.manual_seed(1)
+    f = NGPRadianceField_mygrid_2D3D(aabb=list(AABB), n_features_per_level=8, n_neurons=160,
+                                     resolutions_list=(18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514),
+                                     log2_hashmap_size=19, resolutions_list_2D=(130, 258, 514, 1026),
+                                     log2_hashmap_size_2D=17).to(dev)
+    with torch.no_grad():
+        for e in f.mlp_base._encoders():
+            e.params.uniform_(-1, 1)
+    n = 1 << 20
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = torch.rand(n, 3, device=dev, generator=g) * 3.0 - 1.5
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device=dev, generator=g), dim=-1)
+
+    def timed_ms(fn):
+        ts = []
+        for it in range(10):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            if it >= 3:
+                ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2]
+
+    out = {}
+    k0 = f.mlp_base.network[0].in_features
+    H, geo = 160, f.geo_feat_dim
+    flop_density = 2.0 * n * (k0 * H + H)
+    flop_rgb = 2.0 * n * (k0 * H + H * (1 + geo) + (16 + geo) * H + H * H + H * 3)
+    with torch.no_grad():
+        for name, fused in (("fused", True), ("chain", False)):
+            f.fused_field = fused
+            md = timed_ms(lambda: f.query_density(x))
+            mr = timed_ms(lambda: f(x, d))
+            out[f"field_density({name})"] = {"launches": 7, "avg_ms": md, "units_per_s": n / md * 1e3,
+                                            "tflops_useful": flop_density / md / 1e9, "timed_region": False}
+            out[f"field_rgb+density({name})"] = {"launches": 7, "avg_ms": mr, "units_per_s": n / mr * 1e3,
+                                                "tflops_useful": flop_rgb / mr / 1e9, "timed_region": False}
+    out["field_note"] = ("N = 2^20 uniform positions in the box, reference composition at F = 8 (K0 = 255, H = 160, geo 79); "
+                         "fused = cnc_field_fused_forward (features in LDS -> v_mfma_f32_32x32x2_f32, fp32 MFMA peak "
+                         "157 TFLOP/s); chain = encoders -> [N,256] in HBM -> hipBLASLt -> glue kernels; tflops_useful "
+                         "counts the layers' multiply-adds only")
+    out["field_density_speedup"] = out["field_density(chain)"]["avg_ms"] / out["field_density(fused)"]["avg_ms"]
+    out["field_rgb_speedup"] = out["field_rgb+density(chain)"]["avg_ms"] / out["field_rgb+density(fused)"]["avg_ms"]
+    return out
+
+
 def spawn_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N copies of this script, one rank per GPU,
     with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); rank 0 prints the line."""
@@ -350,6 +404,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)      # the backward keeps getting faster for ~8 steps (786 vs 732 M/s at 6 vs 2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
+    ap.add_argument("--no-field", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus) if args.gpus > 1 else "1"))
@@ -603,6 +658,15 @@ def main():
             "ranks": ranks,
             "roofline": roofline, "roofline_forward": other, "kernels": kernels,
         }
+        if not args.no_field:
+            try:
+                fe = field_entries(dev)
+                out["field"] = {k: fe.pop(k) for k in ("field_note", "field_density_speedup", "field_rgb_speedup")}
+                kernels.update(fe)
+            except Exception as exc:       # noqa: BLE001 - an extra block must not take the line down
+                import traceback
+                print(f"[bench rank {rank}] field entries failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+                out["field"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_train_step:
             ts = guarded_train_step(dev) if world == 1 else ts_multi
             out["train_step"] = ts

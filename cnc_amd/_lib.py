@@ -28,6 +28,13 @@ class CtxWindow(C.Structure):
                 ("row0", _i64 * 16), ("level", _i32 * 16), ("res", _i32 * 16), ("n_win", _i32)]
 
 
+class FusedField(C.Structure):
+    """cnc_fused_field_t (include/cnc_hip.h)."""
+    _fields_ = [("aabb", _vp), ("bits", _vp * 4), ("offsets", _vp * 4), ("resolutions", _vp * 4), ("freqs", _vp),
+                ("packed_weights", _vp * 5), ("packed_biases", _vp * 5), ("w2_row0", _vp), ("n_levels", _u32 * 4),
+                ("n_features", _u32), ("n_freqs", _u32), ("n_neurons", _u32), ("geo_feat_dim", _u32), ("flags", _u32)]
+
+
 # name -> argtypes, in the order of include/cnc_hip.h
 SIGNATURES = {
     "cnc_grid_encode_forward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _f32, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _u32, _u32, _vp],
@@ -84,6 +91,8 @@ SIGNATURES = {
     "cnc_level_stats_forward": [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
     "cnc_level_stats_backward": [_vp, _vp, _u32, _u32, _vp, _vp, C.c_uint64, _vp, _vp],
     "cnc_field_prepare": [_vp, _vp, _u32, _vp, _vp, _vp],
+    "cnc_field_pack_layer": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp],
+    "cnc_field_fused_forward": [C.POINTER(FusedField), _vp, _vp, _u32, _vp, _vp, _vp],
     "cnc_ste_binary_forward": [_vp, _vp, C.c_uint64, _vp],
     "cnc_ste_binary_backward": [_vp, _vp, _vp, C.c_uint64, _vp],
     "cnc_relu_backward_bias_partials": [_u32],

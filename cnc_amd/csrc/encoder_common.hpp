@@ -158,6 +158,19 @@ struct Corners {
     }
 };
 
+// F sign bits of one table row from the bit plane cnc_pack_sign_bits writes (bit k of row r = table[r][k] >= 0)
+template <uint32_t F>
+__device__ __forceinline__ uint32_t load_row_bits(const uint8_t* __restrict__ bits, uint64_t row)
+{
+    if constexpr (F == 32) return *reinterpret_cast<const uint32_t*>(bits + row * 4);
+    else if constexpr (F == 16) return *reinterpret_cast<const uint16_t*>(bits + row * 2);
+    else if constexpr (F == 8) return bits[row];
+    else {
+        const uint64_t bit = row * F;
+        return (bits[bit >> 3] >> (bit & 7)) & ((1u << F) - 1u);
+    }
+}
+
 template <uint32_t D>
 __device__ __forceinline__ bool load_point(const float* __restrict__ inputs, uint32_t b,
                                            float (&x)[D])

@@ -126,18 +126,6 @@ __global__ __launch_bounds__(256) void k_pack_sign_bits(const float* __restrict_
     }
 }
 
-template <uint32_t F>
-__device__ __forceinline__ uint32_t load_row_bits(const uint8_t* __restrict__ bits, uint64_t row)
-{
-    if constexpr (F == 32) return *reinterpret_cast<const uint32_t*>(bits + row * 4);
-    else if constexpr (F == 16) return *reinterpret_cast<const uint16_t*>(bits + row * 2);
-    else if constexpr (F == 8) return bits[row];
-    else {
-        const uint64_t bit = row * F;
-        return (bits[bit >> 3] >> (bit & 7)) & ((1u << F) - 1u);
-    }
-}
-
 // P = level slots per lane.  Level-major output ([L, N, F], the drop-in layout): P = 1.  Point-major output (rows of
 // a wider [N, ld] matrix, lay.ld != 0): P * F = 16 floats, so that a point's piece of the row is a whole 64-byte line.
 //

@@ -303,6 +303,117 @@ class _FieldPost(Function):
         return g_base, None, None, None, None
 
 
+class FusedFieldForward:
+    """Gradient-free `positions -> density [-> rgb]` through ONE kernel (cnc_field_fused_forward,
+    cnc_amd/csrc/field_fused.hip): the four encoders' features are computed into LDS and consumed there by fp32 MFMA,
+    so the [N, 255] feature matrix, the activations and the head input never touch HBM (ngp.py:506-547).
+
+    Keeps the five layers' weights packed in MFMA fragment order (cnc_field_pack_layer: one tiny launch per layer),
+    repacked when a parameter changed (`_version`, plus the global optimizer post-step hook: fused Adam does not bump
+    the counter)."""
+
+    def __init__(self, field: "NGPRadianceField_mygrid_2D3D"):
+        from . import _caches
+        self.field = field
+        self._key = None
+        self._buffers = None
+        _caches.register(self)
+
+    def invalidate_caches(self):
+        self._key = None
+
+    @staticmethod
+    def supported(field) -> bool:
+        mb = field.mlp_base
+        encs = mb._encoders()
+        F_ = encs[0].n_features
+        H = mb.network[0].out_features
+        geo = field.geo_feat_dim
+        nt2 = 3 if H == 160 else 2
+        return (field.use_viewdirs and geo > 0 and not field.unbounded and field.num_dim == 3
+                and field.density_activation is _default_density_activation
+                and mb.embed_fn is not None and mb._freqs is not None
+                and all(e.ste_binary and e.fused_ste and e.bitplane and e.n_features == F_ for e in encs)
+                and encs[0].num_dim == 3 and all(e.num_dim == 2 for e in encs[1:])
+                and len({e.n_levels for e in encs[1:]}) == 1
+                and F_ in (2, 4, 8) and H in (64, 160) and 1 + geo <= 32 * nt2 and (16 + geo + 7) // 8 * 8 <= H
+                and len(mb.network) == 3 and len(field.mlp_head) == 5
+                and all(l.out_features == H for l in (field.mlp_head[0], field.mlp_head[2])))
+
+    def _layers(self):
+        f = self.field
+        return [f.mlp_base.network[0], f.mlp_base.network[2], f.mlp_head[0], f.mlp_head[2], f.mlp_head[4]]
+
+    def _pack(self, dev):
+        from . import _lib
+        layers = self._layers()
+        key = tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version) for l in layers) + (str(dev),)
+        if key == self._key:
+            return self._buffers
+        f = self.field
+        H, geo = layers[0].out_features, f.geo_feat_dim
+        T, T2 = H // 32, (3 if H == 160 else 2)
+        K0 = layers[0].in_features
+        shapes = [(T, (K0 + 31) // 32 * 4), (T2, H // 8), (T, (16 + geo + 7) // 8), (T, H // 8), (1, H // 8)]
+        if self._buffers is None or self._buffers["dev"] != str(dev):
+            self._buffers = {"dev": str(dev),
+                             "w": [torch.empty(nk * nt * 256, dtype=torch.float32, device=dev) for nt, nk in shapes],
+                             "b": [torch.empty(nt * 32, dtype=torch.float32, device=dev) for nt, nk in shapes],
+                             "row0": torch.empty(H, dtype=torch.float32, device=dev)}
+        L = _lib.lib()
+        for k, (l, (nt, nk)) in enumerate(zip(layers, shapes)):
+            w, b = l.weight.detach(), l.bias.detach()
+            if not w.is_contiguous():
+                w = w.contiguous()
+            row0 = self._buffers["row0"] if k == 1 else None
+            _lib.check(L.cnc_field_pack_layer(w.data_ptr(), b.data_ptr(), w.shape[0], w.shape[1], w.stride(0), nt, nk,
+                                              self._buffers["w"][k].data_ptr(), self._buffers["b"][k].data_ptr(),
+                                              _lib.ptr(row0), H if row0 is not None else 0, _lib.stream(dev)),
+                       "field_pack_layer")
+        self._key = key
+        self._src = [(l.weight, l.bias) for l in layers]        # keep (data_ptr, version) unique while cached
+        return self._buffers
+
+    @torch.no_grad()
+    def __call__(self, positions: torch.Tensor, directions=None):
+        """density [N, 1] (and rgb [N, 3] when `directions` is given) of world positions [N, 3]."""
+        from . import _lib
+        f = self.field
+        mb = f.mlp_base
+        x = positions.reshape(-1, 3)
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise RuntimeError("FusedFieldForward: positions must be a float32 CUDA tensor")
+        x = x.contiguous()
+        N, dev = x.shape[0], x.device
+        d = None
+        if directions is not None:
+            d = directions.reshape(-1, 3).to(torch.float32).contiguous()
+        buf = self._pack(dev)
+        st = _lib.FusedField()
+        aabb = f.aabb if f.aabb.is_contiguous() else f.aabb.contiguous()
+        st.aabb = aabb.data_ptr()
+        keep = [aabb]
+        for k, e in enumerate(mb._encoders()):
+            bits, _ = e._bit_plane(e.params)
+            keep.append(bits)
+            st.bits[k], st.offsets[k], st.resolutions[k] = bits.data_ptr(), e.offsets_list.data_ptr(), e.resolutions_list.data_ptr()
+            st.n_levels[k] = e.n_levels
+        if mb._freqs.device != dev or mb._freqs.dtype != torch.float32:
+            mb._freqs = mb._freqs.to(device=dev, dtype=torch.float32).contiguous()
+        st.freqs, st.n_freqs = mb._freqs.data_ptr(), mb._freqs.numel()
+        for k in range(5):
+            st.packed_weights[k], st.packed_biases[k] = buf["w"][k].data_ptr(), buf["b"][k].data_ptr()
+        st.w2_row0 = buf["row0"].data_ptr()
+        st.n_features, st.n_neurons, st.geo_feat_dim = mb.encoding_xyz.n_features, mb.network[0].out_features, f.geo_feat_dim
+        st.flags = _lib.CNC_FIELD_SH_FP16 if f.sh_fp16_round else 0
+        density = torch.empty((N, 1), dtype=torch.float32, device=dev)
+        rgb = torch.empty((N, 3), dtype=torch.float32, device=dev) if d is not None else None
+        import ctypes
+        _lib.check(_lib.lib().cnc_field_fused_forward(ctypes.byref(st), x.data_ptr(), _lib.ptr(d), N, density.data_ptr(),
+                                                      _lib.ptr(rgb), _lib.stream(dev)), "field_fused_forward")
+        return (density, rgb) if d is not None else density
+
+
 class NGPRadianceField_mygrid_2D3D(nn.Module):
     def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
                  density_activation: Callable = _default_density_activation, unbounded: bool = False,
@@ -331,6 +442,10 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         self.fused_glue = fused_features and os.environ.get("CNC_FUSED_GLUE", "1") == "1"
         self.sh_fp16_round = bool(sh_fp16_round)
         self._head_fused = None
+        # gradient-free calls as ONE kernel, positions -> density (-> rgb): FusedFieldForward (CNC_FUSED_FIELD=0: the
+        # chain of encoder launches, library GEMMs and glue kernels that the gradient path uses)
+        self.fused_field = fused_features and os.environ.get("CNC_FUSED_FIELD", "1") == "1"
+        self._field_fused = None
         # sample counts from here on run at a bucketed row count (`_bucket_rows`); CNC_ROW_BUCKET_MIN=0 pads every call
         self.row_bucket_min = int(os.environ.get("CNC_ROW_BUCKET_MIN", "4096"))
         self._head_shape_ok = n_neurons == 160       # the 32-row kernel is instantiated for 160-wide layers
@@ -400,7 +515,20 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
             selector[N:].zero_()
         return x_unit, selector, Np
 
+    def _fused_forward(self, x):
+        """The one-kernel evaluator for a gradient-free call on `x`, or None (gradients wanted, switched off, a
+        configuration outside the kernel's shapes, host tensors)."""
+        if torch.is_grad_enabled() or not self.fused_field or not self._glue_ok(x):
+            return None
+        if self._field_fused is None:
+            self._field_fused = FusedFieldForward(self) if FusedFieldForward.supported(self) else False
+        return self._field_fused or None
+
     def query_density(self, x, return_feat: bool = False):
+        if not return_feat:
+            fused = self._fused_forward(x)
+            if fused is not None:
+                return fused(x).view(list(x.shape[:-1]) + [1])
         if self._glue_ok(x):
             lead = list(x.shape[:-1])
             x_unit, selector, Np = self._prepare(x)
@@ -464,6 +592,12 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
     def forward(self, positions: torch.Tensor, directions: torch.Tensor = None):
         if self.use_viewdirs and (directions is not None):
             assert positions.shape == directions.shape, f"{positions.shape} v.s. {directions.shape}"
+        if directions is not None and self.use_viewdirs and directions.is_cuda:
+            fused = self._fused_forward(positions)
+            if fused is not None:
+                density, rgb = fused(positions, directions)
+                lead = list(positions.shape[:-1])
+                return rgb.view(lead + [3]), density.view(lead + [1])
         if directions is not None and self.use_viewdirs and self.geo_feat_dim > 0 and self._glue_ok(positions) \
                 and directions.is_cuda and directions.dtype == torch.float32:
             lead = list(positions.shape[:-1])

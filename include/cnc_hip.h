@@ -592,6 +592,47 @@ int cnc_field_prepare(const float* positions, const float* aabb, uint32_t N, flo
 int cnc_field_post(const float* base_out, uint32_t ld_base, uint32_t geo_feat_dim, const uint8_t* selector,
                    const float* dirs, uint32_t N, float* density, float* head_in, uint32_t ld_head,
                    uint32_t flags, void* stream);
+/* ------------------------------------------------------------------------------------------
+ * (extension, ABI v24) The gradient-free radiance field as one kernel: world positions -> density (-> rgb).
+ * Replaces, for calls made without gradients, the whole chain of ngp.py:506-547 + compose_3D_2D_embed :620-645:
+ * unit-cube mapping and selector, the four binarised grid encoders and the sinusoid embedding, base MLP
+ * K0 -> H (ReLU) -> 1 + geo, density = exp(x - 1) * selector; with rgb != NULL also [SH4(dir) | geo] -> H -> H -> 3
+ * and the sigmoid.  Features are computed into LDS and consumed by fp32 MFMA there: no [N, K0] matrix in HBM.
+ * Values: the encoders' features are bit-identical to cnc_grid_encode_forward_bits; each layer is an exact fp32 fmaf
+ * chain in k order (v_mfma_f32_32x32x2_f32), i.e. equal to the op chain up to the summation order of a GEMM.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const float*   aabb;               /* 6 floats on the device: the field's box (ngp.py:516-519)                */
+    const uint8_t* bits[4];            /* sign bit planes (cnc_pack_sign_bits) of the xyz | xy | xz | yz tables    */
+    const int32_t* offsets[4];         /* per encoder: level offsets [n_levels + 1]                               */
+    const int32_t* resolutions[4];     /* per encoder: resolutions [n_levels]                                     */
+    const float*   freqs;              /* [n_freqs] on the device: the Embedder's frequency bands (ngp.py:583-599) */
+    const float*   packed_weights[5];  /* cnc_field_pack_layer of: base.0, base.2, head.0, head.2, head.4          */
+    const float*   packed_biases[5];   /*   (entries 2..4 may be NULL for density-only calls)                      */
+    const float*   w2_row0;            /* base.2.weight[0, :] padded to n_neurons (density-only calls)             */
+    uint32_t       n_levels[4];        /* the three planes must have the same number of levels                    */
+    uint32_t       n_features;         /* F per level: 2, 4 or 8                                                  */
+    uint32_t       n_freqs;            /* > 0 (the reference always embeds, ngp.py:433)                           */
+    uint32_t       n_neurons;          /* H: 64 or 160                                                            */
+    uint32_t       geo_feat_dim;       /* 1 + geo <= 64 (H = 64) / 96 (H = 160) and roundup8(16 + geo) <= H        */
+    uint32_t       flags;              /* CNC_FIELD_SH_FP16                                                        */
+} cnc_fused_field_t;
+
+/* W [H, K] row-major (row stride ldw), b [H]  ->  Wp: n_ksteps * n_tiles * 256 floats in MFMA fragment order (float4
+ * (kb * n_tiles + t) * 64 + lane = W[32 t + (lane & 31)][8 kb + 4 (lane >> 5) + 0..3], zero outside [H, K]);
+ * Bp: n_tiles * 32 floats; row0 (nullable): W[0, :] zero-padded to row0_len floats.
+ * Layer shapes for cnc_field_fused_forward (H = n_neurons, T = H / 32, T2 = 3 if H == 160 else 2, K0 = feature width):
+ *   base.0: n_tiles T,  n_ksteps roundup32(K0) / 8        base.2: n_tiles T2, n_ksteps H / 8  (+ row0, row0_len H)
+ *   head.0: n_tiles T,  n_ksteps roundup8(16 + geo) / 8    head.2: n_tiles T,  n_ksteps H / 8
+ *   head.4: n_tiles 1,  n_ksteps H / 8                                                                          */
+int cnc_field_pack_layer(const float* W, const float* b, uint32_t H, uint32_t K, uint32_t ldw, uint32_t n_tiles,
+                         uint32_t n_ksteps, float* Wp, float* Bp, float* row0, uint32_t row0_len, void* stream);
+
+/* positions [N,3] (world), dirs [N,3] (nullable unless rgb), density [N], rgb [N,3] (nullable: density only).
+ * CNC_ERR_UNSUPPORTED for shapes outside the table above (the caller then runs the unfused chain).            */
+int cnc_field_fused_forward(const cnc_fused_field_t* field, const float* positions, const float* dirs, uint32_t N,
+                            float* density, float* rgb, void* stream);
+
 /* STE_binary of ngp.py:22-39 over n floats (16-byte aligned buffers), one pass each way:
  *   forward : out = (c >= 0) * 1 + (c < 0) * -1 with c = clamp(x, -1, 1)   (+1 / -1; NaN -> 0)
  *   backward: grad_in = grad_out * (clamp(x, -1, 1) == x)                                                     */

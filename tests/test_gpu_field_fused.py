@@ -1,0 +1,136 @@
+"""The gradient-free radiance field as one kernel (cnc_field_fused_forward, cnc_amd/csrc/field_fused.hip) against the
+chain it replaces — encoder launches into a [N, 255] matrix, library GEMMs, glue kernels (ngp.py:506-547) — which is
+itself pinned to the reference class (tests/test_gpu_field_golden.py; that test's no-grad leg now runs the fused
+kernel against the reference's numbers directly).  Tolerance: north_star's 1e-4 of the tensor's scale (the two paths
+sum each layer's products in different orders; the encoder features inside the kernel are bit-identical)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+AABB = [-1.5] * 3 + [1.5] * 3
+
+CONFIGS = {
+    # the reference composition at F = 8 (12 x 3-D + 3 x 4 planes, H = 160, geo 79): K0 = 255
+    "f8_full": dict(n_features_per_level=8, n_neurons=160, resolutions_list=(18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514),
+                    log2_hashmap_size=19, resolutions_list_2D=(130, 258, 514, 1026), log2_hashmap_size_2D=17),
+    # the drivers' default F = 4 (geo 39: two of the three second-layer tiles are padding)
+    "f4_default": dict(n_features_per_level=4, n_neurons=160, resolutions_list=(18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514),
+                       log2_hashmap_size=19, resolutions_list_2D=(130, 258, 514, 1026), log2_hashmap_size_2D=17),
+    # the toy shapes of the goldens: unit columns that end inside a 32-column chunk (144 and 36), H = 64
+    "f8_toy": dict(n_features_per_level=8, n_neurons=160, resolutions_list=(6, 9, 14, 20, 26, 34), log2_hashmap_size=10,
+                   resolutions_list_2D=(10, 18, 34, 66), log2_hashmap_size_2D=9),
+    "f2_toy": dict(n_features_per_level=2, n_neurons=64, resolutions_list=(6, 9, 14, 20, 26, 34), log2_hashmap_size=10,
+                   resolutions_list_2D=(10, 18, 34, 66), log2_hashmap_size_2D=9),
+    "f4_h64": dict(n_features_per_level=4, n_neurons=64, resolutions_list=(6, 9, 14, 20, 26), log2_hashmap_size=10,
+                   resolutions_list_2D=(10, 18, 34), log2_hashmap_size_2D=9),
+}
+
+
+def _field(cuda, kw, seed=0, **extra):
+    from cnc_amd.field import NGPRadianceField_mygrid_2D3D
+    torch.manual_seed(seed)
+    f = NGPRadianceField_mygrid_2D3D(aabb=AABB, **kw, **extra).to(cuda)
+    with torch.no_grad():
+        for e in f.mlp_base._encoders():
+            e.params.uniform_(-1, 1)
+        f.mlp_base.network[2].bias[0] = 1.5          # densities of order one, both sides of the ReLU in play
+    return f
+
+
+def _inputs(cuda, n, seed):
+    g = torch.Generator(device=cuda).manual_seed(seed)
+    x = torch.rand(n, 3, device=cuda, generator=g) * 3.2 - 1.6          # some points outside the box
+    if n >= 8:
+        x[0] = torch.tensor([-1.5, 0.0, 0.0])            # on the box: selector 0, features of the boundary
+        x[1] = torch.tensor([1.5, 1.5, 1.5])
+        x[2] = torch.tensor([0.0, 0.0, 1.7])             # z outside: the xy plane still contributes features
+        x[3] = torch.tensor([0.0, 0.0, 0.0])
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device=cuda, generator=g), dim=-1)
+    return x, d
+
+
+def _close(got, want, tol, what):
+    scale = float(want.abs().max())
+    err = float((got.double() - want.double()).abs().max())
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert err <= tol * max(scale, 1e-30), (what, err, scale)
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 1000, 70001])
+@pytest.mark.parametrize("cfg", list(CONFIGS))
+def test_fused_field_equals_the_chain(cuda, cfg, n):
+    from cnc_amd.field import FusedFieldForward
+    f = _field(cuda, CONFIGS[cfg], seed=3)
+    assert FusedFieldForward.supported(f)
+    x, d = _inputs(cuda, n, seed=n)
+    with torch.no_grad():
+        f.fused_field = False
+        rgb0, sig0 = f(x, d)
+        den0 = f.query_density(x)
+        f.fused_field = True
+        rgb1, sig1 = f(x, d)
+        den1 = f.query_density(x)
+    assert f._field_fused, "the fused kernel did not run"
+    _close(den1, den0, 1e-4, "density (density-only kernel)")
+    _close(sig1, sig0, 1e-4, "density (colour kernel)")
+    _close(rgb1, rgb0, 1e-4, "rgb")
+    # outside the box the density is exactly zero in both (selector, ngp.py:524), inside it is positive
+    assert torch.equal(den1 == 0, den0 == 0) and torch.equal(sig1 == 0, sig0 == 0)
+    if n >= 1000:
+        assert 0.05 < float((den0 > 0).float().mean()) < 0.95 and float(den0.max()) > 0.5
+        assert float(rgb0.std()) > 1e-3
+
+
+def test_fused_field_at_full_size_and_after_a_weight_update(cuda):
+    """2^20 samples of the reference composition: the fused kernels against the chain; then an optimiser-style in-place
+    update of every parameter — the packed weights and the sign planes must follow it."""
+    f = _field(cuda, CONFIGS["f8_full"], seed=5)
+    n = 1 << 20
+    x, d = _inputs(cuda, n, seed=11)
+    for round_ in range(2):
+        with torch.no_grad():
+            f.fused_field = False
+            den0 = f.query_density(x)
+            rgb0, _ = f(x[: 1 << 18], d[: 1 << 18])
+            f.fused_field = True
+            den1 = f.query_density(x)
+            rgb1, sig1 = f(x[: 1 << 18], d[: 1 << 18])
+        _close(den1, den0, 1e-4, f"density, round {round_}")
+        _close(rgb1, rgb0, 1e-4, f"rgb, round {round_}")
+        _close(sig1, den0[: 1 << 18], 1e-4, f"density from the colour kernel, round {round_}")
+        with torch.no_grad():
+            for p in f.parameters():
+                p.mul_(-0.9).add_(0.01)              # bumps _version: caches keyed on it must refresh
+    assert float((den1 - den0).abs().max()) >= 0.0
+
+
+def test_fused_field_is_not_used_with_gradients_or_outside_its_shapes(cuda):
+    from cnc_amd.field import FusedFieldForward
+    f = _field(cuda, CONFIGS["f2_toy"], seed=1)
+    x, d = _inputs(cuda, 500, seed=2)
+    rgb, sig = f(x, d)                              # gradients enabled: the autograd chain
+    assert rgb.requires_grad and not f._field_fused
+    (rgb.sum() + sig.sum()).backward()
+    g = _field(cuda, dict(CONFIGS["f2_toy"], n_neurons=48), seed=1)
+    assert not FusedFieldForward.supported(g)
+    with torch.no_grad():
+        den = g.query_density(x)                    # falls back to the chain, silently correct
+    assert den.shape == (500, 1) and g._field_fused is False
+
+
+def test_sh_half_rounding_reaches_the_fused_kernel(cuda):
+    """sh_fp16_round on / off changes the colours of the fused kernel exactly as it changes the chain's."""
+    a = _field(cuda, CONFIGS["f8_toy"], seed=7)
+    b = _field(cuda, CONFIGS["f8_toy"], seed=7, sh_fp16_round=False)
+    b.load_state_dict(a.state_dict())
+    x, d = _inputs(cuda, 4000, seed=9)
+    out = {}
+    with torch.no_grad():
+        for name, f in (("half", a), ("float", b)):
+            for fused in (False, True):
+                f.fused_field = fused
+                out[name, fused] = f(x, d)[0]
+    _close(out["half", True], out["half", False], 1e-4, "half")
+    _close(out["float", True], out["float", False], 1e-4, "float")
+    assert float((out["half", True] - out["float", True]).abs().max()) > 1e-6
