@@ -31,7 +31,8 @@ class CtxWindow(C.Structure):
 class FusedField(C.Structure):
     """cnc_fused_field_t (include/cnc_hip.h)."""
     _fields_ = [("aabb", _vp), ("bits", _vp * 4), ("offsets", _vp * 4), ("resolutions", _vp * 4), ("freqs", _vp),
-                ("packed_weights", _vp * 5), ("packed_biases", _vp * 5), ("w2_row0", _vp), ("n_levels", _u32 * 4),
+                ("packed_weights", _vp * 5), ("packed_biases", _vp * 5), ("w2_row0", _vp), ("packed_weights16", _vp * 5),
+                ("n_levels", _u32 * 4),
                 ("n_features", _u32), ("n_freqs", _u32), ("n_neurons", _u32), ("geo_feat_dim", _u32), ("flags", _u32)]
 
 
@@ -92,6 +93,7 @@ SIGNATURES = {
     "cnc_level_stats_backward": [_vp, _vp, _u32, _u32, _vp, _vp, C.c_uint64, _vp, _vp],
     "cnc_field_prepare": [_vp, _vp, _u32, _vp, _vp, _vp],
     "cnc_field_pack_layer": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp],
+    "cnc_field_pack_layer16": [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp],
     "cnc_field_fused_forward": [C.POINTER(FusedField), _vp, _vp, _u32, _vp, _vp, _vp],
     "cnc_ste_binary_forward": [_vp, _vp, C.c_uint64, _vp],
     "cnc_ste_binary_backward": [_vp, _vp, _vp, C.c_uint64, _vp],
@@ -119,6 +121,7 @@ CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2
 CNC_FLAG_BIN_LANE_STORES = 4
 CNC_FIELD_SH_FP16 = 1
+CNC_FIELD_MFMA_F16X3 = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
 ABI_VERSION = 24          # cnc_abi_version() of the library this table was written for

@@ -25,6 +25,7 @@
 //     layers; one LDS region per wave is reused for the chunk tile, h1, the head input and the head's hidden layers
 //     (a wave's LDS operations execute in order, and every read of a layer is issued before its results exist).
 #include "common.hpp"
+#include <cstdlib>
 
 #include "encoder_common.hpp"
 #include "field_common.hpp"
@@ -32,6 +33,8 @@
 namespace cnc {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+typedef _Float16 half_t_;
 
 struct FieldEnc {
     const uint8_t* bits;
@@ -58,6 +61,9 @@ struct FusedFieldArgs {
     float*       density;
     float*       rgb;
     uint32_t     sh_fp16;
+    const half_t_* Wp16[5];       // fp16 hi / lo fragments (cnc_field_pack_layer16), k_field_fused16
+    uint32_t       nk16_1;        // K-steps of 16 of layer 1 (a multiple of 2)
+    uint32_t       nk16_h;        // K-steps of 16 of the head's first layer: roundup16(16 + geo) / 16
 };
 
 constexpr uint32_t kChunkPitch = 36;     // floats per row of the 32 x 32 chunk tile (+4: conflict-free b128 accesses)
@@ -66,12 +72,19 @@ constexpr uint32_t kPadH = 4;
 // Weight fragments through a buffer resource: address = SGPR base + one VGPR (16 * lane) + a scalar K-step offset + an
 // immediate per tile.  With flat pointers the compiler kept a 64-bit address pair per (layer, K-step, tile) alive across
 // the persistent tile loop (hundreds of spilled registers); this way the whole weight stream costs one VGPR.
+// (clang 22 / ROCm 7.2 lowers __builtin_amdgcn_raw_buffer_load_b128 to a ONE-dword load and splats it — checked in
+// the ISA — so the intrinsic is declared by name, as composable_kernel does.)
 typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
-using wrsrc_t = __amdgpu_buffer_rsrc_t;
+typedef float   f32x4_t __attribute__((ext_vector_type(4)));
+using wrsrc_t = i32x4_t;
+__device__ f32x4_t llvm_raw_buffer_load_f32x4(i32x4_t rsrc, int32_t voffset, int32_t soffset, int32_t aux)
+    __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 
 __device__ __forceinline__ wrsrc_t weight_rsrc(const float* Wp)
 {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wp), 0, 0x7FFFFFFF, 0x00020000);
+    const uint64_t a = reinterpret_cast<uint64_t>(Wp);
+    // base, stride 0, 2 GiB of records, DATA_FORMAT 32 (the gfx9 raw-buffer word composable_kernel uses)
+    return i32x4_t{(int32_t)(uint32_t)a, (int32_t)((uint32_t)(a >> 32) & 0xFFFFu), 0x7FFFFFFF, 0x00020000};
 }
 
 template <int NT>
@@ -80,9 +93,8 @@ __device__ __forceinline__ void load_w(wrsrc_t W, uint32_t kb, uint32_t lane, fl
     const int32_t soff = (int32_t)(kb * NT * 1024u);          // 64 lanes x 16 bytes per (K-step, tile)
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-        const i32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(W, (int32_t)(lane * 16u + t * 1024), soff, 0);
-        dst[t] = make_float4(__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y),
-                             __builtin_bit_cast(float, v.z), __builtin_bit_cast(float, v.w));
+        const f32x4_t v = llvm_raw_buffer_load_f32x4(W, (int32_t)(lane * 16u + t * 1024), soff, 0);
+        dst[t] = make_float4(v.x, v.y, v.z, v.w);
     }
 }
 
@@ -185,11 +197,62 @@ __device__ __forceinline__ void unit_features(const float (&x)[D], bool inside, 
     }
 }
 
+// Where a sample's row of the 32 x 32 chunk tile lives.  Float tile: the A operand of the fp32 MFMA.  Half tile: two
+// planes, x = hi + lo with hi = half(x), lo = half(x - hi) — 22 bits of x — the A operands of the three-product
+// fp16 MFMA scheme (see k_field_fused16).
+struct RowF32 {
+    float* row;
+    template <uint32_t V>
+    __device__ __forceinline__ void put(uint32_t col, const float (&v)[V]) const { store_vec<V>(row + col, v); }
+    __device__ __forceinline__ void put1(uint32_t col, float v) const { row[col] = v; }
+};
+
+typedef _Float16 half_t;
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split_half(float x, half_t& hi, half_t& lo)
+{
+    hi = (half_t)x;
+    lo = (half_t)(x - (float)hi);
+}
+
+struct RowF16 {
+    half_t* hi;
+    half_t* lo;
+    template <uint32_t V>
+    __device__ __forceinline__ void put(uint32_t col, const float (&v)[V]) const
+    {
+        if constexpr (V == 4) {
+            half4_t a, b;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { half_t x, y; split_half(v[j], x, y); a[j] = x; b[j] = y; }
+            *reinterpret_cast<half4_t*>(hi + col) = a;
+            *reinterpret_cast<half4_t*>(lo + col) = b;
+        } else if constexpr (V == 2) {
+            half2_t a, b;
+#pragma unroll
+            for (int j = 0; j < 2; j++) { half_t x, y; split_half(v[j], x, y); a[j] = x; b[j] = y; }
+            *reinterpret_cast<half2_t*>(hi + col) = a;
+            *reinterpret_cast<half2_t*>(lo + col) = b;
+        } else {
+            put1(col, v[0]);
+        }
+    }
+    __device__ __forceinline__ void put1(uint32_t col, float v) const
+    {
+        half_t x, y;
+        split_half(v, x, y);
+        hi[col] = x;
+        lo[col] = y;
+    }
+};
+
 // Columns [w0, w0 + 16) of the feature row of one sample into its row of the chunk tile (`trow`, chunk-relative
 // column w0 & 31).  Feature row = [units: n_units x F | x (3) | sin(f_k x) (3), cos(f_k x) (3) for k < n_freqs | 0 ...].
-template <uint32_t F>
-__device__ __forceinline__ void fill_window(const FusedFieldArgs& p, const float (&xu)[3], uint32_t w0,
-                                            float* __restrict__ trow)
+template <uint32_t F, typename Row>
+__device__ __forceinline__ void fill_window(const FusedFieldArgs& p, const float (&xu)[3], uint32_t w0, const Row& trow)
 {
     constexpr uint32_t V = F < 4 ? F : 4;
     const uint32_t U = p.n_units * F;                 // first sinusoid column
@@ -210,13 +273,13 @@ __device__ __forceinline__ void fill_window(const FusedFieldArgs& p, const float
             const bool     in2 = (pl == 2 ? in_y : in_x) && (pl == 0 ? in_y : in_z);
             unit_features<2, F>(x2, in2, p.enc[1 + pl], level, a);
         }
-        float* o = trow + ((w0 + s * F) & 31u);
+        const uint32_t o = (w0 + s * F) & 31u;
 #pragma unroll
         for (uint32_t k = 0; k < F; k += V) {
             float v[V];
 #pragma unroll
             for (uint32_t j = 0; j < V; j++) v[j] = a[k + j];
-            store_vec<V>(o + k, v);
+            trow.template put<V>(o + k, v);
         }
     }
     // the part of the window behind the units: raw coordinates, sinusoids, zero padding
@@ -225,8 +288,8 @@ __device__ __forceinline__ void fill_window(const FusedFieldArgs& p, const float
     const uint32_t n_sin = 3 + 6 * p.n_freqs;
     for (uint32_t col = lo; col < hi; col++) {
         const uint32_t e = col - U;
-        if (e < 3) trow[col & 31u] = e == 0 ? xu[0] : (e == 1 ? xu[1] : xu[2]);
-        else if (e >= n_sin) trow[col & 31u] = 0.0f;
+        if (e < 3) trow.put1(col & 31u, e == 0 ? xu[0] : (e == 1 ? xu[1] : xu[2]));
+        else if (e >= n_sin) trow.put1(col & 31u, 0.0f);
     }
     // sin column e = 3 + 6 k + a, its cos column e + 3: ONE argument reduction for both (sincosf returns the values of
     // sinf and cosf); a pair that straddles two windows is evaluated by both lanes
@@ -237,8 +300,8 @@ __device__ __forceinline__ void fill_window(const FusedFieldArgs& p, const float
         const float xa = r == 0 ? xu[0] : (r == 1 ? xu[1] : xu[2]);
         float sn, cs;
         sincosf(xa * p.freqs[k], &sn, &cs);
-        if (e >= e_lo) trow[(e + U) & 31u] = sn;
-        if (e + 3 >= e_lo && e + 3 < e_hi) trow[(e + 3 + U) & 31u] = cs;
+        if (e >= e_lo) trow.put1((e + U) & 31u, sn);
+        if (e + 3 >= e_lo && e + 3 < e_hi) trow.put1((e + 3 + U) & 31u, cs);
     }
 }
 
@@ -279,7 +342,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused(FusedFieldArgs p)
         load_w<NT>(W1, 0, lane, wn);
         float* trow = lds + i * kChunkPitch;
         for (uint32_t c = 0; c * 4 < p.nkb1; c++) {
-            fill_window<F>(p, xu, c * 32 + 16 * h, trow);
+            fill_window<F>(p, xu, c * 32 + 16 * h, RowF32{trow});
             wave_lds_order();
 #pragma unroll
             for (uint32_t kb = 0; kb < 4; kb++) {
@@ -392,6 +455,298 @@ __global__ __launch_bounds__(64, 2) void k_field_fused(FusedFieldArgs p)
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------------
+// The same network on the fp16 matrix pipe, three products per term.
+//
+// v_mfma_f32_32x32x2_f32 runs at the f32 VECTOR rate and — measured (docs/engineering_log.md, round 4): the gather
+// alone 0.77 ms, the MFMAs alone 0.91 ms, together 1.34 ms per 2^20 samples — does not overlap with the other wave's
+// vector work: 43 % MFMA busy is what that kernel can do.  v_mfma_f32_32x32x16_f16 is 16x the rate on the real matrix
+// pipe.  Every operand is split x = hi + lo, hi = half(x), lo = half(x - hi) (22 of fp32's 24 significand bits; the
+// weights are scaled by 2^8 first so that their lo parts stay normal numbers) and a product becomes
+//     x w ~= hi_x hi_w + hi_x lo_w + lo_x hi_w          (the dropped lo_x lo_w is 2^-22 relative)
+// accumulated in fp32 by the MFMA: 3 instructions of 32 cycles per 16 k instead of 8 of 64 per 16 k, and a relative error
+// per term of ~5e-7 (fp32 rounding: 6e-8) — two orders below north_star's 1e-4, checked against the chain in
+// tests/test_gpu_field_fused.py at 1e-5.  Activations are assumed below fp16's 65504.
+// -----------------------------------------------------------------------------------------------------------------
+constexpr float kWeightScale = 256.0f, kWeightScaleInv = 1.0f / 256.0f;
+constexpr uint32_t kChunkPitch16 = 40;    // halves per row of a 32 x 32 chunk plane (80 bytes: 16-byte aligned rows)
+constexpr uint32_t kPadH16x = 8;
+
+// Activation planes of the colour variant: 32 rows x H halves.  H = 160: no padding (two planes = 20 KB: eight waves per
+// CU instead of seven) and a swizzle of the 16-byte chunks instead — chunk' = chunk ^ ((row >> 2) & 3): rows are 320
+// bytes apart, i.e. rows r and r + 4 start on the same banks; the swizzle moves them to the four different 16-byte
+// slots of a 64-byte group, so the 16 rows a ds_read_b128 lane group touches cover all 64 banks.  H = 64: padded rows.
+template <int NT>
+struct HPlane {
+    static constexpr uint32_t ld = NT == 5 ? 160u : NT * 32u + kPadH16x;
+    static __device__ __forceinline__ uint32_t at(uint32_t r, uint32_t c)
+    {
+        if constexpr (NT == 5) return r * ld + ((((c >> 3) ^ ((r >> 2) & 3u)) << 3) | (c & 7u));
+        else return r * ld + c;
+    }
+};
+
+template <int NT>
+__device__ __forceinline__ void load_w16(wrsrc_t W, uint32_t ks, uint32_t lane, half8_t (&hi)[NT], half8_t (&lo)[NT])
+{
+    const int32_t soff = (int32_t)(ks * NT * 2048u);          // per (K-step, tile): 64 x 16 bytes hi, 64 x 16 bytes lo
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const f32x4_t a = llvm_raw_buffer_load_f32x4(W, (int32_t)(lane * 16u + t * 2048), soff, 0);
+        const f32x4_t b = llvm_raw_buffer_load_f32x4(W, (int32_t)(lane * 16u + t * 2048 + 1024), soff, 0);
+        hi[t] = __builtin_bit_cast(half8_t, a);
+        lo[t] = __builtin_bit_cast(half8_t, b);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void mfma3(const half8_t& a_hi, const half8_t& a_lo, const half8_t (&w_hi)[NT],
+                                      const half8_t (&w_lo)[NT], f32x16 (&acc)[NT])
+{
+    // the two small products first, consecutive MFMAs on different accumulators
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, w_hi[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, w_lo[t], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, w_hi[t], acc[t], 0, 0, 0);
+}
+
+// acc = A * W^T with A in two half planes (pitch `ld` halves), K = 16 nks.  Weight fragments of the next K-step are
+// requested before the current one's MFMAs (two register sets, the loop unrolled by two): without that every K-step
+// waited for an L2 round trip — 36 of them per tile in the colour variant, 1.6 of its 2.5 ms.
+template <int NT, int NTH>
+__device__ __forceinline__ void layer_lds16(const half_t* __restrict__ a_hi, const half_t* __restrict__ a_lo,
+                                            uint32_t nks, const half_t_* __restrict__ Wp_, f32x16 (&acc)[NT], uint32_t lane)
+{
+    using P = HPlane<NTH>;
+    const uint32_t i = lane & 31u, g = lane >> 5;
+    const wrsrc_t  Wp = weight_rsrc(reinterpret_cast<const float*>(Wp_));
+    zero_acc<NT>(acc);
+    half8_t wh0[NT], wl0[NT], wh1[NT], wl1[NT];
+    load_w16<NT>(Wp, 0, lane, wh0, wl0);
+    for (uint32_t ks = 0; ks < nks; ks += 2) {
+        const bool second = ks + 1 < nks;
+        if (second) load_w16<NT>(Wp, ks + 1, lane, wh1, wl1);
+        {
+            const uint32_t at = P::at(i, ks * 16 + 8 * g);
+            const half8_t  ah = *reinterpret_cast<const half8_t*>(a_hi + at);
+            const half8_t  al = *reinterpret_cast<const half8_t*>(a_lo + at);
+            mfma3<NT>(ah, al, wh0, wl0, acc);
+        }
+        if (second) {
+            if (ks + 2 < nks) load_w16<NT>(Wp, ks + 2, lane, wh0, wl0);
+            const uint32_t at = P::at(i, ks * 16 + 16 + 8 * g);
+            const half8_t  ah = *reinterpret_cast<const half8_t*>(a_hi + at);
+            const half8_t  al = *reinterpret_cast<const half8_t*>(a_lo + at);
+            mfma3<NT>(ah, al, wh1, wl1, acc);
+        }
+    }
+}
+
+// x = acc / 2^8 + bias (+ ReLU) -> the two half planes, C layout -> row-major
+template <bool RELU, int NT>
+__device__ __forceinline__ void acc_to_lds16(half_t* __restrict__ d_hi, half_t* __restrict__ d_lo,
+                                             const float* __restrict__ bias, const f32x16 (&acc)[NT], uint32_t lane)
+{
+    using P = HPlane<NT>;
+    const uint32_t i = lane & 31u, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const float b = bias[t * 32 + i];
+#pragma unroll
+        for (int v = 0; v < 16; v++) {
+            float x = __builtin_fmaf(acc[t][v], kWeightScaleInv, b);
+            if (RELU) x = x > 0 ? x : 0;
+            half_t xh, xl;
+            split_half(x, xh, xl);
+            const uint32_t at = P::at(8 * (v >> 2) + 4 * h + (v & 3), t * 32 + i);
+            d_hi[at] = xh;
+            d_lo[at] = xl;
+        }
+    }
+}
+
+template <uint32_t F, int NT, bool RGB>
+__global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
+{
+    extern __shared__ float lds[];
+    half_t* lds16 = reinterpret_cast<half_t*>(lds);
+    const uint32_t lane = threadIdx.x, i = lane & 31u, h = lane >> 5;
+    using HP = HPlane<NT>;
+    constexpr uint32_t ldh = HP::ld;                            // halves
+    half_t* const c_hi = lds16;                                 // chunk planes
+    half_t* const c_lo = lds16 + 32 * kChunkPitch16;
+    half_t* const h_hi = lds16;                                 // activation planes (colour variant)
+    half_t* const h_lo = lds16 + 32 * ldh;
+    const uint32_t tiles = (p.N + 31u) / 32u;
+    float amin[3], aext[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        amin[a] = p.aabb[a];
+        aext[a] = p.aabb[3 + a] - p.aabb[a];
+    }
+    const wrsrc_t W1 = weight_rsrc(reinterpret_cast<const float*>(p.Wp16[0]));
+    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const uint32_t row0 = tile * 32, row = row0 + i;
+        const bool     live = row < p.N;
+        float xu[3] = {-1.0f, -1.0f, -1.0f};
+        bool  sel = live;
+        if (live) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const float v = (p.pos[(size_t)row * 3 + a] - amin[a]) / aext[a];
+                xu[a] = v;
+                sel = sel && v > 0.0f && v < 1.0f;
+            }
+        }
+        const uint64_t selmask = __ballot(sel);
+
+        // ---- layer 1: a chunk = 32 columns = two K-steps of 16 ----
+        f32x16 acc[NT];
+        zero_acc<NT>(acc);
+        half8_t wh0[NT], wl0[NT], wh1[NT], wl1[NT];
+        // density only: the first K-step's fragments of a chunk are in flight across its gather (40 registers; the
+        // colour variant, at the register limit, requests them after the gather)
+        constexpr bool kAcrossFill = !RGB;
+        if constexpr (kAcrossFill) load_w16<NT>(W1, 0, lane, wh0, wl0);
+        const RowF16 trow{c_hi + i * kChunkPitch16, c_lo + i * kChunkPitch16};
+        const uint32_t n_chunks = p.nk16_1 / 2;
+        for (uint32_t c = 0; c < n_chunks; c++) {
+            fill_window<F>(p, xu, c * 32 + 16 * h, trow);
+            wave_lds_order();
+            if constexpr (!kAcrossFill) load_w16<NT>(W1, 2 * c, lane, wh0, wl0);
+            load_w16<NT>(W1, 2 * c + 1, lane, wh1, wl1);
+            {
+                const half8_t ah = *reinterpret_cast<const half8_t*>(trow.hi + 8 * h);
+                const half8_t al = *reinterpret_cast<const half8_t*>(trow.lo + 8 * h);
+                mfma3<NT>(ah, al, wh0, wl0, acc);
+            }
+            if constexpr (kAcrossFill) {
+                if (c + 1 < n_chunks) load_w16<NT>(W1, 2 * c + 2, lane, wh0, wl0);
+            }
+            {
+                const half8_t ah = *reinterpret_cast<const half8_t*>(trow.hi + 16 + 8 * h);
+                const half8_t al = *reinterpret_cast<const half8_t*>(trow.lo + 16 + 8 * h);
+                mfma3<NT>(ah, al, wh1, wl1, acc);
+            }
+            wave_lds_order();
+        }
+
+        if constexpr (!RGB) {
+            float part[16];
+#pragma unroll
+            for (int v = 0; v < 16; v++) part[v] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const float b = p.Bp[0][t * 32 + i], w2 = p.w2row[t * 32 + i];
+#pragma unroll
+                for (int v = 0; v < 16; v++) {
+                    float x = __builtin_fmaf(acc[t][v], kWeightScaleInv, b);
+                    x = x > 0 ? x : 0;
+                    part[v] = __builtin_fmaf(x, w2, part[v]);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 16; v++) lds[(8 * (v >> 2) + 4 * h + (v & 3)) * kChunkPitch + i] = part[v];
+            wave_lds_order();
+            if (h == 0) {
+                float s = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(lds + i * kChunkPitch + 4 * q);
+                    s += v4.x; s += v4.y; s += v4.z; s += v4.w;
+                }
+                if (live) p.density[row] = expf((s + p.Bp[1][0]) - 1.0f) * (sel ? 1.0f : 0.0f);
+            }
+            wave_lds_order();
+        } else {
+            acc_to_lds16<true, NT>(h_hi, h_lo, p.Bp[0], acc, lane);
+            wave_lds_order();
+            constexpr int NT2 = NT == 5 ? 3 : 2;
+            f32x16 acc2[NT2];
+            layer_lds16<NT2, NT>(h_hi, h_lo, NT * 2, p.Wp16[1], acc2, lane);
+            const uint32_t Kh = p.nk16_h * 16;
+            wave_lds_order();
+#pragma unroll
+            for (int t = 0; t < NT2; t++) {
+                const uint32_t col = t * 32 + i;
+                const float    b = p.Bp[1][col];
+#pragma unroll
+                for (int v = 0; v < 16; v++) {
+                    const uint32_t r = 8 * (v >> 2) + 4 * h + (v & 3);
+                    const float    x = __builtin_fmaf(acc2[t][v], kWeightScaleInv, b);
+                    if (col == 0) {
+                        if (row0 + r < p.N) p.density[row0 + r] = expf(x - 1.0f) * (float)((selmask >> r) & 1ull);
+                    } else if (15 + col < Kh) {
+                        half_t xh, xl;
+                        split_half(col <= p.geo ? x : 0.0f, xh, xl);
+                        h_hi[HP::at(r, 15 + col)] = xh;
+                        h_lo[HP::at(r, 15 + col)] = xl;
+                    }
+                }
+            }
+            {
+                float d3[3] = {0.0f, 0.0f, 1.0f};
+                if (live) {
+#pragma unroll
+                    for (int a = 0; a < 3; a++) d3[a] = ((p.dirs[(size_t)row * 3 + a] + 1.0f) / 2.0f) * 2.0f - 1.0f;
+                }
+                const RowF16 hrow{h_hi, h_lo};
+#pragma unroll
+                for (uint32_t q = 0; q < 2; q++) {
+                    const float4 v = sh4_quad(2 * h + q, d3[0], d3[1], d3[2]);
+                    float v4[4] = {v.x, v.y, v.z, v.w};
+                    if (p.sh_fp16) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) v4[j] = round_through_half(v4[j]);
+                    }
+                    hrow.put<4>(HP::at(i, 8 * h + 4 * q), v4);       // 4 halves inside one 16-byte chunk
+                }
+            }
+            wave_lds_order();
+            layer_lds16<NT, NT>(h_hi, h_lo, p.nk16_h, p.Wp16[2], acc, lane);
+            wave_lds_order();
+            acc_to_lds16<true, NT>(h_hi, h_lo, p.Bp[2], acc, lane);
+            wave_lds_order();
+            layer_lds16<NT, NT>(h_hi, h_lo, NT * 2, p.Wp16[3], acc, lane);
+            wave_lds_order();
+            acc_to_lds16<true, NT>(h_hi, h_lo, p.Bp[3], acc, lane);
+            wave_lds_order();
+            f32x16 acc5[1];
+            layer_lds16<1, NT>(h_hi, h_lo, NT * 2, p.Wp16[4], acc5, lane);
+            if (i < 3) {
+                const float b = p.Bp[4][i];
+#pragma unroll
+                for (int v = 0; v < 16; v++) {
+                    const uint32_t r = 8 * (v >> 2) + 4 * h + (v & 3);
+                    const float    x = __builtin_fmaf(acc5[0][v], kWeightScaleInv, b);
+                    if (row0 + r < p.N) p.rgb[(size_t)(row0 + r) * 3 + i] = 1.0f / (1.0f + expf(-x));
+                }
+            }
+            wave_lds_order();
+        }
+    }
+}
+
+// W [H, K] -> fp16 fragments of `layer_lds16`: per (K-step of 16, tile): 64 lanes x 8 halves hi, then the same of lo,
+// of 2^8 * W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + 0..7] (zero outside [H, K])
+__global__ __launch_bounds__(256) void k_field_pack_layer16(const float* __restrict__ W, uint32_t H, uint32_t K,
+                                                            uint32_t ldw, uint32_t NT, uint32_t nks,
+                                                            half_t* __restrict__ Wp)
+{
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nks * NT * 512) return;
+    const uint32_t e = idx & 7u, lane = (idx >> 3) & 63u, q = idx >> 9;
+    const uint32_t t = q % NT, ks = q / NT;
+    const uint32_t out = t * 32 + (lane & 31u), k = ks * 16 + 8 * (lane >> 5) + e;
+    const float    w = (out < H && k < K) ? W[(size_t)out * ldw + k] * kWeightScale : 0.0f;
+    half_t hi, lo;
+    split_half(w, hi, lo);
+    Wp[((size_t)q * 2 + 0) * 512 + lane * 8 + e] = hi;
+    Wp[((size_t)q * 2 + 1) * 512 + lane * 8 + e] = lo;
+}
+
 // W [H, K] (row stride ldw) -> fragment order for `layer_lds` / layer 1: float4 index (kb * NT + t) * 64 + lane holds
 // W[32 t + (lane & 31)][8 kb + 4 (lane >> 5) + 0..3], zero outside [H, K]; bias padded to NT * 32; row0 (optional):
 // W[0, :] padded to `row0_len` floats.
@@ -426,6 +781,17 @@ extern "C" int cnc_field_pack_layer(const float* W, const float* b, uint32_t H, 
     if (row0 && row0_len > total) total = row0_len;
     hipLaunchKernelGGL(k_field_pack_layer, dim3(div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, W, b, H, K, ldw,
                        n_tiles, n_ksteps, Wp, Bp, row0, row0_len);
+    return launch_status();
+}
+
+extern "C" int cnc_field_pack_layer16(const float* W, uint32_t H, uint32_t K, uint32_t ldw, uint32_t n_tiles,
+                                      uint32_t n_ksteps16, void* Wp16, void* stream)
+{
+    if (!W || !Wp16 || H == 0 || K == 0 || n_tiles == 0 || n_ksteps16 == 0 || ldw < K) return CNC_ERR_INVALID_VALUE;
+    if (H > n_tiles * 32 || K > n_ksteps16 * 16) return CNC_ERR_INVALID_VALUE;
+    const uint32_t total = n_ksteps16 * n_tiles * 512;
+    hipLaunchKernelGGL(k_field_pack_layer16, dim3(div_up(total, 256)), dim3(256), 0, (hipStream_t)stream, W, H, K, ldw,
+                       n_tiles, n_ksteps16, reinterpret_cast<half_t*>(Wp16));
     return launch_status();
 }
 
@@ -471,17 +837,48 @@ extern "C" int cnc_field_fused_forward(const cnc_fused_field_t* f, const float* 
     }
     p.density = density; p.rgb = rgb;
     p.sh_fp16 = (f->flags & CNC_FIELD_SH_FP16) ? 1u : 0u;
+    const bool f16x3 = (f->flags & CNC_FIELD_MFMA_F16X3) != 0;
+    p.nk16_1 = p.nkb1 / 2;
+    p.nk16_h = (16 + p.geo + 15) / 16;
+    if (f16x3) {
+        if (p.nk16_h * 16 > H) return CNC_ERR_UNSUPPORTED;
+        for (int l = 0; l < (want_rgb ? 5 : 1); l++) {
+            if (!f->packed_weights16[l]) return CNC_ERR_INVALID_VALUE;
+            p.Wp16[l] = reinterpret_cast<const half_t_*>(f->packed_weights16[l]);
+        }
+    }
     const uint32_t tiles = (N + 31) / 32;
-    // one wave per workgroup; registers allow two per SIMD, the colour variant's LDS (32 x (H + 4) floats) seven per CU
-    uint32_t blocks = tiles < 256u * 8 ? tiles : 256u * 8;
+    uint32_t blocks = 0;
     uint32_t lds_floats = 32 * kChunkPitch;
     if (want_rgb) lds_floats = 32 * (H + kPadH);
-    const size_t lds_bytes = (size_t)lds_floats * sizeof(float);
+    size_t lds_bytes = (size_t)lds_floats * sizeof(float);
+    if (f16x3) {        // two half planes: 32 x 40 (chunk; the density epilogue's 32 x 36 floats fit) or 32 x HPlane::ld
+        const uint32_t ldh16 = NT == 5 ? 160u : H + kPadH16x;         // HPlane<NT>::ld
+        lds_bytes = want_rgb ? (size_t)2 * 32 * ldh16 * sizeof(half_t) : (size_t)2 * 32 * kChunkPitch16 * sizeof(half_t);
+        if (lds_bytes < 32 * kChunkPitch * sizeof(float)) lds_bytes = 32 * kChunkPitch * sizeof(float);
+    }
     hipStream_t s = (hipStream_t)stream;
-#define CNC_FF(FV, NTV)                                                                                            \
-    do {                                                                                                           \
-        if (want_rgb) hipLaunchKernelGGL((k_field_fused<FV, NTV, true>), dim3(blocks), dim3(64), lds_bytes, s, p); \
-        else hipLaunchKernelGGL((k_field_fused<FV, NTV, false>), dim3(blocks), dim3(64), lds_bytes, s, p);         \
+    // The grid is what is RESIDENT at once (the waves loop over the tiles): registers allow 8 one-wave workgroups per
+    // CU, the colour variant's LDS 7 — with 8 per CU launched the eighth of every CU ran as a second round on an
+    // otherwise idle chip (2.65 instead of 1.72 ms per 2^20 samples).
+#define CNC_FF_GRID(K)                                                                                        \
+    do {                                                                                                      \
+        int per_cu = 0, dev = 0, cus = 0;                                                                     \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, K, 64, lds_bytes) != hipSuccess ||          \
+            hipGetDevice(&dev) != hipSuccess ||                                                               \
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||          \
+            per_cu <= 0 || cus <= 0)                                                                          \
+            return CNC_ERR_LAUNCH;                                                                            \
+        if (per_cu > 8) per_cu = 8;                                                                           \
+        blocks = tiles < (uint32_t)(per_cu * cus) ? tiles : (uint32_t)(per_cu * cus);                         \
+        hipLaunchKernelGGL(K, dim3(blocks), dim3(64), lds_bytes, s, p);                                       \
+    } while (0)
+#define CNC_FF(FV, NTV)                                                                     \
+    do {                                                                                    \
+        if (f16x3 && want_rgb) CNC_FF_GRID((k_field_fused16<FV, NTV, true>));               \
+        else if (f16x3) CNC_FF_GRID((k_field_fused16<FV, NTV, false>));                     \
+        else if (want_rgb) CNC_FF_GRID((k_field_fused<FV, NTV, true>));                     \
+        else CNC_FF_GRID((k_field_fused<FV, NTV, false>));                                  \
     } while (0)
 #define CNC_FF_F(FV)          \
     do {                      \
@@ -493,5 +890,6 @@ extern "C" int cnc_field_fused_forward(const cnc_fused_field_t* f, const float* 
     else CNC_FF_F(2);
 #undef CNC_FF_F
 #undef CNC_FF
+#undef CNC_FF_GRID
     return launch_status();
 }

@@ -354,14 +354,17 @@ class FusedFieldForward:
         H, geo = layers[0].out_features, f.geo_feat_dim
         T, T2 = H // 32, (3 if H == 160 else 2)
         K0 = layers[0].in_features
-        shapes = [(T, (K0 + 31) // 32 * 4), (T2, H // 8), (T, (16 + geo + 7) // 8), (T, H // 8), (1, H // 8)]
+        # (output tiles, K-steps of 8 for the fp32 MFMA, K-steps of 16 for the fp16 one) per layer
+        shapes = [(T, (K0 + 31) // 32 * 4, (K0 + 31) // 32 * 2), (T2, H // 8, H // 16),
+                  (T, (16 + geo + 7) // 8, (16 + geo + 15) // 16), (T, H // 8, H // 16), (1, H // 8, H // 16)]
         if self._buffers is None or self._buffers["dev"] != str(dev):
             self._buffers = {"dev": str(dev),
-                             "w": [torch.empty(nk * nt * 256, dtype=torch.float32, device=dev) for nt, nk in shapes],
-                             "b": [torch.empty(nt * 32, dtype=torch.float32, device=dev) for nt, nk in shapes],
+                             "w": [torch.empty(nk * nt * 256, dtype=torch.float32, device=dev) for nt, nk, _ in shapes],
+                             "w16": [torch.empty(nk16 * nt * 1024, dtype=torch.float16, device=dev) for nt, _, nk16 in shapes],
+                             "b": [torch.empty(nt * 32, dtype=torch.float32, device=dev) for nt, _, _ in shapes],
                              "row0": torch.empty(H, dtype=torch.float32, device=dev)}
         L = _lib.lib()
-        for k, (l, (nt, nk)) in enumerate(zip(layers, shapes)):
+        for k, (l, (nt, nk, nk16)) in enumerate(zip(layers, shapes)):
             w, b = l.weight.detach(), l.bias.detach()
             if not w.is_contiguous():
                 w = w.contiguous()
@@ -370,6 +373,8 @@ class FusedFieldForward:
                                               self._buffers["w"][k].data_ptr(), self._buffers["b"][k].data_ptr(),
                                               _lib.ptr(row0), H if row0 is not None else 0, _lib.stream(dev)),
                        "field_pack_layer")
+            _lib.check(L.cnc_field_pack_layer16(w.data_ptr(), w.shape[0], w.shape[1], w.stride(0), nt, nk16,
+                                                self._buffers["w16"][k].data_ptr(), _lib.stream(dev)), "field_pack_layer16")
         self._key = key
         self._src = [(l.weight, l.bias) for l in layers]        # keep (data_ptr, version) unique while cached
         return self._buffers
@@ -403,9 +408,11 @@ class FusedFieldForward:
         st.freqs, st.n_freqs = mb._freqs.data_ptr(), mb._freqs.numel()
         for k in range(5):
             st.packed_weights[k], st.packed_biases[k] = buf["w"][k].data_ptr(), buf["b"][k].data_ptr()
+            st.packed_weights16[k] = buf["w16"][k].data_ptr()
         st.w2_row0 = buf["row0"].data_ptr()
         st.n_features, st.n_neurons, st.geo_feat_dim = mb.encoding_xyz.n_features, mb.network[0].out_features, f.geo_feat_dim
-        st.flags = _lib.CNC_FIELD_SH_FP16 if f.sh_fp16_round else 0
+        st.flags = (_lib.CNC_FIELD_SH_FP16 if f.sh_fp16_round else 0) | \
+                   (_lib.CNC_FIELD_MFMA_F16X3 if f.fused_field_precision == "f16x3" else 0)
         density = torch.empty((N, 1), dtype=torch.float32, device=dev)
         rgb = torch.empty((N, 3), dtype=torch.float32, device=dev) if d is not None else None
         import ctypes
@@ -445,6 +452,11 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         # gradient-free calls as ONE kernel, positions -> density (-> rgb): FusedFieldForward (CNC_FUSED_FIELD=0: the
         # chain of encoder launches, library GEMMs and glue kernels that the gradient path uses)
         self.fused_field = fused_features and os.environ.get("CNC_FUSED_FIELD", "1") == "1"
+        # "f16x3" (default): the layers on the fp16 matrix pipe, three products per term (~5e-7 per term, against
+        # fp32's 6e-8); "f32": v_mfma_f32_32x32x2_f32, an exact fmaf chain per output — 2x the time
+        self.fused_field_precision = os.environ.get("CNC_FUSED_FIELD_MFMA", "f16x3")
+        if self.fused_field_precision not in ("f16x3", "f32"):
+            raise ValueError("CNC_FUSED_FIELD_MFMA must be f16x3 or f32")
         self._field_fused = None
         # sample counts from here on run at a bucketed row count (`_bucket_rows`); CNC_ROW_BUCKET_MIN=0 pads every call
         self.row_bucket_min = int(os.environ.get("CNC_ROW_BUCKET_MIN", "4096"))

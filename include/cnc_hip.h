@@ -610,13 +610,20 @@ typedef struct {
     const float*   packed_weights[5];  /* cnc_field_pack_layer of: base.0, base.2, head.0, head.2, head.4          */
     const float*   packed_biases[5];   /*   (entries 2..4 may be NULL for density-only calls)                      */
     const float*   w2_row0;            /* base.2.weight[0, :] padded to n_neurons (density-only calls)             */
+    const void*    packed_weights16[5];/* cnc_field_pack_layer16 of the same five layers (CNC_FIELD_MFMA_F16X3)     */
     uint32_t       n_levels[4];        /* the three planes must have the same number of levels                    */
     uint32_t       n_features;         /* F per level: 2, 4 or 8                                                  */
     uint32_t       n_freqs;            /* > 0 (the reference always embeds, ngp.py:433)                           */
     uint32_t       n_neurons;          /* H: 64 or 160                                                            */
     uint32_t       geo_feat_dim;       /* 1 + geo <= 64 (H = 64) / 96 (H = 160) and roundup8(16 + geo) <= H        */
-    uint32_t       flags;              /* CNC_FIELD_SH_FP16                                                        */
+    uint32_t       flags;              /* CNC_FIELD_SH_FP16 | CNC_FIELD_MFMA_F16X3                                  */
 } cnc_fused_field_t;
+
+/* The layers' products on the fp16 matrix pipe, three per term: every operand split x = hi + lo into two halves
+ * (22 significand bits), x w ~= hi hi + hi lo + lo hi accumulated in fp32 (v_mfma_f32_32x32x16_f16): ~5e-7 relative
+ * per term against fp32's 6e-8, at 1/5 of the matrix cycles of the exact fp32 form and on a pipe that overlaps with the
+ * gather's vector work.  Without the flag: v_mfma_f32_32x32x2_f32, an exact fp32 fmaf chain per output.        */
+#define CNC_FIELD_MFMA_F16X3 2u
 
 /* W [H, K] row-major (row stride ldw), b [H]  ->  Wp: n_ksteps * n_tiles * 256 floats in MFMA fragment order (float4
  * (kb * n_tiles + t) * 64 + lane = W[32 t + (lane & 31)][8 kb + 4 (lane >> 5) + 0..3], zero outside [H, K]);
@@ -627,6 +634,13 @@ typedef struct {
  *   head.4: n_tiles 1,  n_ksteps H / 8                                                                          */
 int cnc_field_pack_layer(const float* W, const float* b, uint32_t H, uint32_t K, uint32_t ldw, uint32_t n_tiles,
                          uint32_t n_ksteps, float* Wp, float* Bp, float* row0, uint32_t row0_len, void* stream);
+
+/* The same layer for CNC_FIELD_MFMA_F16X3: Wp16 = n_ksteps16 * n_tiles * 1024 halves (per (K-step of 16, tile): 64 x 8
+ * halves hi, 64 x 8 halves lo of 2^8 W[32 t + (lane & 31)][16 ks + 8 (lane >> 5) + 0..7]).  n_ksteps16: base.0
+ * roundup32(K0) / 16, base.2 / head.2 / head.4 H / 16, head.0 roundup16(16 + geo) / 16 (<= H / 16).  Biases: those of
+ * cnc_field_pack_layer.                                                                                        */
+int cnc_field_pack_layer16(const float* W, uint32_t H, uint32_t K, uint32_t ldw, uint32_t n_tiles, uint32_t n_ksteps16,
+                           void* Wp16, void* stream);
 
 /* positions [N,3] (world), dirs [N,3] (nullable unless rgb), density [N], rgb [N,3] (nullable: density only).
  * CNC_ERR_UNSUPPORTED for shapes outside the table above (the caller then runs the unfused chain).            */
