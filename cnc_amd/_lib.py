@@ -62,6 +62,8 @@ SIGNATURES = {
     "cnc_cnt_np_embed_planned_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_cnt_np_embed_planned_backward3": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_cnt_vote_masks": [_vp, _u32, _u32, _vp, _vp],
+    "cnc_vote_fraction_table": [_vp, _u32, _u32, _vp, _vp, _vp],
+    "cnc_vote_fraction_table_backward": [_vp, _vp, _u32, _u32, _vp, _vp],
     "cnc_cnt_np_embed_planned_masked": [_vp, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_query_mask_3D": [_vp, _u32, _vp, _u32, _vp, _vp, _i32, _u32, _vp],
     "cnc_query_mask_3D_qlist": [_vp, _u32, _vp, _u32, _vp, _vp, _vp, _u32, _vp],

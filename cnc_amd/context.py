@@ -181,6 +181,55 @@ class _cnt_np_embed_planned3(Function):
         return None, grad_embeddings
 
 
+class _vote_tables3(Function):
+    """`_cnt_np_embed_planned3` + the fraction / select / pad chain of `_ring_of_zeros` as one node: returns the three
+    [R * R, F] tables the dimension-wise context encodes from.  One kernel per plane each way for what were five and
+    seven library launches (a keepdim sum over an axis of length 2, add, div, select, pad and their backward)."""
+
+    @staticmethod
+    def forward(ctx, plan, embeddings):
+        from . import _lib
+        F_ = embeddings.shape[-1]
+        embeddings = embeddings.contiguous()
+        S = plan.resolution - 2
+        R = plan.resolution
+        L = _lib.lib()
+        tables, sums = [], []
+        for axis_id in range(3):
+            cnt = torch.empty([S, S, F_, 2], device=embeddings.device)
+            _backend.cnt_np_embed_planned(plan, embeddings, cnt, F_, axis_id)
+            table = torch.empty([R * R, F_], device=embeddings.device)
+            sm = torch.empty([S, S, F_], device=embeddings.device)
+            _lib.check(L.cnc_vote_fraction_table(cnt.data_ptr(), S, F_, table.data_ptr(), sm.data_ptr(),
+                                                 _lib.stream(embeddings.device)), "vote_fraction_table")
+            tables.append(table)
+            sums.append(sm)
+        ctx.save_for_backward(embeddings, *sums)
+        ctx.plan = plan
+        return tuple(tables)
+
+    @staticmethod
+    def backward(ctx, g_xy, g_xz, g_yz):
+        from . import _lib
+        embeddings, *sums = ctx.saved_tensors
+        F_ = embeddings.shape[-1]
+        S = ctx.plan.resolution - 2
+        L = _lib.lib()
+        gs = []
+        for sm, g in zip(sums, (g_xy, g_xz, g_yz)):
+            out = torch.empty([S, S, F_, 2], device=embeddings.device)
+            if g is None:
+                out.zero_()
+            else:
+                _lib.check(L.cnc_vote_fraction_table_backward(g.contiguous().data_ptr(), sm.data_ptr(), S, F_,
+                                                              out.data_ptr(), _lib.stream(embeddings.device)),
+                           "vote_fraction_table_backward")
+            gs.append(out)
+        grad_embeddings = torch.empty_like(embeddings)
+        _backend.cnt_np_embed_planned_backward3(ctx.plan, embeddings, gs, grad_embeddings, F_)
+        return None, grad_embeddings
+
+
 def _encode_host(x, p, file_name):
     """x, p: contiguous float32 HOST tensors.  Writes the .b file, returns its size in bits."""
     n = x.numel()
@@ -692,6 +741,8 @@ class CNC_context_models(nn.Module):
 
     def get_pn_embed_frac_planes(self, embeddings_3D_q, plan):
         """`get_pn_embed_frac` for the xy, xz and yz planes at once (one autograd node, see `_cnt_np_embed_planned3`)."""
+        if self.fused_heads and embeddings_3D_q.is_cuda and embeddings_3D_q.dtype == torch.float32:
+            return list(_vote_tables3.apply(plan, embeddings_3D_q))
         out = []
         for frac in _cnt_np_embed_planned3.apply(plan, embeddings_3D_q):
             out.append(self._ring_of_zeros(frac))

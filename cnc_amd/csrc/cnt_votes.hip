@@ -277,6 +277,69 @@ extern "C" int cnc_cnt_np_embed_planned_backward(const uint32_t* pixels_by_row, 
     return launch_status();
 }
 
+namespace cnc {
+// cnt [S, S, F, 2] -> table [R, R, F] (R = S + 2): the +1 fraction of every inner pixel, a ring of zero pixels around
+// it; sums [S, S, F] = (cnt0 + cnt1) + 1e-6.  The reference spells it sum(-1, keepdim) + 1e-6, a division, a select of
+// channel 0, two permutes and a pad (utils_bpp_acc.py:39-55, 515-526): five library launches per plane, one of them a
+// reduction over an axis of length two that took 0.15 ms.
+__global__ __launch_bounds__(256) void k_vote_fraction_table(const float* __restrict__ cnt, uint32_t S, uint32_t F,
+                                                             float* __restrict__ table, float* __restrict__ sums)
+{
+    const uint32_t R = S + 2;
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (uint64_t)R * R * F) return;
+    const uint32_t f = (uint32_t)(e % F), px = (uint32_t)(e / F);
+    const uint32_t u = px / R, w = px % R;
+    float v = 0.0f;
+    if (u >= 1 && u <= S && w >= 1 && w <= S) {
+        const size_t  at = ((size_t)(u - 1) * S + (w - 1)) * F + f;
+        const float2  c = *reinterpret_cast<const float2*>(cnt + at * 2);
+        const float   sm = (c.x + c.y) + 1e-6f;
+        sums[at] = sm;
+        v = c.x / sm;
+    }
+    table[e] = v;
+}
+
+// g_table [R, R, F] -> grad_over_sum [S, S, F, 2] = [(1 / sums) * g, 0]: what cnt_np_embed_backward consumes
+// (gridencoder.cu:1035-1040); channel 1 (the -1 votes) carries no gradient because only channel 0 is used downstream
+__global__ __launch_bounds__(256) void k_vote_fraction_table_bwd(const float* __restrict__ g_table,
+                                                                 const float* __restrict__ sums, uint32_t S, uint32_t F,
+                                                                 float* __restrict__ grad_over_sum)
+{
+    const uint32_t R = S + 2;
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (uint64_t)S * S * F) return;
+    const uint32_t f = (uint32_t)(e % F), px = (uint32_t)(e / F);
+    const uint32_t u = px / S, w = px % S;
+    const float    g = g_table[((size_t)(u + 1) * R + (w + 1)) * F + f];
+    *reinterpret_cast<float2*>(grad_over_sum + e * 2) = make_float2((1.0f / sums[e]) * g, 0.0f);
+}
+}  // namespace cnc
+
+extern "C" int cnc_vote_fraction_table(const float* cnt, uint32_t S, uint32_t F, float* table, float* sums, void* stream)
+{
+    if (S == 0 || F == 0) return CNC_OK;
+    if (!cnt || !table || !sums) return CNC_ERR_INVALID_VALUE;
+    const uint64_t n = (uint64_t)(S + 2) * (S + 2) * F;
+    if ((n + 255) / 256 >= (1ull << 31)) return CNC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_vote_fraction_table, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cnt, S, F,
+                       table, sums);
+    return launch_status();
+}
+
+extern "C" int cnc_vote_fraction_table_backward(const float* g_table, const float* sums, uint32_t S, uint32_t F,
+                                                float* grad_over_sum, void* stream)
+{
+    if (S == 0 || F == 0) return CNC_OK;
+    if (!g_table || !sums || !grad_over_sum) return CNC_ERR_INVALID_VALUE;
+    const uint64_t n = (uint64_t)S * S * F;
+    if ((n + 255) / 256 >= (1ull << 31)) return CNC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_vote_fraction_table_bwd, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_table,
+                       sums, S, F, grad_over_sum);
+    return launch_status();
+}
+
 extern "C" int cnc_cnt_np_embed_planned_backward3(const uint32_t* pixels_by_row_xy, const uint32_t* pixels_by_row_xz,
                                                   const uint32_t* pixels_by_row_yz, const int32_t* row_seg,
                                                   const float* embeddings_clip, const float* grad_over_sum_xy,

@@ -224,6 +224,13 @@ int cnc_cnt_np_embed_planned_backward(const uint32_t* pixels_by_row, const int32
 /* The same forward counts in two steps, for callers that project one table onto several planes (the three calls
  * of utils_bpp_acc.py:590-600 vote on the same embeddings): masks[r] bit ch = (embeddings_clip[r][ch] > 0.9),
  * F <= 32, packed once; then a 4-byte gather per vertex instead of a 4 F byte row.  Counts are integers: equal. */
+/* (ABI v24) counts [S, S, F, 2] of one projection -> the dense one-level table the dimension-wise context encodes from
+ * (utils_bpp_acc.py:39-55, 515-526): table [R, R, F], R = S + 2 = cnt0 / ((cnt0 + cnt1) + 1e-6) on the inner S x S
+ * pixels, zero on the ring; sums [S, S, F] = the denominators, kept for the backward.  And back: grad_over_sum
+ * [S, S, F, 2] = [(1 / sums) * g_table(inner), 0], the input of cnc_cnt_np_embed_planned_backward{,3}.             */
+int cnc_vote_fraction_table(const float* cnt, uint32_t S, uint32_t F, float* table, float* sums, void* stream);
+int cnc_vote_fraction_table_backward(const float* g_table, const float* sums, uint32_t S, uint32_t F,
+                                     float* grad_over_sum, void* stream);
 /* Backward of the three projections (xy, xz, yz) of ONE table in one pass: grad_embeddings [n_rows, F] is WRITTEN
  * (0 for rows without vertices) = the sum of the three cnc_cnt_np_embed_planned_backward results on a zeroed table. */
 int cnc_cnt_np_embed_planned_backward3(const uint32_t* pixels_by_row_xy, const uint32_t* pixels_by_row_xz,

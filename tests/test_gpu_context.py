@@ -192,6 +192,34 @@ def test_planned_votes_equal_atomic_votes(setup):
         assert (a - b).abs().max() <= 1e-5 * b.abs().max()
 
 
+def test_vote_tables_node_equals_the_op_chain(setup):
+    """`_vote_tables3` (counts -> fraction -> channel 0 -> ring of zeros as one kernel per plane, and one back) against
+    `_cnt_np_embed_planned3` followed by the reference's op chain (`_ring_of_zeros`, utils_bpp_acc.py:515-526): same
+    float operations, so the three tables and the gradient of the finest 3-D level are bit-equal."""
+    from cnc_amd.context import _cnt_np_embed_planned3, _vote_tables3
+    g, m, encs, binary = setup
+    m.planned_votes = True
+    m.forward_binary_vxl_mixPg_3D2D(encs["xyz"], encs["xy"], encs["xz"], encs["yz"], binary, step=0)   # builds the plan
+    plan = m.vote_plan
+    assert plan is not None
+    fine = encs["xyz"].params.detach()[m._off3_host[-2]:m._off3_host[-1]]
+    fine = torch.where(fine >= 0, torch.ones_like(fine), -torch.ones_like(fine))
+    ws = [torch.randn(plan.resolution ** 2, fine.shape[1], device=fine.device) for _ in range(3)]
+    out = {}
+    for name in ("node", "chain"):
+        x = fine.clone().requires_grad_(True)
+        if name == "node":
+            tabs = _vote_tables3.apply(plan, x)
+        else:
+            tabs = [m._ring_of_zeros(f) for f in _cnt_np_embed_planned3.apply(plan, x)]
+        sum((t * w).sum() for t, w in zip(tabs, ws)).backward()
+        out[name] = ([t.detach() for t in tabs], x.grad)
+    for a, b in zip(out["node"][0], out["chain"][0]):
+        assert a.shape == b.shape and torch.equal(a, b)
+        assert float(a.max()) > 0 and float(a.min()) == 0.0
+    assert torch.equal(out["node"][1], out["chain"][1]) and float(out["node"][1].abs().max()) > 0
+
+
 def test_segment_weighted_sum_kernel(cuda):
     from cnc_amd.backends import pack_and_align as pa
     rng = np.random.default_rng(0)

@@ -102,43 +102,91 @@ cfg = TrainConfig(lmbda=2e-3, Pg_level=5, Pg_level_2D=3, log2_hashmap_size=12, l
                   milestones=(100, 130), warmup_iters=20, test_views=2, image_size=48, out_dir={out!r},
                   step_update=4)
 tr = Trainer(cfg, device="cuda")
-assert torch.distributed.is_initialized() and torch.distributed.get_world_size() == 2
-stats = [tr.train_step(s) for s in range(8)]        # replicas are re-aligned after steps 3 and 7
+assert torch.distributed.is_initialized()
+assert torch.distributed.get_world_size() == {world}
+stats = [tr.train_step(s) for s in range({steps})]        # replicas are compared / re-aligned after steps 3, 7, 11, ...
 sums = [float(p.detach().double().sum()) for p in list(tr.field.parameters()) + list(tr.context.parameters())]
 absum = [float(p.detach().double().abs().sum()) for p in list(tr.field.parameters()) + list(tr.context.parameters())]
 rays = [s["num_rays"] for s in stats if s]
 print("RESULT " + json.dumps(dict(rank=tr.rank, device=str(tr.device), sums=sums, absum=absum, rays=rays,
-                                  mse=[s["mse"] for s in stats if s],
-                                  binaries=int(tr.estimator.binaries.sum()))), flush=True)
+                                  mse=[s["mse"] for s in stats if s], samples=[s["n_rendering_samples"] for s in stats if s],
+                                  binaries=int(tr.estimator.binaries.sum()), resync=tr.resync)), flush=True)
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
 """
 
 
-def test_two_rank_trainer_replicas_stay_identical(cuda, tmp_path):
+def _run_trainer_ranks(tmp_path, world, steps):
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
     script = tmp_path / "worker.py"
-    script.write_text(_TRAINER_WORKER.format(root=ROOT, out=str(tmp_path / "bits")))
+    script.write_text(_TRAINER_WORKER.format(root=ROOT, out=str(tmp_path / "bits"), world=world, steps=steps))
     procs = []
-    for rank in range(2):
-        env = _clean_env(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+    for rank in range(world):
+        env = _clean_env(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                          MASTER_PORT=str(port), CNC_DIST_ONE_DEVICE="1", CNC_DIST_BACKEND="gloo")
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
-        o, e = p.communicate(timeout=900)
+        o, e = p.communicate(timeout=1500)
         assert p.returncode == 0, e[-3000:]
         outs.append(json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][0][7:]))
-    a, b = sorted(outs, key=lambda d: d["rank"])
-    assert a["device"] == b["device"] == "cuda:0"          # the one-device hook
-    assert a["sums"] == b["sums"] and a["absum"] == b["absum"]      # bit-identical replicas
-    assert a["binaries"] == b["binaries"] and a["rays"] == b["rays"]
-    assert a["mse"] != b["mse"]                             # ... trained on different rays
+    return sorted(outs, key=lambda d: d["rank"])
+
+
+def _check_replicas(outs, steps, step_update=4):
+    a = outs[0]
+    assert a["device"] == "cuda:0"                             # the one-device hook
+    for b in outs[1:]:
+        assert b["device"] == "cuda:0"
+        assert a["sums"] == b["sums"] and a["absum"] == b["absum"]      # bit-identical replicas at the last comparison
+        assert a["binaries"] == b["binaries"]
+        # the ray budget follows the ALL-REDUCED sample count of the step before (it rides in the gradient bucket's
+        # tail): the same number on every rank, from step 2 on a different one than the initial batch
+        assert a["rays"] == b["rays"]
+        assert a["mse"] != b["mse"]                             # ... trained on different rays
+        assert a["resync"] == b["resync"]                       # every rank took the same decisions
     assert sum(a["absum"]) > 0
+    assert a["rays"][0] == a["rays"][1] == 512 and len(set(a["rays"])) > 2
+    # what rank 0's budget at step k + 1 was computed from: the mean over the ranks of the counts of step k - 1
+    world = len(outs)
+    for k in range(1, steps - 1):
+        mean = sum(o["samples"][k - 1] for o in outs) / world
+        if mean >= 1.0:
+            assert a["rays"][k + 1] == int(a["rays"][k - 1] * ((1 << 14) / mean)), k
+    r = a["resync"]
+    assert r["checks"] == steps // step_update and 0 <= r["fired"] <= r["checks"]
+    assert (r["tensors"] == 0) == (r["fired"] == 0) and (r["bytes"] == 0) == (r["fired"] == 0)
+    return r
+
+
+def test_two_rank_trainer_replicas_stay_identical(cuda, tmp_path):
+    outs = _run_trainer_ranks(tmp_path, 2, 8)
+    _check_replicas(outs, 8)
+
+
+def test_eight_rank_trainer_and_bench(cuda, tmp_path):
+    """The rank-count-dependent paths at the world size the driver uses — `shard_range`, the bucket's division, per-rank
+    seeds, `spawn_ranks`, the count in the bucket's tail, the checksum resync — eight ranks on ONE device over gloo
+    (CNC_DIST_ONE_DEVICE / CNC_BENCH_ONE_DEVICE): 20 data-parallel training steps, then `bench.py --gpus 8`."""
+    outs = _run_trainer_ranks(tmp_path, 8, 20)
+    assert [o["rank"] for o in outs] == list(range(8))
+    r = _check_replicas(outs, 20)
+    print("resync over 20 steps at 8 ranks:", r)
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-train-step", "--no-field"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=1800, env=_clean_env(CNC_BENCH_ONE_DEVICE="1", CNC_BENCH_BACKEND="gloo"))
+    assert b.returncode == 0, b.stderr[-3000:]
+    lines = [l for l in b.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and [x["rank"] for x in out["ranks"]] == list(range(8))
+    assert all(x["world_size"] == 8 for x in out["ranks"])
+    # eight cameras, eight frames: the whole job's samples over the slowest rank's time
+    assert out["value"] * out["ms_per_step"] * 1e-3 > 7.0 * out["config"]["samples_per_step_rank0"] * 0.8
 
 
 def test_two_rank_cli_on_a_real_scene_layout(cuda, tmp_path):
