@@ -49,6 +49,8 @@ class ContextMLP(Function):
                                              *[ptr(w) for w in ws], ptr(out), stream(in_a.device)), "ctx_mlp_forward")
         ctx.save_for_backward(in_a, in_b, pgv, pg_index, *ws)
         ctx.dims = (N, Ca, Cb, n_layers, F, None if pg is None else tuple(pg.shape))
+        from .. import _gradsink
+        ctx.sink = _gradsink.current()     # the caller thread's sink; the backward runs on autograd's own thread
         return out
 
     @staticmethod
@@ -65,6 +67,19 @@ class ContextMLP(Function):
         # accumulates with atomics; _REPLICAS copies: its ~1000 workgroups spread their atomics over them, summed below)
         total = sum(w.numel() for w in ws if w is not None)
         n_pg = 0 if pgv is None else pgv.numel()
+        # With a gradient sink on this thread (the training step, cnc_amd._gradsink) the weight gradients of every head
+        # call of the step accumulate in the sink's replicated buffer — zeroed once, reduced once — and autograd gets
+        # none; only the (tiny) Pg gradient is still a fresh zero-filled vector per call.
+        from .. import _gradsink
+        sink = ctx.sink
+        slots = None if sink is None else sink.small_slot(ws)
+        if slots is not None:
+            g_pg = torch.zeros(n_pg, dtype=torch.float32, device=dev) if pgv is not None else None
+            check(_lib.lib().cnc_ctx_mlp_backward(ptr(in_a), Ca, Ca, ptr(in_b), Cb, Cb, ptr(pgv), ptr(pg_index), N, n_layers, F,
+                                                  *[ptr(w) for w in ws], ptr(g), ptr(g_a), ptr(g_b), ptr(g_pg),
+                                                  *[ptr(w) for w in slots], _gradsink.REPLICAS, sink.stride(), stream(dev)),
+                  "ctx_mlp_backward")
+            return (g_a, g_b, None if g_pg is None else g_pg.reshape(pg_shape)) + (None,) * 7
         zeroed = torch.zeros(_REPLICAS * total + n_pg, dtype=torch.float32, device=dev)
         copies = zeroed[:_REPLICAS * total].view(_REPLICAS, total)
         g_pg = zeroed[_REPLICAS * total:] if pgv is not None else None

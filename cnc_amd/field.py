@@ -170,6 +170,8 @@ class _FusedFeatures(Function):
             feat[:N, c0:].zero_()
         ctx.save_for_backward(*xs, *params, *saved)
         ctx.owner = owner
+        from . import _gradsink
+        ctx.sink = _gradsink.current()     # the caller thread's sink; the backward runs on autograd's own thread
         return feat
 
     @staticmethod
@@ -182,14 +184,16 @@ class _FusedFeatures(Function):
         ld, cols = owner._layout()
         grad = grad.contiguous()
         N = xs[0].shape[0]                 # rows of padding behind them (`rows`) carry no sample
+        sink = ctx.sink                    # the training step's per-table gradient buffers (cnc_amd._gradsink)
         grads = []
         for enc, p, xi, clip, col in zip(encs, params, xs, clips, cols):
-            g = torch.zeros_like(p)
+            sunk = None if sink is None else sink.table(p)
+            g = torch.zeros_like(p) if sunk is None else sunk
             be.grid_encode_backward(grad, xi, p, enc.offsets_list, enc.resolutions_list, g, N,
                                     enc.num_dim, enc.n_features, enc.n_levels, 0, 128, None, None,
                                     None, None, ste_binary=True, ste_clip_count=clip,
                                     grad_ld=ld, grad_col=col, binned=enc._binned_plan(N))
-            grads.append(g)
+            grads.append(g if sunk is None else None)
         return (None, None, None, *grads)
 
 

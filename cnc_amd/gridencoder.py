@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
-from . import _caches
+from . import _caches, _gradsink
 from .backends import gridencoder_backend as _backend
 
 
@@ -126,6 +126,9 @@ class _grid_encode(Function):
         ctx.save_for_backward(inputs, embeddings, offs, ress, binary_vxl, mli, clip_count, occ_sat, vb_words, vb_offs)
         ctx.dims = (N, num_dim, n_features, n_levels_calc, Rb, ste)
         ctx.binned = binned if (binary_vxl is None and mli is None) else None
+        # the caller thread's gradient sink (cnc_amd._gradsink), taken HERE: the backward below runs on autograd's
+        # device thread, where the caller's thread-local is not visible
+        ctx.sink = _gradsink.current()
         return outputs
 
     @staticmethod
@@ -133,14 +136,18 @@ class _grid_encode(Function):
         inputs, embeddings, offs, ress, binary_vxl, mli, clip_count, occ_sat, vb_words, vb_offs = ctx.saved_tensors
         N, num_dim, n_features, n_levels_calc, Rb, ste = ctx.dims
         grad = grad.contiguous()                       # [N, L*F], read in place (grad_ld)
-        grad_embeddings = torch.zeros_like(embeddings)
+        # a gradient sink of the training step (cnc_amd._gradsink): the scatter adds straight into the step's buffer
+        # for this table and autograd is handed nothing to add
+        sink = ctx.sink
+        sunk = None if sink is None else sink.table(embeddings)
+        grad_embeddings = torch.zeros_like(embeddings) if sunk is None else sunk
         _backend.grid_encode_backward(grad, inputs, embeddings, offs, ress, grad_embeddings, N,
                                       num_dim, n_features, n_levels_calc, 0, Rb, None, None,
                                       binary_vxl, mli, ste_binary=ste, ste_clip_count=clip_count,
                                       occ_sat=occ_sat, binned=ctx.binned,
                                       grad_ld=n_levels_calc * n_features, grad_col=0,
                                       vertex_bits=None if vb_words is None else (vb_words, vb_offs))
-        return (None, grad_embeddings) + (None,) * 13
+        return (None, grad_embeddings if sunk is None else None) + (None,) * 13
 
 
 grid_encode = _grid_encode.apply

@@ -23,6 +23,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import _gradsink
 from . import dist as cdist
 from .context import CNC_context_models
 from .field import NGPRadianceField_mygrid_2D3D
@@ -250,6 +251,13 @@ class Trainer:
         # sequential schedule, which keeps the reference's order of random draws (the trajectory goldens need it).
         self.ctx_thread = self.ctx_stream is not None and os.environ.get("CNC_CTX_THREAD", "1") == "1"
         self._pool = None
+        # per-step gradient sinks (cnc_amd._gradsink): the encoder scatters and the context heads' weight gradients add
+        # into ONE buffer per parameter and pass instead of a fresh zero-filled tensor per call (CNC_GRAD_SINK=0: off)
+        self.sink_render = self.sink_ctx = None
+        if self.device.type == "cuda" and os.environ.get("CNC_GRAD_SINK", "1") == "1":
+            tables = [e.params for e in self.field.mlp_base._encoders()]
+            self.sink_render = _gradsink.GradSink(tables, [])
+            self.sink_ctx = _gradsink.GradSink(tables, list(self.context.parameters()))
         self.bucket = None
         self.time_comm = False          # bench hook: HIP events around the wait for the gradient all-reduce
         self._comm_events = []
@@ -325,7 +333,7 @@ class Trainer:
         torch.cuda.set_device(self.device)
         e = self.field.mlp_base
         side.wait_event(fork)
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), _gradsink.activate(self.sink_ctx):
             bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(
                 e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
                 sample_num=None, step=step, sync_MB=False)
@@ -353,6 +361,9 @@ class Trainer:
         if self.world > 1 and step % c.step_update == 0:
             cdist.broadcast_module_buffers(self.estimator, ["occs", "binaries"])
         ctx_future = None
+        for sink in (self.sink_render, self.sink_ctx):      # before either pass forks off: both are ordered after this
+            if sink is not None:
+                sink.zero()
         if self._warn_switch is not None:
             self._warn_switch(False)
         try:
@@ -423,9 +434,10 @@ class Trainer:
     def _train_step_tail(self, step, want_stats, data, ctx_future):
         c = self.cfg
         rays, pixels, bkgd = data["rays"], data["pixels"], data["color_bkgd"]
-        rgb, acc, depth, n_samples, extra = render_image_with_occgrid(
-            self.field, self.estimator, rays, near_plane=c.near_plane, render_step_size=c.render_step_size,
-            render_bkgd=bkgd, cone_angle=c.cone_angle, alpha_thre=c.alpha_thre, return_extra=True)
+        with _gradsink.activate(self.sink_render):
+            rgb, acc, depth, n_samples, extra = render_image_with_occgrid(
+                self.field, self.estimator, rays, near_plane=c.near_plane, render_step_size=c.render_step_size,
+                render_bkgd=bkgd, cone_angle=c.cone_angle, alpha_thre=c.alpha_thre, return_extra=True)
         if self.world == 1:
             if n_samples == 0:
                 if ctx_future is not None:
@@ -468,12 +480,17 @@ class Trainer:
             else:
                 loss = mse
                 if c.lmbda > 0:
-                    bpp, mb = self.context.forward_binary_vxl_mixPg_3D2D(*ctx_args, sample_num=None, step=step,
-                                                                         sync_MB=False)
+                    with _gradsink.activate(self.sink_ctx):
+                        bpp, mb = self.context.forward_binary_vxl_mixPg_3D2D(*ctx_args, sample_num=None, step=step,
+                                                                             sync_MB=False)
                     loss = loss + c.lmbda * bpp
                 self.opt.zero_grad(set_to_none=True)
                 self.opt2.zero_grad(set_to_none=True)
                 (loss * self.loss_scale).backward()
+            # both passes are joined to this stream: what their kernels added to the sinks goes to `.grad`, once
+            for sink in (self.sink_render, self.sink_ctx):
+                if sink is not None:
+                    sink.flush()
         else:
             # Data-parallel step.  The ray loss differs per rank, the entropy loss does not (same tables, same
             # window draw on every rank): so only the ray-loss gradient is exchanged, and its all-reduce runs
@@ -483,13 +500,16 @@ class Trainer:
             A, B = self.bucket, self.bucket_ctx
             if ctx_future is None:
                 if c.lmbda > 0:
-                    bpp, mb = self.context.forward_binary_vxl_mixPg_3D2D(*ctx_args, sample_num=None, step=step,
-                                                                         sync_MB=False)
+                    with _gradsink.activate(self.sink_ctx):
+                        bpp, mb = self.context.forward_binary_vxl_mixPg_3D2D(*ctx_args, sample_num=None, step=step,
+                                                                             sync_MB=False)
                 A.zero()
                 A.bind(force=True)
             self._lagged_sample_count(len(pixels), n_samples)
             if mse.requires_grad:          # a rank whose rays met no sample has nothing to add (its peers do): the
                 (mse * self.loss_scale).backward()     # collective below must still be entered by everyone
+            if self.sink_render is not None:
+                self.sink_render.flush()               # `.grad` = the bucket's views: the encoder scatters join it here
             work = A.allreduce(average=False, async_op=True)
             ctx_grads = None
             if ctx_future is not None:
@@ -498,6 +518,8 @@ class Trainer:
                 B.zero()
                 B.bind(force=True)
                 (c.lmbda * bpp * self.loss_scale).backward()
+                if self.sink_ctx is not None:
+                    self.sink_ctx.flush()              # into `.grad` = B's views
             if work is not None:
                 if self.time_comm:      # how long the compute stream stalls for the collective (what was NOT hidden
                     e0 = torch.cuda.Event(enable_timing=True)        # behind the entropy pass)
@@ -516,6 +538,8 @@ class Trainer:
             if ctx_grads is not None:
                 pairs = [(v, g) for v, g in zip(A.views, ctx_grads) if g is not None]
                 torch._foreach_add_([v for v, _ in pairs], [g for _, g in pairs])
+                if self.sink_ctx is not None:
+                    self.sink_ctx.flush()              # `.grad` = A's views (bound before the fork): after the mean
             elif c.lmbda > 0:
                 A.grads.add_(B.flat)
             A.bind(force=True)

@@ -249,3 +249,35 @@ def test_threaded_context_pass_equals_the_sequential_schedule(cuda, tmp_path):
         assert abs(ref[-1]["bpp"] - got[-1]["bpp"]) <= 0.05 * ref[-1]["bpp"], mode
         assert abs(ref[-1]["mse"] - got[-1]["mse"]) <= 0.2 * ref[-1]["mse"], mode
         assert all(torch.isfinite(p).all() for p in got_p)
+
+
+@pytest.mark.parametrize("mode", ["plain", "stream", "thread"])
+def test_gradient_sinks_give_the_gradients_autograd_gives(cuda, tmp_path, mode):
+    """The per-step gradient sinks (cnc_amd._gradsink: encoder scatters and context-head weight gradients add into one
+    buffer per parameter and pass, `.grad` gets them once) against plain autograd (a fresh zero-filled tensor per
+    call, summed by the engine): the same gradient of every parameter after one step's backward passes, up to the
+    order of float atomics — in all three schedules."""
+    from cnc_amd.trainer import Trainer
+    grads = {}
+    for sinks in (True, False):
+        tr = Trainer(_cfg(tmp_path, seed=5), device=cuda)
+        g = torch.Generator(device=cuda)
+        g.manual_seed(78)
+        tr.context.rand_like = lambda t: torch.rand(t.shape, generator=g, device=t.device, dtype=t.dtype)
+        if mode == "plain":
+            tr.ctx_stream, tr.ctx_thread = None, False
+        elif mode == "stream":
+            tr.ctx_thread = False
+        assert tr.sink_render is not None and tr.sink_ctx is not None
+        if not sinks:
+            tr.sink_render = tr.sink_ctx = None
+        tr.train_step(0)                      # same initial state, same draws: the gradients of this one step
+        torch.cuda.synchronize()
+        named = list(tr.field.named_parameters()) + [("ctx." + n, p) for n, p in tr.context.named_parameters()]
+        grads[sinks] = {n: p.grad.detach().clone() for n, p in named if p.grad is not None}
+        assert len(grads[sinks]) == len(named)
+    for n, want in grads[False].items():
+        got = grads[True][n]
+        scale = float(want.abs().max())
+        assert scale > 0, n
+        assert float((got - want).abs().max()) <= 2e-4 * scale, (n, float((got - want).abs().max()), scale)
