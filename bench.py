@@ -230,7 +230,7 @@ def compulsory_backward_bytes(x, offsets_host):
 
 
 def kernel_source_hashes():
-    """git blob hashes of the kernel sources, as tools/summarise_pmc_r03.py stores them next to the measured traffic."""
+    """git blob hashes of the kernel sources, as tools/summarise_pmc.py stores them next to the measured traffic."""
     import hashlib
     out = {}
     for rel in ("cnc_amd/csrc/grid_encode.hip", "cnc_amd/csrc/grid_encode_merge.hip", "cnc_amd/csrc/grid_encode_binned.hip",

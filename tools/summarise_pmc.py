@@ -1,16 +1,34 @@
-"""Per-kernel HBM traffic from the two rocprofv3 --pmc passes made by tools/collect_profiles.sh.
-FETCH_SIZE / WRITE_SIZE are in KB; FETCH is doubled on gfx950 (MI355X_MICROARCH.md, HBM section).
-Writes profiles/r01_pmc_hbm_traffic.csv and profiles/traffic.json (bytes per encoder call)."""
-import csv, glob, json, os, re, sys
+"""gpurun_out/<tag> (tools/collect_profiles.sh <tag>) -> profiles/<tag>_pmc_hbm_traffic.csv, profiles/traffic.json and
+copies of the kernel-stats CSVs.      python tools/summarise_pmc.py r04
+
+Counter arithmetic (profiles/r03_counter_calibration.md, tools/fetch_calib.hip):
+  * FETCH_SIZE (KB) = L2 -> fabric read requests x 64 B.  A coalesced 16 B/lane stream moves 128 B per request (reported
+    = 1/2 of the known bytes); a gather of one 32-byte row is ONE request whatever it carries (reported = the 64-byte
+    sectors touched).  So:  read bytes = 64 B x requests + 64 B x (requests of the kernel's STREAMED reads), the second
+    term from the byte count the kernel is known to stream (items, table slabs, inputs, upstream gradient).
+  * WRITE_SIZE (KB) is exact for 64-byte write requests (streaming writes: factor 1.000) and charges 32 B for a
+    partial one (a lone 16-byte store: factor 0.5, i.e. it over-counts the useful bytes 2x) — used as reported.
+traffic.json carries, per entry point, the calibrated bytes, both bounds (every read request 64 B / 128 B), the request
+counts, and the git blob hashes of the kernel sources the numbers were measured on (bench.py flags a mismatch)."""
+import csv, glob, hashlib, json, os, re, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r01")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+src = os.path.join(ROOT, "gpurun_out", TAG)
+P = os.path.join(ROOT, "profiles")
+KERNEL_SOURCES = ["cnc_amd/csrc/grid_encode.hip", "cnc_amd/csrc/grid_encode_merge.hip", "cnc_amd/csrc/grid_encode_binned.hip",
+                  "cnc_amd/csrc/grid_encode_overlap.hip", "cnc_amd/csrc/encoder_common.hpp", "cnc_amd/csrc/common.hpp",
+                  "cnc_amd/csrc/march.hip"]
+
+
+def blob_hash(path):
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
 
 
 def per_kernel(counter_dir, counter):
-    per_dispatch = defaultdict(float)
-    name_of = {}
+    per_dispatch, name_of = defaultdict(float), {}
     for f in glob.glob(os.path.join(counter_dir, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
@@ -28,33 +46,90 @@ def per_kernel(counter_dir, counter):
 
 fetch = per_kernel(os.path.join(src, "pmc_fetch"), "FETCH_SIZE")
 write = per_kernel(os.path.join(src, "pmc_write"), "WRITE_SIZE")
-rows = []
-for n in sorted(set(fetch) | set(write)):
-    if not n.startswith("cnc::"):
-        continue
-    f, w = fetch.get(n, (0, 0))[0], write.get(n, (0, 0))[0]
-    rows.append((n, f, w, (2 * f + w) * 1024, fetch.get(n, (0, 0))[1]))
-with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.csv"), "w") as fh:
-    fh.write("kernel,FETCH_SIZE_avg_KB_raw,WRITE_SIZE_avg_KB,hbm_bytes_per_launch(2*FETCH+WRITE)*1024,dispatches\n")
-    for n, f, w, b, c in rows:
-        fh.write(f'"{n}",{f:.1f},{w:.1f},{b:.0f},{c}\n')
-by = {n: b for n, f, w, b, c in rows}
-cnt = {n: c for n, f, w, b, c in rows}
-pick = lambda pat: sum(v for k, v in by.items() if re.search(pat, k))
-# bytes per CALL for kernels that are dispatched more than once per call (the binned levels go out as
-# two groups): total bytes of the kernel / number of calls (= dispatches of the coarse kernel)
-total = lambda pat: sum(by[k] * cnt[k] for k in by if re.search(pat, k))
-calls = max(sum(cnt[k] for k in by if re.search(r"k_grid_encode_bwd(_merge)?<", k)), 1)
+rdreq = per_kernel(os.path.join(src, "pmc_req"), "TCC_EA0_RDREQ_sum")
+wrreq = per_kernel(os.path.join(src, "pmc_req"), "TCC_EA0_WRREQ_sum")
+atom = per_kernel(os.path.join(src, "pmc_atomic"), "TCC_ATOMIC_sum")
+names = sorted(n for n in set(fetch) | set(write) | set(atom) if n.startswith("cnc::"))
+get = lambda d, n: d.get(n, (0.0, 0))[0]
+cnt = {n: max(fetch.get(n, (0, 0))[1], write.get(n, (0, 0))[1], atom.get(n, (0, 0))[1]) for n in names}
+with open(os.path.join(P, f"{TAG}_pmc_hbm_traffic.csv"), "w") as fh:
+    fh.write("kernel,FETCH_SIZE_avg_KB_raw,WRITE_SIZE_avg_KB,read_requests_avg,write_requests_avg,TCC_ATOMIC_sum_avg,dispatches\n")
+    for n in names:
+        fh.write(f'"{n}",{get(fetch, n):.1f},{get(write, n):.1f},{get(rdreq, n):.0f},{get(wrreq, n):.0f},{get(atom, n):.0f},{cnt[n]}\n')
+
+L, F, L_BINNED = 16, 8, 6        # levels of the bench grid on the binned path (gridencoder_backend.plan_binned_levels)
+# samples per encoder call, averaged over the frame's calls like the counters below (the last call of a frame is partial)
+N_CHUNK = 1 << 20
+_bj = os.path.join(src, "bench.json")
+if os.path.exists(_bj) and os.path.getsize(_bj) > 0:
+    try:
+        N_CHUNK = int(round(json.loads([l for l in open(_bj) if l.startswith("{")][0])["roofline"]["samples_per_launch"]))
+    except Exception:
+        pass
+
+
+def call_total(d, pat, calls):
+    return sum(get(d, n) * cnt[n] for n in names if re.search(pat, n)) / calls
+
+
+calls = max(sum(cnt[n] for n in names if re.search(r"k_grid_encode_bwd_merge<", n)), 1)
+fwd_calls = max(sum(cnt[n] for n in names if re.search(r"k_grid_encode_fwd_bits", n)), 1)
+
+
+def entry(pats, n_calls, streamed_read_bytes, note):
+    """calibrated bytes of one entry point = 64 B x read requests + 64 B x (requests that carried a 128-byte stream)
+    + WRITE_SIZE; bounds with every read request at 64 B / 128 B."""
+    pat = "|".join(pats)
+    f_b = call_total(fetch, pat, n_calls) * 1024
+    w_b = call_total(write, pat, n_calls) * 1024
+    rd = call_total(rdreq, pat, n_calls)
+    wr = call_total(wrreq, pat, n_calls)
+    at = call_total(atom, pat, n_calls)
+    streamed_req_bytes = min(streamed_read_bytes / 2.0, f_b)      # a 128-byte stream request is tallied as 64 B
+    return {"bytes": f_b + streamed_req_bytes + w_b, "bytes_min(read requests x 64 B)": f_b + w_b,
+            "bytes_max(read requests x 128 B)": 2 * f_b + w_b, "FETCH_SIZE_bytes_raw": f_b, "WRITE_SIZE_bytes": w_b,
+            "read_requests": rd or f_b / 64.0, "write_requests": wr, "atomic_requests": at,
+            "streamed_read_bytes_known": streamed_read_bytes, "note": note}
+
+
+items = 4 * N_CHUNK * L_BINNED * 16                       # one 16-byte item per (sample, binned level, corner pair)
+slabs = L_BINNED * (1 << 19) * F * 4                      # the owners read every table slab of the binned levels once
 traffic = {
-    "grid_encode_forward": pick(r"k_grid_encode_fwd_bits"),
-    # one backward call = atomic kernel (coarse levels; run-merging variant in the bench) + bin pass +
-    # owner pass (finest levels)
-    "grid_encode_backward": (total(r"k_grid_encode_bwd(_merge)?<") + total(r"k_bwd_bin") + total(r"k_bwd_owner")) / calls,
-    "_note": "HBM bytes per encoder call on a 2^20-sample chunk = (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the "
-             "call's kernels, from separate rocprofv3 --pmc passes of `python bench.py --steps 2 --warmup 1 "
-             "--no-cpu-baseline` (profiles/r01_pmc_hbm_traffic.csv, tools/collect_profiles.sh); FETCH doubled per "
-             "the gfx950 note in MI355X_MICROARCH.md",
+    "grid_encode_forward": entry([r"k_grid_encode_fwd_bits"], fwd_calls, N_CHUNK * 12,
+                                 "reads: the 12-byte points streamed, byte gathers from the 6 MB sign plane (L2 / Infinity-Cache hits "
+                                 "mostly); writes: the [L, N, F] output stream"),
+    "grid_encode_backward": entry([r"k_grid_encode_bwd_merge<", r"k_bwd_bin", r"k_bwd_owner"], calls,
+                                  N_CHUNK * 12 * 2 + N_CHUNK * (L - L_BINNED) * F * 4 + items + slabs,
+                                  "streamed: points (both halves), the coarse levels' gradient rows, the items, the table slabs; the "
+                                  "rest of the read requests are the owners' gathers of 32-byte gradient rows (one request each)"),
+    "k_bwd_bin+k_bwd_owner": entry([r"k_bwd_bin", r"k_bwd_owner"], calls, N_CHUNK * 12 + items + slabs,
+                                   "finest levels alone"),
+    "k_grid_encode_bwd_merge": entry([r"k_grid_encode_bwd_merge<"], calls, N_CHUNK * 12 + N_CHUNK * (L - L_BINNED) * F * 4,
+                                     "coarse levels alone"),
+    "march_samples(count+fill)": entry([r"k_traverse<0", r"k_traverse<2"], max(cnt.get(next((n for n in names if "k_traverse<2" in n), ""), 1), 1),
+                                       2 * 640000 * 24, "per 640k-ray frame; the fill pass also writes the positions (12 B / sample)"),
+    "_sources": {p: blob_hash(os.path.join(ROOT, p)) for p in KERNEL_SOURCES if os.path.exists(os.path.join(ROOT, p))},
+    "_fabric_request_rate_peak_G_per_s": 50.0,
+    "_samples_per_call": N_CHUNK,
+    "_note": "per encoder call of the bench frame (_samples_per_call samples on average); separate rocprofv3 --pmc passes of `python bench.py --steps 2 "
+             "--warmup 1 --no-cpu-baseline --no-train-step` (tools/collect_profiles.sh, profiles/" + TAG + "_pmc_hbm_traffic.csv); counter "
+             "arithmetic per profiles/r03_counter_calibration.md: FETCH_SIZE = read requests x 64 B, a streamed request carries 128 B, a "
+             "gathered 32-byte row is one request; the fabric sustains ~50 G requests/s (streaming 46.9, gathers 51.5: "
+             "tools/fetch_calib.hip)",
 }
-json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-print(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.csv")).read())
-print(traffic)
+json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+for sub, dst in (("stats", f"{TAG}_bench_kernel_stats.csv"), ("stats_no_overlap", f"{TAG}_bench_kernel_stats_no_overlap.csv"),
+                 ("stats_train", f"{TAG}_train_step_kernel_stats.csv")):
+    hits = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if hits:
+        shutil.copy(hits[0], os.path.join(P, dst))
+for f, dst in (("bench.json", f"{TAG}_bench.json"), ("bench_no_overlap.json", f"{TAG}_bench_no_overlap.json")):
+    if os.path.exists(os.path.join(src, f)) and os.path.getsize(os.path.join(src, f)) > 0:
+        shutil.copy(os.path.join(src, f), os.path.join(P, dst))
+if os.path.exists(os.path.join(src, "train.log")):
+    keep = [l for l in open(os.path.join(src, "train.log")) if l.startswith("train step") or l.startswith("setup")]
+    open(os.path.join(P, f"{TAG}_train_step.log"), "w").write(
+        "# tools/bench_train.py --no-profile under rocprofv3 --kernel-trace --stats (tracing overhead included;\n"
+        "# untraced: tools/profile_train_step.py / bench.py train_step)\n" + "".join(keep))
+print(open(os.path.join(P, f"{TAG}_pmc_hbm_traffic.csv")).read())
+print(json.dumps({k: v for k, v in traffic.items() if not k.startswith("_")}, indent=1)[:3000])
