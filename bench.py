@@ -368,7 +368,10 @@ def train_step_entry(dev, world=1, rank=0):
            "config": "full model, F=8, 12x3D(2^19)+3x4x2D(2^17), sample_num=150000, lmbda=2e-3, procedural ball "
                      "scene, target 2^18 samples/step" + ("/rank" if world > 1 else "") +
                      f", steps {warm}-{warm + n_steps - 1} (includes the occupancy refresh every 16 steps)"}
+    if world == 1:
+        out["extras"] = trained_model_entries(tr, dev)
     if world > 1:
+        out["resync"] = dict(tr.resync)      # how often the replicas' checksums differed at the refresh points
         exposed = sum(a.elapsed_time(b) for a, b in tr._comm_events) / max(len(tr._comm_events), 1)
         tr.time_comm = False
         flat = tr.bucket.flat
@@ -394,6 +397,56 @@ def train_step_entry(dev, world=1, rank=0):
                     "allreduce_note": "alone = blocking all-reduce of the same flat gradient bucket on an idle GPU (median "
                                       "of 5, slowest rank); exposed = HIP-event time the compute stream waits for the "
                                       "asynchronous all-reduce after the context backward (mean per step, slowest rank)"})
+    return out
+
+
+def trained_model_entries(tr, dev):
+    """On the model `train_step_entry` has just trained for ~300 steps (full size, F = 8): the 800x800 evaluation render
+    (`render_image_with_occgrid_test`, examples/utils.py:317-489 — march in bounded rounds, fused gradient-free field,
+    fused compositing) and the codec round trip (`encode_binary_vxl_mixPg_3D2D` / `decode_...`, context models on the
+    GPU + the CPU range coder).  Outside the timed region; reported with what was measured."""
+    from cnc_amd.render import render_image_with_occgrid_test
+    from cnc_amd.trainer import SyntheticBallDataset
+    c = tr.cfg
+    out = {}
+    try:
+        tr.field.eval(); tr.estimator.eval()
+        view = SyntheticBallDataset(800, device=dev, seed=0).view(0)
+        args = dict(near_plane=c.near_plane, render_step_size=c.render_step_size, render_bkgd=view["color_bkgd"],
+                    cone_angle=c.cone_angle, alpha_thre=c.alpha_thre)
+        with torch.no_grad():
+            for _ in range(2):
+                render_image_with_occgrid_test(1024, tr.field, tr.estimator, view["rays"], **args)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                rgb, _, _, n_shaded = render_image_with_occgrid_test(1024, tr.field, tr.estimator, view["rays"], **args)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            mse = torch.nn.functional.mse_loss(rgb, view["pixels"]).item()
+        out["eval_render"] = {"ms_per_image": dt * 1e3, "rays": 640000, "shaded_samples": int(n_shaded),
+                              "rays_per_s": 640000 / dt, "psnr_vs_procedural_scene": -10.0 * np.log10(max(mse, 1e-12)),
+                              "timed_region": False,
+                              "note": "800x800 view of the procedural ball after the ~300 training steps above"}
+    except Exception as exc:       # noqa: BLE001
+        out["eval_render"] = {"error": f"{type(exc).__name__}: {exc}"}
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        Pgs, est_MB, coded_MB, prefix = tr.encode()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):     # `update_embedding_params` prints, as the reference's does
+            tr.decode_into_field(Pgs, prefix)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        out["codec"] = {"encode_s": t1 - t0, "decode_s": t2 - t1, "estimated_MB": float(est_MB), "coded_MB": float(coded_MB),
+                        "coded_over_estimate": float(coded_MB) / max(float(est_MB), 1e-12), "timed_region": False,
+                        "note": "four tables (12x3-D T=2^19 + 3x4 planes T=2^17, F = 8) -> .b files and back"}
+    except Exception as exc:       # noqa: BLE001
+        out["codec"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
 
 
@@ -669,6 +722,8 @@ def main():
                 out["field"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_train_step:
             ts = guarded_train_step(dev) if world == 1 else ts_multi
+            if isinstance(ts, dict) and "extras" in ts:
+                out.update(ts.pop("extras"))
             out["train_step"] = ts
             if "error" not in ts:
                 kernels["train_step(full model: march+field+render+context+adam)"] = {

@@ -32,7 +32,7 @@ class FusedField(C.Structure):
     """cnc_fused_field_t (include/cnc_hip.h)."""
     _fields_ = [("aabb", _vp), ("bits", _vp * 4), ("offsets", _vp * 4), ("resolutions", _vp * 4), ("freqs", _vp),
                 ("packed_weights", _vp * 5), ("packed_biases", _vp * 5), ("w2_row0", _vp), ("packed_weights16", _vp * 5),
-                ("n_levels", _u32 * 4),
+                ("units", _vp), ("n_levels", _u32 * 4),
                 ("n_features", _u32), ("n_freqs", _u32), ("n_neurons", _u32), ("geo_feat_dim", _u32), ("flags", _u32)]
 
 

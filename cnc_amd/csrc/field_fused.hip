@@ -61,6 +61,7 @@ struct FusedFieldArgs {
     float*       density;
     float*       rgb;
     uint32_t     sh_fp16;
+    const uint4* units;           // per unit {first row, rows, resolution, encoder} of its level (cnc_fused_field_t.units)
     const half_t_* Wp16[5];       // fp16 hi / lo fragments (cnc_field_pack_layer16), k_field_fused16
     uint32_t       nk16_1;        // K-steps of 16 of layer 1 (a multiple of 2)
     uint32_t       nk16_h;        // K-steps of 16 of the head's first layer: roundup16(16 + geo) / 16
@@ -169,23 +170,70 @@ __device__ __forceinline__ void acc_to_lds(float* __restrict__ dst, uint32_t ld,
 }
 
 // The F features of one (encoder, level) unit at a point: the body of k_grid_encode_fwd_bits (same corner order, same
-// fmaf chain: bit-identical), no occupancy mask.
+// fmaf chain: bit-identical), no occupancy mask — in two halves, so that a lane can have the sign-plane gathers of
+// BOTH units of its window in flight before it consumes either (two waves per SIMD do not hide an L2 round trip per
+// unit: the gather alone ran at half the vector rate).
+struct UnitGather {
+    float    tw[8];       // weight / sum of the valid weights per corner, 0 for an invalid corner
+    uint32_t rb[8];       // the corner rows' F sign bits
+};
+
+// One 16-byte record per unit, built by the caller from the encoders' level tables (cnc_fused_field_t.units): a lane
+// needs ONE L1-resident load before it can form its corner rows.  Reading the level tables through the encoder array
+// of the kernel arguments (a dynamically indexed pointer, then the table entry, then the sign bytes) put three
+// dependent memory round trips in front of every unit.
+struct UnitRec {
+    uint32_t off, hs, R, enc;
+};
+
+__device__ __forceinline__ UnitRec load_unit(const FusedFieldArgs& p, uint32_t u)
+{
+    const uint4 v = p.units[u];
+    return UnitRec{v.x, v.y, v.z, v.w};
+}
+
+__device__ __forceinline__ const uint8_t* unit_bits(const FusedFieldArgs& p, uint32_t enc)
+{
+    const uint8_t* b = p.enc[0].bits;
+    b = enc == 1 ? p.enc[1].bits : b;
+    b = enc == 2 ? p.enc[2].bits : b;
+    b = enc == 3 ? p.enc[3].bits : b;
+    return b;
+}
+
 template <uint32_t D, uint32_t F>
-__device__ __forceinline__ void unit_features(const float (&x)[D], bool inside, const FieldEnc& e, uint32_t level,
-                                              float (&acc)[F])
+__device__ __forceinline__ void unit_issue(const float (&x)[D], bool inside, const uint8_t* __restrict__ bits,
+                                           const UnitRec& r, UnitGather& u)
+{
+    constexpr uint32_t C = 1u << D;
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) { u.tw[q] = 0.0f; u.rb[q] = 0u; }
+    if (!inside) return;
+    const uint32_t off = r.off, hs = r.hs, R = r.R;
+    Corners<D, false> c;
+    c.setup(x, R, hs, 128u, nullptr);
+#pragma unroll
+    for (uint32_t q = 0; q < C; q++) {
+        u.rb[q] = c.valid[q] ? load_row_bits<F>(bits, (uint64_t)off + c.row[q]) : 0u;
+        u.tw[q] = c.valid[q] ? c.w[q] * c.wn_re : 0.0f;
+    }
+}
+
+// ... and in one piece, for the colour variants (no room for a second unit's registers)
+template <uint32_t D, uint32_t F>
+__device__ __forceinline__ void unit_features(const float (&x)[D], bool inside, const uint8_t* __restrict__ bits,
+                                              const UnitRec& r, float (&acc)[F])
 {
     constexpr uint32_t C = 1u << D;
 #pragma unroll
     for (uint32_t k = 0; k < F; k++) acc[k] = 0;
     if (!inside) return;
-    const uint32_t off = (uint32_t)e.offsets[level];
-    const uint32_t hs = (uint32_t)e.offsets[level + 1] - off;
-    const uint32_t R = (uint32_t)e.res[level];
+    const uint32_t off = r.off, hs = r.hs, R = r.R;
     Corners<D, false> c;
     c.setup(x, R, hs, 128u, nullptr);
     uint32_t rb[C];
 #pragma unroll
-    for (uint32_t q = 0; q < C; q++) rb[q] = c.valid[q] ? load_row_bits<F>(e.bits, (uint64_t)off + c.row[q]) : 0u;
+    for (uint32_t q = 0; q < C; q++) rb[q] = c.valid[q] ? load_row_bits<F>(bits, (uint64_t)off + c.row[q]) : 0u;
 #pragma unroll
     for (uint32_t q = 0; q < C; q++) {
         const float tw = c.valid[q] ? c.w[q] * c.wn_re : 0.0f;
@@ -193,6 +241,21 @@ __device__ __forceinline__ void unit_features(const float (&x)[D], bool inside, 
         for (uint32_t k = 0; k < F; k++) {
             const float s = ((rb[q] >> k) & 1u) ? 1.0f : -1.0f;
             acc[k] = __builtin_fmaf(tw, s, acc[k]);
+        }
+    }
+}
+
+template <uint32_t C, uint32_t F>
+__device__ __forceinline__ void unit_consume(const UnitGather& u, float (&acc)[F])
+{
+#pragma unroll
+    for (uint32_t k = 0; k < F; k++) acc[k] = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < C; q++) {
+#pragma unroll
+        for (uint32_t k = 0; k < F; k++) {
+            const float s = ((u.rb[q] >> k) & 1u) ? 1.0f : -1.0f;
+            acc[k] = __builtin_fmaf(u.tw[q], s, acc[k]);
         }
     }
 }
@@ -251,36 +314,83 @@ struct RowF16 {
 
 // Columns [w0, w0 + 16) of the feature row of one sample into its row of the chunk tile (`trow`, chunk-relative
 // column w0 & 31).  Feature row = [units: n_units x F | x (3) | sin(f_k x) (3), cos(f_k x) (3) for k < n_freqs | 0 ...].
-template <uint32_t F, typename Row>
+template <uint32_t F, bool PAIR, typename Row>
 __device__ __forceinline__ void fill_window(const FusedFieldArgs& p, const float (&xu)[3], uint32_t w0, const Row& trow)
 {
+    constexpr uint32_t B = PAIR ? 2u : 1u;            // units gathered before any is consumed
     constexpr uint32_t V = F < 4 ? F : 4;
     const uint32_t U = p.n_units * F;                 // first sinusoid column
     const bool in_x = xu[0] >= 0.0f && xu[0] <= 1.0f, in_y = xu[1] >= 0.0f && xu[1] <= 1.0f,
                in_z = xu[2] >= 0.0f && xu[2] <= 1.0f;
-    const uint32_t L3 = p.enc[0].n_levels, L2 = p.enc[1].n_levels;
+    if constexpr (!PAIR) {
 #pragma unroll
-    for (uint32_t s = 0; s < 16 / F; s++) {
-        const uint32_t col = w0 + s * F;
-        const uint32_t u = col / F;
-        if (u >= p.n_units) break;
-        float a[F];
-        if (u < L3) {
-            unit_features<3, F>(xu, in_x && in_y && in_z, p.enc[0], u, a);
-        } else {
-            const uint32_t q = u - L3, pl = q / L2, level = q - pl * L2;      // plane 0 = xy, 1 = xz, 2 = yz
-            const float    x2[2] = {pl == 2 ? xu[1] : xu[0], pl == 0 ? xu[1] : xu[2]};
-            const bool     in2 = (pl == 2 ? in_y : in_x) && (pl == 0 ? in_y : in_z);
-            unit_features<2, F>(x2, in2, p.enc[1 + pl], level, a);
+        for (uint32_t s = 0; s < 16 / F; s++) {
+            const uint32_t u = (w0 + s * F) / F;
+            if (u >= p.n_units) break;
+            float a[F];
+            const UnitRec  rec = load_unit(p, u);
+            const uint8_t* bits = unit_bits(p, rec.enc);
+            if (rec.enc == 0) {
+                unit_features<3, F>(xu, in_x && in_y && in_z, bits, rec, a);
+            } else {
+                const uint32_t pl = rec.enc - 1;                                  // plane 0 = xy, 1 = xz, 2 = yz
+                const float    x2[2] = {pl == 2 ? xu[1] : xu[0], pl == 0 ? xu[1] : xu[2]};
+                const bool     in2 = (pl == 2 ? in_y : in_x) && (pl == 0 ? in_y : in_z);
+                unit_features<2, F>(x2, in2, bits, rec, a);
+            }
+            const uint32_t o = (w0 + s * F) & 31u;
+#pragma unroll
+            for (uint32_t k = 0; k < F; k += V) {
+                float v[V];
+#pragma unroll
+                for (uint32_t j = 0; j < V; j++) v[j] = a[k + j];
+                trow.template put<V>(o + k, v);
+            }
         }
-        const uint32_t o = (w0 + s * F) & 31u;
+    } else {
+    // two units at a time: their gathers issued, then consumed (16 more registers: not in the colour variants, which
+    // sit at the 256-register limit of two waves per SIMD)
 #pragma unroll
-        for (uint32_t k = 0; k < F; k += V) {
-            float v[V];
+    for (uint32_t s0 = 0; s0 < 16 / F; s0 += B) {
+        UnitGather ug[B];
+        bool       is3[B], live[B];
 #pragma unroll
-            for (uint32_t j = 0; j < V; j++) v[j] = a[k + j];
-            trow.template put<V>(o + k, v);
+        for (uint32_t j = 0; j < B; j++) { is3[j] = false; live[j] = false; }
+#pragma unroll
+        for (uint32_t j = 0; j < B; j++) {
+            const uint32_t s = s0 + j;
+            if (s >= 16 / F) continue;
+            const uint32_t u = (w0 + s * F) / F;
+            if (u >= p.n_units) continue;
+            live[j] = true;
+            const UnitRec  rec = load_unit(p, u);
+            const uint8_t* bits = unit_bits(p, rec.enc);
+            if (rec.enc == 0) {
+                is3[j] = true;
+                unit_issue<3, F>(xu, in_x && in_y && in_z, bits, rec, ug[j]);
+            } else {
+                const uint32_t pl = rec.enc - 1;                                  // plane 0 = xy, 1 = xz, 2 = yz
+                const float    x2[2] = {pl == 2 ? xu[1] : xu[0], pl == 0 ? xu[1] : xu[2]};
+                const bool     in2 = (pl == 2 ? in_y : in_x) && (pl == 0 ? in_y : in_z);
+                unit_issue<2, F>(x2, in2, bits, rec, ug[j]);
+            }
         }
+#pragma unroll
+        for (uint32_t j = 0; j < B; j++) {
+            if (!live[j]) continue;
+            float a[F];
+            if (is3[j]) unit_consume<8, F>(ug[j], a);
+            else unit_consume<4, F>(ug[j], a);
+            const uint32_t o = (w0 + (s0 + j) * F) & 31u;
+#pragma unroll
+            for (uint32_t k = 0; k < F; k += V) {
+                float v[V];
+#pragma unroll
+                for (uint32_t jj = 0; jj < V; jj++) v[jj] = a[k + jj];
+                trow.template put<V>(o + k, v);
+            }
+        }
+    }
     }
     // the part of the window behind the units: raw coordinates, sinusoids, zero padding
     const uint32_t lo = w0 > U ? w0 : U, hi = w0 + 16;
@@ -332,7 +442,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused(FusedFieldArgs p)
                 sel = sel && v > 0.0f && v < 1.0f;
             }
         }
-        const uint64_t selmask = __ballot(sel);          // bit r (< 32) = selector of sample r
+        [[maybe_unused]] const uint64_t selmask = __ballot(sel);          // bit r (< 32) = selector of sample r
 
         // ---- layer 1, chunk by chunk ----
         f32x16 acc[NT];
@@ -342,7 +452,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused(FusedFieldArgs p)
         load_w<NT>(W1, 0, lane, wn);
         float* trow = lds + i * kChunkPitch;
         for (uint32_t c = 0; c * 4 < p.nkb1; c++) {
-            fill_window<F>(p, xu, c * 32 + 16 * h, RowF32{trow});
+            fill_window<F, !RGB>(p, xu, c * 32 + 16 * h, RowF32{trow});
             wave_lds_order();
 #pragma unroll
             for (uint32_t kb = 0; kb < 4; kb++) {
@@ -545,12 +655,36 @@ __device__ __forceinline__ void layer_lds16(const half_t* __restrict__ a_hi, con
 }
 
 // x = acc / 2^8 + bias (+ ReLU) -> the two half planes, C layout -> row-major
+// C layout -> plane index of accumulator element v of lane (i, h), output column `col_lane` + 32 t (col_lane = i, or
+// i + 15 for the head input): row r = 8 (v >> 2) + 4 h + (v & 3), so the row's swizzle (r >> 2) & 3 = (2 (v >> 2) + h) & 3
+// = k | h with k = 2 ((v >> 2) & 1) known at compile time — two lane bases (k = 0, 2) and immediates, instead of an
+// address computation per element (which cost the colour variant 100 spilled registers).
+template <int NT>
+struct CLayoutAt {
+    uint32_t base[2];                    // k = 0, k = 2
+    __device__ __forceinline__ CLayoutAt(uint32_t h, uint32_t col_lane)
+    {
+        using P = HPlane<NT>;
+        const uint32_t chunk = col_lane >> 3, within = col_lane & 7u;
+        if constexpr (NT == 5) {
+            base[0] = 4 * h * P::ld + (((chunk & 4u) | ((chunk & 3u) ^ h)) << 3) + within;
+            base[1] = 4 * h * P::ld + (((chunk & 4u) | ((chunk & 3u) ^ (2u | h))) << 3) + within;
+        } else {
+            base[0] = base[1] = 4 * h * P::ld + col_lane;
+        }
+    }
+    __device__ __forceinline__ uint32_t operator()(int t, int v) const
+    {
+        return base[(v >> 2) & 1] + (uint32_t)(8 * (v >> 2) + (v & 3)) * HPlane<NT>::ld + (uint32_t)t * 32u;
+    }
+};
+
 template <bool RELU, int NT>
 __device__ __forceinline__ void acc_to_lds16(half_t* __restrict__ d_hi, half_t* __restrict__ d_lo,
                                              const float* __restrict__ bias, const f32x16 (&acc)[NT], uint32_t lane)
 {
-    using P = HPlane<NT>;
     const uint32_t i = lane & 31u, h = lane >> 5;
+    const CLayoutAt<NT> at(h, i);
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         const float b = bias[t * 32 + i];
@@ -560,9 +694,8 @@ __device__ __forceinline__ void acc_to_lds16(half_t* __restrict__ d_hi, half_t* 
             if (RELU) x = x > 0 ? x : 0;
             half_t xh, xl;
             split_half(x, xh, xl);
-            const uint32_t at = P::at(8 * (v >> 2) + 4 * h + (v & 3), t * 32 + i);
-            d_hi[at] = xh;
-            d_lo[at] = xl;
+            d_hi[at(t, v)] = xh;
+            d_lo[at(t, v)] = xl;
         }
     }
 }
@@ -600,7 +733,6 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
                 sel = sel && v > 0.0f && v < 1.0f;
             }
         }
-        const uint64_t selmask = __ballot(sel);
 
         // ---- layer 1: a chunk = 32 columns = two K-steps of 16 ----
         f32x16 acc[NT];
@@ -613,7 +745,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
         const RowF16 trow{c_hi + i * kChunkPitch16, c_lo + i * kChunkPitch16};
         const uint32_t n_chunks = p.nk16_1 / 2;
         for (uint32_t c = 0; c < n_chunks; c++) {
-            fill_window<F>(p, xu, c * 32 + 16 * h, trow);
+            fill_window<F, !RGB>(p, xu, c * 32 + 16 * h, trow);
             wave_lds_order();
             if constexpr (!kAcrossFill) load_w16<NT>(W1, 2 * c, lane, wh0, wl0);
             load_w16<NT>(W1, 2 * c + 1, lane, wh1, wl1);
@@ -668,6 +800,12 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
             layer_lds16<NT2, NT>(h_hi, h_lo, NT * 2, p.Wp16[1], acc2, lane);
             const uint32_t Kh = p.nk16_h * 16;
             wave_lds_order();
+            const CLayoutAt<NT> hin_at(h, i + 15);             // output column c -> head-input column 15 + c
+            // density_raw (output column 0, held by the two lanes with i = 0 for 16 samples each) goes through a float
+            // slot at the end of each sample's row of the hi plane — the head input only uses the first Kh <= 96 (64)
+            // columns and its swizzle stays inside them — so that ONE lane per sample evaluates the exponential and
+            // the store is coalesced (16 inlined expf under a divergent branch cost the kernel 40 spilled registers)
+            constexpr uint32_t kDensAt = NT == 5 ? 152u : 64u;
 #pragma unroll
             for (int t = 0; t < NT2; t++) {
                 const uint32_t col = t * 32 + i;
@@ -677,12 +815,12 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
                     const uint32_t r = 8 * (v >> 2) + 4 * h + (v & 3);
                     const float    x = __builtin_fmaf(acc2[t][v], kWeightScaleInv, b);
                     if (col == 0) {
-                        if (row0 + r < p.N) p.density[row0 + r] = expf(x - 1.0f) * (float)((selmask >> r) & 1ull);
+                        *reinterpret_cast<float*>(h_hi + r * ldh + kDensAt) = x;
                     } else if (15 + col < Kh) {
                         half_t xh, xl;
                         split_half(col <= p.geo ? x : 0.0f, xh, xl);
-                        h_hi[HP::at(r, 15 + col)] = xh;
-                        h_lo[HP::at(r, 15 + col)] = xl;
+                        h_hi[hin_at(t, v)] = xh;
+                        h_lo[hin_at(t, v)] = xl;
                     }
                 }
             }
@@ -705,6 +843,10 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
                 }
             }
             wave_lds_order();
+            if (h == 0 && live) {
+                const float x = *reinterpret_cast<const float*>(h_hi + i * ldh + kDensAt);
+                p.density[row] = expf(x - 1.0f) * (sel ? 1.0f : 0.0f);
+            }
             layer_lds16<NT, NT>(h_hi, h_lo, p.nk16_h, p.Wp16[2], acc, lane);
             wave_lds_order();
             acc_to_lds16<true, NT>(h_hi, h_lo, p.Bp[2], acc, lane);
@@ -813,6 +955,8 @@ extern "C" int cnc_field_fused_forward(const cnc_fused_field_t* f, const float* 
         units += f->n_levels[e];
     }
     if (f->n_levels[1] != f->n_levels[2] || f->n_levels[1] != f->n_levels[3]) return CNC_ERR_UNSUPPORTED;
+    if (!f->units) return CNC_ERR_INVALID_VALUE;
+    p.units = reinterpret_cast<const uint4*>(f->units);
     if (f->n_freqs == 0) return CNC_ERR_UNSUPPORTED;
     if (!f->freqs) return CNC_ERR_INVALID_VALUE;
     p.freqs = f->freqs; p.n_freqs = f->n_freqs; p.n_units = units;

@@ -321,6 +321,7 @@ class FusedFieldForward:
         self.field = field
         self._key = None
         self._buffers = None
+        self._units = None
         _caches.register(self)
 
     def invalidate_caches(self):
@@ -414,6 +415,14 @@ class FusedFieldForward:
             st.packed_weights[k], st.packed_biases[k] = buf["w"][k].data_ptr(), buf["b"][k].data_ptr()
             st.packed_weights16[k] = buf["w16"][k].data_ptr()
         st.w2_row0 = buf["row0"].data_ptr()
+        if self._units is None or self._units.device != dev:
+            # the level tables as one record per (encoder, level) unit, in feature-row order (static per model)
+            recs = []
+            for k, e in enumerate(mb._encoders()):
+                for l in range(e.n_levels):
+                    recs.append([e._off_host[l], e._off_host[l + 1] - e._off_host[l], e._res_host[l], k])
+            self._units = torch.tensor(recs, dtype=torch.int32).to(dev).contiguous()
+        st.units = self._units.data_ptr()
         st.n_features, st.n_neurons, st.geo_feat_dim = mb.encoding_xyz.n_features, mb.network[0].out_features, f.geo_feat_dim
         st.flags = (_lib.CNC_FIELD_SH_FP16 if f.sh_fp16_round else 0) | \
                    (_lib.CNC_FIELD_MFMA_F16X3 if f.fused_field_precision == "f16x3" else 0)

@@ -618,6 +618,9 @@ typedef struct {
     const float*   packed_biases[5];   /*   (entries 2..4 may be NULL for density-only calls)                      */
     const float*   w2_row0;            /* base.2.weight[0, :] padded to n_neurons (density-only calls)             */
     const void*    packed_weights16[5];/* cnc_field_pack_layer16 of the same five layers (CNC_FIELD_MFMA_F16X3)     */
+    const uint32_t* units;             /* [sum n_levels][4] on the device, in feature-row order (xyz levels, then the
+                                          xy, xz, yz planes' levels): {offsets[l], offsets[l+1] - offsets[l],
+                                          resolutions[l], encoder 0..3} — the level tables as one record per unit   */
     uint32_t       n_levels[4];        /* the three planes must have the same number of levels                    */
     uint32_t       n_features;         /* F per level: 2, 4 or 8                                                  */
     uint32_t       n_freqs;            /* > 0 (the reference always embeds, ngp.py:433)                           */
