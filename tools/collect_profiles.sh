@@ -28,6 +28,12 @@ if [ "$WHAT" = "all" ]; then
   timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_field -o p -- python $ROOT/tools/bench_field.py --reps 3 > $OUT/pmc_field.log 2>&1
   CNC_FUSED_FIELD_MFMA=f32 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_field_f32 -o p -- python $ROOT/tools/bench_field.py --only fused --reps 3 > $OUT/pmc_field_f32.log 2>&1
   timeout 600 python $ROOT/tools/bench_field.py > $OUT/field_untraced.log 2>&1
+  # the 800x800 evaluation render: kernel stats; the training step's phase timeline (no profiler) and library launches
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_eval -o eval -- python $ROOT/tools/bench_eval.py > $OUT/eval.log 2>&1
+  timeout 600 python $ROOT/tools/bench_eval.py > $OUT/eval_untraced.log 2>&1
+  timeout 600 python $ROOT/tools/step_phases.py > $OUT/step_phases.txt 2>&1
+  timeout 600 python $ROOT/tools/aten_by_range.py > $OUT/aten_by_range.txt 2>&1
+  timeout 600 python $ROOT/tools/bench_train.py --no-profile > $OUT/train_untraced.log 2>&1
 fi
 find $OUT -name "*kernel_trace.csv" -delete      # large; the stats csv is what is kept
 find $OUT -name "*.db" -delete

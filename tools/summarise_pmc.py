@@ -131,5 +131,66 @@ if os.path.exists(os.path.join(src, "train.log")):
     open(os.path.join(P, f"{TAG}_train_step.log"), "w").write(
         "# tools/bench_train.py --no-profile under rocprofv3 --kernel-trace --stats (tracing overhead included;\n"
         "# untraced: tools/profile_train_step.py / bench.py train_step)\n" + "".join(keep))
+hits = glob.glob(os.path.join(src, "stats_eval", "**", "*kernel_stats.csv"), recursive=True)
+if hits:
+    shutil.copy(hits[0], os.path.join(P, f"{TAG}_eval_render_kernel_stats.csv"))
+
+
+def _grep(path, pat):
+    return [l.rstrip() for l in open(path)] if os.path.exists(path) and pat is None else \
+        ([l.rstrip() for l in open(path) if re.search(pat, l)] if os.path.exists(path) else [])
+
+
+# the training step's phase timeline + where the library launches come from
+ph = _grep(os.path.join(src, "step_phases.txt"), r"^boundary|^\w+(:begin)? +\w{3} +[0-9.]+ +[0-9.]+")
+ab = _grep(os.path.join(src, "aten_by_range.txt"), None)
+if ph:
+    with open(os.path.join(P, f"{TAG}_train_step_phases.md"), "w") as fh:
+        fh.write(f"# {TAG} — where a training step's wall time goes (full model, F = 8, one MI355X)\n\n"
+                 "`python tools/step_phases.py`: host clock and a HIP event at every phase boundary of `Trainer.train_step`, both\n"
+                 "host threads (`Mai` = main: fetch, occupancy, render, optimisers; `cnc` = the context thread), no profiler;\n"
+                 "host ms / GPU ms since the step's start, mean over the non-refresh steps.  host > gpu at a boundary: the GPU\n"
+                 "had finished that work before the host returned (host-bound there); gpu > host: the GPU is behind.\n\n```\n"
+                 + "\n".join(ph) + "\n```\n\n" +
+                 "\n".join(_grep(os.path.join(src, "train_untraced.log"), r"^train step")) + "\n")
+        if ab:
+            i = next((k for k, l in enumerate(ab) if l.startswith("library kernels")), 0)
+            fh.write("\n## Library (ATen / rocPRIM / copy) launches of one step by call site (`tools/aten_by_range.py`, sequential schedule)\n\n```\n"
+                     + "\n".join(ab[i:i + 45]) + "\n```\n")
+
+# MFMA busy of the fused field kernels (and of the chain's GEMMs beside them)
+rows = []
+for sub, label in (("pmc_field", "default (fp16 three-product MFMA)"), ("pmc_field_f32", "CNC_FUSED_FIELD_MFMA=f32 (exact fp32 MFMA)")):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            acc[re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, d in acc.items():
+        if not ("k_field_fused" in k or k.startswith("Cijk") or "fwd_bits" in k):
+            continue
+        n = len(d.get("GRBM_GUI_ACTIVE", []))
+        if not n:
+            continue
+        mean = lambda c: sum(d.get(c, [0])) / max(len(d.get(c, [0])), 1)
+        cyc = mean("GRBM_GUI_ACTIVE") / 8.0                      # per XCD: the kernel's duration in shader cycles
+        rows.append((label, k[:70], n, mean("SQ_INSTS_MFMA"), mean("SQ_VALU_MFMA_BUSY_CYCLES"), mean("SQ_INSTS_VALU"), cyc,
+                     mean("SQ_VALU_MFMA_BUSY_CYCLES") / 1024.0 / max(cyc, 1), mean("SQ_INSTS_VALU") * 4.0 / 1024.0 / max(cyc, 1)))
+if rows:
+    with open(os.path.join(P, f"{TAG}_mfma_utilisation.md"), "w") as fh:
+        fh.write(f"# {TAG} — matrix-pipe and vector-pipe occupancy of the gradient-free field (MI355X, N = 2^20, F = 8)\n\n"
+                 "`rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE`\n"
+                 "around `tools/bench_field.py` (fused kernel and the chain it replaces; `tools/collect_profiles.sh`).  duration =\n"
+                 "GRBM_GUI_ACTIVE / 8 XCDs (shader cycles, profiled run); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs /\n"
+                 "duration; vector issue = SQ_INSTS_VALU x 4 cycles / 1024 SIMDs / duration (MFMA instructions included).  The f32\n"
+                 "MFMA runs at the vector rate and shares its issue with the gather (busy + issue ~ the kernel); the fp16 form is\n"
+                 "a sixth of the matrix cycles on the real matrix pipe (DESIGN 4.5).\n\n"
+                 "| run | kernel | dispatches | MFMA instr | MFMA busy cycles | VALU instr | duration (cycles) | MFMA busy | vector issue |\n|---|---|---|---|---|---|---|---|---|\n")
+        for r in sorted(rows, key=lambda t: (t[0], -t[6])):
+            fh.write(f"| {r[0]} | `{r[1]}` | {r[2]} | {r[3]:.3g} | {r[4]:.3g} | {r[5]:.3g} | {r[6]:.3g} | {r[7] * 100:.1f} % | {r[8] * 100:.1f} % |\n")
+        fh.write("\nWall clock of the same calls, untraced (`tools/bench_field.py`):\n\n```\n" +
+                 "\n".join(_grep(os.path.join(src, "field_untraced.log"), r"^(fused|chain)")) + "\n```\n")
+ev = _grep(os.path.join(src, "eval_untraced.log"), r"^eval render")
+if ev:
+    open(os.path.join(P, f"{TAG}_eval_render.log"), "w").write("# tools/bench_eval.py, untraced (200 training steps of the full model, then 800x800)\n" + "\n".join(ev) + "\n")
 print(open(os.path.join(P, f"{TAG}_pmc_hbm_traffic.csv")).read())
 print(json.dumps({k: v for k, v in traffic.items() if not k.startswith("_")}, indent=1)[:3000])
