@@ -951,7 +951,7 @@ static void launch_fwd_bits(const float* inputs, const uint8_t* bits, const int3
     }
     // wave-transposed stores (see the kernel): whenever a point's piece is 2, 4 or 8 whole 16-byte chunks in every
     // pass and the rows keep them aligned (CNC_FWD_TR=0: measurement switch, the round-3 per-lane stores)
-    static const int tr_mode = getenv("CNC_FWD_TR") ? atoi(getenv("CNC_FWD_TR")) : 1;
+    const int tr_mode = getenv("CNC_FWD_TR") ? atoi(getenv("CNC_FWD_TR")) : 1;
     const uint32_t W = P * F, tail = (L % P) * F;
     const bool tr = tr_mode && (W == 8 || W == 16 || W == 32) && tail % 4 == 0 && lay.ld % 4 == 0 && lay.col % 4 == 0 &&
                     (reinterpret_cast<uintptr_t>(outputs) & 15u) == 0;
@@ -959,7 +959,7 @@ static void launch_fwd_bits(const float* inputs, const uint8_t* bits, const int3
     // streaming stores of the level-major outputs (a wave writes whole lines): the bit plane keeps the L2
     // (CNC_FWD_NT=0: measurement switch).  Point-major rows: only with the transposed stores — a lane's own 16-byte
     // pieces need the L2 to merge into lines (streamed they cost 3.7x).
-    static const int nt_mode = getenv("CNC_FWD_NT") ? atoi(getenv("CNC_FWD_NT")) : 1;
+    const int nt_mode = getenv("CNC_FWD_NT") ? atoi(getenv("CNC_FWD_NT")) : 1;
     lay.nt = (nt_mode == 1 && lay.ld == 0) || (nt_mode == 2 && tr) ? 1u : 0u;
     const dim3 grid(div_up(N, 256), div_up(L, P), 1);
     const size_t lds = tr ? (size_t)256 * W * sizeof(float) : 0;

@@ -250,9 +250,9 @@ void launch_bwd_merge(const float* grad, const float* inputs, const float* emb, 
 {
     lay.n_slots = L;
     const dim3 grid(div_up(N, kMB) * L);
-    // measurement switch: bytes of unused dynamic LDS per block (> 10 KB leaves ONE block per CU, i.e. half the wave slots
-    // and ~85 KB of LDS free for the owner waves of the binned levels running next to this kernel)
-    static const uint32_t pad = getenv("CNC_MERGE_PAD_LDS") ? (uint32_t)atoi(getenv("CNC_MERGE_PAD_LDS")) : 0u;
+    // (round 3 measured this kernel with padded dynamic LDS — one block per CU, to leave room for the owner waves of
+    // the binned levels: slower; the switch is gone, the library keeps no state between calls)
+    const uint32_t pad = 0u;
     if (ste) hipLaunchKernelGGL((k_grid_encode_bwd_merge<true>), grid, dim3(kMB), pad, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
     else hipLaunchKernelGGL((k_grid_encode_bwd_merge<false>), grid, dim3(kMB), pad, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
 }

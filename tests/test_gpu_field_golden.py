@@ -375,7 +375,10 @@ def test_training_trajectory(cuda, tag, fused, tmp_path):
             print(k, "want", np.array2string(g[k], precision=5, max_line_width=250))
     # ---- while no table entry has a different sign: the same model, so the same numbers (at least the first 3 steps)
     agree = next((k for k, d in enumerate(differ) if d), steps)
-    assert agree >= 3, differ       # measured: 8 (reference schedule) / 4 (compressed warm-up), on every run so far
+    print("steps before the first differing sign:", agree, "(tag", tag, "fused", fused, ")")
+    # measured on every run so far: 8 (reference schedule) / 4 (compressed warm-up) — rounds 3 and 4, with and without
+    # the fused field kernel in the sampler; one step of slack
+    assert agree >= (7 if tag == "ref" else 3), differ
     for k in range(agree):
         assert r["n_samples"][k] == g["n_samples"][k] and r["num_rays"][k] == g["num_rays"][k], k
         assert r["occupied"][k] == g["occupied"][k], k
