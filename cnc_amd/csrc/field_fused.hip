@@ -264,6 +264,7 @@ __device__ __forceinline__ void unit_consume(const UnitGather& u, float (&acc)[F
 // planes, x = hi + lo with hi = half(x), lo = half(x - hi) — 22 bits of x — the A operands of the three-product
 // fp16 MFMA scheme (see k_field_fused16).
 struct RowF32 {
+    static constexpr bool kFastSin = false;
     float* row;
     template <uint32_t V>
     __device__ __forceinline__ void put(uint32_t col, const float (&v)[V]) const { store_vec<V>(row + col, v); }
@@ -282,6 +283,7 @@ __device__ __forceinline__ void split_half(float x, half_t& hi, half_t& lo)
 }
 
 struct RowF16 {
+    static constexpr bool kFastSin = true;
     half_t* hi;
     half_t* lo;
     template <uint32_t V>
@@ -311,6 +313,20 @@ struct RowF16 {
         lo[col] = y;
     }
 };
+
+// sin and cos of x in [0, 512] (a unit-cube coordinate times 2^k) on the hardware's v_sin_f32 / v_cos_f32 (arguments in
+// revolutions) behind a two-term 1 / (2 pi) reduction: 8 instructions instead of ocml's ~80 for sincosf, 2.6e-7 from
+// the float64 value where sincosf is 7e-8 (tools/sincos_probe.hip, 4 M arguments) — used by the fp16 kernels, whose
+// products carry 5e-7 anyway; the exact-fp32 kernels keep sincosf.
+__device__ __forceinline__ void fast_sincos(float x, float* s, float* c)
+{
+    const float hi = 0.15915494f, lo = 6.4206383e-09f;       // 1 / (2 pi) = hi + lo
+    const float q = rintf(x * hi);
+    float r = __builtin_fmaf(x, hi, -q);
+    r = __builtin_fmaf(x, lo, r);
+    *s = __builtin_amdgcn_sinf(r);
+    *c = __builtin_amdgcn_cosf(r);
+}
 
 // Columns [w0, w0 + 16) of the feature row of one sample into its row of the chunk tile (`trow`, chunk-relative
 // column w0 & 31).  Feature row = [units: n_units x F | x (3) | sin(f_k x) (3), cos(f_k x) (3) for k < n_freqs | 0 ...].
@@ -409,7 +425,8 @@ __device__ __forceinline__ void fill_window(const FusedFieldArgs& p, const float
         if (r >= 3) continue;
         const float xa = r == 0 ? xu[0] : (r == 1 ? xu[1] : xu[2]);
         float sn, cs;
-        sincosf(xa * p.freqs[k], &sn, &cs);
+        if constexpr (Row::kFastSin) fast_sincos(xa * p.freqs[k], &sn, &cs);
+        else sincosf(xa * p.freqs[k], &sn, &cs);
         if (e >= e_lo) trow.put1((e + U) & 31u, sn);
         if (e + 3 >= e_lo && e + 3 < e_hi) trow.put1((e + 3 + U) & 31u, cs);
     }
