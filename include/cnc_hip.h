@@ -5,8 +5,12 @@
  * (`_gridencoder`, `pack_and_align`, `nerfacc.csrc`); the reference interface each one stands in
  * for is cited next to it (paths relative to the reference checkout).  The ABI is plain C:
  * raw DEVICE pointers, sizes and a HIP stream (passed as void*, i.e. a hipStream_t; NULL = the
- * legacy default stream).  No torch types, no allocation inside the library, no globals: all
- * calls are re-entrant and stream-ordered (asynchronous; nothing here synchronises the device).
+ * legacy default stream).  No torch types, no allocation inside the library, no state kept between
+ * calls: all calls are re-entrant and stream-ordered (asynchronous; nothing here synchronises the
+ * device).  Two exceptions, both opt-in: a cnc_backward_plan object the caller creates and owns, and the
+ * measurement switch cnc_mlp_set_variant (kernel selection for tools/mlp_probe.py; results are the same).
+ * Environment variables named CNC_* that a few entry points read are measurement switches too: they are
+ * read on every call, never cached.
  *
  * Ownership: the caller owns every buffer.  Where the reference's host wrapper allocates its
  * result (torch::zeros / torch::empty inside the extension), the host-side mirror in
