@@ -435,3 +435,76 @@ def test_field_row_buckets_and_vertex_set_host_logic():
                 out.narrow(axis, sft, n).logical_or_(up)
             m = out
         assert torch.equal(torch.nonzero(m), want)
+
+
+def test_gradient_sink_bookkeeping_on_cpu():
+    """cnc_amd._gradsink without a GPU: buffers are handed out by tensor identity, only inside an `activate` scope of
+    the calling thread; `flush` adds what was accumulated to `.grad` (or assigns it), skips what nobody touched, and
+    the arena it hands out is not aliased by the gradient it leaves behind."""
+    import threading
+
+    from cnc_amd import _gradsink as gs
+    torch.manual_seed(0)
+    t1, t2 = torch.nn.Parameter(torch.randn(40, 8)), torch.nn.Parameter(torch.randn(16, 8))
+    w, b = torch.nn.Parameter(torch.randn(4, 9)), torch.nn.Parameter(torch.randn(4))
+    other = torch.nn.Parameter(torch.randn(40, 8))
+    sink = gs.GradSink([t1, t2], [w, b])
+    assert gs.current() is None
+    with gs.activate(sink):
+        assert gs.current() is sink
+        seen = []
+        th = threading.Thread(target=lambda: seen.append(gs.current()))     # another thread: no sink
+        th.start(); th.join()
+        assert seen == [None]
+        with gs.activate(None):
+            assert gs.current() is None
+        assert gs.current() is sink
+    assert gs.current() is None
+    sink.zero()
+    assert sink.table(other) is None and sink.table(t1.detach()[:10]) is None       # not one of its tables / wrong shape
+    v1 = sink.table(t1)
+    v1 += 2.0                                                 # what an encoder backward's atomics would do
+    v1 += 1.0
+    slots = sink.small_slot([w, b, None])
+    assert slots[2] is None and slots[0].numel() == 36 and slots[1].numel() == 4
+    assert sink.small_slot([w, other]) is None                # a parameter the sink does not hold: caller falls back
+    for r in range(gs.REPLICAS):                              # workgroups spread their atomics over the replicas
+        sink.replicas[r, :36] += float(r)
+    t1.grad = torch.ones_like(t1)
+    sink.flush()
+    assert torch.equal(t1.grad, torch.full_like(t1, 4.0))     # 1 (autograd's) + 3 (the sink's)
+    assert t2.grad is None                                    # untouched table: nothing assigned, nothing added
+    assert torch.equal(w.grad, torch.full_like(w, float(sum(range(gs.REPLICAS))))) and torch.equal(b.grad, torch.zeros(4))
+    t1.grad = None
+    sink.flush()                                              # `.grad` was None: it gets a COPY of the arena's view
+    kept = t1.grad.clone()
+    sink.zero()
+    assert torch.equal(t1.grad, kept) and float(kept.abs().max()) == 3.0
+    sink.flush()                                              # nothing used since zero(): a no-op
+    assert torch.equal(t1.grad, kept)
+    bucket = {id(t1): torch.zeros_like(t1)}
+    sink.table(t1).add_(5.0)
+    sink.flush(grads_of=lambda p: bucket.get(id(p)))          # data-parallel form: add into the bucket's views
+    assert torch.equal(bucket[id(t1)], torch.full_like(t1, 5.0)) and torch.equal(t1.grad, kept)
+
+
+def test_fused_field_shape_table_on_cpu():
+    """Which configurations `FusedFieldForward` takes (the kernel's shape table, include/cnc_hip.h) and which fall
+    back to the chain — decided on the host, no GPU needed."""
+    from cnc_amd.field import FusedFieldForward, NGPRadianceField_mygrid_2D3D
+    base = dict(aabb=[-1.5] * 3 + [1.5] * 3, resolutions_list=(6, 9, 14), log2_hashmap_size=8,
+                resolutions_list_2D=(10, 18), log2_hashmap_size_2D=8)
+    ok = lambda **kw: FusedFieldForward.supported(NGPRadianceField_mygrid_2D3D(**base, **kw))
+    assert ok(n_features_per_level=8, n_neurons=160) and ok(n_features_per_level=4, n_neurons=160)
+    assert ok(n_features_per_level=2, n_neurons=64) and ok(n_features_per_level=4, n_neurons=64)
+    assert not ok(n_features_per_level=8, n_neurons=64)        # geo 79: the head input does not fit 64 columns
+    assert not ok(n_features_per_level=2, n_neurons=128)       # hidden width outside {64, 160}
+    assert not ok(n_features_per_level=1, n_neurons=64)        # F outside {2, 4, 8}
+    assert not ok(n_features_per_level=8, n_neurons=160, unbounded=True)
+    assert not ok(n_features_per_level=8, n_neurons=160, fused_ste=False)
+    f = NGPRadianceField_mygrid_2D3D(**base, n_features_per_level=8, n_neurons=160)
+    assert f.sh_fp16_round and f.fused_field and f.fused_field_precision == "f16x3"
+    x = torch.rand(5, 3)
+    assert f._fused_forward(x) is None                          # host tensors, gradients on: the chain
+    with torch.no_grad():
+        assert f._fused_forward(x) is None                      # host tensors: still the chain (no CPU fallback of a kernel)
