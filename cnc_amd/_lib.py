@@ -58,6 +58,7 @@ SIGNATURES = {
     "cnc_cnt_np_embed": [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp],
     "cnc_cnt_np_embed_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp],
     "cnc_cnt_np_plan": [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp],
+    "cnc_cnt_np_plan3": [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
     "cnc_cnt_np_embed_planned": [_vp, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_cnt_np_embed_planned_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_cnt_np_embed_planned_backward3": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp],
@@ -105,8 +106,9 @@ SIGNATURES = {
     "cnc_field_post": [_vp, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp],
     "cnc_field_post_backward": [_vp, _u32, _u32, _vp, _vp, _vp, _u32, _u32, _vp, _vp],
     "cnc_ctx_mlp_forward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp, _vp],
-    "cnc_ctx_mlp_backward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp] * 10 + [_u32, _u32, _vp],
+    "cnc_ctx_mlp_backward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp] * 10 + [_u32, _u32, _u32, _u32, _vp],
     "cnc_ctx_window_gather": [_vp] * 8,
+    "cnc_plane_ring_vertices": [_vp, C.c_uint64, _u32, _u32, C.c_uint64, _vp, _vp, _vp],
     "cnc_bernoulli_bits_partials": [C.c_uint64, _u32],
     "cnc_bernoulli_bits_forward": [_vp, _vp, _vp, C.c_uint64, _u32, _vp, _vp],
     "cnc_bernoulli_bits_backward": [_vp, _vp, _vp, _vp, C.c_uint64, _u32, _vp, _vp, _vp],
@@ -126,7 +128,7 @@ CNC_FIELD_SH_FP16 = 1
 CNC_FIELD_MFMA_F16X3 = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 24          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 25          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

@@ -77,7 +77,7 @@ class ContextMLP(Function):
             g_pg = torch.zeros(n_pg, dtype=torch.float32, device=dev) if pgv is not None else None
             check(_lib.lib().cnc_ctx_mlp_backward(ptr(in_a), Ca, Ca, ptr(in_b), Cb, Cb, ptr(pgv), ptr(pg_index), N, n_layers, F,
                                                   *[ptr(w) for w in ws], ptr(g), ptr(g_a), ptr(g_b), ptr(g_pg),
-                                                  *[ptr(w) for w in slots], _gradsink.REPLICAS, sink.stride(), stream(dev)),
+                                                  *[ptr(w) for w in slots], _gradsink.REPLICAS, sink.stride(), 0, 0, stream(dev)),
                   "ctx_mlp_backward")
             return (g_a, g_b, None if g_pg is None else g_pg.reshape(pg_shape)) + (None,) * 7
         zeroed = torch.zeros(_REPLICAS * total + n_pg, dtype=torch.float32, device=dev)
@@ -89,13 +89,117 @@ class ContextMLP(Function):
             at += 0 if w is None else w.numel()
         check(_lib.lib().cnc_ctx_mlp_backward(ptr(in_a), Ca, Ca, ptr(in_b), Cb, Cb, ptr(pgv), ptr(pg_index), N, n_layers, F,
                                               *[ptr(w) for w in ws], ptr(g), ptr(g_a), ptr(g_b), ptr(g_pg),
-                                              *[ptr(w) for w in first], _REPLICAS, total, stream(dev)), "ctx_mlp_backward")
+                                              *[ptr(w) for w in first], _REPLICAS, total, 0, 0, stream(dev)), "ctx_mlp_backward")
         flat = copies.sum(0) if _REPLICAS > 1 else copies[0]
         gws, at = [], 0
         for w in ws:
             gws.append(None if w is None else flat[at:at + w.numel()].view_as(w))
             at += 0 if w is None else w.numel()
         return (g_a, g_b, None if g_pg is None else g_pg.reshape(pg_shape), *gws, None)
+
+
+class ContextHeads(Function):
+    """Several one-layer heads on row ranges of ONE input matrix (the coded levels of a plane, utils_bpp_acc.py:556-566,
+    evaluated together): rows [r0, r1) of segment i see the columns [c0, c0 + Ca) of in_a, all of in_b and pg[pg_i],
+    through Linear(W_i, b_i).  One output matrix, one gradient matrix per input (columns outside a segment's window get
+    zero), per-head weight gradients — no slicing nodes, no concatenation."""
+
+    @staticmethod
+    def forward(ctx, in_a, in_b, pg, segs, *wb):
+        ctx.set_materialize_grads(False)
+        in_a = _f32c(in_a.contiguous(), "in_a")
+        in_b = None if in_b is None else _f32c(in_b.contiguous(), "in_b")
+        pgv = None if pg is None else _f32c(pg.reshape(-1).contiguous(), "pg")
+        ws = [_f32c(w.contiguous(), "weight") for w in wb]
+        if len(ws) != 2 * len(segs):
+            raise RuntimeError("ContextHeads: one (weight, bias) pair per segment")
+        N, lda = in_a.shape
+        Cb = 0 if in_b is None else in_b.shape[1]
+        F = ws[0].shape[0]
+        out = torch.empty((N, F), dtype=torch.float32, device=in_a.device)
+        L, st = _lib.lib(), stream(in_a.device)
+        at = 0
+        for i, (r0, r1, c0, Ca, pg_i) in enumerate(segs):
+            W, b = ws[2 * i], ws[2 * i + 1]
+            if r0 != at or r1 < r0 or c0 + Ca > lda or W.shape != (F, Ca + Cb + (pgv is not None)) or b.shape != (F,):
+                raise RuntimeError("ContextHeads: segments must tile the rows in order and fit their heads")
+            at = r1
+            if r1 == r0:
+                continue
+            check(L.cnc_ctx_mlp_forward(in_a.data_ptr() + 4 * (r0 * lda + c0), lda, Ca,
+                                        None if in_b is None else in_b.data_ptr() + 4 * r0 * Cb, Cb, Cb,
+                                        None if pgv is None else pgv.data_ptr() + 4 * pg_i, None, r1 - r0, 1, F,
+                                        ptr(W), ptr(b), None, None, None, None, out.data_ptr() + 4 * r0 * F, st),
+                  "ctx_mlp_forward")
+        if at != N:
+            raise RuntimeError("ContextHeads: segments must cover every row")
+        ctx.save_for_backward(in_a, in_b, pgv, *ws)
+        ctx.segs, ctx.pg_shape = tuple(segs), None if pg is None else tuple(pg.shape)
+        from .. import _gradsink
+        ctx.sink = _gradsink.current()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        in_a, in_b, pgv, *ws = ctx.saved_tensors
+        none = (None,) * (4 + len(ws))
+        if g is None:
+            return none
+        g = _f32c(g.contiguous(), "grad_out")
+        dev = in_a.device
+        N, lda = in_a.shape
+        Cb = 0 if in_b is None else in_b.shape[1]
+        F = ws[0].shape[0]
+        full = all(c0 == 0 and Ca == lda for (_, _, c0, Ca, _) in ctx.segs)
+        g_a = (torch.empty_like if full else torch.zeros_like)(in_a)
+        g_b = torch.empty_like(in_b) if (in_b is not None and ctx.needs_input_grad[1]) else None
+        g_pg = torch.zeros_like(pgv) if pgv is not None else None
+        from .. import _gradsink
+        sink = ctx.sink
+        slots = None if sink is None else sink.small_slot(ws)
+        if slots is not None:
+            firsts, reps, stride = slots, _gradsink.REPLICAS, sink.stride()
+        else:
+            total = sum(w.numel() for w in ws)
+            copies = torch.zeros((_REPLICAS, total), dtype=torch.float32, device=dev)
+            firsts, o = [], 0
+            for w in ws:
+                firsts.append(copies[0, o:o + w.numel()])
+                o += w.numel()
+            reps, stride = _REPLICAS, total
+        L, st = _lib.lib(), stream(dev)
+        for i, (r0, r1, c0, Ca, pg_i) in enumerate(ctx.segs):
+            if r1 == r0:
+                continue
+            check(L.cnc_ctx_mlp_backward(in_a.data_ptr() + 4 * (r0 * lda + c0), lda, Ca,
+                                         None if in_b is None else in_b.data_ptr() + 4 * r0 * Cb, Cb, Cb,
+                                         None if pgv is None else pgv.data_ptr() + 4 * pg_i, None, r1 - r0, 1, F,
+                                         ptr(ws[2 * i]), ptr(ws[2 * i + 1]), None, None, None, None,
+                                         g.data_ptr() + 4 * r0 * F, g_a.data_ptr() + 4 * (r0 * lda + c0),
+                                         None if g_b is None else g_b.data_ptr() + 4 * r0 * Cb,
+                                         None if g_pg is None else g_pg.data_ptr() + 4 * pg_i,
+                                         ptr(firsts[2 * i]), ptr(firsts[2 * i + 1]), None, None, None, None,
+                                         reps, stride, lda, Cb, st), "ctx_mlp_backward")
+        g_pg_out = None if g_pg is None else g_pg.reshape(ctx.pg_shape)
+        if slots is not None:
+            return (g_a, g_b, g_pg_out, None) + (None,) * len(ws)
+        flat = copies.sum(0)
+        gws, o = [], 0
+        for w in ws:
+            gws.append(flat[o:o + w.numel()].view_as(w))
+            o += w.numel()
+        return (g_a, g_b, g_pg_out, None, *gws)
+
+
+def context_heads(heads, in_a, in_b, pg, segs):
+    """`ContextHeads` over nn.Linear modules `heads` (one per segment); segs = [(row0, row1, col0, n_cols, pg_index)]."""
+    wb = []
+    for h in heads:
+        lin = [m for m in h if isinstance(m, torch.nn.Linear)] if isinstance(h, torch.nn.Sequential) else [h]
+        if len(lin) != 1:
+            raise RuntimeError("context_heads: every head is one Linear")
+        wb += [lin[0].weight, lin[0].bias]
+    return ContextHeads.apply(in_a, in_b, pg, tuple(tuple(int(v) for v in s) for s in segs), *wb)
 
 
 def context_mlp(seq, in_a, in_b=None, pg=None, pg_index=None):
@@ -201,6 +305,22 @@ class LevelStats(Function):
 
 def level_stats(table, off_host):
     return LevelStats.apply(table, tuple(off_host))
+
+
+def plane_ring_vertices(cells, T, resolution, hashmap_size):
+    """cells i32 [M, 2] (occupied cells of a projected occupancy plane) -> (rows i32 [M (T+2)^2], points f32 [., 2]) of
+    the 2-D level's vertices inside / one ring around them — `fetch_2D_batches` (utils_bpp_acc.py:431-456) as one
+    kernel (cnc_plane_ring_vertices)."""
+    if cells.dim() != 2 or cells.shape[1] != 2 or cells.dtype not in (torch.int32, torch.int64):
+        raise RuntimeError("plane_ring_vertices: cells must be int32 [M, 2]")
+    cells = cells.to(torch.int32).contiguous()
+    check_input(cells, "cells")
+    n = cells.shape[0] * (int(T) + 2) ** 2
+    rows = torch.empty(n, dtype=torch.int32, device=cells.device)
+    points = torch.empty((n, 2), dtype=torch.float32, device=cells.device)
+    check(_lib.lib().cnc_plane_ring_vertices(ptr(cells), cells.shape[0], int(T), int(resolution), int(hashmap_size),
+                                             ptr(rows), ptr(points), stream(cells.device)), "plane_ring_vertices")
+    return rows, points
 
 
 def window_gather(levels, device):

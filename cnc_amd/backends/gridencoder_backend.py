@@ -340,20 +340,21 @@ class VotePlan:
         self.n_pixels = (self.resolution - 2) ** 2
         self._masks = self._masks_key = self._masks_src = None
         L = _lib.lib()
+        # one kernel: table row and the three planes' pixels of every vertex; the vertices cnt_np_embed skips are keyed
+        # past the last row / pixel, so a sort leaves them behind the last segment and nothing is compacted; the same
+        # kernel says which pixel lists are already ascending (the xy plane of an (x, y, z)-sorted list)
         rows = torch.empty(N, dtype=torch.int32, device=dev)
         pix = [torch.empty(N, dtype=torch.int32, device=dev) for _ in range(3)]
-        for axis in range(3):
-            rc = L.cnc_cnt_np_plan(ptr(inputs_i16), N, self.resolution, self.hashmap_size, axis,
-                                   ptr(rows) if axis == 0 else None, ptr(pix[axis]), stream(inputs_i16.device))
-            check(rc, "cnt_np_plan")
-        valid = rows >= 0                       # 0xFFFFFFFF reads as -1
-        rows, pix = rows[valid], [p[valid] for p in pix]
+        unsorted = torch.zeros(3, dtype=torch.int32, device=dev)
+        check(L.cnc_cnt_np_plan3(ptr(inputs_i16), N, self.resolution, self.hashmap_size, ptr(rows), ptr(pix[0]),
+                                 ptr(pix[1]), ptr(pix[2]), ptr(unsorted), stream(dev)), "cnt_np_plan3")
+        unsorted = unsorted.tolist() if N else [0, 0, 0]
         # forward: rows ordered by pixel, per plane (32-bit keys: half the radix passes of int64)
         self.rows_by_pixel, self.pixel_seg = [], []
         for axis in range(3):
             p = pix[axis]
-            if bool((p[1:] >= p[:-1]).all()) if p.numel() > 1 else True:
-                rows_sorted, p_sorted = rows, p         # the xy plane of an (x, y, z)-sorted list
+            if not unsorted[axis]:
+                rows_sorted, p_sorted = rows, p
             else:
                 p_sorted, order = torch.sort(p, stable=True)
                 rows_sorted = rows[order]

@@ -522,6 +522,7 @@ class CNC_context_models(nn.Module):
         self._off3_host = [int(v) for v in self.offsets_list.tolist()]
         self._res3_host = [int(v) for v in resolutions_list.tolist()]
         self._off2_host = [int(v) for v in self.offsets_list_2D.tolist()]
+        self._res2_host = [int(v) for v in self.resolutions_list_2D.tolist()]
 
         # finest level that is still stored densely (utils_bpp_acc.py:288-293)
         self.n_levels_thresh = n_levels - 1
@@ -547,7 +548,7 @@ class CNC_context_models(nn.Module):
                 # unstable CUDA sort leaves that order unspecified; nothing downstream depends on it)
                 indexes_sorted, order = torch.sort(indexes, descending=False, dim=0, stable=True)
                 pos_sorted = torch.index_select(pos_grid.to(torch.int16), dim=0, index=order)
-                unique_value, unique_cnt = torch.unique(indexes_sorted, return_counts=True)
+                unique_value, unique_cnt = torch.unique_consecutive(indexes_sorted, return_counts=True)   # sorted already: no second sort
                 del pos_grid, indexes, indexes_sorted, order
                 _save_level_table(table_cache_dir, R, rows_i, num_dim, pos_sorted, unique_value, unique_cnt)
             if R <= self.resolution_thresh:
@@ -607,6 +608,10 @@ class CNC_context_models(nn.Module):
         self.vote_plan = None
         self.batched_inputs_list = None
         self._rows_2D_cat = [None, None, None]
+        self._plane_cat = [None, None, None]
+        self._noncoded_2D = None
+        # (extension) the coded levels of a plane in one pass instead of one pass per level — same numbers
+        self.plane_batched = os.environ.get("CNC_CTX_PLANE_BATCH", "1") == "1"
 
     # ------------------------------------------------------------------------------- helpers
     def _sample_allocation(self, sample_num):
@@ -639,19 +644,25 @@ class CNC_context_models(nn.Module):
     def fetch_2D_batches(self, binary_vxl_2D, n):
         """All vertices of 2-D level n inside (or one ring around) occupied projected cells:
         their hash rows and normalised positions (utils_bpp_acc.py:431-456)."""
+        # level constants from the host copies and the occupied cells of a plane listed once for its levels: the
+        # refresh pass runs this 9 times inside a training step, each device scalar read here was a stall
         Rb = binary_vxl_2D.shape[-1]
-        T = self.scales_list_2D[n] / Rb
-        assert T % 1 == 0
-        T = int(T)
-        R = self.resolutions_list_2D[n]
-        occ = self.binary_vxl_2D_idx.view(-1, 2)[binary_vxl_2D.reshape(-1) == 1]
-        occ = occ.view(-1, 1, 1, 2) * T
+        R = self._res2_host[n]
+        T, rem = divmod(R - 2, Rb)
+        assert rem == 0
+        cached = getattr(self, "_occ_cells_2D", None)
+        if cached is None or cached[0] is not binary_vxl_2D or cached[1] != binary_vxl_2D._version:
+            cached = (binary_vxl_2D, binary_vxl_2D._version,
+                      self.binary_vxl_2D_idx.view(-1, 2)[binary_vxl_2D.reshape(-1) == 1])
+            self._occ_cells_2D = cached
+        if self.fused_segments and cached[2].is_cuda:
+            return _ctxk.plane_ring_vertices(cached[2].contiguous(), T, R, self._off2_host[n + 1] - self._off2_host[n])
+        occ = cached[2].view(-1, 1, 1, 2) * T
         ar = torch.arange(0, T + 2, device=self.dev)
         ring = torch.stack(torch.meshgrid(ar, ar, indexing="ij"), dim=-1).view(1, T + 2, T + 2, 2)
-        points_n_orig = (occ + ring + 0.0).to(torch.long)
-        indexes_2D = get_grid_index(int(self.offsets_list_2D[n + 1] - self.offsets_list_2D[n]),
-                                    int(R.item()), points_n_orig.view(-1, 2))
-        points_n = (points_n_orig - 0.5) / self.scales_list_2D[n].item()
+        points_n_orig = (occ + ring).to(torch.long)
+        indexes_2D = get_grid_index(self._off2_host[n + 1] - self._off2_host[n], R, points_n_orig.view(-1, 2))
+        points_n = (points_n_orig - 0.5) / float(R - 2)
         return indexes_2D, points_n.view(-1, 2)
 
     def get_STE_params(self, Encoding, mode="ste_binary"):
@@ -855,8 +866,52 @@ class CNC_context_models(nn.Module):
     def _sorted_slots_2D(self, binary_vxl_2D, n):
         indexes_2D, points_n = self.fetch_2D_batches(binary_vxl_2D, n)
         indexes_sorted, order = torch.sort(indexes_2D, descending=False, dim=0, stable=True)
-        unique_value, unique_cnt = torch.unique(indexes_sorted, return_counts=True)
-        return points_n, order, unique_value.to(torch.long) + self.offsets_list_2D[n], unique_cnt
+        unique_value, unique_cnt = torch.unique_consecutive(indexes_sorted, return_counts=True)   # sorted already: no second sort
+        return points_n, order, unique_value.to(torch.long) + self._off2_host[n], unique_cnt
+
+    def _plane_batch_ok(self, p_q):
+        """The coded levels of a plane can be evaluated together when every one of them looks at the levels below it
+        down to level 0 (n <= max_context_layer_num: the windows [n - min(n, max), n) all start at 0) and the fused
+        kernels are in use."""
+        coded = [n for n in range(self.n_levels_2D) if self._coded_2D(n)]
+        return (self.plane_batched and self.fused_heads and self.fused_segments and p_q.is_cuda and len(coded) > 1
+                and min(coded) >= 1 and max(coded) <= self.max_context_layer_num)
+
+    def _plane_bits(self, k, Ec, p_q, Pg_all, bits_all, binary_vxl_2D, pn_frac, refresh):
+        """Rate of one plane's table: zero-order bits of the levels that are not coded + the context-coded levels
+        (utils_bpp_acc.py:556-572 for n = 1 ..) as ONE encoder call over the concatenated vertex lists (levels
+        [0, max n); level n's head reads the first n F columns), one dimension-wise lookup, the heads on their row
+        ranges, one per-slot mean, one rate kernel.  Same numbers as the level-by-level loop; a third of the launches."""
+        coded = [n for n in range(self.n_levels_2D) if self._coded_2D(n)]
+        F = self.n_features
+        if refresh or self._plane_cat[k] is None:
+            levels = self.batched_inputs_list[k]
+            at, p_at = 0, []
+            for (pts, *_rest) in levels:
+                p_at.append(at)
+                at += pts.shape[0]
+            p_at.append(at)
+            cnt = torch.cat([lv[3] for lv in levels])
+            self._plane_cat[k] = dict(
+                pts=torch.cat([lv[0] for lv in levels]).contiguous(),
+                order=torch.cat([lv[1] + p_at[i] for i, lv in enumerate(levels)]),
+                rows=torch.cat([lv[2] for lv in levels]), cum=_cum(cnt),
+                segs=[(p_at[i], p_at[i + 1], 0, n * F, n) for i, n in enumerate(coded)])
+            if self._noncoded_2D is None or self._noncoded_2D.device != bits_all.device:
+                self._noncoded_2D = torch.tensor([0.0 if n in coded else 1.0 for n in range(self.n_levels_2D)],
+                                                 dtype=bits_all.dtype, device=bits_all.device)
+        pb = self._plane_cat[k]
+        with _range("ctx/2D_mean"):
+            context = Ec(pb["pts"], 0, max(coded), binary_vxl=binary_vxl_2D, PV=0)
+            context_pn = None
+            if self.use_dimension_wise:
+                context_pn = Ec.forward_given_params(pb["pts"], self.pn_frac_offsets_list, self.pn_frac_resolutions_list,
+                                                     pn_frac, binary_vxl_2D)
+            mean_pts = _ctxk.context_heads([self.context_model_2D[n - 1] for n in coded], context, context_pn, Pg_all,
+                                           pb["segs"])
+            mean = _segment_reduce.apply(mean_pts, pb["cum"], None, 2, pb["order"])
+        with _range("ctx/2D_entropy"):
+            return torch.dot(bits_all, self._noncoded_2D) + self._bits(p_q, pb["rows"], mean)
 
     def _bits(self, table_q, rows, mean):
         """Rate of the coded rows of a binarised table under the predicted P(+1): sum of
@@ -920,6 +975,12 @@ class CNC_context_models(nn.Module):
             batches = iter(self.batched_inputs_list[k])
             with _range("ctx/level_Pg"):
                 Pg_all, bits_all = self.level_stats(p_q, self._off2_host)
+            if self._plane_batch_ok(p_q):
+                # the coded levels of the plane in one pass (their context windows all start at level 0)
+                ttl_bit_sum = ttl_bit_sum + self._plane_bits(k, Ec, p_q, Pg_all, bits_all, binary_2D[k], pn_frac, refresh)
+                ttl_num_sum += p_q.numel()
+                continue
+            with _range("ctx/level_Pg"):
                 # one unbind each instead of a select per level: a select's backward is a zero-filled [L] vector plus
                 # a copy — 43 five-microsecond kernels per step for the 27 selects of the four tables
                 Pg_all, bits_all = Pg_all.unbind(0), bits_all.unbind(0)

@@ -36,6 +36,42 @@ __global__ __launch_bounds__(256) void k_cnt_plan(const int16_t* __restrict__ in
     if (pixels) pixels[b] = inside ? (u - 1) * (R - 2) + (w - 1) : 0xFFFFFFFFu;
 }
 
+// The whole plan input in one pass: table row and the three planes' pixels of every vertex, skipped vertices keyed
+// PAST the last row / pixel (hs, (R-2)^2) so that a sort leaves them behind the last segment instead of having to be
+// compacted away, and per plane whether the list is already in pixel order (unsorted[a] != 0 if some key is smaller
+// than its predecessor's) — the host then sorts only what needs sorting and reads one 12-byte answer.
+__global__ __launch_bounds__(256) void k_cnt_plan3(const int16_t* __restrict__ inputs, uint32_t N, uint32_t R,
+                                                   uint32_t hs, int32_t* __restrict__ rows,
+                                                   int32_t* __restrict__ pix_xy, int32_t* __restrict__ pix_xz,
+                                                   int32_t* __restrict__ pix_yz, int32_t* __restrict__ unsorted)
+{
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= N) return;
+    const uint32_t S = R - 2, P = S * S;
+    uint32_t       key[2][3];
+#pragma unroll
+    for (int w = 0; w < 2; w++) {                      // w = 1: the predecessor (for the order flags)
+        const uint32_t i = b >= (uint32_t)w ? b - w : b;
+        uint32_t       q[3];
+        bool           inside = true;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            q[d] = (uint32_t)(int32_t)inputs[(size_t)i * 3 + d];
+            inside &= !(q[d] <= 0 || q[d] >= R - 1);
+        }
+        key[w][0] = inside ? (q[0] - 1) * S + (q[1] - 1) : P;
+        key[w][1] = inside ? (q[0] - 1) * S + (q[2] - 1) : P;
+        key[w][2] = inside ? (q[1] - 1) * S + (q[2] - 1) : P;
+        if (w == 0) rows[b] = inside ? (int32_t)grid_row<3>(q, hs, R) : (int32_t)hs;
+    }
+    pix_xy[b] = (int32_t)key[0][0];
+    pix_xz[b] = (int32_t)key[0][1];
+    pix_yz[b] = (int32_t)key[0][2];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        if (key[0][a] < key[1][a]) atomicOr(&unsorted[a], 1);     // rare (never, for a list in that plane's order)
+}
+
 // forward: one wave per pixel; lane = (vertex slot, channel); out[p][ch][{pos, neg}]
 template <uint32_t F>
 __global__ __launch_bounds__(64) void k_cnt_votes(const uint32_t* __restrict__ rows_by_pixel,
@@ -217,6 +253,19 @@ extern "C" int cnc_cnt_np_plan(const int16_t* inputs, uint32_t N, uint32_t resol
         return CNC_ERR_INVALID_VALUE;
     hipLaunchKernelGGL(k_cnt_plan, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, inputs, N,
                        resolution, hashmap_size, axis, rows, pixels);
+    return launch_status();
+}
+
+extern "C" int cnc_cnt_np_plan3(const int16_t* inputs, uint32_t N, uint32_t resolution, uint32_t hashmap_size,
+                                int32_t* rows, int32_t* pix_xy, int32_t* pix_xz, int32_t* pix_yz,
+                                int32_t* unsorted, void* stream)
+{
+    if (N == 0) return CNC_OK;
+    if (!inputs || !rows || !pix_xy || !pix_xz || !pix_yz || !unsorted || resolution < 3 || hashmap_size == 0 ||
+        hashmap_size > 0x7fffffffu || (uint64_t)(resolution - 2) * (resolution - 2) > 0x7fffffffu)
+        return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_cnt_plan3, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, inputs, N, resolution,
+                       hashmap_size, rows, pix_xy, pix_xz, pix_yz, unsorted);
     return launch_status();
 }
 

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void k_ctx_mlp_fwd(MlpArgs a, float* __restric
 struct MlpGrads {
     const float* g_out;                       // [N, F]
     float *g_a, *g_b, *g_pg;                  // [N, Ca], [N, Cb] or null, scalar accumulator or null
+    uint32_t ldga, ldgb;                      // row pitch of g_a / g_b (Ca / Cb when packed)
     float *gW1, *gb1, *gW2, *gb2, *gW3, *gb3; // accumulated with atomicAdd: zeroed by the caller
     uint32_t n_rep, rep_stride;               // block b adds into copy b % n_rep, rep_stride floats further on
 };
@@ -312,10 +313,10 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
         };
         if (on) {
             uint32_t c = 0;
-            auto     seg = [&](const float* base, uint32_t ld, uint32_t n, float* gout) {
+            auto     seg = [&](const float* base, uint32_t ld, uint32_t n, float* gout, uint32_t ldg) {
                 const float* r = base + (size_t)row * ld;
-                float*       go = gout ? gout + (size_t)row * n : nullptr;
-                if (seg_vec_ok(base, ld, n) && (!gout || seg_vec_ok(gout, n, n))) {
+                float*       go = gout ? gout + (size_t)row * ldg : nullptr;
+                if (seg_vec_ok(base, ld, n) && (!gout || seg_vec_ok(gout, ldg, n))) {
                     for (uint32_t k = 0; k < n; k += 4, c += 4) {
                         const float4 v = *reinterpret_cast<const float4*>(r + k);
                         tB[lane * kPitch + c] = v.x; tB[lane * kPitch + c + 1] = v.y;
@@ -329,8 +330,8 @@ __global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads
                     }
                 }
             };
-            seg(a.in_a, a.lda, a.Ca, g.g_a);
-            if (a.Cb) seg(a.in_b, a.ldb, a.Cb, g.g_b);
+            seg(a.in_a, a.lda, a.Ca, g.g_a, g.ldga);
+            if (a.Cb) seg(a.in_b, a.ldb, a.Cb, g.g_b, g.ldgb);
             if (a.pg) {
                 tB[lane * kPitch + c] = a.pg[a.pg_index ? a.pg_index[row] : 0];
                 const float s = d_in(c);
@@ -510,15 +511,19 @@ extern "C" int cnc_ctx_mlp_backward(const float* in_a, uint32_t lda, uint32_t Ca
                                     const float* W1, const float* b1, const float* W2, const float* b2,
                                     const float* W3, const float* b3, const float* grad_out, float* grad_a,
                                     float* grad_b, float* grad_pg, float* gW1, float* gb1, float* gW2, float* gb2,
-                                    float* gW3, float* gb3, uint32_t n_replicas, uint32_t replica_stride, void* stream)
+                                    float* gW3, float* gb3, uint32_t n_replicas, uint32_t replica_stride,
+                                    uint32_t ldga, uint32_t ldgb, void* stream)
 {
     if (N == 0) return CNC_OK;
     if (n_replicas == 0) n_replicas = 1;
+    if (ldga == 0) ldga = Ca;
+    if (ldgb == 0) ldgb = Cb;
+    if (ldga < Ca || (in_b && grad_b && ldgb < Cb)) return CNC_ERR_INVALID_VALUE;
     MlpArgs a{in_a, lda, Ca, in_b, ldb, in_b ? Cb : 0u, pg, pg ? pg_index : nullptr, N,
               Ca + (in_b ? Cb : 0u) + (pg ? 1u : 0u), W1, b1, W2, b2, W3, b3};
     if (!grad_out || !grad_a || !gW1 || !gb1 || !mlp_args_ok(a, n_layers)) return CNC_ERR_INVALID_VALUE;
     if (n_layers == 3 && (!gW2 || !gb2 || !gW3 || !gb3)) return CNC_ERR_INVALID_VALUE;
-    MlpGrads g{grad_out, grad_a, grad_b, pg ? grad_pg : nullptr, gW1, gb1, gW2, gb2, gW3, gb3, n_replicas, replica_stride};
+    MlpGrads g{grad_out, grad_a, grad_b, pg ? grad_pg : nullptr, ldga, ldgb, gW1, gb1, gW2, gb2, gW3, gb3, n_replicas, replica_stride};
     return n_layers == 1 ? launch_mlp<1>(true, F, a, nullptr, g, (hipStream_t)stream)
                          : launch_mlp<3>(true, F, a, nullptr, g, (hipStream_t)stream);
 }
@@ -790,5 +795,46 @@ extern "C" int cnc_ctx_window_gather(const cnc_ctx_window_t* win, int16_t* pts, 
     if (!pts || !pts_n || !level_ids || !resolutions || !slot_counts || !table_rows) return CNC_ERR_INVALID_VALUE;
     hipLaunchKernelGGL(cnc::k_ctx_window_gather, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d,
                        pts, pts_n, level_ids, resolutions, slot_counts, table_rows);
+    return cnc::launch_status();
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Vertices of one 2-D level inside / one ring around the occupied cells of a projected occupancy plane
+// (utils_bpp_acc.py:431-456): cell c covers the (T+2)^2 vertices c T + {0 .. T+1}^2 (duplicates between neighbouring
+// cells kept, as the reference keeps them); per vertex its table row (examples/utils.py:492-511, 64-bit arithmetic as
+// the int64 tensors there) and its position (v - 0.5) / (R - 2).  Vertex order: cell-major, then ring row, ring column.
+// ---------------------------------------------------------------------------------------------
+namespace cnc {
+
+__global__ __launch_bounds__(256) void k_plane_ring_vertices(const int32_t* __restrict__ cells, uint64_t n_points, uint32_t T,
+                                                             uint32_t R, uint64_t hs, int32_t* __restrict__ rows,
+                                                             float* __restrict__ points)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_points) return;
+    const uint32_t W = T + 2, per = W * W;
+    const uint64_t c = t / per;
+    const uint32_t k = (uint32_t)(t - c * per), a = k / W, b = k - a * W;
+    const uint64_t x = (uint64_t)(uint32_t)cells[c * 2] * T + a, y = (uint64_t)(uint32_t)cells[c * 2 + 1] * T + b;
+    const uint64_t idx = (uint64_t)R * R <= hs ? x + y * R : x ^ (y * 2654435761ull);
+    rows[t] = (int32_t)(idx % hs);
+    const float scale = (float)(R - 2);
+    points[t * 2] = ((float)(int64_t)x - 0.5f) / scale;
+    points[t * 2 + 1] = ((float)(int64_t)y - 0.5f) / scale;
+}
+
+}  // namespace cnc
+
+extern "C" int cnc_plane_ring_vertices(const int32_t* cells, uint64_t n_cells, uint32_t T, uint32_t resolution,
+                                       uint64_t hashmap_size, int32_t* rows, float* points, void* stream)
+{
+    if (n_cells == 0) return CNC_OK;
+    if (!cells || !rows || !points || resolution < 3 || hashmap_size == 0 || hashmap_size > 0x7fffffffull || T > 1022)
+        return CNC_ERR_INVALID_VALUE;
+    const uint64_t n = n_cells * (uint64_t)(T + 2) * (T + 2);
+    if (n > 0xffffffffull * 256) return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(cnc::k_plane_ring_vertices, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cells,
+                       n, T, resolution, hashmap_size, rows, points);
     return cnc::launch_status();
 }

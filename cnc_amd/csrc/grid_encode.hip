@@ -1067,4 +1067,4 @@ extern "C" const char* cnc_error_string(int code)
     }
 }
 
-extern "C" int cnc_abi_version(void) { return 24; }
+extern "C" int cnc_abi_version(void) { return 25; }

@@ -219,6 +219,12 @@ int cnc_cnt_np_embed_backward(const int16_t* inputs, const float* embeddings_cli
  *     grad_embeddings [n_rows, F] is accumulated into (rows without vertices untouched).           */
 int cnc_cnt_np_plan(const int16_t* inputs, uint32_t N, uint32_t resolution, uint32_t hashmap_size,
                     uint32_t axis, uint32_t* rows, uint32_t* pixels, void* stream);
+/* (ABI v25) The plan's input in one pass: rows [N] and the pixels of the xy / xz / yz planes [N] each, as int32, with
+ * the vertices cnt_np_embed skips keyed PAST the end (row = hashmap_size, pixel = (res-2)^2) so that sorting leaves
+ * them behind the last segment — no compaction; unsorted [3] (zeroed by the caller) gets a non-zero word for every
+ * plane whose pixel list is not already ascending.                                                               */
+int cnc_cnt_np_plan3(const int16_t* inputs, uint32_t N, uint32_t resolution, uint32_t hashmap_size, int32_t* rows,
+                     int32_t* pix_xy, int32_t* pix_xz, int32_t* pix_yz, int32_t* unsorted, void* stream);
 int cnc_cnt_np_embed_planned(const uint32_t* rows_by_pixel, const int32_t* pixel_seg,
                              const float* embeddings_clip, float* outputs, uint32_t n_pixels,
                              uint32_t F, void* stream);
@@ -517,14 +523,17 @@ int cnc_ctx_mlp_forward(const float* in_a, uint32_t lda, uint32_t Ca, const floa
  * gradient ACCUMULATED with atomics (the caller zero-fills them).  n_replicas (>= 1) zero-filled copies of the
  * weight / bias gradients, replica_stride floats apart (gW1 ... gb3 point into copy 0): workgroup b adds into copy
  * b % n_replicas and the caller sums the copies — ~1000 workgroups adding into the same few hundred addresses
- * serialise at the memory side.                                                                         */
+ * serialise at the memory side.  (ABI v25) ldga / ldgb = row pitch of grad_a / grad_b in floats (0: packed, Ca /
+ * Cb) — a caller that runs several heads on row ranges and column windows of one matrix (the three coded levels of a
+ * plane, utils_bpp_acc.py:556-566) gets one gradient matrix for the encoder behind them.                    */
 int cnc_ctx_mlp_backward(const float* in_a, uint32_t lda, uint32_t Ca, const float* in_b, uint32_t ldb,
                          uint32_t Cb, const float* pg, const int64_t* pg_index, uint32_t N, uint32_t n_layers,
                          uint32_t F,
                          const float* W1, const float* b1, const float* W2, const float* b2,
                          const float* W3, const float* b3, const float* grad_out, float* grad_a,
                          float* grad_b, float* grad_pg, float* gW1, float* gb1, float* gW2, float* gb2,
-                         float* gW3, float* gb3, uint32_t n_replicas, uint32_t replica_stride, void* stream);
+                         float* gW3, float* gb3, uint32_t n_replicas, uint32_t replica_stride,
+                         uint32_t ldga, uint32_t ldgb, void* stream);
 /* The per-step sample of the 3-D context pass (utils_bpp_acc.py:619-667), all coded levels at once: level i
  * contributes the vertices pos[i][0 .. p_at[i+1]-p_at[i]) (int16 triples, already offset to the window start)
  * and the slots cnt[i] / val[i][0 .. v_at[i+1]-v_at[i]).  Written, concatenated over the levels: pts i16 [P,3],
@@ -543,6 +552,13 @@ typedef struct {
 } cnc_ctx_window_t;
 int cnc_ctx_window_gather(const cnc_ctx_window_t* win, int16_t* pts, float* pts_n, int64_t* level_ids,
                           int64_t* resolutions, int64_t* slot_counts, int64_t* table_rows, void* stream);
+
+/* (ABI v25) Vertices of one 2-D level inside / one ring around the occupied cells of a projected occupancy plane
+ * (utils_bpp_acc.py:431-456 `fetch_2D_batches`): cells [n_cells, 2] int32 = the occupied (i, j) of the plane, T =
+ * (resolution - 2) / plane size; writes, cell-major then ring row / column, n_cells (T+2)^2 entries of rows (the
+ * vertex's table row, examples/utils.py:492-511, int32) and points [., 2] = (vertex - 0.5) / (resolution - 2).   */
+int cnc_plane_ring_vertices(const int32_t* cells, uint64_t n_cells, uint32_t T, uint32_t resolution,
+                            uint64_t hashmap_size, int32_t* rows, float* points, void* stream);
 
 /* bits = sum_{slot, f} -log2(p) (1 + x)/2 - log2(1 - p) (1 - x)/2, p = clamp(mean, 1e-6, 1 - 1e-6)
  * (utils_bpp_acc.py:1005-1013), x = table[rows[slot], f] (rows NULL: x = table[slot, f]).  The kernel writes

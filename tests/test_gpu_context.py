@@ -170,6 +170,66 @@ def test_vertex_set_fast_path_equals_the_candidate_lattice_branch(setup):
     m.fused_segments = True
 
 
+def test_plane_ring_vertices_kernel_equals_the_tensor_expression(setup, cuda):
+    """`fetch_2D_batches` (utils_bpp_acc.py:431-456) as one kernel against the reference's tensor expression: same
+    table rows, same positions bit for bit, every 2-D level of the toy model (dense and hashed) on its three planes;
+    then the slot lists built from them; then the row formula alone at the full-size levels (R up to 1026, T = 2^17)."""
+    from cnc_amd.backends import context_backend as ck
+    from cnc_amd.context import get_grid_index
+    g, m, encs, binary = setup
+    for axis in ("xy", "xz", "yz"):
+        plane = m._project(binary, axis)
+        for n in range(m.n_levels_2D):
+            got = {}
+            for fused in (True, False):
+                m.fused_segments = fused
+                got[fused] = (m.fetch_2D_batches(plane, n), m._sorted_slots_2D(plane, n))
+            m.fused_segments = True
+            (ri, pi), si = got[True]
+            (rt, pt), st = got[False]
+            assert ri.dtype == torch.int32 and ri.shape[0] > 0
+            assert torch.equal(ri.long(), rt) and torch.equal(pi, pt), (axis, n)
+            for a, b in zip(si, st):
+                assert a.dtype == b.dtype and torch.equal(a, b), (axis, n)
+    gen = torch.Generator(device=cuda).manual_seed(4)
+    for R, T, hs in ((130, 1, 130 * 130), (258, 2, 258 * 258), (514, 4, 2 ** 17), (1026, 8, 2 ** 17), (1026, 8, 100003)):
+        cells = torch.randint(0, 128, (3000, 2), device=cuda, generator=gen)
+        rows, pts = ck.plane_ring_vertices(cells, T, R, hs)
+        ar = torch.arange(T + 2, device=cuda)
+        ring = torch.stack(torch.meshgrid(ar, ar, indexing="ij"), dim=-1).view(1, T + 2, T + 2, 2)
+        v = (cells.view(-1, 1, 1, 2) * T + ring).view(-1, 2)
+        assert torch.equal(rows.long(), get_grid_index(hs, R, v)), (R, hs)
+        assert torch.equal(pts, (v - 0.5) / float(R - 2)), (R, hs)
+        assert int(rows.max()) < hs and int(rows.min()) >= 0
+    rows, pts = ck.plane_ring_vertices(torch.zeros((0, 2), dtype=torch.long, device=cuda), 4, 514, 2 ** 17)
+    assert rows.shape == (0,) and pts.shape == (0, 2)
+
+
+def test_plane_batched_levels_equal_the_level_by_level_pass(setup):
+    """The coded levels of a plane evaluated together (one encoder call over levels [0, max n), the heads on row ranges
+    of one matrix through `ContextHeads`, one per-slot mean) against one pass per level: the same rate to fp32 summation
+    order, the same gradients into the plane tables, the finest 3-D level (votes), every 2-D head and the level
+    frequencies behind Pg."""
+    g, m, encs, binary = setup
+    assert m._plane_batch_ok(encs["xy"].params)
+    res = {}
+    for batched in (True, False):
+        m.plane_batched = batched
+        torch.manual_seed(5)
+        for e in encs.values():
+            e.zero_grad()
+        m.zero_grad()
+        bpp, _ = m.forward_binary_vxl_mixPg_3D2D(encs["xyz"], encs["xy"], encs["xz"], encs["yz"], binary, step=0)
+        bpp.backward()
+        res[batched] = [bpp.detach().clone()] + [encs[k].params.grad.clone() for k in ("xyz", "xy", "xz", "yz")] + \
+                       [p.grad.clone() for p in m.context_model_2D.parameters()]
+    m.plane_batched = True
+    assert abs(float(res[True][0]) - float(res[False][0])) <= 2e-6 * abs(float(res[False][0]))
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert float(b.abs().max()) > 0
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+
+
 def test_planned_votes_equal_atomic_votes(setup):
     """planned_votes=True (vertex list sorted once per refresh, segmented gathers) vs the atomic
     cnt_np_embed kernels: same entropy estimate, same gradients into the finest 3-D level and planes."""

@@ -61,14 +61,22 @@ for _ in range(245):
     step += 1
 torch.cuda.synchronize()
 marks.clear()
-N = 48
+REFRESH = "--refresh" in sys.argv           # average the refresh steps (every `step_update`-th) instead of the others
+wrap(tr.context, "get_idx_coords2", "ctx/idx_coords2")
+wrap(tr.context, "fetch_2D_batches", "ctx/fetch_2D")
+wrap(tr.context, "_sorted_slots_2D", "ctx/sorted_slots_2D")
+wrap(tr.context, "get_pn_embed_frac_planes", "ctx/pn_frac")
+import cnc_amd.context as _C
+wrap(_C._backend, "VotePlan", "ctx/vote_plan")
+wrap(tr.context, "_project", "ctx/project")
+N = 48 if not REFRESH else 16 * 12
 for _ in range(N):
-    if step % cfg.step_update == 0:          # keep refresh steps out of the averages
+    if (step % cfg.step_update == 0) != REFRESH:          # keep the other kind of step out of the averages
         tr.train_step(step, want_stats=False)
         step += 1
         torch.cuda.synchronize()
-        marks.clear() if not any(m[0] == "start" for m in marks) else None
         continue
+    torch.cuda.synchronize()
     mark("start")
     tr.train_step(step, want_stats=False)
     step += 1
@@ -81,15 +89,19 @@ for name, th, h, e in sorted(marks, key=lambda m: m[2]):
     if name == "start":
         cur = (h, e)
         n_steps += 1
+        seen = collections.Counter()
         continue
     if cur is None:
         continue
+    seen[name, th] += 1                     # a boundary crossed several times in a step: one row per crossing
+    if seen[name, th] > 1 or name in ("ctx/fetch_2D", "ctx/sorted_slots_2D"):
+        name = f"{name} #{seen[name, th]}"
     a = agg.setdefault((name, th), [0.0, 0.0, 0])
     a[0] += (h - cur[0]) * 1e3
     a[1] += cur[1].elapsed_time(e)
     a[2] += 1
-    if name == "end":
+    if name.startswith("end"):
         cur = None
-print(f"{'boundary':28s} thr  host ms   gpu ms    (since the step's start; mean over {n_steps} non-refresh steps)")
+print(f"{'boundary':28s} thr  host ms   gpu ms    (since the step's start; mean over {n_steps} {'refresh' if REFRESH else 'non-refresh'} steps)")
 for (name, th), (h, g, c) in sorted(agg.items(), key=lambda t: t[1][0] / max(t[1][2], 1)):
     print(f"{name:28s} {th}  {h / c:7.2f} {g / c:8.2f}   x{c / max(n_steps, 1):.1f}")
