@@ -90,6 +90,7 @@ SIGNATURES = {
     "cnc_compact_samples": [_vp] * 9 + [_u32, _vp],
     "cnc_ray_window_samples": [_vp] * 10 + [_u32, _vp],
     "cnc_ray_transmittance": [_vp] * 6 + [_u32, _vp],
+    "cnc_ray_window_next": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _i32, _u32, _vp],
     "cnc_interval_edges_to_samples": [_vp] * 9 + [_u32, _vp],
     "cnc_pack_bounds": [_vp, _i64, _vp, _vp, _i64, _vp],
     "cnc_level_stats_forward": [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp],

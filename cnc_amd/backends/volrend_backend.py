@@ -143,11 +143,12 @@ def compact_samples(starts, counts, mask, kept, t_starts, t_ends) -> Tuple[torch
     return o_r, o_s, o_e, new_starts, kept
 
 
-def window_samples(starts, first, cnts, t_starts, t_ends, total):
+def window_samples(starts, first, cnts, t_starts, t_ends, total, ends=None):
     """(ray_indices, t_starts, t_ends, source_index) of samples [first[r], first[r] + cnts[r]) of every ray; `total` =
-    cnts.sum() (the caller read it back together with whatever else it needed)."""
+    cnts.sum() (the caller read it back together with whatever else it needed); `ends` = cumsum(cnts) if the caller
+    has it."""
     n_rays, dev = starts.shape[0], t_starts.device
-    out_starts = torch.cumsum(cnts, 0) - cnts
+    out_starts = (torch.cumsum(cnts, 0) if ends is None else ends) - cnts
     o_s = torch.empty(total, dtype=torch.float32, device=dev)
     o_e = torch.empty(total, dtype=torch.float32, device=dev)
     o_r = torch.empty(total, dtype=torch.int64, device=dev)
@@ -166,6 +167,14 @@ def ray_transmittance(starts, cnts, t_starts, t_ends, sigmas):
     check(_lib.lib().cnc_ray_transmittance(ptr(starts), ptr(cnts), _p(t_starts), _p(t_ends), _p(sigmas), ptr(out), n_rays,
                                            stream(sigmas.device)), "ray_transmittance")
     return out
+
+
+def ray_window_next(starts, counts, t_starts, t_ends, sigmas, done, take, window, threshold, first):
+    """One step of the front-to-back sampler, in place on `done` / `take` (int64 [n_rays]): see cnc_ray_window_next."""
+    n_rays = starts.shape[0]
+    check(_lib.lib().cnc_ray_window_next(ptr(starts), ptr(counts), _p(t_starts), _p(t_ends), _p(sigmas), ptr(done), ptr(take),
+                                         -1 if window is None else int(window), float(threshold), int(bool(first)), n_rays,
+                                         stream(sigmas.device)), "ray_window_next")
 
 
 def samples_from_intervals(intervals, sample_counts, total: Optional[int] = None):

@@ -339,6 +339,30 @@ __global__ __launch_bounds__(256) void k_ray_transmittance(
     if (live && j == 0) trans[ray] = expf(-acc);
 }
 
+// One step of the front-to-back sampler (occ_grid.py `_density_front_to_back`): the window just evaluated is added to
+// the ray's evaluated prefix, what is left of the ray after it decides whether the ray goes on, and the next window is
+// sized — `done` and `take` are updated in place (first call: done = 0, take ignored).
+__global__ __launch_bounds__(256) void k_ray_window_next(
+    const int64_t* __restrict__ starts, const int64_t* __restrict__ cnts, const float* __restrict__ t_starts,
+    const float* __restrict__ t_ends, const float* __restrict__ sigmas, int64_t* __restrict__ done,
+    int64_t* __restrict__ take, int64_t window, float threshold, int first, uint32_t n_rays)
+{
+    const uint32_t j = threadIdx.x & 31;
+    const uint32_t ray = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const bool     live = ray < n_rays;
+    const int64_t  s0 = live ? starts[ray] : 0, total = live ? cnts[ray] : 0;
+    const int64_t  n = (live && !first) ? done[ray] + take[ray] : 0;
+    float          acc = 0.0f;
+    for (int64_t k = j; k < n; k += 32) acc += sigmas[s0 + k] * (t_ends[s0 + k] - t_starts[s0 + k]);
+    acc = half_wave_sum(acc);
+    if (live && j == 0) {
+        const bool    alive = first ? total > 0 : (expf(-acc) >= threshold && n < total);
+        const int64_t left = total - n;
+        done[ray] = n;
+        take[ray] = alive ? (window < 0 || left < window ? left : window) : 0;
+    }
+}
+
 // t_starts = intervals.vals[is_left], t_ends = intervals.vals[is_right] (occ_grid.py:176-177,
 // utils.py:408-409) and the samples' ray ids, without boolean indexing: the k-th left (right) edge of a ray
 // is the start (end) of its k-th sample.  iv_starts may describe the over-allocated layout.
@@ -486,6 +510,18 @@ extern "C" int cnc_ray_transmittance(const int64_t* chunk_starts, const int64_t*
     if (!chunk_starts || !chunk_cnts || !t_starts || !t_ends || !sigmas || !transmittance) return CNC_ERR_INVALID_VALUE;
     hipLaunchKernelGGL(k_ray_transmittance, ray_grid(n_rays), dim3(256), 0, (hipStream_t)stream, chunk_starts, chunk_cnts,
                        t_starts, t_ends, sigmas, transmittance, n_rays);
+    return launch_status();
+}
+
+extern "C" int cnc_ray_window_next(const int64_t* chunk_starts, const int64_t* chunk_cnts, const float* t_starts,
+                                   const float* t_ends, const float* sigmas, int64_t* done, int64_t* take,
+                                   int64_t window, float threshold, int first, uint32_t n_rays, void* stream)
+{
+    if (n_rays == 0) return CNC_OK;
+    if (!chunk_starts || !chunk_cnts || !done || !take || (!first && (!t_starts || !t_ends || !sigmas)))
+        return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_ray_window_next, ray_grid(n_rays), dim3(256), 0, (hipStream_t)stream, chunk_starts, chunk_cnts,
+                       t_starts, t_ends, sigmas, done, take, window, threshold, first, n_rays);
     return launch_status();
 }
 

@@ -156,29 +156,25 @@ class OccGridEstimator(AbstractEstimator):
         from ...backends import volrend_backend as _K
         sigmas = torch.zeros_like(t_starts)
         done = torch.zeros_like(counts)
-        alive = counts > 0
-        done_any = False
-        for w in self._WINDOWS + (None,):
-            left = counts - done
-            take = torch.where(alive, left if w is None else left.clamp(max=w), torch.zeros_like(left))
-            if w is self._WINDOWS[0] and done_any is False and self._first_window_total is not None:
+        take = torch.empty_like(counts)
+        # a margin below the threshold: the window test's sum and the visibility test's prefix scan associate differently
+        threshold = early_stop_eps * (1.0 - 1e-3)
+        for i, w in enumerate(self._WINDOWS + (None,)):
+            # the window just evaluated joins the ray's prefix, what is left of the ray decides whether it goes on, the
+            # next window is sized: one kernel, in place on (done, take)
+            _K.ray_window_next(starts, counts, t_starts, t_ends, sigmas, done, take, w, threshold, first=i == 0)
+            ends = torch.cumsum(take, 0)
+            if i == 0 and self._first_window_total is not None:
                 total = int(self._first_window_total)          # came back with the march's own sample total
             else:
-                total = int(take.sum().item())
-            done_any = True
+                total = int(ends[-1].item())
             if total == 0:
                 break
-            ri_w, ts_w, te_w, src = _K.window_samples(starts, done, take, t_starts, t_ends, total)
+            ri_w, ts_w, te_w, src = _K.window_samples(starts, done, take, t_starts, t_ends, total, ends=ends)
             values = sigma_fn(ts_w, te_w, ri_w)
             if values.shape != ts_w.shape:
                 raise AssertionError("sigmas must have shape of (N,)! Got {}".format(values.shape))
             sigmas.index_copy_(0, src, values.to(sigmas.dtype))
-            done = done + take
-            if w is None:
-                break
-            # a margin below the threshold: this sum and the test's prefix scan associate differently
-            left_of_ray = _K.ray_transmittance(starts, done, t_starts, t_ends, sigmas)
-            alive = (left_of_ray >= early_stop_eps * (1.0 - 1e-3)) & (done < counts)
         return sigmas
 
     # ------------------------------------------------------------------------------------- upkeep

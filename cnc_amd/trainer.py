@@ -135,13 +135,28 @@ class SyntheticBallDataset:
         rgb = (tex * lam).clamp(0, 1)
         return rgb, hit.float()[:, None]
 
+    def _train_images(self):
+        """The training views as RGBA images in device memory, as SubjectLoader holds its images
+        (nerf_synthetic.py:133-146): the analytic shading evaluated once per pixel instead of once per fetched ray."""
+        if getattr(self, "_images", None) is None:
+            ys, xs = torch.meshgrid(torch.arange(self.H, device=self.device),
+                                    torch.arange(self.W, device=self.device), indexing="ij")
+            x, y = xs.reshape(-1).float(), ys.reshape(-1).float()
+            views = []
+            for c2w in self.train_c2w:
+                o, d = self._rays(c2w[None].expand(x.shape[0], 3, 4), x, y)
+                views.append(torch.cat(self._shade(o, d), dim=-1).view(self.H, self.W, 4))
+            self._images = torch.stack(views)
+        return self._images
+
     def fetch(self, num_rays=None):
         n = self.num_rays if num_rays is None else num_rays
         img = torch.randint(0, self.train_c2w.shape[0], (n,), device=self.device, generator=self.gen)
-        x = torch.randint(0, self.W, (n,), device=self.device, generator=self.gen).float()
-        y = torch.randint(0, self.H, (n,), device=self.device, generator=self.gen).float()
-        o, d = self._rays(self.train_c2w[img], x, y)
-        rgb, alpha = self._shade(o, d)
+        xi = torch.randint(0, self.W, (n,), device=self.device, generator=self.gen)
+        yi = torch.randint(0, self.H, (n,), device=self.device, generator=self.gen)
+        o, d = self._rays(self.train_c2w[img], xi.float(), yi.float())
+        rgba = self._train_images()[img, yi, xi]            # the same numbers as shading the fetched rays
+        rgb, alpha = rgba[:, :3], rgba[:, 3:]
         bkgd = torch.rand(3, device=self.device, generator=self.gen)     # random bkgd in training
         return {"rays": Rays(o, d), "pixels": rgb * alpha + bkgd * (1 - alpha), "color_bkgd": bkgd}
 

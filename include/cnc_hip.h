@@ -489,6 +489,13 @@ int cnc_ray_window_samples(const int64_t* chunk_starts, const int64_t* window_fi
                            void* stream);
 int cnc_ray_transmittance(const int64_t* chunk_starts, const int64_t* chunk_cnts, const float* t_starts,
                           const float* t_ends, const float* sigmas, float* transmittance, uint32_t n_rays, void* stream);
+/* (ABI v25) One step of that sampler as one kernel: done[r] += take[r] (the window just evaluated; first != 0: done = 0),
+ * the ray goes on iff exp(-sum sigma dt over its first done[r] samples) >= threshold and done[r] < chunk_cnts[r] (first:
+ * iff it has samples), take[r] = what it evaluates next: min(window, what is left), everything left for window < 0,
+ * 0 for a ray that stopped.  done / take int64 [n_rays], updated in place.                                        */
+int cnc_ray_window_next(const int64_t* chunk_starts, const int64_t* chunk_cnts, const float* t_starts,
+                        const float* t_ends, const float* sigmas, int64_t* done, int64_t* take, int64_t window,
+                        float threshold, int first, uint32_t n_rays, void* stream);
 /* intervals.vals[is_left], intervals.vals[is_right], samples.ray_indices[is_valid] (occ_grid.py:176-178,
  * utils.py:408-410): the k-th left / right edge of a ray opens / closes its k-th sample.  iv_chunk_starts may be
  * the over-allocated layout of traverse_grids; out_starts [n_rays] = packed sample starts.                  */

@@ -194,6 +194,33 @@ def test_visibility_and_compaction(cuda, oracle, alpha_thre):
     assert np.array_equal(m2.cpu().numpy().astype(bool)[~edge_a], want_a[~edge_a])
 
 
+def test_ray_window_next_equals_the_tensor_expression(cuda):
+    """cnc_ray_window_next (one step of the front-to-back sampler) against the op chain it replaced — done += take;
+    alive = (exp(-sum sigma dt over the prefix) >= thr) & (done < counts); take = where(alive, min(left, w), 0) — over
+    three windows, rays without samples and rays that finish early included."""
+    from cnc_amd.backends import volrend_backend as K
+    starts, cnts, ri, t0, t1, sig, rgb = _ragged(700, seed=33)
+    sig = sig * 40                                              # many rays die inside the first windows
+    s_, c_, t0_, t1_, sig_ = _dev(cuda, starts, cnts, t0, t1, sig)
+    assert int((c_ == 0).sum()) > 0
+    thr = 1e-2 * (1 - 1e-3)
+    done = torch.zeros_like(c_)
+    take = torch.empty_like(c_)
+    done_ref, alive = torch.zeros_like(c_), c_ > 0
+    died = 0
+    for i, w in enumerate((4, 9, None)):
+        K.ray_window_next(s_, c_, t0_, t1_, sig_, done, take, w, thr, first=i == 0)
+        left = c_ - done_ref
+        take_ref = torch.where(alive, left if w is None else left.clamp(max=w), torch.zeros_like(left))
+        assert torch.equal(done, done_ref) and torch.equal(take, take_ref), i
+        done_ref = done_ref + take_ref
+        trans = K.ray_transmittance(s_, done_ref, t0_, t1_, sig_)
+        now = (trans >= thr) & (done_ref < c_)
+        died += int((alive & ~now & (done_ref < c_)).sum())
+        alive = now
+    assert died > 20 and int(take.sum()) > 0                    # both outcomes are exercised
+
+
 def test_pack_bounds_and_pack_info(cuda):
     import cnc_amd.nerfacc as n
     ri = torch.tensor([0, 0, 1, 1, 1, 2, 2, 2, 2], device=cuda)

@@ -508,3 +508,24 @@ def test_fused_field_shape_table_on_cpu():
     assert f._fused_forward(x) is None                          # host tensors, gradients on: the chain
     with torch.no_grad():
         assert f._fused_forward(x) is None                      # host tensors: still the chain (no CPU fallback of a kernel)
+
+
+def test_procedural_dataset_fetch_reads_prerendered_views():
+    """SyntheticBallDataset.fetch indexes training views rendered once (as the reference's loader indexes its images,
+    nerf_synthetic.py:164-239): the pixels are exactly what shading the fetched rays gives, and the random draws
+    (view, x, y, background) are consumed in the same order as before."""
+    from cnc_amd.trainer import SyntheticBallDataset
+    ds = SyntheticBallDataset(image_size=24, n_train_views=5, device="cpu", seed=3)
+    ref = SyntheticBallDataset(image_size=24, n_train_views=5, device="cpu", seed=3)
+    for n in (7, 300):
+        got = ds.fetch(n)
+        img = torch.randint(0, 5, (n,), generator=ref.gen)
+        x = torch.randint(0, 24, (n,), generator=ref.gen).float()
+        y = torch.randint(0, 24, (n,), generator=ref.gen).float()
+        o, d = ref._rays(ref.train_c2w[img], x, y)
+        rgb, alpha = ref._shade(o, d)
+        bk = torch.rand(3, generator=ref.gen)
+        assert torch.equal(got["rays"].origins, o) and torch.equal(got["rays"].viewdirs, d)
+        assert torch.equal(got["color_bkgd"], bk)
+        assert torch.equal(got["pixels"], rgb * alpha + bk * (1 - alpha))
+    assert ds._images.shape == (5, 24, 24, 4) and 0.02 < float(ds._images[..., 3].mean()) < 0.5

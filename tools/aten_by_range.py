@@ -20,7 +20,8 @@ tr = Trainer(cfg, device=torch.device("cuda:0"))
 for step in range(243):
     tr.train_step(step, want_stats=False)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+STACK = "--stack" in sys.argv       # also: the package line (first cnc_amd/ frame) each library launch comes from
+with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], with_stack=STACK) as prof:
     tr.train_step(243, want_stats=False)      # not a refresh step (243 % 16 = 3)
     torch.cuda.synchronize()
 evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CPU]
@@ -36,6 +37,17 @@ def lib(k):
     return not (k.name.startswith("cnc::") or "cnc::" in k.name[:16] or k.name.startswith("Cijk") or "_ZN3cnc" in k.name)
 
 
+def frame(e):
+    x = e
+    while x is not None:
+        for f in (x.stack or []):
+            if "cnc_amd/" in f and "_lib.py" not in f:
+                return re.sub(r".*cnc_amd/", "", f)[:60]
+        x = x.cpu_parent
+    return "(autograd thread / no package frame)"
+
+
+by_line = collections.defaultdict(lambda: [0, 0.0])
 acc = collections.defaultdict(lambda: [0, 0.0])
 for e in evs:
     if not e.kernels:
@@ -53,6 +65,10 @@ for e in evs:
             a = acc[(site, e.name[:28], short(k.name))]
             a[0] += 1
             a[1] += k.duration
+            if STACK:
+                b = by_line[frame(e) if site.startswith("- | aten::") or site.startswith("- | hip") else site]
+                b[0] += 1
+                b[1] += k.duration
 tot_n = sum(a[0] for a in acc.values())
 tot_t = sum(a[1] for a in acc.values())
 print(f"library kernels in one step: {tot_n} launches, {tot_t / 1e3:.3f} ms")
@@ -66,3 +82,7 @@ for site, a in sorted(by_site.items(), key=lambda t: -t[1][0])[:60]:
 print("---- by (site, op, kernel)")
 for (site, op, k), a in sorted(acc.items(), key=lambda t: -t[1][0])[:120]:
     print(f"{a[0]:4d} {a[1]:8.0f}us  {site:70s} {op:28s} {k}")
+if STACK:
+    print("---- by package line (top-level ops) / site")
+    for site, a in sorted(by_line.items(), key=lambda t: -t[1][0])[:80]:
+        print(f"{a[0]:4d} {a[1]:8.0f}us  {site}")
