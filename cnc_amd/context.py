@@ -25,10 +25,17 @@ from typing import Optional
 
 import numpy as np
 import torch
-from torch.profiler import record_function as _range
+import contextlib
 import torch.nn as nn
 import torch.nn.functional as nnf
 from torch.autograd import Function
+
+if os.environ.get("CNC_PROFILE_RANGES", "0") == "1":      # named ranges for tools/aten_by_range.py; two dispatcher
+    from torch.profiler import record_function as _range   # calls each, ~40 per training pass, so off by default
+else:
+    def _range(name):
+        return _NO_RANGE
+    _NO_RANGE = contextlib.nullcontext()
 
 from .backends import context_backend as _ctxk
 from .backends import gridencoder_backend as _backend

@@ -41,6 +41,19 @@ def wrap(obj, attr, name, before=False):
 wrap(tr.dataset, "fetch", "fetch")
 wrap(tr.estimator, "update_every_n_steps", "occ_update")
 wrap(T, "render_image_with_occgrid", "render_fwd")
+wrap(tr.estimator, "sampling", "  sampling", before=True)
+wrap(tr.estimator, "_march", "    march")
+import cnc_amd.render as _R
+_cd = _R._FieldOnRays.colour_and_density
+
+
+def _cd_marked(self, *a, **k):
+    r = _cd(self, *a, **k)
+    mark("  field(colour, density)")
+    return r
+
+
+_R._FieldOnRays.colour_and_density = _cd_marked
 wrap(tr.context, "forward_binary_vxl_mixPg_3D2D", "ctx_fwd", before=True)
 wrap(tr, "_context_pass", "ctx_pass_done", before=True)
 _bw = torch.Tensor.backward
