@@ -150,8 +150,12 @@ class ContextHeads(Function):
         N, lda = in_a.shape
         Cb = 0 if in_b is None else in_b.shape[1]
         F = ws[0].shape[0]
-        full = all(c0 == 0 and Ca == lda for (_, _, c0, Ca, _) in ctx.segs)
-        g_a = (torch.empty_like if full else torch.zeros_like)(in_a)
+        g_a = torch.empty_like(in_a)
+        for (r0, r1, c0, Ca, _) in ctx.segs:          # columns outside a segment's window: zero (only those are filled)
+            if r1 > r0 and c0 > 0:
+                g_a[r0:r1, :c0].zero_()
+            if r1 > r0 and c0 + Ca < lda:
+                g_a[r0:r1, c0 + Ca:].zero_()
         g_b = torch.empty_like(in_b) if (in_b is not None and ctx.needs_input_grad[1]) else None
         g_pg = torch.zeros_like(pgv) if pgv is not None else None
         from .. import _gradsink

@@ -371,12 +371,22 @@ __global__ __launch_bounds__(256) void k_grid_encode_bwd(
                 validmask |= (c.valid[i] ? 1u : 0u) << i;
             }
             const float* gp = grad + feat_index(lay, slot, N, b, F);
+            bool         nonzero = false;
 #pragma unroll
             for (uint32_t k = 0; k < F; k += V) {
                 float gv[V];
                 load_vec<V>(gp + k, gv);
 #pragma unroll
-                for (uint32_t j = 0; j < V; j++) s_g[tid][k + j] = gv[j];
+                for (uint32_t j = 0; j < V; j++) {
+                    s_g[tid][k + j] = gv[j];
+                    nonzero |= gv[j] != 0.0f;
+                }
+            }
+            // a point whose gradient row is all zeros adds nothing: no atomics for it (samples behind an opaque surface;
+            // the levels outside a vertex's context window when several windows share one call, context.py _plane_bits)
+            if (!nonzero) {
+                key = ~0ull;
+                validmask = 0;
             }
         }
         s_key[tid] = key;
