@@ -62,6 +62,9 @@ SIGNATURES = {
     "cnc_cnt_np_embed_planned": [_vp, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_cnt_np_embed_planned_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_cnt_np_embed_planned_backward3": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp],
+    "cnc_cnt_np_embed_planned_backward3_xyz": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp],
+    "cnc_vote_plan_count": [_vp, _u32, _u32, _vp, _vp, _vp],
+    "cnc_vote_plan_fill": [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp],
     "cnc_cnt_vote_masks": [_vp, _u32, _u32, _vp, _vp],
     "cnc_vote_fraction_table": [_vp, _u32, _u32, _vp, _vp, _vp],
     "cnc_vote_fraction_table_backward": [_vp, _vp, _u32, _u32, _vp, _vp],

@@ -362,8 +362,59 @@ class VotePlan:
             self.pixel_seg.append(self._segments(p_sorted, self.n_pixels))
         # backward: pixels ordered by row (one order for the three planes)
         rows_sorted, order = torch.sort(rows, stable=True)
-        self.pixels_by_row = [p[order].contiguous() for p in pix]
+        self._pixels_by_row = [p[order].contiguous() for p in pix]
+        self.xyz_by_row = None
         self.row_seg = self._segments(rows_sorted, self.hashmap_size)
+
+    @classmethod
+    def from_occupancy(cls, occupancy, t, resolution, hashmap_size):
+        """The same plan as `VotePlan(get_idx_coords2(binary_vxl), ...)` without the vertex list: per-pixel counts of the
+        vertex set decided line by line from the bit-packed occupancy (cnc_vote_plan_count), their running sums, rows
+        written in each plane's pixel-major order (cnc_vote_plan_fill: what a stable sort by pixel of the (x, y,
+        z)-ordered list gives), ONE sort by table row of the packed vertices for the backward.  occupancy: bool / uint8
+        [Rb, Rb, Rb], Rb <= 128; resolution = Rb t + 2 <= 1024."""
+        _common_checks([("occupancy", occupancy)])
+        Rb = occupancy.shape[-1]
+        if occupancy.dim() != 3 or occupancy.shape != (Rb, Rb, Rb) or occupancy.dtype not in (torch.bool, torch.uint8) \
+                or int(resolution) != Rb * int(t) + 2 or int(resolution) > 1024 or Rb > 128:
+            raise RuntimeError("VotePlan.from_occupancy: occupancy [Rb, Rb, Rb] of bytes and resolution = Rb t + 2 <= 1024")
+        self = cls.__new__(cls)
+        dev, R = occupancy.device, int(resolution)
+        self.resolution, self.hashmap_size = R, int(hashmap_size)
+        self.n_pixels = (R - 2) ** 2
+        self._masks = self._masks_key = self._masks_src = None
+        L, st = _lib.lib(), stream(dev)
+        bits = torch.empty(3 * Rb * Rb * 4, dtype=torch.int32, device=dev)
+        counts = torch.empty((3, self.n_pixels), dtype=torch.int32, device=dev)
+        check(L.cnc_vote_plan_count(ptr(occupancy), Rb, int(t), ptr(bits), ptr(counts), st), "vote_plan_count")
+        # running sums per plane from ONE flat scan (a [3, P] scan along P is three serial rows: 0.5 ms)
+        flat = torch.cumsum(counts.view(-1), 0, dtype=torch.int32).view(3, self.n_pixels)
+        seg = torch.zeros((3, self.n_pixels + 1), dtype=torch.int32, device=dev)
+        seg[:, 1:] = flat
+        seg[1:, 1:] -= flat[:-1, -1:]                       # every plane holds the same n vertices
+        n = int(seg[0, -1].item())                          # the one sync: sizes the lists
+        rows = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(3)]
+        xyz = torch.empty(n, dtype=torch.int32, device=dev)
+        self.pixel_seg = [seg[0], seg[1], seg[2]]
+        if n:
+            check(L.cnc_vote_plan_fill(ptr(bits), Rb, int(t), self.hashmap_size, ptr(seg), ptr(rows[0]), ptr(rows[1]),
+                                       ptr(rows[2]), ptr(xyz), st), "vote_plan_fill")
+        self.rows_by_pixel = rows
+        rows_sorted, order = torch.sort(rows[0], stable=True)      # rows[0] is in (x, y, z) order, as xyz is
+        self.xyz_by_row = xyz[order].contiguous()
+        self.row_seg = self._segments(rows_sorted, self.hashmap_size)
+        self._pixels_by_row = None
+        return self
+
+    @property
+    def pixels_by_row(self):
+        """Per plane, the vertices' pixels ordered by table row — kept by the list constructor, derived from the packed
+        vertices (only the single-plane backward asks for them) by `from_occupancy`."""
+        if self._pixels_by_row is None:
+            q, S = self.xyz_by_row, self.resolution - 2
+            x, y, z = (q & 1023) - 1, ((q >> 10) & 1023) - 1, ((q >> 20) & 1023) - 1
+            self._pixels_by_row = [(x * S + y).contiguous(), (x * S + z).contiguous(), (y * S + z).contiguous()]
+        return self._pixels_by_row
 
     @staticmethod
     def _segments(sorted_keys, n):
@@ -422,6 +473,12 @@ def cnt_np_embed_planned_backward3(plan, embeddings_clip, grads_over_sum, grad_e
     if len(grads_over_sum) != 3 or any(g.numel() != plan.n_pixels * n_features * 2 for g in grads_over_sum) \
             or grad_embeddings.shape != embeddings_clip.shape or embeddings_clip.shape[0] > plan.hashmap_size:
         raise RuntimeError("cnt_np_embed_planned_backward3: tensor sizes do not match the plan")
+    if plan.xyz_by_row is not None:        # one packed vertex per entry instead of three pixels
+        check(_lib.lib().cnc_cnt_np_embed_planned_backward3_xyz(
+            ptr(plan.xyz_by_row), ptr(plan.row_seg), ptr(embeddings_clip), ptr(grads_over_sum[0]), ptr(grads_over_sum[1]),
+            ptr(grads_over_sum[2]), ptr(grad_embeddings), embeddings_clip.shape[0], int(n_features), plan.resolution,
+            stream(grad_embeddings.device)), "cnt_np_embed_planned_backward3_xyz")
+        return
     rc = _lib.lib().cnc_cnt_np_embed_planned_backward3(
         ptr(plan.pixels_by_row[0]), ptr(plan.pixels_by_row[1]), ptr(plan.pixels_by_row[2]), ptr(plan.row_seg),
         ptr(embeddings_clip), ptr(grads_over_sum[0]), ptr(grads_over_sum[1]), ptr(grads_over_sum[2]),

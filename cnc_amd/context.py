@@ -948,11 +948,22 @@ class CNC_context_models(nn.Module):
 
         refresh = step % self.step_update == 0
         if refresh and self.use_dimension_wise:
-            self.idx_coords2_tmp = self.get_idx_coords2(binary_vxl)
-            # the vertex list is fixed until the next refresh: sort it once for the vote kernels
-            self.vote_plan = (_backend.VotePlan(self.idx_coords2_tmp.to(torch.int16).contiguous(),
-                                                self.dimension_wise_resolution, 2 ** self.log2_hashmap_size)
-                              if self.planned_votes else None)
+            occ = binary_vxl.squeeze(0)
+            R_fine = self.dimension_wise_resolution
+            t = (R_fine - 2) // self.binary_vxl_len
+            if (self.planned_votes and self.fused_segments and occ.is_cuda and occ.dim() == 3 and t >= 1
+                    and R_fine == self.binary_vxl_len * t + 2 and R_fine <= 1024 and self.binary_vxl_len <= 128
+                    and t == getattr(self, "_idx_coord_t", t)):
+                # the plan straight from the occupancy grid: no vertex list, no sort by pixel (the list itself is only
+                # made if the unplanned fallback below asks for it)
+                self.vote_plan = _backend.VotePlan.from_occupancy(occ.contiguous(), t, R_fine, 2 ** self.log2_hashmap_size)
+                self.idx_coords2_tmp = None
+            else:
+                self.idx_coords2_tmp = self.get_idx_coords2(binary_vxl)
+                # the vertex list is fixed until the next refresh: sort it once for the vote kernels
+                self.vote_plan = (_backend.VotePlan(self.idx_coords2_tmp.to(torch.int16).contiguous(),
+                                                    self.dimension_wise_resolution, 2 ** self.log2_hashmap_size)
+                                  if self.planned_votes else None)
         idx_coords2 = self.idx_coords2_tmp
         if refresh or getattr(self, "_binary_2D_src", None) is not binary_vxl:
             # the projections (and, keyed on them, the encoders' summed-area tables) live until the occupancy changes
@@ -977,6 +988,8 @@ class CNC_context_models(nn.Module):
                 if pn_fracs is not None:
                     pn_frac = pn_fracs[k]
                 else:
+                    if self.use_dimension_wise and idx_coords2 is None and self.vote_plan is None:
+                        idx_coords2 = self.idx_coords2_tmp = self.get_idx_coords2(binary_vxl)
                     pn_frac = (self.get_pn_embed_frac(finest_3D, idx_coords2, axis=axes[k], plan=self.vote_plan)
                                if self.use_dimension_wise else None)
             batches = iter(self.batched_inputs_list[k])

@@ -197,9 +197,11 @@ __global__ __launch_bounds__(64) void k_cnt_votes_bwd(const uint32_t* __restrict
 struct Votes3 {
     const uint32_t* pixels_by_row[3];
     const float*    G[3];
+    const uint32_t* xyz_by_row;      // XYZ form: one packed vertex (x | y << 10 | z << 20) instead of three pixels
+    uint32_t        S;               // resolution - 2
 };
 
-template <uint32_t F>
+template <uint32_t F, bool XYZ = false>
 __global__ __launch_bounds__(64) void k_cnt_votes_bwd3(Votes3 v3, const int32_t* __restrict__ seg,
                                                        const float* __restrict__ emb, float* __restrict__ grad_emb,
                                                        uint32_t rows)
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(64) void k_cnt_votes_bwd3(Votes3 v3, const int32_t*
     if (s != e) {
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            const uint32_t* __restrict__ pbr = v3.pixels_by_row[a];
+            const uint32_t* __restrict__ pbr = XYZ ? v3.xyz_by_row : v3.pixels_by_row[a];
             const float* __restrict__    G = v3.G[a];
             float                        part = 0;
             for (int32_t k = s + (int32_t)vs; k < e; k += (int32_t)(4 * VPI)) {
@@ -225,6 +227,11 @@ __global__ __launch_bounds__(64) void k_cnt_votes_bwd3(Votes3 v3, const int32_t*
                 for (int u = 0; u < 4; u++) {
                     const int32_t kk = k + u * (int32_t)VPI;
                     px[u] = kk < e ? pbr[kk] : 0xFFFFFFFFu;
+                    if (XYZ && px[u] != 0xFFFFFFFFu) {       // the plane's pixel of the packed vertex
+                        const uint32_t x = px[u] & 1023u, y = (px[u] >> 10) & 1023u, z = px[u] >> 20;
+                        const uint32_t uu = a == 2 ? y : x, ww = a == 0 ? y : z;
+                        px[u] = (uu - 1u) * v3.S + (ww - 1u);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++)
@@ -238,6 +245,121 @@ __global__ __launch_bounds__(64) void k_cnt_votes_bwd3(Votes3 v3, const int32_t*
         }
     }
     if (vs == 0) grad_emb[(size_t)r * F + ch] = acc;
+}
+
+// ---- the plan straight from the occupancy grid (no vertex list, no vertex volume, no sorting by pixel) -------------
+// utils_bpp_acc.py:498-512: the finest-level vertices inside / one ring around occupied cells.  Cell c of an axis covers
+// the vertices c t .. c t + t + 1, so vertex u is in the set iff one of the FINE cells u - 2, u - 1, u (fine cell i =
+// coarse cell i / t, 0 <= i < Rb t) is occupied on every axis, i.e. iff some coarse cell of the box A(x) x A(y) x A(z)
+// is, A(u) = [(max(u, 2) - 2) / t, min(u, Rb t - 1) / t] (one to three cells).  For a LINE of vertices along one axis the
+// other two boxes are fixed: the OR of the (at most 3 x 3) occupancy bit rows along the line's axis is a mask of Rb bits,
+// and vertex v of the line is in the set iff the mask has a bit in A(v).  So the occupancy is bit-packed along each
+// axis (3 x Rb^2 rows of 128 bits) and every pixel of every plane is a handful of bit operations on four words — no
+// [R, R, R] volume (136 MB at R = 514), no vertex list.
+constexpr uint32_t kOccWords = 4;            // Rb <= 128
+
+// bits[axis][i][j][word]: axis 0 packs along z (row (x, y) = (i, j)), axis 1 along y (row (x, z)), axis 2 along x (row (y, z))
+__global__ __launch_bounds__(256) void k_pack_occupancy_bits(const uint8_t* __restrict__ occ, uint32_t Rb,
+                                                             uint32_t* __restrict__ bits)
+{
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 3 * Rb * Rb * kOccWords) return;
+    const uint32_t w = idx % kOccWords, j = (idx / kOccWords) % Rb, i = (idx / kOccWords / Rb) % Rb, axis = idx / kOccWords / Rb / Rb;
+    uint32_t v = 0;
+    for (uint32_t b = 0; b < 32; b++) {
+        const uint32_t k = w * 32 + b;
+        if (k >= Rb) break;
+        const size_t at = axis == 0 ? ((size_t)i * Rb + j) * Rb + k : axis == 1 ? ((size_t)i * Rb + k) * Rb + j
+                                                                               : ((size_t)k * Rb + i) * Rb + j;
+        v |= (occ[at] ? 1u : 0u) << b;
+    }
+    bits[idx] = v;
+}
+
+struct OccLine {
+    uint32_t m[kOccWords];
+    __device__ __forceinline__ bool any(uint32_t lo, uint32_t hi) const       // a bit in [lo, hi] (hi - lo <= 2)?
+    {
+        bool r = false;
+        for (uint32_t c = lo; c <= hi; c++) {
+            const uint32_t w = c >> 5;
+            const uint32_t word = w == 0 ? m[0] : w == 1 ? m[1] : w == 2 ? m[2] : m[3];
+            r |= (word >> (c & 31u)) & 1u;
+        }
+        return r;
+    }
+};
+
+// (t is a power of two in every configuration of the drivers — 514 = 128 x 4 + 2: a shift, not a ~25-instruction
+// division twice per vertex)
+__device__ __forceinline__ uint32_t div_t(uint32_t x, uint32_t t)
+{
+    return (t & (t - 1u)) == 0 ? x >> (31u - (uint32_t)__builtin_clz(t)) : x / t;
+}
+
+__device__ __forceinline__ void coarse_range(uint32_t u, uint32_t t, uint32_t n, uint32_t& lo, uint32_t& hi)
+{
+    lo = div_t(u >= 2 ? u - 2 : 0, t);
+    hi = div_t(u < n ? u : n - 1, t);
+}
+
+// the line mask of pixel (u, w) of `plane` (0: xy, line along z; 1: xz, along y; 2: yz, along x)
+__device__ __forceinline__ OccLine line_mask(const uint32_t* __restrict__ bits, uint32_t Rb, uint32_t t, uint32_t plane,
+                                             uint32_t u, uint32_t w)
+{
+    const uint32_t  n = Rb * t;
+    const uint32_t* base = bits + (size_t)plane * Rb * Rb * kOccWords;
+    uint32_t        ulo, uhi, wlo, whi;
+    coarse_range(u, t, n, ulo, uhi);
+    coarse_range(w, t, n, wlo, whi);
+    OccLine L{{0, 0, 0, 0}};
+    for (uint32_t a = ulo; a <= uhi; a++)
+        for (uint32_t b = wlo; b <= whi; b++) {
+            const uint4 r = *reinterpret_cast<const uint4*>(base + ((size_t)a * Rb + b) * kOccWords);
+            L.m[0] |= r.x; L.m[1] |= r.y; L.m[2] |= r.z; L.m[3] |= r.w;
+        }
+    return L;
+}
+
+// One wave per pixel of a plane (blockIdx.y = plane), lanes = 64 consecutive vertices of the pixel's line.
+// FILL = false: counts[plane][pixel] = vertices of the set on the line (inner vertices 1 .. R-2 only: the ones
+// cnt_np_embed does not skip).  FILL = true: their table rows at seg[pixel] + rank — the pixel-major order a stable sort
+// by pixel of the (x, y, z)-ordered vertex list gives; the xy plane (whose order IS the list's) also writes the packed
+// vertices x | y << 10 | z << 20.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_vote_plan_lines(const uint32_t* __restrict__ bits, uint32_t Rb, uint32_t t, uint32_t hs,
+                                                         int32_t* __restrict__ counts, const int32_t* __restrict__ seg,
+                                                         int32_t* __restrict__ rows_xy, int32_t* __restrict__ rows_xz,
+                                                         int32_t* __restrict__ rows_yz, uint32_t* __restrict__ xyz)
+{
+    const uint32_t n = Rb * t, R = n + 2, S = R - 2, plane = blockIdx.y;
+    const uint32_t p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (p >= S * S) return;
+    const uint32_t u = p / S + 1, w = p % S + 1;
+    const OccLine  L = line_mask(bits, Rb, t, plane, u, w);
+    int32_t*       out = plane == 0 ? rows_xy : plane == 1 ? rows_xz : rows_yz;
+    uint32_t       at = FILL ? (uint32_t)seg[(size_t)plane * (S * S + 1) + p] : 0u;
+    for (uint32_t v0 = 1; v0 <= S; v0 += 64) {
+        const uint32_t v = v0 + lane;
+        bool           in = false;
+        if (v <= S) {
+            uint32_t lo, hi;
+            coarse_range(v, t, n, lo, hi);
+            in = L.any(lo, hi);
+        }
+        const uint64_t b = __ballot(in);
+        if (FILL && in) {
+            uint32_t q[3];
+            if (plane == 0) { q[0] = u; q[1] = w; q[2] = v; }
+            else if (plane == 1) { q[0] = u; q[1] = v; q[2] = w; }
+            else { q[0] = v; q[1] = u; q[2] = w; }
+            const uint32_t k = at + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+            out[k] = (int32_t)grid_row<3>(q, hs, R);
+            if (plane == 0) xyz[k] = q[0] | q[1] << 10 | q[2] << 20;
+        }
+        at += (uint32_t)__popcll(b);
+    }
+    if (!FILL && lane == 0) counts[(size_t)plane * S * S + p] = (int32_t)at;
 }
 
 }  // namespace cnc
@@ -266,6 +388,31 @@ extern "C" int cnc_cnt_np_plan3(const int16_t* inputs, uint32_t N, uint32_t reso
         return CNC_ERR_INVALID_VALUE;
     hipLaunchKernelGGL(k_cnt_plan3, dim3(div_up(N, 256)), dim3(256), 0, (hipStream_t)stream, inputs, N, resolution,
                        hashmap_size, rows, pix_xy, pix_xz, pix_yz, unsorted);
+    return launch_status();
+}
+
+extern "C" int cnc_vote_plan_count(const uint8_t* occupancy, uint32_t Rb, uint32_t t, uint32_t* bits, int32_t* counts,
+                                   void* stream)
+{
+    if (!occupancy || !bits || !counts || Rb == 0 || Rb > 32 * kOccWords || t == 0 || (uint64_t)Rb * t + 2 > 1024)
+        return CNC_ERR_INVALID_VALUE;
+    hipStream_t    s = (hipStream_t)stream;
+    const uint32_t S = Rb * t;
+    hipLaunchKernelGGL(k_pack_occupancy_bits, dim3(div_up(3 * Rb * Rb * kOccWords, 256)), dim3(256), 0, s, occupancy, Rb, bits);
+    hipLaunchKernelGGL((k_vote_plan_lines<false>), dim3(div_up(S * S, 4), 3), dim3(256), 0, s, bits, Rb, t, 1u, counts, nullptr,
+                       nullptr, nullptr, nullptr, nullptr);
+    return launch_status();
+}
+
+extern "C" int cnc_vote_plan_fill(const uint32_t* bits, uint32_t Rb, uint32_t t, uint32_t hashmap_size, const int32_t* seg,
+                                  int32_t* rows_xy, int32_t* rows_xz, int32_t* rows_yz, uint32_t* xyz, void* stream)
+{
+    if (!bits || !seg || !rows_xy || !rows_xz || !rows_yz || !xyz || Rb == 0 || Rb > 32 * kOccWords || t == 0 ||
+        (uint64_t)Rb * t + 2 > 1024 || hashmap_size == 0 || hashmap_size > 0x7fffffffu)
+        return CNC_ERR_INVALID_VALUE;
+    const uint32_t S = Rb * t;
+    hipLaunchKernelGGL((k_vote_plan_lines<true>), dim3(div_up(S * S, 4), 3), dim3(256), 0, (hipStream_t)stream, bits, Rb, t,
+                       hashmap_size, nullptr, seg, rows_xy, rows_xz, rows_yz, xyz);
     return launch_status();
 }
 
@@ -399,8 +546,26 @@ extern "C" int cnc_cnt_np_embed_planned_backward3(const uint32_t* pixels_by_row_
     if (!row_seg || !embeddings_clip || !grad_over_sum_xy || !grad_over_sum_xz || !grad_over_sum_yz || !grad_embeddings)
         return CNC_ERR_INVALID_VALUE;
     hipStream_t s = (hipStream_t)stream;
-    Votes3      v3{{pixels_by_row_xy, pixels_by_row_xz, pixels_by_row_yz}, {grad_over_sum_xy, grad_over_sum_xz, grad_over_sum_yz}};
+    Votes3      v3{{pixels_by_row_xy, pixels_by_row_xz, pixels_by_row_yz}, {grad_over_sum_xy, grad_over_sum_xz, grad_over_sum_yz},
+               nullptr, 0};
     CNC_VOTE_SWITCH(F, hipLaunchKernelGGL((k_cnt_votes_bwd3<FF>), dim3(n_rows), dim3(64), 0, s, v3, row_seg,
+                                          embeddings_clip, grad_embeddings, n_rows));
+    return launch_status();
+}
+
+extern "C" int cnc_cnt_np_embed_planned_backward3_xyz(const uint32_t* xyz_by_row, const int32_t* row_seg,
+                                                      const float* embeddings_clip, const float* grad_over_sum_xy,
+                                                      const float* grad_over_sum_xz, const float* grad_over_sum_yz,
+                                                      float* grad_embeddings, uint32_t n_rows, uint32_t F,
+                                                      uint32_t resolution, void* stream)
+{
+    if (n_rows == 0) return CNC_OK;
+    if (!xyz_by_row || !row_seg || !embeddings_clip || !grad_over_sum_xy || !grad_over_sum_xz || !grad_over_sum_yz ||
+        !grad_embeddings || resolution < 3 || resolution > 1024)
+        return CNC_ERR_INVALID_VALUE;
+    hipStream_t s = (hipStream_t)stream;
+    Votes3      v3{{nullptr, nullptr, nullptr}, {grad_over_sum_xy, grad_over_sum_xz, grad_over_sum_yz}, xyz_by_row, resolution - 2};
+    CNC_VOTE_SWITCH(F, hipLaunchKernelGGL((k_cnt_votes_bwd3<FF, true>), dim3(n_rows), dim3(64), 0, s, v3, row_seg,
                                           embeddings_clip, grad_embeddings, n_rows));
     return launch_status();
 }

@@ -248,6 +248,25 @@ int cnc_cnt_np_embed_planned_backward3(const uint32_t* pixels_by_row_xy, const u
                                        const float* embeddings_clip, const float* grad_over_sum_xy,
                                        const float* grad_over_sum_xz, const float* grad_over_sum_yz,
                                        float* grad_embeddings, uint32_t n_rows, uint32_t F, void* stream);
+/* (ABI v25) The plan straight from the occupancy grid — no vertex list, no sort by pixel.  The finest-level vertices
+ * inside / one ring around occupied cells (utils_bpp_acc.py:498-512, the set get_idx_coords2 lists; resolution R = Rb t
+ * + 2 <= 1024, Rb <= 128) are decided per line of vertices from the occupancy bit-packed along the line's axis.
+ *   cnc_vote_plan_count: occupancy [Rb, Rb, Rb] bytes -> bits (scratch, 3 Rb^2 4 words, kept for the fill call) and
+ *     counts [3, (R-2)^2] int32: per pixel of the xy / xz / yz plane the vertices of the set on its line, inner vertices
+ *     only (the ones cnt_np_embed does not skip).
+ *   cnc_vote_plan_fill: seg [3, (R-2)^2 + 1] = the caller's exclusive running sums of the counts; writes rows_* [n] =
+ *     the table rows in pixel-major order of each plane (what a stable sort by pixel of the (x, y, z)-ordered list
+ *     gives) and xyz [n] = the vertices x | y << 10 | z << 20 in (x, y, z) order.  Sorting xyz by row (rows_xy is that
+ *     key) gives the backward plan;
+ *   cnc_cnt_np_embed_planned_backward3_xyz = ..._backward3 reading one packed vertex per entry instead of three pixels. */
+int cnc_vote_plan_count(const uint8_t* occupancy, uint32_t Rb, uint32_t t, uint32_t* bits, int32_t* counts, void* stream);
+int cnc_vote_plan_fill(const uint32_t* bits, uint32_t Rb, uint32_t t, uint32_t hashmap_size, const int32_t* seg,
+                       int32_t* rows_xy, int32_t* rows_xz, int32_t* rows_yz, uint32_t* xyz, void* stream);
+int cnc_cnt_np_embed_planned_backward3_xyz(const uint32_t* xyz_by_row, const int32_t* row_seg,
+                                           const float* embeddings_clip, const float* grad_over_sum_xy,
+                                           const float* grad_over_sum_xz, const float* grad_over_sum_yz,
+                                           float* grad_embeddings, uint32_t n_rows, uint32_t F, uint32_t resolution,
+                                           void* stream);
 int cnc_cnt_vote_masks(const float* embeddings_clip, uint32_t n_rows, uint32_t F, uint32_t* masks, void* stream);
 int cnc_cnt_np_embed_planned_masked(const uint32_t* rows_by_pixel, const int32_t* pixel_seg, const uint32_t* masks,
                                     float* outputs, uint32_t n_pixels, uint32_t F, void* stream);

@@ -230,6 +230,58 @@ def test_plane_batched_levels_equal_the_level_by_level_pass(setup):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
 
 
+@pytest.mark.parametrize("Rb,t,log2T", [(8, 4, 10), (8, 1, 12), (16, 2, 19), (128, 4, 19)])
+def test_vote_plan_from_the_occupancy_grid_equals_the_plan_from_the_vertex_list(cuda, Rb, t, log2T):
+    """`VotePlan.from_occupancy` (vertex volume -> per-pixel counts -> rows written in pixel-major order, one sort by
+    table row of packed vertices) against `VotePlan(get_idx_coords2 list)` (three stable sorts by pixel, one by row):
+    the same rows per pixel in the same order, the same segments, the same vertices per table row in the same order —
+    toy sizes, a dense finest level (R^3 < T), occupancy touching the border (skipped vertices), and the full size."""
+    from cnc_amd.backends import gridencoder_backend as be
+    g = torch.Generator(device=cuda).manual_seed(Rb * 10 + t)
+    if Rb == 128:
+        from cnc_amd.synthetic import ball_binaries
+        occ = ball_binaries(128, device=cuda)[0].bool()
+    else:
+        occ = torch.rand(Rb, Rb, Rb, device=cuda, generator=g) < 0.15
+        occ[0, 0, :] = True                                  # cells on the box: vertices cnt_np_embed skips
+        occ[-1, :, -1] = True
+    R, hs = Rb * t + 2, 2 ** log2T
+    m = occ
+    for axis in range(3):                                    # get_idx_coords2's construction (context.py)
+        up = m.repeat_interleave(t, dim=axis)
+        n = up.shape[axis]
+        shape = list(up.shape)
+        shape[axis] = n + 2
+        out = torch.zeros(shape, dtype=torch.bool, device=cuda)
+        for sft in range(3):
+            out.narrow(axis, sft, n).logical_or_(up)
+        m = out
+    verts = torch.nonzero(m).to(torch.int16).contiguous()
+    a = be.VotePlan(verts, R, hs)
+    b = be.VotePlan.from_occupancy(occ, t, R, hs)
+    n = int(b.pixel_seg[0][-1])
+    assert n > 0 and n == int(a.pixel_seg[0][-1])
+    for k in range(3):
+        assert torch.equal(a.pixel_seg[k], b.pixel_seg[k]), k
+        assert torch.equal(a.rows_by_pixel[k][:n], b.rows_by_pixel[k]), k
+        assert torch.equal(a.pixels_by_row[k][:n], b.pixels_by_row[k]), k
+    assert torch.equal(a.row_seg, b.row_seg)
+    # and the kernels that consume the two forms: counts and the three-plane backward
+    F = 8
+    emb = torch.where(torch.rand(min(hs, R ** 3), F, device=cuda, generator=g) < 0.5, 1.0, -1.0)
+    for axis in range(3):
+        oa = torch.empty(R - 2, R - 2, F, 2, device=cuda)
+        ob = torch.empty_like(oa)
+        be.cnt_np_embed_planned(a, emb, oa, F, axis)
+        be.cnt_np_embed_planned(b, emb, ob, F, axis)
+        assert torch.equal(oa, ob)
+    gs = [torch.randn(R - 2, R - 2, F, 2, device=cuda, generator=g) for _ in range(3)]
+    ga, gb = torch.empty_like(emb), torch.empty_like(emb)
+    be.cnt_np_embed_planned_backward3(a, emb, gs, ga, F)
+    be.cnt_np_embed_planned_backward3(b, emb, gs, gb, F)
+    assert torch.equal(ga, gb) and float(ga.abs().max()) > 0
+
+
 def test_planned_votes_equal_atomic_votes(setup):
     """planned_votes=True (vertex list sorted once per refresh, segmented gathers) vs the atomic
     cnt_np_embed kernels: same entropy estimate, same gradients into the finest 3-D level and planes."""

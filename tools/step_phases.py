@@ -80,7 +80,7 @@ wrap(tr.context, "fetch_2D_batches", "ctx/fetch_2D")
 wrap(tr.context, "_sorted_slots_2D", "ctx/sorted_slots_2D")
 wrap(tr.context, "get_pn_embed_frac_planes", "ctx/pn_frac")
 import cnc_amd.context as _C
-wrap(_C._backend, "VotePlan", "ctx/vote_plan")
+wrap(_C._backend.VotePlan, "from_occupancy", "ctx/vote_plan")
 wrap(tr.context, "_project", "ctx/project")
 N = 48 if not REFRESH else 16 * 12
 for _ in range(N):
