@@ -876,6 +876,53 @@ class CNC_context_models(nn.Module):
         unique_value, unique_cnt = torch.unique_consecutive(indexes_sorted, return_counts=True)   # sorted already: no second sort
         return points_n, order, unique_value.to(torch.long) + self._off2_host[n], unique_cnt
 
+    def _slot_lists_2D(self, binary_2D):
+        """Per plane and coded level: (points, slot order, table rows, slot counts, their running sums)."""
+        return [[(lambda t: t + (_cum(t[3]),))(self._sorted_slots_2D(binary_2D[k], n))
+                 for n in range(self.n_levels_2D) if self._coded_2D(n)]
+                for k in range(3)]
+
+    def _refresh_plane_cats(self, binary_2D):
+        """What `_plane_bits` needs of the three planes, from ONE sort: the vertices of every (plane, coded level) keyed
+        (plane, level, table row) in one int32, sorted stably once, distinct keys counted once — the same slot order,
+        rows and counts as a stable sort + unique per level (nine sorts, nine syncs), concatenated per plane.  Returns
+        False when the keys do not fit (the caller then builds the per-level lists)."""
+        coded = [n for n in range(self.n_levels_2D) if self._coded_2D(n)]
+        nl, F = self.n_levels_2D, self.n_features
+        shift = max(int(self._off2_host[n + 1] - self._off2_host[n] - 1).bit_length() for n in coded)
+        if (3 * nl) << shift >= 2 ** 31:
+            return False
+        keys, pts, sizes = [], [], []
+        for k in range(3):
+            for n in coded:
+                r, p = self.fetch_2D_batches(binary_2D[k], n)
+                if r.dtype != torch.int32:
+                    return False
+                keys.append(r + ((k * nl + n) << shift))
+                pts.append(p)
+                sizes.append(r.shape[0])
+        keys_sorted, order = torch.sort(torch.cat(keys), stable=True)
+        uv, uc = torch.unique_consecutive(keys_sorted, return_counts=True)          # sync 1: the number of slots
+        bases = torch.tensor([(k * nl) << shift for k in range(4)], dtype=uv.dtype, device=uv.device)
+        slot_at = torch.searchsorted(uv, bases).tolist()                            # sync 2: slots per plane
+        pts_all = torch.cat(pts)
+        off_lut = torch.tensor(self._off2_host[:nl], dtype=torch.long, device=uv.device)
+        at = 0
+        for k in range(3):
+            a, b = slot_at[k], slot_at[k + 1]
+            p_at = [at]
+            for i in range(len(coded)):
+                p_at.append(p_at[-1] + sizes[k * len(coded) + i])
+            A, B = p_at[0], p_at[-1]
+            uvk = uv[a:b]
+            self._plane_cat[k] = dict(
+                pts=pts_all[A:B], order=order[A:B] - A,
+                rows=(uvk & ((1 << shift) - 1)).to(torch.long) + off_lut[(uvk >> shift) - k * nl],
+                cum=_cum(uc[a:b]),
+                segs=[(p_at[i] - A, p_at[i + 1] - A, 0, n * F, n) for i, n in enumerate(coded)])
+            at = B
+        return True
+
     def _plane_batch_ok(self, p_q):
         """The coded levels of a plane can be evaluated together when every one of them looks at the levels below it
         down to level 0 (n <= max_context_layer_num: the windows [n - min(n, max), n) all start at 0) and the fused
@@ -891,7 +938,7 @@ class CNC_context_models(nn.Module):
         ranges, one per-slot mean, one rate kernel.  Same numbers as the level-by-level loop; a third of the launches."""
         coded = [n for n in range(self.n_levels_2D) if self._coded_2D(n)]
         F = self.n_features
-        if refresh or self._plane_cat[k] is None:
+        if self._plane_cat[k] is None:
             levels = self.batched_inputs_list[k]
             at, p_at = 0, []
             for (pts, *_rest) in levels:
@@ -904,9 +951,9 @@ class CNC_context_models(nn.Module):
                 order=torch.cat([lv[1] + p_at[i] for i, lv in enumerate(levels)]),
                 rows=torch.cat([lv[2] for lv in levels]), cum=_cum(cnt),
                 segs=[(p_at[i], p_at[i + 1], 0, n * F, n) for i, n in enumerate(coded)])
-            if self._noncoded_2D is None or self._noncoded_2D.device != bits_all.device:
-                self._noncoded_2D = torch.tensor([0.0 if n in coded else 1.0 for n in range(self.n_levels_2D)],
-                                                 dtype=bits_all.dtype, device=bits_all.device)
+        if self._noncoded_2D is None or self._noncoded_2D.device != bits_all.device:
+            self._noncoded_2D = torch.tensor([0.0 if n in coded else 1.0 for n in range(self.n_levels_2D)],
+                                             dtype=bits_all.dtype, device=bits_all.device)
         pb = self._plane_cat[k]
         with _range("ctx/2D_mean"):
             context = Ec(pb["pts"], 0, max(coded), binary_vxl=binary_vxl_2D, PV=0)
@@ -972,10 +1019,11 @@ class CNC_context_models(nn.Module):
         binary_2D = self._binary_2D
         if refresh:
             # vertex lists, slot order and the slots' cumulative counts are fixed until the next refresh
-            self.batched_inputs_list = [
-                [(lambda t: t + (_cum(t[3]),))(self._sorted_slots_2D(binary_2D[k], n))
-                 for n in range(self.n_levels_2D) if self._coded_2D(n)]
-                for k in range(3)]
+            if self._plane_batch_ok(params_q_xy) and self._refresh_plane_cats(binary_2D):
+                self.batched_inputs_list = None           # the per-level lists: only the level-by-level loop wants them
+            else:
+                self.batched_inputs_list = self._slot_lists_2D(binary_2D)
+                self._plane_cat = [None, None, None]
 
         finest_3D = params_q_xyz[self._off3_host[-2]:self._off3_host[-1]]
         pn_fracs = None
@@ -992,14 +1040,16 @@ class CNC_context_models(nn.Module):
                         idx_coords2 = self.idx_coords2_tmp = self.get_idx_coords2(binary_vxl)
                     pn_frac = (self.get_pn_embed_frac(finest_3D, idx_coords2, axis=axes[k], plan=self.vote_plan)
                                if self.use_dimension_wise else None)
-            batches = iter(self.batched_inputs_list[k])
             with _range("ctx/level_Pg"):
                 Pg_all, bits_all = self.level_stats(p_q, self._off2_host)
-            if self._plane_batch_ok(p_q):
+            if self._plane_batch_ok(p_q) and (self._plane_cat[k] is not None or self.batched_inputs_list is not None):
                 # the coded levels of the plane in one pass (their context windows all start at level 0)
                 ttl_bit_sum = ttl_bit_sum + self._plane_bits(k, Ec, p_q, Pg_all, bits_all, binary_2D[k], pn_frac, refresh)
                 ttl_num_sum += p_q.numel()
                 continue
+            if self.batched_inputs_list is None:
+                self.batched_inputs_list = self._slot_lists_2D(binary_2D)
+            batches = iter(self.batched_inputs_list[k])
             with _range("ctx/level_Pg"):
                 # one unbind each instead of a select per level: a select's backward is a zero-filled [L] vector plus
                 # a copy — 43 five-microsecond kernels per step for the 27 selects of the four tables

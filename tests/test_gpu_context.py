@@ -224,6 +224,20 @@ def test_plane_batched_levels_equal_the_level_by_level_pass(setup):
         res[batched] = [bpp.detach().clone()] + [encs[k].params.grad.clone() for k in ("xyz", "xy", "xz", "yz")] + \
                        [p.grad.clone() for p in m.context_model_2D.parameters()]
     m.plane_batched = True
+    # the plane records from ONE composite-key sort (refresh path) against per-level sorts concatenated
+    binary_2D = [m._project(binary, a) for a in ("xy", "xz", "yz")]
+    assert m._refresh_plane_cats(binary_2D)
+    one_sort = [dict(c) for c in m._plane_cat]
+    m.batched_inputs_list, m._plane_cat = m._slot_lists_2D(binary_2D), [None, None, None]
+    Pg_all, bits_all = m.level_stats(m.get_STE_params(encs["xy"]), m._off2_host)
+    for k, name in enumerate(("xy", "xz", "yz")):
+        with torch.no_grad():
+            m._plane_bits(k, encs[name], m.get_STE_params(encs[name]), Pg_all, bits_all, binary_2D[k], None if not m.use_dimension_wise
+                          else torch.zeros(m.dimension_wise_resolution ** 2, m.n_features, device=binary.device), False)
+        for key in ("pts", "order", "rows", "cum"):
+            assert one_sort[k][key].dtype == m._plane_cat[k][key].dtype, (k, key)
+            assert torch.equal(one_sort[k][key], m._plane_cat[k][key]), (k, key)
+        assert one_sort[k]["segs"] == m._plane_cat[k]["segs"]
     assert abs(float(res[True][0]) - float(res[False][0])) <= 2e-6 * abs(float(res[False][0]))
     for a, b in zip(res[True][1:], res[False][1:]):
         assert float(b.abs().max()) > 0
