@@ -4,7 +4,7 @@
 // a marched frame (200-400 samples per ray), so the runs it merges are runs along ONE ray.  The rays of
 // neighbouring pixels cross the same cells: of the runs in 1024 consecutive samples (3-4 rays) only 0.29
 // (level 0) to 0.46 (resolution 214) open a cell no earlier run of the block visited; in 256 samples it is
-// 0.93-0.96.  This kernel takes kMB = 1024 samples per block, chains the runs of equal cells through a
+// 0.93-0.96.  This kernel takes MB = 1024 (or 512) samples per block, chains the runs of equal cells through a
 // small LDS hash table and sends ONE set of atomics per distinct cell — the coarse levels are bound by the
 // memory-side atomic units (docs/engineering_log.md §4.2b), so the number of atomic instructions is what their time was
 // made of.
@@ -32,16 +32,18 @@ namespace cnc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr uint32_t kMB = 1024;            // samples (= threads) per block, a multiple of 64
-constexpr uint32_t kMW = kMB / 64;        // waves per block
-constexpr uint32_t kMSlots = kMB <= 512 ? 1024 : 2048;   // hash slots, power of two, >= 2 x the most runs a block can have
-
-template <bool STE>
-__global__ __launch_bounds__(kMB) void k_grid_encode_bwd_merge(
+// MB = samples (= threads) per block, a multiple of 64: 1024 for the frames of the bench (more samples per block merge
+// more), 512 when the whole launch is only a few rounds of 1024-sample blocks — a training batch of 2^18 samples x 11
+// levels is 2.8 k such blocks on 512 block slots, and ran 4x less efficiently than the 2^20-sample chunks.
+template <bool STE, uint32_t MB>
+__global__ __launch_bounds__(MB) void k_grid_encode_bwd_merge(
     const float* __restrict__ grad, const float* __restrict__ inputs, const float* __restrict__ emb,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
     float* __restrict__ grad_emb, uint32_t N, const uint32_t* __restrict__ clip_count, FeatLayout lay)
 {
+    constexpr uint32_t kMB = MB;
+    constexpr uint32_t kMW = kMB / 64;        // waves per block
+    constexpr uint32_t kMSlots = kMB <= 512 ? 1024 : 2048;   // hash slots, power of two, >= 2 x the most runs a block can have
     constexpr uint32_t D = 3, F = 8, C = 8, END = 0x7FFu;
     static_assert(kMB <= 1024, "run records pack start (10 bits) / end (11) / next (11)");
     // the three fractional positions and 1 / (sum of valid weights): the lane rebuilds its corner's
@@ -249,12 +251,18 @@ void launch_bwd_merge(const float* grad, const float* inputs, const float* emb, 
                       const uint32_t* clip_count, FeatLayout lay, bool ste, hipStream_t s)
 {
     lay.n_slots = L;
-    const dim3 grid(div_up(N, kMB) * L);
     // (round 3 measured this kernel with padded dynamic LDS — one block per CU, to leave room for the owner waves of
     // the binned levels: slower; the switch is gone, the library keeps no state between calls)
-    const uint32_t pad = 0u;
-    if (ste) hipLaunchKernelGGL((k_grid_encode_bwd_merge<true>), grid, dim3(kMB), pad, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
-    else hipLaunchKernelGGL((k_grid_encode_bwd_merge<false>), grid, dim3(kMB), pad, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
+    const bool small = (uint64_t)div_up(N, 1024u) * L < 4096u;       // fewer than eight rounds of 1024-sample blocks
+    if (small) {
+        const dim3 grid(div_up(N, 512u) * L);
+        if (ste) hipLaunchKernelGGL((k_grid_encode_bwd_merge<true, 512>), grid, dim3(512), 0, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
+        else hipLaunchKernelGGL((k_grid_encode_bwd_merge<false, 512>), grid, dim3(512), 0, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
+    } else {
+        const dim3 grid(div_up(N, 1024u) * L);
+        if (ste) hipLaunchKernelGGL((k_grid_encode_bwd_merge<true, 1024>), grid, dim3(1024), 0, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
+        else hipLaunchKernelGGL((k_grid_encode_bwd_merge<false, 1024>), grid, dim3(1024), 0, s, grad, inputs, emb, offsets, resolutions, grad_emb, N, clip_count, lay);
+    }
 }
 
 }  // namespace cnc

@@ -113,8 +113,9 @@ def test_plan_and_mirror_route(cuda):
     N = 1 << 16
     x = torch.rand(N, 3, device=cuda)
     g = torch.randn(len(res), N, 8, device=cuda)
-    plan = be.plan_binned_levels(res, offs, 3, 8, N, min_resolution=64)
+    plan = be.plan_binned_levels(res, offs, 3, 8, N, min_resolution=64, min_work=0)
     assert plan == (2, 1 << 16)
+    assert be.plan_binned_levels(res, offs, 3, 8, N, min_resolution=64) is None      # too little work for the bin pass
     t = lambda a: torch.as_tensor(a, device=cuda)
     outs = []
     for binned in (None, plan):

@@ -219,8 +219,11 @@ def test_plan_binned_levels_host_only():
     assert plan_binned_levels(RES_16L, off16, 3, 16, 1 << 20) is None         # F = 16: atomic kernel only
     assert plan_binned_levels(RES_16L, off16, 2, 8, 1 << 20) is None          # planes stay on atomics
     off12 = level_offsets(RES_3D_REF, 19, 3)
-    n, rows = plan_binned_levels(RES_3D_REF, off12, 3, 8, 1 << 18)
-    assert rows == 1 << 19 and n == sum(1 for r in RES_3D_REF if r >= 400)
+    n, rows = plan_binned_levels(RES_3D_REF, off12, 3, 8, 1 << 18, min_work=0)
+    assert rows == 1 << 19 and n == sum(1 for r in RES_3D_REF if r >= 400) == 1
+    # samples x binned levels below 1.5 M: the bin pass would be a handful of blocks, the atomic kernel takes the call
+    assert plan_binned_levels(RES_3D_REF, off12, 3, 8, 1 << 18) is None and plan_binned_levels(RES_3D_REF, off12, 3, 8, 1 << 20) is None
+    assert plan_binned_levels(RES_16L, off16, 3, 8, 1 << 17) is None and plan_binned_levels(RES_16L, off16, 3, 8, 1 << 18) == (6, 1 << 19)
     # a coarse level after a fine one breaks the suffix
     assert plan_binned_levels([600, 20], [0, 1 << 19, (1 << 19) + 8000], 3, 8, 1 << 20) is None
 
