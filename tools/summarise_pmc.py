@@ -73,7 +73,9 @@ def call_total(d, pat, calls):
 
 
 calls = max(sum(cnt[n] for n in names if re.search(r"k_grid_encode_bwd_merge<", n)), 1)
-fwd_calls = max(sum(cnt[n] for n in names if re.search(r"k_grid_encode_fwd_bits", n)), 1)
+# the bench frame's forward is the 3-D instantiation only: the `field` block of bench.py also dispatches the 2-D planes' kernel
+FWD_PAT = r"k_grid_encode_fwd_bits<3u"
+fwd_calls = max(sum(cnt[n] for n in names if re.search(FWD_PAT, n)), 1)
 
 
 def entry(pats, n_calls, streamed_read_bytes, note):
@@ -95,7 +97,7 @@ def entry(pats, n_calls, streamed_read_bytes, note):
 items = 4 * N_CHUNK * L_BINNED * 16                       # one 16-byte item per (sample, binned level, corner pair)
 slabs = L_BINNED * (1 << 19) * F * 4                      # the owners read every table slab of the binned levels once
 traffic = {
-    "grid_encode_forward": entry([r"k_grid_encode_fwd_bits"], fwd_calls, N_CHUNK * 12,
+    "grid_encode_forward": entry([FWD_PAT], fwd_calls, N_CHUNK * 12,
                                  "reads: the 12-byte points streamed, byte gathers from the 6 MB sign plane (L2 / Infinity-Cache hits "
                                  "mostly); writes: the [L, N, F] output stream"),
     "grid_encode_backward": entry([r"k_grid_encode_bwd_merge<", r"k_bwd_bin", r"k_bwd_owner"], calls,
@@ -106,7 +108,9 @@ traffic = {
                                    "finest levels alone"),
     "k_grid_encode_bwd_merge": entry([r"k_grid_encode_bwd_merge<"], calls, N_CHUNK * 12 + N_CHUNK * (L - L_BINNED) * F * 4,
                                      "coarse levels alone"),
-    "march_samples(count+fill)": entry([r"k_traverse<0", r"k_traverse<2"], max(cnt.get(next((n for n in names if "k_traverse<2" in n), ""), 1), 1),
+    # cnc_march_samples = the count pass with positions requested (<0, 32, true>) + the resumed fill (<2, ...>); the
+    # <0, 32, false> / <1, ...> dispatches are the drop-in traverse_grids probe of bench.py's kernel table
+    "march_samples(count+fill)": entry([r"k_traverse<0, \d+, true>", r"k_traverse<2"], max(cnt.get(next((n for n in names if "k_traverse<2" in n), ""), 1), 1),
                                        2 * 640000 * 24, "per 640k-ray frame; the fill pass also writes the positions (12 B / sample)"),
     "_sources": {p: blob_hash(os.path.join(ROOT, p)) for p in KERNEL_SOURCES if os.path.exists(os.path.join(ROOT, p))},
     "_fabric_request_rate_peak_G_per_s": 50.0,
