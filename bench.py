@@ -144,7 +144,7 @@ def step(w, timed, world):
             binned=enc.plan_binned_levels(synthetic.RES_16L, w["offsets_host"], D, F, n)))
     mid = (S // CHUNK // 2) * CHUNK              # a chunk from the middle of the frame (the first one is atypical:
     w["probe_chunk"] = x[mid:mid + min(CHUNK, S)]    # 36k grazing rays of ~30 samples, 2.1 ms against 1.1-1.16)
-    if world > 1:
+    if w.get("exchange_on", world > 1):
         # the only exchange of the path: one flat-bucket all-reduce of the table gradient, asynchronous on the
         # communicator's stream.  What the next frame does before it needs the table or its gradient again — the march
         # (occupancy grid and rays only) — runs next to it; `finish_exchange` is where the compute stream joins.
@@ -478,8 +478,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend = "none"
-    if world > 1:
+    # CNC_DIST_FORCE=1 (test hook, cnc_amd.dist.forced): a ONE-rank process group on RCCL — the frame's gradient exchange
+    # (async all-reduce next to the following march, join, mean) runs through the communicator on a 1-GPU box
+    exchange_on = world > 1 or os.environ.get("CNC_DIST_FORCE") == "1"
+    if exchange_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("CNC_BENCH_BACKEND", "nccl")
         if backend == "nccl":
@@ -495,10 +501,11 @@ def main():
         ranks = [{"rank": 0, "device": str(dev), "world_size": 1, "backend": backend}]
 
     w = build_workload(dev, rank)
+    w["exchange_on"] = exchange_on
     timed = Timed()
 
     def barrier():
-        if world > 1:
+        if exchange_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -569,7 +576,7 @@ def main():
         extra.collect()
 
     tot = torch.tensor([float(samples), elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if exchange_on:
         s = tot[0:1].clone()
         e = tot[1:2].clone()
         torch.distributed.all_reduce(s, op=torch.distributed.ReduceOp.SUM)
@@ -732,7 +739,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             out["cpu_baseline"], out["cpu_baseline_torch"] = cpu_baseline(w)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if exchange_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

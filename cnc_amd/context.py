@@ -657,14 +657,20 @@ class CNC_context_models(nn.Module):
         R = self._res2_host[n]
         T, rem = divmod(R - 2, Rb)
         assert rem == 0
-        cached = getattr(self, "_occ_cells_2D", None)
-        if cached is None or cached[0] is not binary_vxl_2D or cached[1] != binary_vxl_2D._version:
-            cached = (binary_vxl_2D, binary_vxl_2D._version,
-                      self.binary_vxl_2D_idx.view(-1, 2)[binary_vxl_2D.reshape(-1) == 1])
-            self._occ_cells_2D = cached
-        if self.fused_segments and cached[2].is_cuda:
-            return _ctxk.plane_ring_vertices(cached[2].contiguous(), T, R, self._off2_host[n + 1] - self._off2_host[n])
-        occ = cached[2].view(-1, 1, 1, 2) * T
+        # one entry per plane, keyed on the storage a (fresh) view of the plane points at — `binary_2D[k]` is a new tensor
+        # object at every call, the nonzero below is a host sync
+        key = (binary_vxl_2D.data_ptr(), binary_vxl_2D._version, tuple(binary_vxl_2D.shape), tuple(binary_vxl_2D.stride()))
+        cache = self.__dict__.setdefault("_occ_cells_2D", {})
+        cached = cache.get(key)
+        if cached is None:
+            if len(cache) >= 8:
+                cache.clear()
+            cached = (binary_vxl_2D, self.binary_vxl_2D_idx.view(-1, 2)[binary_vxl_2D.reshape(-1) == 1])
+            cache[key] = cached
+        cells = cached[1]
+        if self.fused_segments and cells.is_cuda:
+            return _ctxk.plane_ring_vertices(cells.contiguous(), T, R, self._off2_host[n + 1] - self._off2_host[n])
+        occ = cells.view(-1, 1, 1, 2) * T
         ar = torch.arange(0, T + 2, device=self.dev)
         ring = torch.stack(torch.meshgrid(ar, ar, indexing="ij"), dim=-1).view(1, T + 2, T + 2, 2)
         points_n_orig = (occ + ring).to(torch.long)
@@ -999,6 +1005,7 @@ class CNC_context_models(nn.Module):
             R_fine = self.dimension_wise_resolution
             t = (R_fine - 2) // self.binary_vxl_len
             if (self.planned_votes and self.fused_segments and occ.is_cuda and occ.dim() == 3 and t >= 1
+                    and tuple(occ.shape) == (self.binary_vxl_len,) * 3 and occ.dtype in (torch.bool, torch.uint8)
                     and R_fine == self.binary_vxl_len * t + 2 and R_fine <= 1024 and self.binary_vxl_len <= 128
                     and t == getattr(self, "_idx_coord_t", t)):
                 # the plan straight from the occupancy grid: no vertex list, no sort by pixel (the list itself is only

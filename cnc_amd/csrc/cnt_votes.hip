@@ -586,7 +586,9 @@ extern "C" int cnc_cnt_np_embed_planned_backward3_xyz(const uint32_t* xyz_by_row
                                                       uint32_t resolution, void* stream)
 {
     if (n_rows == 0) return CNC_OK;
-    if (!xyz_by_row || !row_seg || !embeddings_clip || !grad_over_sum_xy || !grad_over_sum_xz || !grad_over_sum_yz ||
+    // xyz_by_row may be NULL: the plan of an all-empty occupancy grid has no vertices (every row segment is empty and the
+    // kernel then reads nothing through it) — the forward and the three-array backward accept that too
+    if (!row_seg || !embeddings_clip || !grad_over_sum_xy || !grad_over_sum_xz || !grad_over_sum_yz ||
         !grad_embeddings || resolution < 3 || resolution > 1024)
         return CNC_ERR_INVALID_VALUE;
     hipStream_t s = (hipStream_t)stream;

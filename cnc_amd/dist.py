@@ -21,10 +21,19 @@ def env_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def forced() -> bool:
+    """CNC_DIST_FORCE=1 (test hook): treat a ONE-rank world as data-parallel — the process group is created, every
+    collective of the N > 1 path is issued (on RCCL they run through the same communicator code as at N = 8), the
+    Trainer builds its buckets.  This is how the one GPU of a test box exercises the `nccl` backend."""
+    return os.environ.get("CNC_DIST_FORCE") == "1"
+
+
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """Initialise the default process group from the torchrun environment (no-op for world 1)."""
+    """Initialise the default process group from the torchrun environment (no-op for world 1 unless `forced()`)."""
     rank, local_rank, world = env_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -48,10 +57,10 @@ def local_device_index() -> int:
 
 
 def _active() -> bool:
-    """True when there is a process group with more than one rank.  WORLD_SIZE > 1 in the environment
-    WITHOUT a process group is an error, not a silent single-rank run: replicas would drift apart."""
+    """True when there is a process group with more than one rank (or any group under `forced()`).  WORLD_SIZE > 1 in
+    the environment WITHOUT a process group is an error, not a silent single-rank run: replicas would drift apart."""
     if dist.is_available() and dist.is_initialized():
-        return dist.get_world_size() > 1
+        return dist.get_world_size() > 1 or forced()
     if env_world()[2] > 1:
         raise RuntimeError("WORLD_SIZE > 1 but torch.distributed is not initialised: call cnc_amd.dist.init() first")
     return False
@@ -102,7 +111,7 @@ class GradBucket:
             return None
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
         if average and not async_op:
-            self.flat.div_(dist.get_world_size())
+            self.grads.div_(dist.get_world_size())       # the tail carries sums (sample counts): never averaged
         return work
 
     @property
@@ -134,12 +143,24 @@ def broadcast_parameters(params: Iterable[torch.nn.Parameter], src: int = 0) -> 
             p.add_(0)            # in-place no-op that bumps p._version: caches keyed on it (sign plane) refresh
 
 
+_CHECKSUM_CHUNK = 1 << 22
+
+
 def _checksums(params) -> torch.Tensor:
     """Two wrapping int64 checksums of every tensor's BITS (sum and sum of squares of its int32 view): [P, 2]."""
     out = []
     for p in params:
-        v = p.detach().reshape(-1).view(torch.int32).to(torch.int64)
-        out.append(torch.stack([v.sum(), (v * v).sum()]))
+        if p.element_size() != 4:
+            raise TypeError(f"resync checksums are defined on 4-byte parameters, got {p.dtype}")
+        v = p.detach().reshape(-1).view(torch.int32)
+        s1 = s2 = None
+        for lo in range(0, max(v.numel(), 1), _CHECKSUM_CHUNK):      # transient memory: 8 bytes per chunk element
+            c = v[lo:lo + _CHECKSUM_CHUNK]
+            a = torch.sum(c, dtype=torch.int64)
+            c64 = c.to(torch.int64)
+            b = torch.sum(c64 * c64)                                   # wraps mod 2^64 like the one-shot form did
+            s1, s2 = (a, b) if s1 is None else (s1 + a, s2 + b)
+        out.append(torch.stack([s1, s2]))
     return torch.stack(out)
 
 

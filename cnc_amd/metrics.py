@@ -1,6 +1,6 @@
 """Image metrics of the results line.  PSNR as the reference computes it (train_CNC_nerf_synthetic.py:416-418);
-SSIM in the standard 11x11 Gaussian (sigma 1.5) formulation that the reference's third-party `pytorch_ssim`
-implements (not part of the reference tree: restated from the published definition, parity unpinned);
+SSIM in the standard 11x11 Gaussian (sigma 1.5) formulation of the reference's vendored `examples/pytorch_ssim.py`
+(out of scope per SURVEY §2 row 15: restated from the published definition, parity unpinned);
 LPIPS needs pretrained weights that cannot be had offline and is reported as NaN."""
 from __future__ import annotations
 

@@ -232,7 +232,8 @@ class Trainer:
         # world > 1: join the process group (RCCL; gloo under CNC_DIST_BACKEND) and take this rank's GPU
         self.rank, self.local_rank, self.world = cdist.init()
         self.device = torch.device(device)
-        if self.world > 1 and self.device.type == "cuda":
+        self.dp = self.world > 1 or cdist.forced()       # data-parallel control flow (forced: a one-rank group, test hook)
+        if self.dp and self.device.type == "cuda":
             self.device = torch.device("cuda", cdist.local_device_index())
         set_random_seed(cfg.seed)
         c = cfg
@@ -276,7 +277,7 @@ class Trainer:
         self.bucket = None
         self.time_comm = False          # bench hook: HIP events around the wait for the gradient all-reduce
         self._comm_events = []
-        if self.world > 1:
+        if self.dp:
             plist = list(self.field.parameters()) + list(self.context.parameters())
             # ray-loss gradients (all-reduced) + ONE tail slot: this rank's sample count, so that the sum over the
             # ranks arrives with the gradients instead of through a blocking collective in the middle of the step
@@ -373,13 +374,16 @@ class Trainer:
         self.estimator.update_every_n_steps(
             step=step, occ_eval_fn=lambda x: self.field.query_density(x) * c.render_step_size,
             occ_thre=1e-2, n=c.step_update)
-        if self.world > 1 and step % c.step_update == 0:
+        if self.dp and step % c.step_update == 0:
             cdist.broadcast_module_buffers(self.estimator, ["occs", "binaries"])
         ctx_future = None
         for sink in (self.sink_render, self.sink_ctx):      # before either pass forks off: both are ordered after this
             if sink is not None:
                 sink.zero()
+        warn_before = True
         if self._warn_switch is not None:
+            # process-global: held for this step only and put back to what the caller had (private getter when there is one)
+            warn_before = bool(getattr(torch._C, "_warn_on_accumulate_grad_stream_mismatch", lambda: True)())
             self._warn_switch(False)
         try:
             if self.ctx_thread and self.ctx_stream is not None and c.lmbda > 0:
@@ -426,7 +430,7 @@ class Trainer:
             raise
         finally:
             if self._warn_switch is not None:
-                self._warn_switch(True)
+                self._warn_switch(warn_before)
 
     def _lagged_sample_count(self, num_rays_now: int, n_samples: int) -> None:
         """Data-parallel ray budget without a collective of its own.  The reference resizes the next batch from this
@@ -453,7 +457,7 @@ class Trainer:
             rgb, acc, depth, n_samples, extra = render_image_with_occgrid(
                 self.field, self.estimator, rays, near_plane=c.near_plane, render_step_size=c.render_step_size,
                 render_bkgd=bkgd, cone_angle=c.cone_angle, alpha_thre=c.alpha_thre, return_extra=True)
-        if self.world == 1:
+        if not self.dp:
             if n_samples == 0:
                 if ctx_future is not None:
                     torch.cuda.current_stream(self.device).wait_event(ctx_future.result()[2])

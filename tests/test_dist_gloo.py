@@ -161,3 +161,40 @@ def test_bucket_tail_and_checksum_resync(world):
         assert first == (0, 0) and third == (0, 0)
         assert second == (1, mlp_w_bytes) and fourth == (1, table_bytes)
         assert sums == res[0][8]                                          # replicas identical again
+
+
+def _forced_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      CNC_DIST_FORCE="1")
+    from cnc_amd import dist as cd
+    assert cd.init("gloo") == (0, 0, 1) and torch.distributed.is_initialized() and cd._active()
+    p = [torch.nn.Parameter(torch.arange(5000, dtype=torch.float32)), torch.nn.Parameter(torch.ones(3, 3))]
+    b = cd.GradBucket(p, tail=1)
+    b.bind()
+    p[0].grad.add_(2.0)
+    b.tail.fill_(9.0)
+    b.allreduce(average=True)
+    ok = float(b.tail[0]) == 9.0 and float(p[0].grad[0]) == 2.0        # the tail is never averaged
+    w = b.allreduce(average=False, async_op=True)
+    w.wait()
+    old = cd._CHECKSUM_CHUNK
+    one = cd._checksums(p)
+    cd._CHECKSUM_CHUNK = 1000                                          # several chunks == one
+    many = cd._checksums(p)
+    cd._CHECKSUM_CHUNK = old
+    q.put((ok, cd.resync_parameters(p), bool(torch.equal(one, many)), cd.sum_over_ranks([1.0, 2.0], "cpu")))
+    torch.distributed.destroy_process_group()
+
+
+def test_forced_one_rank_group_runs_every_collective():
+    """CNC_DIST_FORCE=1: a one-rank process group counts as data-parallel (the hook tests/test_gpu_rccl.py uses to put
+    the N > 1 path on RCCL with one GPU)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(_free_port(), q))
+    p.start()
+    ok, resync, same, sums = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert ok and resync == (0, 0) and same and sums == [1.0, 2.0]
