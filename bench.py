@@ -289,9 +289,11 @@ def field_entries(dev):
             out[f"field_rgb+density({name})"] = {"launches": 7, "avg_ms": mr, "units_per_s": n / mr * 1e3,
                                                 "tflops_useful": flop_rgb / mr / 1e9, "timed_region": False}
     out["field_note"] = ("N = 2^20 uniform positions in the box, reference composition at F = 8 (K0 = 255, H = 160, geo 79); "
-                         "fused = cnc_field_fused_forward (features in LDS -> v_mfma_f32_32x32x2_f32, fp32 MFMA peak "
-                         "157 TFLOP/s); chain = encoders -> [N,256] in HBM -> hipBLASLt -> glue kernels; tflops_useful "
-                         "counts the layers' multiply-adds only")
+                         f"fused = cnc_field_fused_forward, precision {f.fused_field_precision}, kernel {f.fused_field_kernel} "
+                         "(default: two waves per 32-sample tile, features in LDS -> v_mfma_f32_16x16x32_f16, three fp16 "
+                         "products per term, i.e. a matrix ceiling of 2.5 PFLOP/s / 3; the exact-fp32 kernel of the range "
+                         "guard is enqueued behind every call and returns at once); chain = encoders -> [N,256] in HBM -> "
+                         "hipBLASLt -> glue kernels; tflops_useful counts the layers' multiply-adds only")
     out["field_density_speedup"] = out["field_density(chain)"]["avg_ms"] / out["field_density(fused)"]["avg_ms"]
     out["field_rgb_speedup"] = out["field_rgb+density(chain)"]["avg_ms"] / out["field_rgb+density(fused)"]["avg_ms"]
     return out

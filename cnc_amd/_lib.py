@@ -33,7 +33,20 @@ class FusedField(C.Structure):
     _fields_ = [("aabb", _vp), ("bits", _vp * 4), ("offsets", _vp * 4), ("resolutions", _vp * 4), ("freqs", _vp),
                 ("packed_weights", _vp * 5), ("packed_biases", _vp * 5), ("w2_row0", _vp), ("packed_weights16", _vp * 5),
                 ("units", _vp), ("n_levels", _u32 * 4),
-                ("n_features", _u32), ("n_freqs", _u32), ("n_neurons", _u32), ("geo_feat_dim", _u32), ("flags", _u32)]
+                ("n_features", _u32), ("n_freqs", _u32), ("n_neurons", _u32), ("geo_feat_dim", _u32), ("flags", _u32),
+                ("packed_weights16q", _vp * 5), ("guard", _vp), ("call_id", _u32), ("pack_id", _u32)]
+
+
+class FieldPackLayer(C.Structure):
+    """cnc_field_pack_layer_t (include/cnc_hip.h)."""
+    _fields_ = [("W", _vp), ("b", _vp), ("H", _u32), ("K", _u32), ("ldw", _u32), ("n_tiles", _u32), ("n_ksteps", _u32),
+                ("n_ksteps16", _u32), ("n_colblocks", _u32), ("n_ksteps32", _u32), ("Wp", _vp), ("Bp", _vp),
+                ("Wp16", _vp), ("Wq16", _vp)]
+
+
+class FieldPack(C.Structure):
+    """cnc_field_pack_t (include/cnc_hip.h)."""
+    _fields_ = [("layer", FieldPackLayer * 5), ("row0", _vp), ("row0_len", _u32), ("guard", _vp), ("pack_id", _u32)]
 
 
 # name -> argtypes, in the order of include/cnc_hip.h
@@ -101,6 +114,7 @@ SIGNATURES = {
     "cnc_field_prepare": [_vp, _vp, _u32, _vp, _vp, _vp],
     "cnc_field_pack_layer": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp],
     "cnc_field_pack_layer16": [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp],
+    "cnc_field_pack_all": [C.POINTER(FieldPack), _vp],
     "cnc_field_fused_forward": [C.POINTER(FusedField), _vp, _vp, _u32, _vp, _vp, _vp],
     "cnc_ste_binary_forward": [_vp, _vp, C.c_uint64, _vp],
     "cnc_ste_binary_backward": [_vp, _vp, _vp, C.c_uint64, _vp],
@@ -130,9 +144,11 @@ CNC_FLAG_LEVELS_FINEST_FIRST = 2
 CNC_FLAG_BIN_LANE_STORES = 4
 CNC_FIELD_SH_FP16 = 1
 CNC_FIELD_MFMA_F16X3 = 2
+CNC_FIELD_TWO_WAVES = 4
+CNC_FIELD_WAVES4 = 8
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 25          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 26          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

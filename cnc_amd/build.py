@@ -24,7 +24,7 @@ HIP_FLAGS = [
     "-ffp-contract=off",          # arithmetic policy: nothing fuses unless written as fmaf
     "-munsafe-fp-atomics",        # fp32 atomicAdd -> global_atomic_add_f32 (no CAS loop)
     "-Wall", "-Wno-unused-function",
-]
+] + os.environ.get("CNC_HIP_EXTRA_FLAGS", "").split()      # diagnostics builds only (e.g. -DCNC_W2_PROF)
 
 
 def _newer(srcs, target):

@@ -24,418 +24,17 @@
 //     transpose), no further MFMA.  With colours: activations go through LDS (C layout -> row-major, bias + ReLU) between
 //     layers; one LDS region per wave is reused for the chunk tile, h1, the head input and the head's hidden layers
 //     (a wave's LDS operations execute in order, and every read of a layer is issued before its results exist).
-#include "common.hpp"
-#include <cstdlib>
-
-#include "encoder_common.hpp"
-#include "field_common.hpp"
+#include "field_fused_common.hpp"
 
 namespace cnc {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-typedef _Float16 half_t_;
-
-struct FieldEnc {
-    const uint8_t* bits;
-    const int32_t* offsets;
-    const int32_t* res;
-    uint32_t       n_levels;
-};
-
-struct FusedFieldArgs {
-    const float* pos;
-    const float* dirs;
-    const float* aabb;
-    uint32_t     N;
-    FieldEnc     enc[4];          // xyz | xy | xz | yz
-    const float* freqs;
-    uint32_t     n_freqs;
-    uint32_t     n_units;         // (encoder, level) units = sum of n_levels
-    uint32_t     nkb1;            // K-steps of 8 of layer 1 (a multiple of 4: K padded to whole 32-column chunks)
-    const float* Wp[5];           // packed weights (cnc_field_pack_layer)
-    const float* Bp[5];           // padded biases
-    const float* w2row;           // density only: W2[0, :] padded to NT * 32
-    uint32_t     geo;
-    uint32_t     nkbh;            // K-steps of the head's first layer: roundup8(16 + geo) / 8
-    float*       density;
-    float*       rgb;
-    uint32_t     sh_fp16;
-    const uint4* units;           // per unit {first row, rows, resolution, encoder} of its level (cnc_fused_field_t.units)
-    const half_t_* Wp16[5];       // fp16 hi / lo fragments (cnc_field_pack_layer16), k_field_fused16
-    uint32_t       nk16_1;        // K-steps of 16 of layer 1 (a multiple of 2)
-    uint32_t       nk16_h;        // K-steps of 16 of the head's first layer: roundup16(16 + geo) / 16
-};
-
-constexpr uint32_t kChunkPitch = 36;     // floats per row of the 32 x 32 chunk tile (+4: conflict-free b128 accesses)
-constexpr uint32_t kPadH = 4;
-
-// Weight fragments through a buffer resource: address = SGPR base + one VGPR (16 * lane) + a scalar K-step offset + an
-// immediate per tile.  With flat pointers the compiler kept a 64-bit address pair per (layer, K-step, tile) alive across
-// the persistent tile loop (hundreds of spilled registers); this way the whole weight stream costs one VGPR.
-// (clang 22 / ROCm 7.2 lowers __builtin_amdgcn_raw_buffer_load_b128 to a ONE-dword load and splats it — checked in
-// the ISA — so the intrinsic is declared by name, as composable_kernel does.)
-typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
-typedef float   f32x4_t __attribute__((ext_vector_type(4)));
-using wrsrc_t = i32x4_t;
-__device__ f32x4_t llvm_raw_buffer_load_f32x4(i32x4_t rsrc, int32_t voffset, int32_t soffset, int32_t aux)
-    __asm("llvm.amdgcn.raw.buffer.load.v4f32");
-
-__device__ __forceinline__ wrsrc_t weight_rsrc(const float* Wp)
-{
-    const uint64_t a = reinterpret_cast<uint64_t>(Wp);
-    // base, stride 0, 2 GiB of records, DATA_FORMAT 32 (the gfx9 raw-buffer word composable_kernel uses)
-    return i32x4_t{(int32_t)(uint32_t)a, (int32_t)((uint32_t)(a >> 32) & 0xFFFFu), 0x7FFFFFFF, 0x00020000};
-}
-
-template <int NT>
-__device__ __forceinline__ void load_w(wrsrc_t W, uint32_t kb, uint32_t lane, float4 (&dst)[NT])
-{
-    const int32_t soff = (int32_t)(kb * NT * 1024u);          // 64 lanes x 16 bytes per (K-step, tile)
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const f32x4_t v = llvm_raw_buffer_load_f32x4(W, (int32_t)(lane * 16u + t * 1024), soff, 0);
-        dst[t] = make_float4(v.x, v.y, v.z, v.w);
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void mfma_step(const float4& a, const float4 (&w)[NT], f32x16 (&acc)[NT])
-{
-    // k-step outermost: consecutive MFMAs go to different accumulators
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w[t].w, acc[t], 0, 0, 0);
-}
-
-template <int NT>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT])
-{
-#pragma unroll
-    for (int t = 0; t < NT; t++)
-#pragma unroll
-        for (int v = 0; v < 16; v++) acc[t][v] = 0;
-}
-
-// One wave's LDS writes followed by its own reads: DS operations of a wave execute in order, so only the compiler has
-// to be kept from moving them (a workgroup fence would also wait for the weight prefetch in flight: vmcnt(0)).
-__device__ __forceinline__ void wave_lds_order()
-{
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("" ::: "memory");
-}
-
-// acc (32 x NT*32, C layout) = A (32 x nkb*8, LDS row-major, pitch lda) * W^T
-template <int NT>
-__device__ __forceinline__ void layer_lds(const float* __restrict__ a_lds, uint32_t lda, uint32_t nkb,
-                                          const float* __restrict__ Wp_, f32x16 (&acc)[NT], uint32_t lane)
-{
-    const wrsrc_t Wp = weight_rsrc(Wp_);
-    const uint32_t i = lane & 31u, h = lane >> 5;
-    zero_acc<NT>(acc);
-    float4 wn[NT];
-    load_w<NT>(Wp, 0, lane, wn);
-    for (uint32_t kb = 0; kb < nkb; kb++) {
-        const float4 a = *reinterpret_cast<const float4*>(a_lds + i * lda + kb * 8 + 4 * h);
-        float4 w[NT];
-#pragma unroll
-        for (int t = 0; t < NT; t++) w[t] = wn[t];
-        if (kb + 1 < nkb) load_w<NT>(Wp, kb + 1, lane, wn);
-        mfma_step<NT>(a, w, acc);
-    }
-}
-
-// bias (+ ReLU), C layout -> row-major LDS: D[row = 8 (v >> 2) + 4 h + (v & 3)][col = 32 t + i]
-template <bool RELU, int NT>
-__device__ __forceinline__ void acc_to_lds(float* __restrict__ dst, uint32_t ld, const float* __restrict__ bias,
-                                           const f32x16 (&acc)[NT], uint32_t lane)
-{
-    const uint32_t i = lane & 31u, h = lane >> 5;
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const float b = bias[t * 32 + i];
-#pragma unroll
-        for (int v = 0; v < 16; v++) {
-            float x = acc[t][v] + b;
-            if (RELU) x = x > 0 ? x : 0;
-            dst[(8 * (v >> 2) + 4 * h + (v & 3)) * ld + t * 32 + i] = x;
-        }
-    }
-}
-
-// The F features of one (encoder, level) unit at a point: the body of k_grid_encode_fwd_bits (same corner order, same
-// fmaf chain: bit-identical), no occupancy mask — in two halves, so that a lane can have the sign-plane gathers of
-// BOTH units of its window in flight before it consumes either (two waves per SIMD do not hide an L2 round trip per
-// unit: the gather alone ran at half the vector rate).
-struct UnitGather {
-    float    tw[8];       // weight / sum of the valid weights per corner, 0 for an invalid corner
-    uint32_t rb[8];       // the corner rows' F sign bits
-};
-
-// One 16-byte record per unit, built by the caller from the encoders' level tables (cnc_fused_field_t.units): a lane
-// needs ONE L1-resident load before it can form its corner rows.  Reading the level tables through the encoder array
-// of the kernel arguments (a dynamically indexed pointer, then the table entry, then the sign bytes) put three
-// dependent memory round trips in front of every unit.
-struct UnitRec {
-    uint32_t off, hs, R, enc;
-};
-
-__device__ __forceinline__ UnitRec load_unit(const FusedFieldArgs& p, uint32_t u)
-{
-    const uint4 v = p.units[u];
-    return UnitRec{v.x, v.y, v.z, v.w};
-}
-
-__device__ __forceinline__ const uint8_t* unit_bits(const FusedFieldArgs& p, uint32_t enc)
-{
-    const uint8_t* b = p.enc[0].bits;
-    b = enc == 1 ? p.enc[1].bits : b;
-    b = enc == 2 ? p.enc[2].bits : b;
-    b = enc == 3 ? p.enc[3].bits : b;
-    return b;
-}
-
-template <uint32_t D, uint32_t F>
-__device__ __forceinline__ void unit_issue(const float (&x)[D], bool inside, const uint8_t* __restrict__ bits,
-                                           const UnitRec& r, UnitGather& u)
-{
-    constexpr uint32_t C = 1u << D;
-#pragma unroll
-    for (uint32_t q = 0; q < 8; q++) { u.tw[q] = 0.0f; u.rb[q] = 0u; }
-    if (!inside) return;
-    const uint32_t off = r.off, hs = r.hs, R = r.R;
-    Corners<D, false> c;
-    c.setup(x, R, hs, 128u, nullptr);
-#pragma unroll
-    for (uint32_t q = 0; q < C; q++) {
-        u.rb[q] = c.valid[q] ? load_row_bits<F>(bits, (uint64_t)off + c.row[q]) : 0u;
-        u.tw[q] = c.valid[q] ? c.w[q] * c.wn_re : 0.0f;
-    }
-}
-
-// ... and in one piece, for the colour variants (no room for a second unit's registers)
-template <uint32_t D, uint32_t F>
-__device__ __forceinline__ void unit_features(const float (&x)[D], bool inside, const uint8_t* __restrict__ bits,
-                                              const UnitRec& r, float (&acc)[F])
-{
-    constexpr uint32_t C = 1u << D;
-#pragma unroll
-    for (uint32_t k = 0; k < F; k++) acc[k] = 0;
-    if (!inside) return;
-    const uint32_t off = r.off, hs = r.hs, R = r.R;
-    Corners<D, false> c;
-    c.setup(x, R, hs, 128u, nullptr);
-    uint32_t rb[C];
-#pragma unroll
-    for (uint32_t q = 0; q < C; q++) rb[q] = c.valid[q] ? load_row_bits<F>(bits, (uint64_t)off + c.row[q]) : 0u;
-#pragma unroll
-    for (uint32_t q = 0; q < C; q++) {
-        const float tw = c.valid[q] ? c.w[q] * c.wn_re : 0.0f;
-#pragma unroll
-        for (uint32_t k = 0; k < F; k++) {
-            const float s = ((rb[q] >> k) & 1u) ? 1.0f : -1.0f;
-            acc[k] = __builtin_fmaf(tw, s, acc[k]);
-        }
-    }
-}
-
-template <uint32_t C, uint32_t F>
-__device__ __forceinline__ void unit_consume(const UnitGather& u, float (&acc)[F])
-{
-#pragma unroll
-    for (uint32_t k = 0; k < F; k++) acc[k] = 0;
-#pragma unroll
-    for (uint32_t q = 0; q < C; q++) {
-#pragma unroll
-        for (uint32_t k = 0; k < F; k++) {
-            const float s = ((u.rb[q] >> k) & 1u) ? 1.0f : -1.0f;
-            acc[k] = __builtin_fmaf(u.tw[q], s, acc[k]);
-        }
-    }
-}
-
-// Where a sample's row of the 32 x 32 chunk tile lives.  Float tile: the A operand of the fp32 MFMA.  Half tile: two
-// planes, x = hi + lo with hi = half(x), lo = half(x - hi) — 22 bits of x — the A operands of the three-product
-// fp16 MFMA scheme (see k_field_fused16).
-struct RowF32 {
-    static constexpr bool kFastSin = false;
-    float* row;
-    template <uint32_t V>
-    __device__ __forceinline__ void put(uint32_t col, const float (&v)[V]) const { store_vec<V>(row + col, v); }
-    __device__ __forceinline__ void put1(uint32_t col, float v) const { row[col] = v; }
-};
-
-typedef _Float16 half_t;
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void split_half(float x, half_t& hi, half_t& lo)
-{
-    hi = (half_t)x;
-    lo = (half_t)(x - (float)hi);
-}
-
-struct RowF16 {
-    static constexpr bool kFastSin = true;
-    half_t* hi;
-    half_t* lo;
-    template <uint32_t V>
-    __device__ __forceinline__ void put(uint32_t col, const float (&v)[V]) const
-    {
-        if constexpr (V == 4) {
-            half4_t a, b;
-#pragma unroll
-            for (int j = 0; j < 4; j++) { half_t x, y; split_half(v[j], x, y); a[j] = x; b[j] = y; }
-            *reinterpret_cast<half4_t*>(hi + col) = a;
-            *reinterpret_cast<half4_t*>(lo + col) = b;
-        } else if constexpr (V == 2) {
-            half2_t a, b;
-#pragma unroll
-            for (int j = 0; j < 2; j++) { half_t x, y; split_half(v[j], x, y); a[j] = x; b[j] = y; }
-            *reinterpret_cast<half2_t*>(hi + col) = a;
-            *reinterpret_cast<half2_t*>(lo + col) = b;
-        } else {
-            put1(col, v[0]);
-        }
-    }
-    __device__ __forceinline__ void put1(uint32_t col, float v) const
-    {
-        half_t x, y;
-        split_half(v, x, y);
-        hi[col] = x;
-        lo[col] = y;
-    }
-};
-
-// sin and cos of x in [0, 512] (a unit-cube coordinate times 2^k) on the hardware's v_sin_f32 / v_cos_f32 (arguments in
-// revolutions) behind a two-term 1 / (2 pi) reduction: 8 instructions instead of ocml's ~80 for sincosf, 2.6e-7 from
-// the float64 value where sincosf is 7e-8 (tools/sincos_probe.hip, 4 M arguments) — used by the fp16 kernels, whose
-// products carry 5e-7 anyway; the exact-fp32 kernels keep sincosf.
-__device__ __forceinline__ void fast_sincos(float x, float* s, float* c)
-{
-    const float hi = 0.15915494f, lo = 6.4206383e-09f;       // 1 / (2 pi) = hi + lo
-    const float q = rintf(x * hi);
-    float r = __builtin_fmaf(x, hi, -q);
-    r = __builtin_fmaf(x, lo, r);
-    *s = __builtin_amdgcn_sinf(r);
-    *c = __builtin_amdgcn_cosf(r);
-}
-
-// Columns [w0, w0 + 16) of the feature row of one sample into its row of the chunk tile (`trow`, chunk-relative
-// column w0 & 31).  Feature row = [units: n_units x F | x (3) | sin(f_k x) (3), cos(f_k x) (3) for k < n_freqs | 0 ...].
-template <uint32_t F, bool PAIR, typename Row>
-__device__ __forceinline__ void fill_window(const FusedFieldArgs& p, const float (&xu)[3], uint32_t w0, const Row& trow)
-{
-    constexpr uint32_t B = PAIR ? 2u : 1u;            // units gathered before any is consumed
-    constexpr uint32_t V = F < 4 ? F : 4;
-    const uint32_t U = p.n_units * F;                 // first sinusoid column
-    const bool in_x = xu[0] >= 0.0f && xu[0] <= 1.0f, in_y = xu[1] >= 0.0f && xu[1] <= 1.0f,
-               in_z = xu[2] >= 0.0f && xu[2] <= 1.0f;
-    if constexpr (!PAIR) {
-#pragma unroll
-        for (uint32_t s = 0; s < 16 / F; s++) {
-            const uint32_t u = (w0 + s * F) / F;
-            if (u >= p.n_units) break;
-            float a[F];
-            const UnitRec  rec = load_unit(p, u);
-            const uint8_t* bits = unit_bits(p, rec.enc);
-            if (rec.enc == 0) {
-                unit_features<3, F>(xu, in_x && in_y && in_z, bits, rec, a);
-            } else {
-                const uint32_t pl = rec.enc - 1;                                  // plane 0 = xy, 1 = xz, 2 = yz
-                const float    x2[2] = {pl == 2 ? xu[1] : xu[0], pl == 0 ? xu[1] : xu[2]};
-                const bool     in2 = (pl == 2 ? in_y : in_x) && (pl == 0 ? in_y : in_z);
-                unit_features<2, F>(x2, in2, bits, rec, a);
-            }
-            const uint32_t o = (w0 + s * F) & 31u;
-#pragma unroll
-            for (uint32_t k = 0; k < F; k += V) {
-                float v[V];
-#pragma unroll
-                for (uint32_t j = 0; j < V; j++) v[j] = a[k + j];
-                trow.template put<V>(o + k, v);
-            }
-        }
-    } else {
-    // two units at a time: their gathers issued, then consumed (16 more registers: not in the colour variants, which
-    // sit at the 256-register limit of two waves per SIMD)
-#pragma unroll
-    for (uint32_t s0 = 0; s0 < 16 / F; s0 += B) {
-        UnitGather ug[B];
-        bool       is3[B], live[B];
-#pragma unroll
-        for (uint32_t j = 0; j < B; j++) { is3[j] = false; live[j] = false; }
-#pragma unroll
-        for (uint32_t j = 0; j < B; j++) {
-            const uint32_t s = s0 + j;
-            if (s >= 16 / F) continue;
-            const uint32_t u = (w0 + s * F) / F;
-            if (u >= p.n_units) continue;
-            live[j] = true;
-            const UnitRec  rec = load_unit(p, u);
-            const uint8_t* bits = unit_bits(p, rec.enc);
-            if (rec.enc == 0) {
-                is3[j] = true;
-                unit_issue<3, F>(xu, in_x && in_y && in_z, bits, rec, ug[j]);
-            } else {
-                const uint32_t pl = rec.enc - 1;                                  // plane 0 = xy, 1 = xz, 2 = yz
-                const float    x2[2] = {pl == 2 ? xu[1] : xu[0], pl == 0 ? xu[1] : xu[2]};
-                const bool     in2 = (pl == 2 ? in_y : in_x) && (pl == 0 ? in_y : in_z);
-                unit_issue<2, F>(x2, in2, bits, rec, ug[j]);
-            }
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < B; j++) {
-            if (!live[j]) continue;
-            float a[F];
-            if (is3[j]) unit_consume<8, F>(ug[j], a);
-            else unit_consume<4, F>(ug[j], a);
-            const uint32_t o = (w0 + (s0 + j) * F) & 31u;
-#pragma unroll
-            for (uint32_t k = 0; k < F; k += V) {
-                float v[V];
-#pragma unroll
-                for (uint32_t jj = 0; jj < V; jj++) v[jj] = a[k + jj];
-                trow.template put<V>(o + k, v);
-            }
-        }
-    }
-    }
-    // the part of the window behind the units: raw coordinates, sinusoids, zero padding
-    const uint32_t lo = w0 > U ? w0 : U, hi = w0 + 16;
-    if (lo >= hi) return;
-    const uint32_t n_sin = 3 + 6 * p.n_freqs;
-    for (uint32_t col = lo; col < hi; col++) {
-        const uint32_t e = col - U;
-        if (e < 3) trow.put1(col & 31u, e == 0 ? xu[0] : (e == 1 ? xu[1] : xu[2]));
-        else if (e >= n_sin) trow.put1(col & 31u, 0.0f);
-    }
-    // sin column e = 3 + 6 k + a, its cos column e + 3: ONE argument reduction for both (sincosf returns the values of
-    // sinf and cosf); a pair that straddles two windows is evaluated by both lanes
-    const uint32_t e_lo = lo - U, e_hi = hi - U;
-    for (uint32_t e = e_lo > 6 ? e_lo - 3 : 3; e < e_hi && e < n_sin; e++) {
-        const uint32_t k = (e - 3) / 6, r = (e - 3) - 6 * k;
-        if (r >= 3) continue;
-        const float xa = r == 0 ? xu[0] : (r == 1 ? xu[1] : xu[2]);
-        float sn, cs;
-        if constexpr (Row::kFastSin) fast_sincos(xa * p.freqs[k], &sn, &cs);
-        else sincosf(xa * p.freqs[k], &sn, &cs);
-        if (e >= e_lo) trow.put1((e + U) & 31u, sn);
-        if (e + 3 >= e_lo && e + 3 < e_hi) trow.put1((e + 3 + U) & 31u, cs);
-    }
-}
 
 template <uint32_t F, int NT, bool RGB>
 __global__ __launch_bounds__(64, 2) void k_field_fused(FusedFieldArgs p)
 {
     extern __shared__ float lds[];
+    // launched behind an fp16 kernel as its fallback: runs only if that kernel (or the weight packer) raised the flag
+    if (p.only_if_flagged && *reinterpret_cast<volatile const uint32_t*>(p.guard) != p.call_id) return;
     const uint32_t lane = threadIdx.x, i = lane & 31u, h = lane >> 5;
     constexpr uint32_t ldh = NT * 32 + kPadH;
     const uint32_t tiles = (p.N + 31u) / 32u;
@@ -510,7 +109,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused(FusedFieldArgs p)
                     const float4 v4 = *reinterpret_cast<const float4*>(lds + i * kChunkPitch + 4 * q);
                     s += v4.x; s += v4.y; s += v4.z; s += v4.w;
                 }
-                if (live) p.density[row] = expf((s + p.Bp[1][0]) - 1.0f) * (sel ? 1.0f : 0.0f);
+                if (live) p.density[row] = sel ? expf((s + p.Bp[1][0]) - 1.0f) : 0.0f;
             }
             wave_lds_order();
         } else {
@@ -535,7 +134,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused(FusedFieldArgs p)
                     const uint32_t r = 8 * (v >> 2) + 4 * h + (v & 3);
                     const float    x = acc2[t][v] + b;
                     if (col == 0) {
-                        if (row0 + r < p.N) p.density[row0 + r] = expf(x - 1.0f) * (float)((selmask >> r) & 1ull);
+                        if (row0 + r < p.N) p.density[row0 + r] = ((selmask >> r) & 1ull) ? expf(x - 1.0f) : 0.0f;
                     } else if (15 + col < Kh) {
                         lds[r * ldi + 15 + col] = col <= p.geo ? x : 0.0f;
                     }
@@ -698,7 +297,8 @@ struct CLayoutAt {
 
 template <bool RELU, int NT>
 __device__ __forceinline__ void acc_to_lds16(half_t* __restrict__ d_hi, half_t* __restrict__ d_lo,
-                                             const float* __restrict__ bias, const f32x16 (&acc)[NT], uint32_t lane)
+                                             const float* __restrict__ bias, const f32x16 (&acc)[NT], uint32_t lane,
+                                             float& mx)
 {
     const uint32_t i = lane & 31u, h = lane >> 5;
     const CLayoutAt<NT> at(h, i);
@@ -709,6 +309,7 @@ __device__ __forceinline__ void acc_to_lds16(half_t* __restrict__ d_hi, half_t* 
         for (int v = 0; v < 16; v++) {
             float x = __builtin_fmaf(acc[t][v], kWeightScaleInv, b);
             if (RELU) x = x > 0 ? x : 0;
+            mx = fmaxf(mx, fabsf(x));
             half_t xh, xl;
             split_half(x, xh, xl);
             d_hi[at(t, v)] = xh;
@@ -737,6 +338,8 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
         aext[a] = p.aabb[3 + a] - p.aabb[a];
     }
     const wrsrc_t W1 = weight_rsrc(reinterpret_cast<const float*>(p.Wp16[0]));
+    if (guard_weights_flagged(p, RGB)) return;
+    float mx = 0.0f;                     // largest |value| split into halves by this lane (the range guard)
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const uint32_t row0 = tile * 32, row = row0 + i;
         const bool     live = row < p.N;
@@ -806,11 +409,11 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
                     const float4 v4 = *reinterpret_cast<const float4*>(lds + i * kChunkPitch + 4 * q);
                     s += v4.x; s += v4.y; s += v4.z; s += v4.w;
                 }
-                if (live) p.density[row] = expf((s + p.Bp[1][0]) - 1.0f) * (sel ? 1.0f : 0.0f);
+                if (live) p.density[row] = sel ? expf((s + p.Bp[1][0]) - 1.0f) : 0.0f;
             }
             wave_lds_order();
         } else {
-            acc_to_lds16<true, NT>(h_hi, h_lo, p.Bp[0], acc, lane);
+            acc_to_lds16<true, NT>(h_hi, h_lo, p.Bp[0], acc, lane, mx);
             wave_lds_order();
             constexpr int NT2 = NT == 5 ? 3 : 2;
             f32x16 acc2[NT2];
@@ -835,6 +438,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
                         *reinterpret_cast<float*>(h_hi + r * ldh + kDensAt) = x;
                     } else if (15 + col < Kh) {
                         half_t xh, xl;
+                        mx = fmaxf(mx, col <= p.geo ? fabsf(x) : 0.0f);
                         split_half(col <= p.geo ? x : 0.0f, xh, xl);
                         h_hi[hin_at(t, v)] = xh;
                         h_lo[hin_at(t, v)] = xl;
@@ -862,15 +466,15 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
             wave_lds_order();
             if (h == 0 && live) {
                 const float x = *reinterpret_cast<const float*>(h_hi + i * ldh + kDensAt);
-                p.density[row] = expf(x - 1.0f) * (sel ? 1.0f : 0.0f);
+                p.density[row] = sel ? expf(x - 1.0f) : 0.0f;
             }
             layer_lds16<NT, NT>(h_hi, h_lo, p.nk16_h, p.Wp16[2], acc, lane);
             wave_lds_order();
-            acc_to_lds16<true, NT>(h_hi, h_lo, p.Bp[2], acc, lane);
+            acc_to_lds16<true, NT>(h_hi, h_lo, p.Bp[2], acc, lane, mx);
             wave_lds_order();
             layer_lds16<NT, NT>(h_hi, h_lo, NT * 2, p.Wp16[3], acc, lane);
             wave_lds_order();
-            acc_to_lds16<true, NT>(h_hi, h_lo, p.Bp[3], acc, lane);
+            acc_to_lds16<true, NT>(h_hi, h_lo, p.Bp[3], acc, lane, mx);
             wave_lds_order();
             f32x16 acc5[1];
             layer_lds16<1, NT>(h_hi, h_lo, NT * 2, p.Wp16[4], acc5, lane);
@@ -886,6 +490,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
             wave_lds_order();
         }
     }
+    guard_raise(p, mx);
 }
 
 // W [H, K] -> fp16 fragments of `layer_lds16`: per (K-step of 16, tile): 64 lanes x 8 halves hi, then the same of lo,
@@ -998,48 +603,66 @@ extern "C" int cnc_field_fused_forward(const cnc_fused_field_t* f, const float* 
     }
     p.density = density; p.rgb = rgb;
     p.sh_fp16 = (f->flags & CNC_FIELD_SH_FP16) ? 1u : 0u;
-    const bool f16x3 = (f->flags & CNC_FIELD_MFMA_F16X3) != 0;
+    const bool two_waves = (f->flags & CNC_FIELD_TWO_WAVES) != 0;
+    const bool f16x3 = two_waves || (f->flags & CNC_FIELD_MFMA_F16X3) != 0;
     p.nk16_1 = p.nkb1 / 2;
     p.nk16_h = (16 + p.geo + 15) / 16;
+    p.nk32_h = (16 + p.geo + 31) / 32;
     if (f16x3) {
-        if (p.nk16_h * 16 > H) return CNC_ERR_UNSUPPORTED;
+        if (p.nk16_h * 16 > H || p.nk32_h * 32 > H) return CNC_ERR_UNSUPPORTED;
+        // the range guard is part of the fp16 form: without it a value above 65504 would come out as inf / NaN
+        if (!f->guard || f->call_id == 0 || f->pack_id == 0) return CNC_ERR_INVALID_VALUE;
+        p.guard = f->guard; p.call_id = f->call_id; p.pack_id = f->pack_id;
         for (int l = 0; l < (want_rgb ? 5 : 1); l++) {
-            if (!f->packed_weights16[l]) return CNC_ERR_INVALID_VALUE;
-            p.Wp16[l] = reinterpret_cast<const half_t_*>(f->packed_weights16[l]);
+            const void* w16 = two_waves ? f->packed_weights16q[l] : f->packed_weights16[l];
+            if (!w16) return CNC_ERR_INVALID_VALUE;
+            (two_waves ? p.Wq16[l] : p.Wp16[l]) = reinterpret_cast<const half_t_*>(w16);
         }
+        if (two_waves && 1 + p.geo > (NT == 5 ? 80u : 64u)) return CNC_ERR_UNSUPPORTED;
     }
     const uint32_t tiles = (N + 31) / 32;
-    uint32_t blocks = 0;
     uint32_t lds_floats = 32 * kChunkPitch;
     if (want_rgb) lds_floats = 32 * (H + kPadH);
-    size_t lds_bytes = (size_t)lds_floats * sizeof(float);
+    const size_t lds32 = (size_t)lds_floats * sizeof(float);
+    size_t lds16 = 0;
     if (f16x3) {        // two half planes: 32 x 40 (chunk; the density epilogue's 32 x 36 floats fit) or 32 x HPlane::ld
         const uint32_t ldh16 = NT == 5 ? 160u : H + kPadH16x;         // HPlane<NT>::ld
-        lds_bytes = want_rgb ? (size_t)2 * 32 * ldh16 * sizeof(half_t) : (size_t)2 * 32 * kChunkPitch16 * sizeof(half_t);
-        if (lds_bytes < 32 * kChunkPitch * sizeof(float)) lds_bytes = 32 * kChunkPitch * sizeof(float);
+        lds16 = want_rgb ? (size_t)2 * 32 * ldh16 * sizeof(half_t) : (size_t)2 * 32 * kChunkPitch16 * sizeof(half_t);
+        if (lds16 < 32 * kChunkPitch * sizeof(float)) lds16 = 32 * kChunkPitch * sizeof(float);
     }
     hipStream_t s = (hipStream_t)stream;
     // The grid is what is RESIDENT at once (the waves loop over the tiles): registers allow 8 one-wave workgroups per
     // CU, the colour variant's LDS 7 — with 8 per CU launched the eighth of every CU ran as a second round on an
-    // otherwise idle chip (2.65 instead of 1.72 ms per 2^20 samples).
-#define CNC_FF_GRID(K)                                                                                        \
+    // otherwise idle chip (2.65 instead of 1.72 ms per 2^20 samples).  Residency is a fact of the binary and the
+    // device: asked once per (thread, kernel, device), not at every launch.
+    int rc = CNC_OK;
+#define CNC_FF_GRID(K, LDS)                                                                                   \
     do {                                                                                                      \
-        int per_cu = 0, dev = 0, cus = 0;                                                                     \
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, K, 64, lds_bytes) != hipSuccess ||          \
-            hipGetDevice(&dev) != hipSuccess ||                                                               \
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||          \
-            per_cu <= 0 || cus <= 0)                                                                          \
-            return CNC_ERR_LAUNCH;                                                                            \
-        if (per_cu > 8) per_cu = 8;                                                                           \
-        blocks = tiles < (uint32_t)(per_cu * cus) ? tiles : (uint32_t)(per_cu * cus);                         \
-        hipLaunchKernelGGL(K, dim3(blocks), dim3(64), lds_bytes, s, p);                                       \
+        struct Slot { int dev; uint32_t n; };                                                                 \
+        static thread_local Slot slot = {-1, 0};                                                              \
+        int dev = 0;                                                                                          \
+        if (hipGetDevice(&dev) != hipSuccess) { rc = CNC_ERR_LAUNCH; break; }                                 \
+        if (slot.dev != dev) {                                                                                \
+            int per_cu = 0, cus = 0;                                                                          \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, K, 64, LDS) != hipSuccess ||            \
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||      \
+                per_cu <= 0 || cus <= 0) { rc = CNC_ERR_LAUNCH; break; }                                      \
+            if (per_cu > 8) per_cu = 8;                                                                       \
+            slot = Slot{dev, (uint32_t)(per_cu * cus)};                                                       \
+        }                                                                                                     \
+        const uint32_t blocks = tiles < slot.n ? tiles : slot.n;                                              \
+        hipLaunchKernelGGL(K, dim3(blocks), dim3(64), LDS, s, p);                                             \
     } while (0)
-#define CNC_FF(FV, NTV)                                                                     \
-    do {                                                                                    \
-        if (f16x3 && want_rgb) CNC_FF_GRID((k_field_fused16<FV, NTV, true>));               \
-        else if (f16x3) CNC_FF_GRID((k_field_fused16<FV, NTV, false>));                     \
-        else if (want_rgb) CNC_FF_GRID((k_field_fused<FV, NTV, true>));                     \
-        else CNC_FF_GRID((k_field_fused<FV, NTV, false>));                                  \
+#define CNC_FF(FV, NTV)                                                                                 \
+    do {                                                                                                \
+        if (two_waves) rc = launch_field_fused_w2(p, want_rgb, FV, H, (f->flags & CNC_FIELD_WAVES4) ? 4 : 3, s); \
+        else if (f16x3 && want_rgb) CNC_FF_GRID((k_field_fused16<FV, NTV, true>), lds16);               \
+        else if (f16x3) CNC_FF_GRID((k_field_fused16<FV, NTV, false>), lds16);                          \
+        if (rc != CNC_OK) break;                                                                        \
+        /* the exact form: the whole call without the fp16 flag, the guard's conditional fallback with it */ \
+        p.only_if_flagged = f16x3 ? 1u : 0u;                                                            \
+        if (want_rgb) CNC_FF_GRID((k_field_fused<FV, NTV, true>), lds32);                               \
+        else CNC_FF_GRID((k_field_fused<FV, NTV, false>), lds32);                                       \
     } while (0)
 #define CNC_FF_F(FV)          \
     do {                      \
@@ -1052,5 +675,6 @@ extern "C" int cnc_field_fused_forward(const cnc_fused_field_t* f, const float* 
 #undef CNC_FF_F
 #undef CNC_FF
 #undef CNC_FF_GRID
+    if (rc != CNC_OK) return rc;
     return launch_status();
 }

@@ -1077,4 +1077,4 @@ extern "C" const char* cnc_error_string(int code)
     }
 }
 
-extern "C" int cnc_abi_version(void) { return 25; }
+extern "C" int cnc_abi_version(void) { return 26; }

@@ -309,12 +309,13 @@ class _FieldPost(Function):
 
 class FusedFieldForward:
     """Gradient-free `positions -> density [-> rgb]` through ONE kernel (cnc_field_fused_forward,
-    cnc_amd/csrc/field_fused.hip): the four encoders' features are computed into LDS and consumed there by fp32 MFMA,
+    cnc_amd/csrc/field_fused{,2}.hip): the four encoders' features are computed into LDS and consumed there by MFMA,
     so the [N, 255] feature matrix, the activations and the head input never touch HBM (ngp.py:506-547).
 
-    Keeps the five layers' weights packed in MFMA fragment order (cnc_field_pack_layer: one tiny launch per layer),
-    repacked when a parameter changed (`_version`, plus the global optimizer post-step hook: fused Adam does not bump
-    the counter)."""
+    Keeps the five layers' weights packed in MFMA fragment order (cnc_field_pack_all: one launch), repacked when a
+    parameter changed (`_version`, plus the global optimizer post-step hook: fused Adam does not bump the counter).
+    The default three-product fp16 form carries a range guard: a call in which a hidden activation or a weight left
+    fp16's range is recomputed by the exact-fp32 kernel, decided on the device (include/cnc_hip.h)."""
 
     def __init__(self, field: "NGPRadianceField_mygrid_2D3D"):
         from . import _caches
@@ -322,6 +323,8 @@ class FusedFieldForward:
         self._key = None
         self._buffers = None
         self._units = None
+        self._pack_id = 0          # cnc_field_pack_t.pack_id / cnc_fused_field_t.call_id: the range guard's stamps
+        self._call_id = 0
         _caches.register(self)
 
     def invalidate_caches(self):
@@ -343,13 +346,24 @@ class FusedFieldForward:
                 and len({e.n_levels for e in encs[1:]}) == 1
                 and F_ in (2, 4, 8) and H in (64, 160) and 1 + geo <= 32 * nt2 and (16 + geo + 7) // 8 * 8 <= H
                 and len(mb.network) == 3 and len(field.mlp_head) == 5
-                and all(l.out_features == H for l in (field.mlp_head[0], field.mlp_head[2])))
+                and all(l.out_features == H for l in (field.mlp_head[0], field.mlp_head[2]))
+                # the kernel derives the first layer's K from the unit table and the frequency count
+                and mb.network[0].in_features == sum(e.n_levels for e in encs) * F_ + 3 + 6 * mb._freqs.numel()
+                and mb.network[2].out_features == 1 + geo and field.mlp_head[0].in_features == 16 + geo
+                and field.mlp_head[4].out_features == 3
+                # every level dense (R^D rows fit) or hashed into a power-of-two table: what the kernels' index
+                # arithmetic assumes (no modulo, every index in range; GridEncoder makes nothing else)
+                and all(e._res_host[l] ** e.num_dim <= e._off_host[l + 1] - e._off_host[l]
+                        or ((e._off_host[l + 1] - e._off_host[l]) & (e._off_host[l + 1] - e._off_host[l] - 1)) == 0
+                        for e in encs for l in range(e.n_levels)))
 
     def _layers(self):
         f = self.field
         return [f.mlp_base.network[0], f.mlp_base.network[2], f.mlp_head[0], f.mlp_head[2], f.mlp_head[4]]
 
     def _pack(self, dev):
+        """The five layers in every fragment order the kernels read — fp32 (exact form and the range guard's fallback),
+        fp16 hi / lo for the one-wave and for the two-wave kernels — in ONE launch (cnc_field_pack_all)."""
         from . import _lib
         layers = self._layers()
         key = tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version) for l in layers) + (str(dev),)
@@ -359,30 +373,45 @@ class FusedFieldForward:
         H, geo = layers[0].out_features, f.geo_feat_dim
         T, T2 = H // 32, (3 if H == 160 else 2)
         K0 = layers[0].in_features
-        # (output tiles, K-steps of 8 for the fp32 MFMA, K-steps of 16 for the fp16 one) per layer
-        shapes = [(T, (K0 + 31) // 32 * 4, (K0 + 31) // 32 * 2), (T2, H // 8, H // 16),
-                  (T, (16 + geo + 7) // 8, (16 + geo + 15) // 16), (T, H // 8, H // 16), (1, H // 8, H // 16)]
+        r32 = lambda k: (k + 31) // 32
+        # per layer: (32-column tiles, K-steps of 8 [fp32 MFMA], K-steps of 16 [32x32x16 halves],
+        #             16-column blocks, K-steps of 32 [16x16x32 halves: the two-wave kernels])
+        shapes = [(T, r32(K0) * 4, r32(K0) * 2, H // 16, r32(K0)),
+                  (T2, H // 8, H // 16, 5 if H == 160 else 4, H // 32),
+                  (T, (16 + geo + 7) // 8, (16 + geo + 15) // 16, H // 16, r32(16 + geo)),
+                  (T, H // 8, H // 16, H // 16, H // 32),
+                  (1, H // 8, H // 16, 1, H // 32)]
         if self._buffers is None or self._buffers["dev"] != str(dev):
             self._buffers = {"dev": str(dev),
-                             "w": [torch.empty(nk * nt * 256, dtype=torch.float32, device=dev) for nt, nk, _ in shapes],
-                             "w16": [torch.empty(nk16 * nt * 1024, dtype=torch.float16, device=dev) for nt, _, nk16 in shapes],
-                             "b": [torch.empty(nt * 32, dtype=torch.float32, device=dev) for nt, _, _ in shapes],
-                             "row0": torch.empty(H, dtype=torch.float32, device=dev)}
-        L = _lib.lib()
-        for k, (l, (nt, nk, nk16)) in enumerate(zip(layers, shapes)):
+                             "w": [torch.empty(nk * nt * 256, dtype=torch.float32, device=dev) for nt, nk, _, _, _ in shapes],
+                             "w16": [torch.empty(nk16 * nt * 1024, dtype=torch.float16, device=dev) for nt, _, nk16, _, _ in shapes],
+                             "wq16": [torch.empty(nk32 * ncb * 1024, dtype=torch.float16, device=dev) for _, _, _, ncb, nk32 in shapes],
+                             "b": [torch.empty(nt * 32, dtype=torch.float32, device=dev) for nt, _, _, _, _ in shapes],
+                             "row0": torch.empty(H, dtype=torch.float32, device=dev),
+                             # the fp16 range guard's words (cnc_hip.h): zero once, stamped with ids afterwards
+                             # (64 words: a -DCNC_W2_PROF build adds its phase clocks behind the guard's eight)
+                             "guard": torch.zeros(64, dtype=torch.int32, device=dev)}
+        buf = self._buffers
+        self._pack_id += 1
+        d = _lib.FieldPack()
+        keep = []
+        for k, (l, (nt, nk, nk16, ncb, nk32)) in enumerate(zip(layers, shapes)):
             w, b = l.weight.detach(), l.bias.detach()
             if not w.is_contiguous():
                 w = w.contiguous()
-            row0 = self._buffers["row0"] if k == 1 else None
-            _lib.check(L.cnc_field_pack_layer(w.data_ptr(), b.data_ptr(), w.shape[0], w.shape[1], w.stride(0), nt, nk,
-                                              self._buffers["w"][k].data_ptr(), self._buffers["b"][k].data_ptr(),
-                                              _lib.ptr(row0), H if row0 is not None else 0, _lib.stream(dev)),
-                       "field_pack_layer")
-            _lib.check(L.cnc_field_pack_layer16(w.data_ptr(), w.shape[0], w.shape[1], w.stride(0), nt, nk16,
-                                                self._buffers["w16"][k].data_ptr(), _lib.stream(dev)), "field_pack_layer16")
+            keep += [w, b]
+            L = d.layer[k]
+            L.W, L.b, L.H, L.K, L.ldw = w.data_ptr(), b.data_ptr(), w.shape[0], w.shape[1], w.stride(0)
+            L.n_tiles, L.n_ksteps, L.n_ksteps16, L.n_colblocks, L.n_ksteps32 = nt, nk, nk16, ncb, nk32
+            L.Wp, L.Bp = buf["w"][k].data_ptr(), buf["b"][k].data_ptr()
+            L.Wp16, L.Wq16 = buf["w16"][k].data_ptr(), buf["wq16"][k].data_ptr()
+        d.row0, d.row0_len = buf["row0"].data_ptr(), H
+        d.guard, d.pack_id = buf["guard"].data_ptr(), self._pack_id
+        import ctypes
+        _lib.check(_lib.lib().cnc_field_pack_all(ctypes.byref(d), _lib.stream(dev)), "field_pack_all")
         self._key = key
         self._src = [(l.weight, l.bias) for l in layers]        # keep (data_ptr, version) unique while cached
-        return self._buffers
+        return buf
 
     @torch.no_grad()
     def __call__(self, positions: torch.Tensor, directions=None):
@@ -414,6 +443,7 @@ class FusedFieldForward:
         for k in range(5):
             st.packed_weights[k], st.packed_biases[k] = buf["w"][k].data_ptr(), buf["b"][k].data_ptr()
             st.packed_weights16[k] = buf["w16"][k].data_ptr()
+            st.packed_weights16q[k] = buf["wq16"][k].data_ptr()
         st.w2_row0 = buf["row0"].data_ptr()
         if self._units is None or self._units.device != dev:
             # the level tables as one record per (encoder, level) unit, in feature-row order (static per model)
@@ -424,14 +454,29 @@ class FusedFieldForward:
             self._units = torch.tensor(recs, dtype=torch.int32).to(dev).contiguous()
         st.units = self._units.data_ptr()
         st.n_features, st.n_neurons, st.geo_feat_dim = mb.encoding_xyz.n_features, mb.network[0].out_features, f.geo_feat_dim
-        st.flags = (_lib.CNC_FIELD_SH_FP16 if f.sh_fp16_round else 0) | \
-                   (_lib.CNC_FIELD_MFMA_F16X3 if f.fused_field_precision == "f16x3" else 0)
+        flags = _lib.CNC_FIELD_SH_FP16 if f.sh_fp16_round else 0
+        if f.fused_field_precision == "f16x3":
+            flags |= _lib.CNC_FIELD_MFMA_F16X3
+            if f.fused_field_kernel == "w2":
+                # two cooperating waves per tile; the density-only kernel fits four waves per SIMD, the colour kernel three
+                flags |= _lib.CNC_FIELD_TWO_WAVES
+                waves = f.fused_field_waves or (4 if d is None else 3)
+                if waves >= 4:
+                    flags |= _lib.CNC_FIELD_WAVES4
+        st.flags = flags
+        self._call_id = self._call_id % 0xFFFFFFF0 + 1
+        st.guard, st.call_id, st.pack_id = buf["guard"].data_ptr(), self._call_id, self._pack_id
         density = torch.empty((N, 1), dtype=torch.float32, device=dev)
         rgb = torch.empty((N, 3), dtype=torch.float32, device=dev) if d is not None else None
         import ctypes
         _lib.check(_lib.lib().cnc_field_fused_forward(ctypes.byref(st), x.data_ptr(), _lib.ptr(d), N, density.data_ptr(),
                                                       _lib.ptr(rgb), _lib.stream(dev)), "field_fused_forward")
         return (density, rgb) if d is not None else density
+
+    def range_guard_fired(self) -> bool:
+        """True when the LAST call left fp16's range and was recomputed by the exact kernel (reads one word back: a
+        host synchronisation — for tests and diagnostics, never on the hot path)."""
+        return self._buffers is not None and int(self._buffers["guard"][0].item()) == self._call_id
 
 
 class NGPRadianceField_mygrid_2D3D(nn.Module):
@@ -470,6 +515,11 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         self.fused_field_precision = os.environ.get("CNC_FUSED_FIELD_MFMA", "f16x3")
         if self.fused_field_precision not in ("f16x3", "f32"):
             raise ValueError("CNC_FUSED_FIELD_MFMA must be f16x3 or f32")
+        # "w2" (default): two cooperating waves per 32-sample tile (csrc/field_fused2.hip); "w1": one wave per tile
+        self.fused_field_kernel = os.environ.get("CNC_FUSED_FIELD_KERNEL", "w2")
+        if self.fused_field_kernel not in ("w1", "w2"):
+            raise ValueError("CNC_FUSED_FIELD_KERNEL must be w1 or w2")
+        self.fused_field_waves = int(os.environ.get("CNC_FUSED_FIELD_WAVES", "0"))     # 0: per kernel (4 density, 3 colour)
         self._field_fused = None
         # sample counts from here on run at a bucketed row count (`_bucket_rows`); CNC_ROW_BUCKET_MIN=0 pads every call
         self.row_bucket_min = int(os.environ.get("CNC_ROW_BUCKET_MIN", "4096"))

@@ -672,7 +672,13 @@ typedef struct {
     uint32_t       n_freqs;            /* > 0 (the reference always embeds, ngp.py:433)                           */
     uint32_t       n_neurons;          /* H: 64 or 160                                                            */
     uint32_t       geo_feat_dim;       /* 1 + geo <= 64 (H = 64) / 96 (H = 160) and roundup8(16 + geo) <= H        */
-    uint32_t       flags;              /* CNC_FIELD_SH_FP16 | CNC_FIELD_MFMA_F16X3                                  */
+    uint32_t       flags;              /* CNC_FIELD_SH_FP16 | CNC_FIELD_MFMA_F16X3 | CNC_FIELD_TWO_WAVES | ...      */
+    /* ---- ABI v26 ---- */
+    const void*    packed_weights16q[5];/* cnc_field_pack_all's 16x16x32 fragments (CNC_FIELD_TWO_WAVES)              */
+    uint32_t*      guard;              /* 8 zero-initialised words on the device, owned by the caller for the life of
+                                          the field: the fp16 range guard (below).  Required with CNC_FIELD_MFMA_F16X3 */
+    uint32_t       call_id;            /* a number the caller increases with every call (> 0)                      */
+    uint32_t       pack_id;            /* cnc_field_pack_t.pack_id of the pack that wrote the fragments in use      */
 } cnc_fused_field_t;
 
 /* The layers' products on the fp16 matrix pipe, three per term: every operand split x = hi + lo into two halves
@@ -680,6 +686,17 @@ typedef struct {
  * per term against fp32's 6e-8, at 1/5 of the matrix cycles of the exact fp32 form and on a pipe that overlaps with the
  * gather's vector work.  Without the flag: v_mfma_f32_32x32x2_f32, an exact fp32 fmaf chain per output.        */
 #define CNC_FIELD_MFMA_F16X3 2u
+/* (ABI v26) Two cooperating waves per 32-sample tile (csrc/field_fused2.hip): each owns half the output columns of a
+ * layer — half the accumulators and weight registers of the one-wave kernel, so 3-4 waves per SIMD hide the latency of
+ * the feature gathers.  Implies the three-product fp16 scheme; needs packed_weights16q.  CNC_FIELD_WAVES4 selects the
+ * variant compiled for four waves per SIMD (128 registers) instead of three (168).                                */
+#define CNC_FIELD_TWO_WAVES 4u
+#define CNC_FIELD_WAVES4 8u
+/* The fp16 range guard.  The three-product kernels split every operand into two halves; a hidden activation above
+ * fp16's 65504, or a weight with |2^8 w| above it, would become inf / NaN silently.  Both are detected exactly, on the
+ * device: a kernel that split such a value (or whose fragments cnc_field_pack_all stamped) writes call_id into guard[0],
+ * and cnc_field_fused_forward enqueues the exact-fp32 kernel behind every fp16 launch — it returns at once unless
+ * guard[0] == call_id, and recomputes the call otherwise.  No host synchronisation; the cost is one empty launch.   */
 
 /* W [H, K] row-major (row stride ldw), b [H]  ->  Wp: n_ksteps * n_tiles * 256 floats in MFMA fragment order (float4
  * (kb * n_tiles + t) * 64 + lane = W[32 t + (lane & 31)][8 kb + 4 (lane >> 5) + 0..3], zero outside [H, K]);
@@ -697,6 +714,32 @@ int cnc_field_pack_layer(const float* W, const float* b, uint32_t H, uint32_t K,
  * cnc_field_pack_layer.                                                                                        */
 int cnc_field_pack_layer16(const float* W, uint32_t H, uint32_t K, uint32_t ldw, uint32_t n_tiles, uint32_t n_ksteps16,
                            void* Wp16, void* stream);
+
+/* (ABI v26) All five layers (base.0, base.2, head.0, head.2, head.4) into every fragment order the fused kernels read,
+ * in ONE launch.  Per layer: W [H, K] (row stride ldw), b [H]; Wp / Bp as cnc_field_pack_layer (n_tiles, n_ksteps);
+ * Wp16 (nullable) as cnc_field_pack_layer16 (n_ksteps16); Wq16 (nullable): n_ksteps32 * n_colblocks * 1024 halves — per
+ * (K-step of 32, column block of 16): 64 x 8 halves hi, then lo, of 2^8 W[16 cb + (lane & 15)][32 ks + 8 (lane >> 4)
+ * + 0..7].  Column blocks for CNC_FIELD_TWO_WAVES: base.0 / head.0 / head.2: H / 16; base.2: 5 (H = 160) or 4 (H = 64);
+ * head.4: 1.  K-steps of 32: roundup32(K) / 32.  row0 / row0_len: base.2's row 0 as in cnc_field_pack_layer.
+ * guard / pack_id: a layer holding a weight with |2^8 w| > 65504 gets guard[1 + layer] = pack_id (see the guard). */
+typedef struct {
+    const float* W;
+    const float* b;
+    uint32_t     H, K, ldw;
+    uint32_t     n_tiles, n_ksteps, n_ksteps16, n_colblocks, n_ksteps32;
+    float*       Wp;
+    float*       Bp;
+    void*        Wp16;
+    void*        Wq16;
+} cnc_field_pack_layer_t;
+typedef struct {
+    cnc_field_pack_layer_t layer[5];
+    float*                 row0;
+    uint32_t               row0_len;
+    uint32_t*              guard;
+    uint32_t               pack_id;
+} cnc_field_pack_t;
+int cnc_field_pack_all(const cnc_field_pack_t* desc, void* stream);
 
 /* positions [N,3] (world), dirs [N,3] (nullable unless rgb), density [N], rgb [N,3] (nullable: density only).
  * CNC_ERR_UNSUPPORTED for shapes outside the table above (the caller then runs the unfused chain).            */

@@ -58,8 +58,14 @@ def _close(got, want, tol, what):
 
 
 # "f32": each layer an exact fp32 fmaf chain (v_mfma_f32_32x32x2_f32); "f16x3" (the default): three fp16 products per
-# term — the bound below is the SAME 1e-4 for both, and the fp16 form is additionally held to 2e-5
-PRECISIONS = pytest.mark.parametrize("precision", ["f16x3", "f32"])
+# term — the bound below is the SAME 1e-4 for both, and the fp16 form is additionally held to 2e-5.  "w2" (the default):
+# two cooperating waves per 32-sample tile (field_fused2.hip, v_mfma_f32_16x16x32_f16); "w1": one wave per tile.
+PRECISIONS = pytest.mark.parametrize("precision", ["f16x3-w2", "f16x3-w1", "f32"])
+
+
+def _select(f, precision):
+    f.fused_field_precision = precision.split("-")[0]
+    f.fused_field_kernel = precision.split("-")[1] if "-" in precision else "w1"
 
 
 @PRECISIONS
@@ -68,7 +74,7 @@ PRECISIONS = pytest.mark.parametrize("precision", ["f16x3", "f32"])
 def test_fused_field_equals_the_chain(cuda, cfg, n, precision):
     from cnc_amd.field import FusedFieldForward
     f = _field(cuda, CONFIGS[cfg], seed=3)
-    f.fused_field_precision = precision
+    _select(f, precision)
     assert FusedFieldForward.supported(f)
     x, d = _inputs(cuda, n, seed=n)
     with torch.no_grad():
@@ -79,7 +85,8 @@ def test_fused_field_equals_the_chain(cuda, cfg, n, precision):
         rgb1, sig1 = f(x, d)
         den1 = f.query_density(x)
     assert f._field_fused, "the fused kernel did not run"
-    tol = 2e-5 if precision == "f16x3" else 1e-4
+    tol = 2e-5 if precision.startswith("f16x3") else 1e-4
+    assert not (precision.startswith("f16x3") and f._field_fused.range_guard_fired())      # in range: the fp16 kernel's own numbers
     _close(den1, den0, tol, "density (density-only kernel)")
     _close(sig1, sig0, tol, "density (colour kernel)")
     _close(rgb1, rgb0, tol, "rgb")
@@ -95,7 +102,7 @@ def test_fused_field_at_full_size_and_after_a_weight_update(cuda, precision):
     """2^20 samples of the reference composition: the fused kernels against the chain; then an optimiser-style in-place
     update of every parameter — the packed weights and the sign planes must follow it."""
     f = _field(cuda, CONFIGS["f8_full"], seed=5)
-    f.fused_field_precision = precision
+    _select(f, precision)
     n = 1 << 20
     x, d = _inputs(cuda, n, seed=11)
     for round_ in range(2):
@@ -144,3 +151,87 @@ def test_sh_half_rounding_reaches_the_fused_kernel(cuda):
     _close(out["half", True], out["half", False], 1e-4, "half")
     _close(out["float", True], out["float", False], 1e-4, "float")
     assert float((out["half", True] - out["float", True]).abs().max()) > 1e-6
+
+
+@pytest.mark.parametrize("kernel", ["w2", "w1"])
+@pytest.mark.parametrize("cfg", ["f8_full", "f2_toy"])
+def test_fp16_range_guard(cuda, cfg, kernel):
+    """The three-product kernels split operands into two halves: above fp16's 65504 that would be inf / NaN.  The guard
+    detects it on the device and the exact-fp32 kernel enqueued behind recomputes the call: finite, chain-equal output
+    (i) with hidden activations driven past 65504, (ii) with a weight whose 2^8 multiple does not fit; and it does NOT
+    fire for an ordinary model, nor for samples far outside the box."""
+    f = _field(cuda, CONFIGS[cfg], seed=4)
+    f.fused_field_precision, f.fused_field_kernel = "f16x3", kernel
+    x, d = _inputs(cuda, 5000, seed=5)
+    x[7] = torch.tensor([3.0e5, -2.0e6, 1.0e9])          # selector 0, raw coordinates beyond fp16
+
+    def both():
+        with torch.no_grad():
+            f.fused_field = False
+            rgb0, sig0 = f(x, d)
+            den0 = f.query_density(x)
+            f.fused_field = True
+            rgb1, sig1 = f(x, d)
+            fired_rgb = f._field_fused.range_guard_fired()
+            den1 = f.query_density(x)
+            fired_den = f._field_fused.range_guard_fired()
+        return (rgb0, sig0, den0), (rgb1, sig1, den1), (fired_rgb, fired_den)
+
+    ref, got, fired = both()
+    assert fired == (False, False)
+    assert all(bool(torch.isfinite(t).all()) for t in got)
+    keep = torch.ones(x.shape[0], dtype=torch.bool, device=cuda)
+    keep[7] = False                                       # its colour comes from clamped coordinates (density 0 either way)
+    for a, b, what in zip(got, ref, ("rgb", "density (colour kernel)", "density")):
+        _close(a[keep], b[keep], 2e-5, what)
+    assert float(got[1][7]) == 0.0 and float(got[2][7]) == 0.0
+
+    # (i) hidden activations of the base network far beyond 65504, pulled back by a small second layer
+    with torch.no_grad():
+        f.mlp_base.network[0].weight.mul_(300.0)
+        f.mlp_base.network[0].bias.fill_(7.0e4)
+        f.mlp_base.network[2].weight.mul_(1.0e-5)
+    ref, got, fired = both()
+    assert fired == (True, False)       # the density-only kernel keeps h1 in fp32 registers: nothing of it is split
+    # (the chain's own density of the far-away sample is exp(huge) * 0 = NaN; the kernels select 0)
+    assert all(bool(torch.isfinite(t).all()) for t in got) and all(bool(torch.isfinite(t[keep]).all()) for t in ref)
+    for a, b, what in zip(got, ref, ("rgb", "density (colour kernel)", "density")):
+        _close(a[keep], b[keep], 1e-4, what + ", activations beyond fp16")
+    assert float(ref[2][keep].max()) > 0.01
+
+    # (ii) a first-layer weight of 300: 2^8 * 300 > 65504 — flagged by the packer, every call takes the exact kernel
+    g = _field(cuda, CONFIGS[cfg], seed=4)
+    g.fused_field_precision, g.fused_field_kernel = "f16x3", kernel
+    with torch.no_grad():
+        g.mlp_base.network[0].weight[3, 5] = 300.0
+        g.mlp_head[2].weight[1, 2] = -400.0
+    f = g
+    ref, got, fired = both()
+    assert fired == (True, True)
+    for a, b, what in zip(got, ref, ("rgb", "density (colour kernel)", "density")):
+        _close(a[keep], b[keep], 1e-4, what + ", weight beyond fp16")
+    # ... and once the weights are back in range the fp16 kernels serve the calls again
+    with torch.no_grad():
+        g.mlp_base.network[0].weight[3, 5] = 0.25
+        g.mlp_head[2].weight[1, 2] = -0.25
+    ref, got, fired = both()
+    assert fired == (False, False)
+    for a, b, what in zip(got, ref, ("rgb", "density (colour kernel)", "density")):
+        _close(a[keep], b[keep], 2e-5, what)
+
+
+@pytest.mark.parametrize("kernel", ["w2", "w1"])
+def test_fused_field_is_repeatable(cuda, kernel):
+    """The kernels have no atomics and a fixed summation order: the same call returns the same bits.  (A race between
+    the two waves of a tile shows up here as a handful of rows of one tile differing in one call out of a few — that is
+    how a build with the direction load moved in front of layer 2 was caught.)"""
+    f = _field(cuda, CONFIGS["f8_full"], seed=3)
+    f.fused_field_precision, f.fused_field_kernel = "f16x3", kernel
+    x, d = _inputs(cuda, 70001, seed=70001)
+    with torch.no_grad():
+        rgb0, sig0 = f(x, d)
+        den0 = f.query_density(x)
+        for rep in range(60):
+            rgb, sig = f(x, d)
+            den = f.query_density(x)
+            assert torch.equal(rgb, rgb0) and torch.equal(sig, sig0) and torch.equal(den, den0), rep

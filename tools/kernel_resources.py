@@ -7,7 +7,7 @@ import sys
 
 src = sys.argv[1]
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-       "-munsafe-fp-atomics", "-c", "-I", "include", "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null", src]
+       "-munsafe-fp-atomics", "-c", "-I", "include", "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null", src] + sys.argv[2:]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
 for line in err.splitlines():
