@@ -171,6 +171,142 @@ __device__ __forceinline__ uint32_t load_row_bits(const uint8_t* __restrict__ bi
     }
 }
 
+// One 16-byte record per unit, built by the caller from the encoders' level tables (cnc_fused_field_t.units): a lane
+// needs ONE L1-resident load before it can form its corner rows.  Reading the level tables through the encoder array
+// of the kernel arguments (a dynamically indexed pointer, then the table entry, then the sign bytes) put three
+// dependent memory round trips in front of every unit.
+struct UnitRec {
+    uint32_t off, hs, R, enc;
+};
+
+// The same F features with the vector work cut down (566 -> ~370 instructions per 3-D unit; the kernel was 53 % vector
+// issue, tools/pmc_field.sh), BIT-IDENTICAL to `unit_features` / k_grid_encode_fwd_bits on the units a GridEncoder makes:
+//   * a level is either dense (R^D <= rows: index = q0 + q1 R + q2 R^2 < rows) or hashed into a power-of-two table
+//     (index = xor of primes & (rows - 1)) — the host refuses anything else (`FusedFieldForward._unit_table`) — so every
+//     index is in range by construction: no modulo, no per-corner branch around the gather (an invalid corner's byte
+//     is read and multiplied by a zero weight), coordinates of an outside point are replaced by 0 first;
+//   * per-axis work is shared by the corners: 2 D multiplies for the index parts, the D = 3 weights as four x-y
+//     products times two z factors (same association (wx wy) wz), border tests per axis value;
+//   * the sign goes into the weight with shift + v_bfi (the weight is non-negative) and is ADDED: fmaf(tw, +-1, acc)
+//     is acc +- tw rounded once — the same value — at 3 instead of 4 instructions per (corner, feature).
+// ... in two halves: everything up to the gathers (their results stay in flight in `u.rb`), then the weights' sum, the
+// division and the features — so that a lane can have two units' gathers under way before it consumes either.
+struct UnitFast {
+    float    m[8];        // corner weight, 0 for a border corner or an outside point
+    uint32_t rb[8];       // the corner rows' sign bits (bits 0 .. F-1)
+    float    wn;          // sum of m in corner order
+};
+
+template <uint32_t D, uint32_t F>
+__device__ __forceinline__ void unit_issue_fast(const float (&x_)[D], bool inside, const uint8_t* __restrict__ bits,
+                                                const UnitRec& r, UnitFast& u)
+{
+    static_assert(D == 2 || D == 3, "planes and volumes");
+    constexpr uint32_t C = 1u << D;
+    float (&m)[8] = u.m;
+    uint32_t (&rb)[8] = u.rb;
+    const uint32_t R = r.R, hs = r.hs;
+    // the stride walk of grid_row: hashed iff the level does not fit its table
+    uint32_t stride = 1, sd[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        sd[d] = stride;
+        if (stride <= hs) stride *= R;
+    }
+    const bool     hashed = stride > hs;
+    const uint32_t mask = hashed ? hs - 1u : 0xFFFFFFFFu;
+    constexpr uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+    uint32_t pa[D][2];
+    float    wa[D][2];
+    bool     ba[D][2];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        const float xd = inside ? x_[d] : 0.0f;
+        float p = xd * (float)(R - 2);
+        p = p + 0.5f;
+        const float    fl = floorf(p);
+        const uint32_t g = (uint32_t)fl, q1 = min(g + 1u, R - 1u);
+        wa[d][1] = p - fl;
+        wa[d][0] = 1 - wa[d][1];
+        ba[d][0] = (g == 0u) | (g == R - 1u);
+        ba[d][1] = (q1 == 0u) | (q1 == R - 1u);
+        if (d == 0) {
+            pa[d][0] = g;
+            pa[d][1] = q1;
+        } else {
+            const uint32_t m = hashed ? primes[d] : sd[d];
+            pa[d][0] = g * m;
+            pa[d][1] = q1 * m;
+        }
+    }
+    float w01[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) w01[j] = wa[0][j & 1u] * wa[1][j >> 1];
+    float    wn = 0;
+    const uint8_t* const base = bits + (uint64_t)r.off * F / 8u;        // F in {2, 4, 8}: off is a multiple of 8 rows
+    uint32_t index[C];
+#pragma unroll
+    for (uint32_t i = 0; i < C; i++) {
+        const uint32_t b0 = i & 1u, b1 = (i >> 1) & 1u, b2 = D == 3 ? (i >> 2) & 1u : 0u;
+        float    wi = w01[i & 3u];
+        bool     border = ba[0][b0] | ba[1][b1];
+        uint32_t ix = pa[0][b0] ^ pa[1][b1], ia = pa[0][b0] + pa[1][b1];
+        if constexpr (D == 3) {
+            wi = wi * wa[2][b2];
+            border = border | ba[2][b2];
+            ix ^= pa[2][b2];
+            ia += pa[2][b2];
+        }
+#ifdef CNC_EXP_SAMEROW      // timing experiment (tools/gpu_w2_exp.sh): every gather of a unit reads one row
+        index[i] = ((hashed ? ix : ia) & mask) & 1u;
+#else
+        index[i] = (hashed ? ix : ia) & mask;
+#endif
+        m[i] = (!border && inside) ? wi : 0.0f;
+        wn += m[i];
+    }
+    // (Serving the two x-neighbours of a corner pair with ONE 16-bit load — adjacent bytes on a dense level, an aligned
+    // byte pair on a hashed level when the cell's x is even — was built and measured: level-major forward 0.218 -> 0.255 ms
+    // per 2^20 marched samples, fused field unchanged at 0.855 ms on uniform points; the selects and the second,
+    // conditional load cost more than the lookups saved.  One byte gather per corner it stays.)
+#pragma unroll
+    for (uint32_t i = 0; i < C; i++) rb[i] = load_row_bits<F>(base, index[i]);
+    u.wn = wn;
+}
+
+template <uint32_t D, uint32_t F>
+__device__ __forceinline__ void unit_finish_fast(const UnitFast& u, float (&acc)[F])
+{
+    constexpr uint32_t C = 1u << D;
+    float wn = u.wn;
+    if (wn == 0) wn = 1e-9f;
+    const float wn_re = 1.0f / wn;
+#pragma unroll
+    for (uint32_t k = 0; k < F; k++) acc[k] = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < C; i++) {
+        const uint32_t tw = __builtin_bit_cast(uint32_t, u.m[i] * wn_re);        // >= +0
+        const uint32_t nb = ~u.rb[i];                                            // bit k clear = feature +1
+#pragma unroll
+        for (uint32_t k = 0; k < F; k++) {
+            // sign from bit k of nb, magnitude from tw: shift + v_bfi_b32 (the compiler's own choice for the C
+            // expression is shift + and + or: VOP3 takes no literal on gfx9, so it will not form the bfi by itself)
+            uint32_t sw;
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sw) : "s"(0x80000000u), "v"(nb << (31u - k)), "v"(tw));
+            acc[k] = acc[k] + __builtin_bit_cast(float, sw);
+        }
+    }
+}
+
+template <uint32_t D, uint32_t F>
+__device__ __forceinline__ void unit_features_fast(const float (&x)[D], bool inside, const uint8_t* __restrict__ bits,
+                                                   const UnitRec& r, float (&acc)[F])
+{
+    UnitFast u;
+    unit_issue_fast<D, F>(x, inside, bits, r, u);
+    unit_finish_fast<D, F>(u, acc);
+}
+
 template <uint32_t D>
 __device__ __forceinline__ bool load_point(const float* __restrict__ inputs, uint32_t b,
                                            float (&x)[D])

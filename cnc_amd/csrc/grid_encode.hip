@@ -138,7 +138,10 @@ __global__ __launch_bounds__(256) void k_pack_sign_bits(const float* __restrict_
 // order: level-major a wave's instruction writes 1 KB contiguous, point-major every instruction writes whole lines
 // (64 / Cp points x Cp*16 bytes).  The arithmetic is untouched (same corner order, same fmaf chain).
 template <uint32_t D, uint32_t F, bool VXL, bool TR>
-__global__ __launch_bounds__(256) void k_grid_encode_fwd_bits(
+#ifndef CNC_FWD_BITS_BOUNDS
+#define CNC_FWD_BITS_BOUNDS __launch_bounds__(256)
+#endif
+__global__ CNC_FWD_BITS_BOUNDS void k_grid_encode_fwd_bits(
     const float* __restrict__ inputs, const uint8_t* __restrict__ bits,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ resolutions,
     float* __restrict__ out, uint32_t N, uint32_t L, uint32_t P, uint32_t cp_log2, uint32_t Rb,
@@ -166,7 +169,27 @@ __global__ __launch_bounds__(256) void k_grid_encode_fwd_bits(
         float  acc[F];
 #pragma unroll
         for (uint32_t k = 0; k < F; k++) acc[k] = 0;
-        if (inside) {
+        // The lean evaluator (encoder_common.hpp, unit_features_fast: per-axis index parts, no per-corner branch, x-pair
+        // 16-bit gathers, shift + bfi signs — the same values bit for bit) whenever the level is the same for the whole
+        // grid row (no per-point windows) and is what a GridEncoder makes: dense (R^D rows fit) or hashed into a
+        // power-of-two table.  Anything else — odd caller-made tables, the occupancy mask — takes the general path below.
+        bool done = false;
+        if constexpr (!VXL && (D == 2 || D == 3)) {
+            if (min_level_id == nullptr) {
+                const uint32_t off = (uint32_t)offsets[slot];
+                const uint32_t hs = (uint32_t)offsets[slot + 1] - off;
+                const uint32_t R = (uint32_t)resolutions[slot];
+                uint64_t rd = 1;
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) rd *= R;
+                const bool dense = rd <= hs, pow2 = (hs & (hs - 1u)) == 0u;
+                if ((dense || pow2) && (off & 7u) == 0u) {
+                    unit_features_fast<D, F>(x, inside, bits, UnitRec{off, hs, R, 0u}, acc);
+                    done = true;
+                }
+            }
+        }
+        if (inside && !done) {
             const uint32_t off = (uint32_t)offsets[level];
             const uint32_t hs = (uint32_t)offsets[level + 1] - off;
             const uint32_t R = (uint32_t)resolutions[level];
