@@ -286,13 +286,21 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                     const uint32_t e_last = __builtin_amdgcn_readfirstlane(p.units[u_last].w);
                     kind = e_last == 0 ? 0u : (e_first != 0 ? 1u : 3u);          // units are ordered 3-D first
                 }
+#ifdef CNC_EXP_NOFILL        // timing experiment: no features at all (the tile keeps whatever it held)
+                if (kind == 99) fill_tail<RowF16, 8>(p, xu, w0, p.n_units * F, trow);
+#else
                 if (kind == 0) fill_units<F, 3, RowF16, 8>(p, units, xu, w0, trow);
                 else if (kind == 1) fill_units<F, 2, RowF16, 8>(p, units, xu, w0, trow);
                 else if (kind == 2) fill_tail<RowF16, 8>(p, xu, w0, p.n_units * F, trow);
                 else fill_window<F, false, RowF16, 8>(p, xu, w0, trow);
+#endif
             }
             W2_MARK(0);
+#ifdef CNC_EXP_HOTWEIGHTS    // timing experiment: every chunk reads chunk 0's fragments (L1-resident)
+            load_wq<NCB>(W1, 0, NCBT, voff1, wh, wl);
+#else
             load_wq<NCB>(W1, c, NCBT, voff1, wh, wl);
+#endif
 #ifndef CNC_EXP_NOBARRIER    // timing experiment: no workgroup barrier in the chunk loop (results are garbage)
             __syncthreads();
 #endif
@@ -303,7 +311,15 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                 ah[rb] = *reinterpret_cast<const half8_t*>(c_hi + (rb * 16 + r) * kCP + 8 * kq);
                 al[rb] = *reinterpret_cast<const half8_t*>(c_lo + (rb * 16 + r) * kCP + 8 * kq);
             }
+#ifdef CNC_EXP_NOMFMA        // timing experiment: operands are loaded, one product per accumulator keeps them alive
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++)
+                    acc[rb][cb][0] += (float)ah[rb][0] + (float)al[rb][0] + (float)wh[cb][0] + (float)wl[cb][0];
+#else
             mfma3q<2, NCB>(ah, al, wh, wl, acc);
+#endif
             W2_MARK(2);
         }
 
