@@ -34,7 +34,8 @@ class FusedField(C.Structure):
                 ("packed_weights", _vp * 5), ("packed_biases", _vp * 5), ("w2_row0", _vp), ("packed_weights16", _vp * 5),
                 ("units", _vp), ("n_levels", _u32 * 4),
                 ("n_features", _u32), ("n_freqs", _u32), ("n_neurons", _u32), ("geo_feat_dim", _u32), ("flags", _u32),
-                ("packed_weights16q", _vp * 5), ("guard", _vp), ("call_id", _u32), ("pack_id", _u32)]
+                ("packed_weights16q", _vp * 5), ("guard", _vp), ("call_id", _u32), ("pack_id", _u32),
+                ("debug_features", _vp), ("debug_ld", _u32)]
 
 
 class FieldPackLayer(C.Structure):

@@ -613,6 +613,10 @@ extern "C" int cnc_field_fused_forward(const cnc_fused_field_t* f, const float* 
         // the range guard is part of the fp16 form: without it a value above 65504 would come out as inf / NaN
         if (!f->guard || f->call_id == 0 || f->pack_id == 0) return CNC_ERR_INVALID_VALUE;
         p.guard = f->guard; p.call_id = f->call_id; p.pack_id = f->pack_id;
+        if (f->debug_features) {         // test hook: the two-wave density kernel only, rows wide enough for K padded to 32
+            if (!two_waves || want_rgb || f->debug_ld < p.nkb1 * 8) return CNC_ERR_UNSUPPORTED;
+            p.dbg_features = f->debug_features; p.dbg_ld = f->debug_ld;
+        }
         for (int l = 0; l < (want_rgb ? 5 : 1); l++) {
             const void* w16 = two_waves ? f->packed_weights16q[l] : f->packed_weights16[l];
             if (!w16) return CNC_ERR_INVALID_VALUE;

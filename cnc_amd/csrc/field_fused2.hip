@@ -23,6 +23,8 @@
 // The fp16 range guard (field_fused_common.hpp) covers every value that is split into halves here.
 #include "field_fused_common.hpp"
 
+#include <type_traits>
+
 namespace cnc {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -210,9 +212,10 @@ __device__ __forceinline__ void acc_to_planes(half_t* __restrict__ d_hi, half_t*
 #define W2_MARK(k) do { } while (0)
 #endif
 
-template <uint32_t F, int NT, bool RGB, int WPE>
+template <uint32_t F, int NT, bool RGB, int WPE, bool DUMP = false>
 __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
 {
+    using RowT = std::conditional_t<DUMP, RowDump<RowF16>, RowF16>;
 #ifdef CNC_W2_PROF
     uint64_t prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t t_prev = __builtin_amdgcn_s_memtime();
@@ -276,7 +279,10 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
             half_t* const c_lo = c_hi + 32 * kCP;
             {   // what this wave's 16 columns of the chunk hold is a wave-uniform fact: branch on it (scalar), so that a
                 // chunk of 3-D units issues the 3-D code only
-                const RowF16   trow{c_hi + fi * kCP, c_lo + fi * kCP};
+                RowT trow;
+                trow.hi = c_hi + fi * kCP;
+                trow.lo = c_lo + fi * kCP;
+                if constexpr (DUMP) trow.dbg = live ? p.dbg_features + (size_t)frow * p.dbg_ld + c * 32 : nullptr;
                 const uint32_t w0 = c * 32 + 8 * fq, col0 = c * 32 + 16 * wu;
                 const uint32_t u_first = col0 / F, u_last = (col0 + 15) / F;
                 uint32_t       kind = 3;                                         // 3: mixed -> the general fill
@@ -287,12 +293,12 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                     kind = e_last == 0 ? 0u : (e_first != 0 ? 1u : 3u);          // units are ordered 3-D first
                 }
 #ifdef CNC_EXP_NOFILL        // timing experiment: no features at all (the tile keeps whatever it held)
-                if (kind == 99) fill_tail<RowF16, 8>(p, xu, w0, p.n_units * F, trow);
+                if (kind == 99) fill_tail<RowT, 8>(p, xu, w0, p.n_units * F, trow);
 #else
-                if (kind == 0) fill_units<F, 3, RowF16, 8>(p, units, xu, w0, trow);
-                else if (kind == 1) fill_units<F, 2, RowF16, 8>(p, units, xu, w0, trow);
-                else if (kind == 2) fill_tail<RowF16, 8>(p, xu, w0, p.n_units * F, trow);
-                else fill_window<F, false, RowF16, 8>(p, xu, w0, trow);
+                if (kind == 0) fill_units<F, 3, RowT, 8>(p, units, xu, w0, trow);
+                else if (kind == 1) fill_units<F, 2, RowT, 8>(p, units, xu, w0, trow);
+                else if (kind == 2) fill_tail<RowT, 8>(p, xu, w0, p.n_units * F, trow);
+                else fill_window<F, false, RowT, 8>(p, xu, w0, trow);
 #endif
             }
             W2_MARK(0);
@@ -587,7 +593,10 @@ int launch_field_fused_w2(const FusedFieldArgs& p, bool rgb, uint32_t F, uint32_
     } while (0)
 #define CNC_W2_RGB(FV, NTV)                 \
     do {                                    \
-        if (rgb) CNC_W2_W(FV, NTV, true);   \
+        if (p.dbg_features) {               \
+            rc = resident_grid(k_field_fused16w2<FV, NTV, false, 3, true>, lds_bytes, tiles, 16, &blocks); \
+            if (rc == CNC_OK) hipLaunchKernelGGL((k_field_fused16w2<FV, NTV, false, 3, true>), dim3(blocks), dim3(128), lds_bytes, s, p); \
+        } else if (rgb) CNC_W2_W(FV, NTV, true); \
         else CNC_W2_W(FV, NTV, false);      \
     } while (0)
 #define CNC_W2_NT(FV)                   \

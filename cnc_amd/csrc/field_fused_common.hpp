@@ -51,7 +51,9 @@ struct FusedFieldArgs {
     uint32_t       pack_id;       // id of the cnc_field_pack_all that produced the fragments in use (> 0)
     uint32_t       nk32_h;        // K-steps of 32 of the head's first layer: roundup32(16 + geo) / 32
     uint32_t       only_if_flagged;   // exact-fp32 kernels: return at once unless guard[0] == call_id
-    const half_t_* Wq16[5];       // fragments of the 16x16x32 form (cnc_field_pack_layer16x32), k_field_fused16w2
+    const half_t_* Wq16[5];       // fragments of the 16x16x32 form (cnc_field_pack_all), k_field_fused16w2
+    float*         dbg_features;  // test hook (cnc_fused_field_t.debug_features): [N, dbg_ld] first-layer input rows
+    uint32_t       dbg_ld;
 };
 
 constexpr uint32_t kChunkPitch = 36;     // floats per row of the 32 x 32 chunk tile (+4: conflict-free b128 accesses)
@@ -299,6 +301,28 @@ __device__ __forceinline__ void split_half(float x, half_t& hi, half_t& lo)
     hi = (half_t)x;
     lo = (half_t)(x - (float)hi);
 }
+
+struct RowF16;
+// RowF16 that also writes every value it is given, as float32, into a [N, ld] dump (the test hook that lets a parity test
+// hold the kernel's OWN features against the oracle's encoder): `dbg` = the sample's dump row at this chunk's first column
+template <typename Base>
+struct RowDump : Base {
+    float* dbg;
+    template <uint32_t V>
+    __device__ __forceinline__ void put(uint32_t col, const float (&v)[V]) const
+    {
+        Base::template put<V>(col, v);
+        if (dbg) {
+#pragma unroll
+            for (uint32_t j = 0; j < V; j++) dbg[col + j] = v[j];
+        }
+    }
+    __device__ __forceinline__ void put1(uint32_t col, float v) const
+    {
+        Base::put1(col, v);
+        if (dbg) dbg[col] = v;
+    }
+};
 
 struct RowF16 {
     static constexpr bool kFastSin = true;

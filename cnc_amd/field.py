@@ -414,8 +414,10 @@ class FusedFieldForward:
         return buf
 
     @torch.no_grad()
-    def __call__(self, positions: torch.Tensor, directions=None):
-        """density [N, 1] (and rgb [N, 3] when `directions` is given) of world positions [N, 3]."""
+    def __call__(self, positions: torch.Tensor, directions=None, debug_features=None):
+        """density [N, 1] (and rgb [N, 3] when `directions` is given) of world positions [N, 3].  `debug_features` (test
+        hook, density-only two-wave calls): a float32 [N, >= roundup32(K0)] tensor that receives the first layer's input
+        rows as the kernel computed them."""
         from . import _lib
         f = self.field
         mb = f.mlp_base
@@ -466,6 +468,9 @@ class FusedFieldForward:
         st.flags = flags
         self._call_id = self._call_id % 0xFFFFFFF0 + 1
         st.guard, st.call_id, st.pack_id = buf["guard"].data_ptr(), self._call_id, self._pack_id
+        if debug_features is not None:
+            assert debug_features.dtype == torch.float32 and debug_features.is_contiguous() and debug_features.shape[0] == N
+            st.debug_features, st.debug_ld = debug_features.data_ptr(), debug_features.shape[1]
         density = torch.empty((N, 1), dtype=torch.float32, device=dev)
         rgb = torch.empty((N, 3), dtype=torch.float32, device=dev) if d is not None else None
         import ctypes

@@ -679,6 +679,11 @@ typedef struct {
                                           the field: the fp16 range guard (below).  Required with CNC_FIELD_MFMA_F16X3 */
     uint32_t       call_id;            /* a number the caller increases with every call (> 0)                      */
     uint32_t       pack_id;            /* cnc_field_pack_t.pack_id of the pack that wrote the fragments in use      */
+    float*         debug_features;     /* test hook (nullable): [N, debug_ld] floats receive the first layer's INPUT row of
+                                          every sample exactly as the kernel computed it — the four encoders' features,
+                                          the raw coordinates, the sinusoids, zero padding to a multiple of 32 — before
+                                          it is split into halves.  CNC_FIELD_TWO_WAVES density-only calls only.        */
+    uint32_t       debug_ld;           /* >= roundup32(K0)                                                         */
 } cnc_fused_field_t;
 
 /* The layers' products on the fp16 matrix pipe, three per term: every operand split x = hi + lo into two halves

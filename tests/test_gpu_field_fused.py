@@ -235,3 +235,58 @@ def test_fused_field_is_repeatable(cuda, kernel):
             rgb, sig = f(x, d)
             den = f.query_density(x)
             assert torch.equal(rgb, rgb0) and torch.equal(sig, sig0) and torch.equal(den, den0), rep
+
+
+def test_fused_field_features_and_density_against_the_oracle_at_full_size(cuda, oracle):
+    """The full-size anchor: not the repo's own chain but the ORACLE.  The two-wave kernel dumps the first layer's input
+    rows as it computed them (`debug_features`); on the reference composition (12 x 3-D levels at T = 2^19, 3 planes x 4
+    levels at T = 2^17, F = 8) and 2^16 points they must equal, bit for bit, oracle.grid_encode_forward on the binarised
+    tables (gridencoder.cu:114-316) for the four encoders; the raw-coordinate / sinusoid columns are held to float64
+    NumPy (the kernel's v_sin / v_cos: 3e-7), and the density to a float64 NumPy MLP on those very features (1e-4:
+    north_star's bound)."""
+    f = _field(cuda, CONFIGS["f8_full"], seed=21)
+    f.fused_field_precision, f.fused_field_kernel = "f16x3", "w2"
+    n = 1 << 16
+    g = torch.Generator(device=cuda).manual_seed(5)
+    x = torch.rand(n, 3, device=cuda, generator=g) * 3.0 - 1.5            # inside the box (up to rounding at the faces)
+    x[:64] = torch.rand(64, 3, device=cuda, generator=g) * 3.4 - 1.7      # and a few outside
+    mb = f.mlp_base
+    k0 = mb.network[0].in_features
+    feats = torch.full((n, 256), float("nan"), device=cuda)
+    with torch.no_grad():
+        f.fused_field = True
+        f.query_density(x[:8])                                           # builds the evaluator
+        den = f._field_fused(x, debug_features=feats)
+    feats = feats.cpu().numpy()
+    xu = ((x - f.aabb[:3]) / (f.aabb[3:] - f.aabb[:3])).cpu().numpy().astype(np.float32)
+    col = 0
+    for e, dims in zip(mb._encoders(), ((0, 1, 2), (0, 1), (0, 2), (1, 2))):
+        table = e.params.detach().cpu().numpy()
+        signs = np.where(table >= 0, 1.0, -1.0).astype(np.float32)      # STE_binary, ngp.py:24-39
+        want = oracle.grid_encode_forward(np.ascontiguousarray(xu[:, dims]), signs, e.offsets_list.cpu().numpy(),
+                                          e.resolutions_list.cpu().numpy(), threads=8)          # [L, N, F]
+        want = np.transpose(want, (1, 0, 2)).reshape(n, -1)
+        got = feats[:, col:col + want.shape[1]]
+        assert np.array_equal(got, want), (dims, float(np.abs(got - want).max()))
+        assert float(np.abs(want).max()) > 0.5
+        col += want.shape[1]
+    assert col == 192
+    freqs = mb._freqs.cpu().numpy().astype(np.float64)
+    x64 = xu.astype(np.float64)
+    # raw coordinates, then per frequency sin (3) and cos (3); padding column 255
+    assert np.array_equal(feats[:, col:col + 3], xu)
+    for k, fr in enumerate(freqs):
+        arg = (xu * np.float32(fr)).astype(np.float64)                    # the kernel multiplies in float32
+        assert np.abs(feats[:, col + 3 + 6 * k: col + 6 + 6 * k] - np.sin(arg)).max() < 1e-6
+        assert np.abs(feats[:, col + 6 + 6 * k: col + 9 + 6 * k] - np.cos(arg)).max() < 1e-6
+    assert k0 == col + 3 + 6 * len(freqs) == 255 and np.all(feats[:, 255] == 0)
+    # density from those features in float64
+    w1, b1 = (t.detach().cpu().numpy().astype(np.float64) for t in (mb.network[0].weight, mb.network[0].bias))
+    w2, b2 = (t.detach().cpu().numpy().astype(np.float64) for t in (mb.network[2].weight, mb.network[2].bias))
+    h1 = np.maximum(feats[:, :255].astype(np.float64) @ w1.T + b1, 0.0)
+    raw = h1 @ w2[0] + b2[0]
+    sel = np.all((xu > 0) & (xu < 1), axis=1)
+    want_den = np.where(sel, np.exp(raw - 1.0), 0.0)
+    got_den = den.cpu().numpy().reshape(-1).astype(np.float64)
+    assert np.abs(got_den - want_den).max() <= 1e-4 * want_den.max()
+    assert np.array_equal(got_den == 0, ~sel) and sel[64:].all() and not sel[:64].all()
