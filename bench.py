@@ -370,6 +370,22 @@ def train_step_entry(dev, world=1, rank=0):
            "config": "full model, F=8, 12x3D(2^19)+3x4x2D(2^17), sample_num=150000, lmbda=2e-3, procedural ball "
                      "scene, target 2^18 samples/step" + ("/rank" if world > 1 else "") +
                      f", steps {warm}-{warm + n_steps - 1} (includes the occupancy refresh every 16 steps)"}
+    # occupancy refreshes inside the timed steps and how many of them found the grid unchanged (context.py keeps the vote
+    # plan and the planes' slot lists then); refresh-step wall time from a second, short loop over whole refresh periods
+    rs0 = dict(tr.context.refresh_stats)
+    per_step = []
+    for step in range(warm + n_steps, warm + n_steps + 32):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        tr.train_step(step, want_stats=False)
+        torch.cuda.synchronize()
+        per_step.append(((time.perf_counter() - t1) * 1e3, step % cfg.step_update == 0))
+    rs1 = dict(tr.context.refresh_stats)
+    ref_ms = [m for m, r in per_step if r]
+    ord_ms = sorted(m for m, r in per_step if not r)
+    out["refresh"] = {"every": cfg.step_update, "refresh_step_ms": ref_ms, "ordinary_step_ms_median_synced": ord_ms[len(ord_ms) // 2],
+                      "refreshes_since_start": rs1["refreshes"], "unchanged_grid_kept_plan": rs1["skipped"],
+                      "in_the_last_32_steps": {k: rs1[k] - rs0[k] for k in rs1}}
     if world == 1:
         out["extras"] = trained_model_entries(tr, dev)
     if world > 1:

@@ -611,6 +611,10 @@ class CNC_context_models(nn.Module):
         self.dimension_wise_resolution = dimension_wise_resolution
         self.init_binary_vxl_coords(scale=dimension_wise_resolution - 2)
         self.step_update = step_update
+        # a refresh whose occupancy grid equals the one the structures were built from keeps them (forward_..._3D2D)
+        self.skip_unchanged_refresh = os.environ.get("CNC_SKIP_UNCHANGED_REFRESH", "1") == "1"
+        self.refresh_stats = {"refreshes": 0, "skipped": 0}
+        self._occ_built_from = None
         self.idx_coords2_tmp = None
         self.vote_plan = None
         self.batched_inputs_list = None
@@ -1000,6 +1004,20 @@ class CNC_context_models(nn.Module):
         axes = ("xy", "xz", "yz")
 
         refresh = step % self.step_update == 0
+        if refresh and binary_vxl is not None:
+            # Everything a refresh rebuilds (vote plan: three radix sorts and five gathers over ~2e7 vertices; the planes'
+            # vertex lists and slot orders) is a function of the occupancy grid alone.  The estimator re-thresholds its
+            # EMA every `step_update` steps, but once surfaces have formed most refreshes change no cell at all: compare
+            # with the grid the structures were built from (2 MB, one small kernel + the sync a refresh pays anyway) and
+            # keep them when nothing flipped.
+            last = getattr(self, "_occ_built_from", None)
+            self.refresh_stats["refreshes"] += 1
+            if (self.skip_unchanged_refresh and last is not None and last.shape == binary_vxl.shape
+                    and last.device == binary_vxl.device and bool(torch.equal(last, binary_vxl))):
+                refresh = False
+                self.refresh_stats["skipped"] += 1
+            else:
+                self._occ_built_from = binary_vxl.clone()
         if refresh and self.use_dimension_wise:
             occ = binary_vxl.squeeze(0)
             R_fine = self.dimension_wise_resolution

@@ -47,6 +47,7 @@ def build_parser():
     ap.add_argument("--max_steps", type=int, default=20000)
     ap.add_argument("--test_views", type=int, default=None, help="evaluate this many test images (default: all)")
     ap.add_argument("--image_size", type=int, default=200, help="procedural scene only")
+    ap.add_argument("--seed", type=int, default=42, help="set_random_seed value (the reference drivers fix 42, train:135)")
     ap.add_argument("--results", type=str, default=None, help="results file (default ./results/<dataset>/output.txt)")
     ap.add_argument("--out_dir", type=str, default=None, help="bitstream directory (default ./bitstreams/<scene>)")
     return ap
@@ -61,7 +62,7 @@ def make_config_and_data(args, device, rank=0, world=1):
     kw = dict(scene=scene, lmbda=args.lmbda, Pg_level=args.Pg_level, Pg_level_2D=args.Pg_level_2D,
               log2_hashmap_size=args.log2_hashmap_size, log2_hashmap_size_2D=args.log2_hashmap_size_2D,
               sample_num=args.sample_num, max_context_layer_num=args.max_context_layer_num,
-              n_features=args.n_features, max_steps=args.max_steps, image_size=args.image_size,
+              n_features=args.n_features, max_steps=args.max_steps, image_size=args.image_size, seed=args.seed,
               out_dir=args.out_dir or f"./bitstreams/{scene}",
               weight_decay=2e-5 if scene == "drums" else 2e-6)           # train:170-172
     if args.max_steps != 20000:      # the milestones of a shortened run keep their relative positions

@@ -445,3 +445,33 @@ def test_configs2_training_pass_forward_backward(cuda):
     ctx_grads = [p.grad for p in m.parameters() if p.grad is not None]
     assert ctx_grads and all(torch.isfinite(g).all() for g in ctx_grads)
     assert any(float(g.abs().max()) > 0 for g in ctx_grads)
+
+
+def test_a_refresh_with_an_unchanged_occupancy_keeps_the_plan(setup):
+    """Everything a refresh rebuilds is a function of the occupancy grid: when the estimator hands over a NEW tensor with the
+    SAME cells at a refresh step, the structures are kept (and the pass returns what a full rebuild returns); a flipped
+    cell rebuilds them."""
+    g, m, encs, binary = setup
+
+    def run(step, occ, skip):
+        m.skip_unchanged_refresh = skip
+        torch.manual_seed(5)
+        bpp, _ = m.forward_binary_vxl_mixPg_3D2D(encs["xyz"], encs["xy"], encs["xz"], encs["yz"], occ, step=step)
+        return float(bpp)
+
+    base = run(0, binary, True)                                   # builds
+    before = dict(m.refresh_stats)
+    same = run(16, binary.clone(), True)                          # a fresh tensor, equal cells: kept
+    assert m.refresh_stats["skipped"] == before["skipped"] + 1 and m.refresh_stats["refreshes"] == before["refreshes"] + 1
+    plan = m.vote_plan
+    rebuilt = run(32, binary.clone(), False)                      # forced rebuild
+    assert m.vote_plan is not plan
+    assert same == rebuilt == base
+    flipped = binary.clone()
+    idx = torch.nonzero(flipped.reshape(-1) == 0)[:3, 0]
+    flipped.view(-1)[idx] = 1
+    plan = m.vote_plan
+    run(48, flipped, True)
+    assert m.vote_plan is not plan and m.refresh_stats["skipped"] == before["skipped"] + 1
+    m.skip_unchanged_refresh = True
+    run(0, binary, True)                                          # leave the module fixture as the other tests expect it
