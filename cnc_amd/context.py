@@ -614,7 +614,7 @@ class CNC_context_models(nn.Module):
         # a refresh whose occupancy grid equals the one the structures were built from keeps them (forward_..._3D2D)
         self.skip_unchanged_refresh = os.environ.get("CNC_SKIP_UNCHANGED_REFRESH", "1") == "1"
         self.refresh_stats = {"refreshes": 0, "skipped": 0}
-        self._occ_built_from = None
+        self._occ_built_from, self._occ_built_how = None, None
         self.idx_coords2_tmp = None
         self.vote_plan = None
         self.batched_inputs_list = None
@@ -1011,13 +1011,16 @@ class CNC_context_models(nn.Module):
             # with the grid the structures were built from (2 MB, one small kernel + the sync a refresh pays anyway) and
             # keep them when nothing flipped.
             last = getattr(self, "_occ_built_from", None)
+            how = (self.planned_votes, self.fused_segments, self.use_dimension_wise, self.fused_heads,
+                   self.plane_batched)                                                              # what gets built
             self.refresh_stats["refreshes"] += 1
-            if (self.skip_unchanged_refresh and last is not None and last.shape == binary_vxl.shape
-                    and last.device == binary_vxl.device and bool(torch.equal(last, binary_vxl))):
+            if (self.skip_unchanged_refresh and last is not None and how == self._occ_built_how
+                    and last.shape == binary_vxl.shape and last.device == binary_vxl.device
+                    and bool(torch.equal(last, binary_vxl))):
                 refresh = False
                 self.refresh_stats["skipped"] += 1
             else:
-                self._occ_built_from = binary_vxl.clone()
+                self._occ_built_from, self._occ_built_how = binary_vxl.clone(), how
         if refresh and self.use_dimension_wise:
             occ = binary_vxl.squeeze(0)
             R_fine = self.dimension_wise_resolution

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
 #else
                 if (kind == 0) fill_units<F, 3, RowT, 8>(p, units, xu, w0, trow);
                 else if (kind == 1) fill_units<F, 2, RowT, 8>(p, units, xu, w0, trow);
-                else if (kind == 2) fill_tail<RowT, 8>(p, xu, w0, p.n_units * F, trow);
+                else if (kind == 2) fill_tail_window<RowT, 8>(p, xu, w0, p.n_units * F, trow);
                 else fill_window<F, false, RowT, 8>(p, xu, w0, trow);
 #endif
             }

@@ -485,6 +485,39 @@ __device__ __forceinline__ void fill_tail(const FusedFieldArgs& p, const float (
     }
 }
 
+// A whole window of WC columns behind the units (w0 >= U: raw coordinates, sinusoids, padding) as straight-line code:
+// one column = one argument reduction, no loops, no per-column branches (the general `fill_tail` walks the columns and
+// the sin / cos pairs in two data-dependent loops: ~2.5x the instructions for the two sinusoid chunks of a tile).
+// Same values: fast_sincos / sincosf of the same float32 argument x_a * freq_k, the raw coordinate through clamp_raw.
+template <typename Row, uint32_t WC>
+__device__ __forceinline__ void fill_tail_window(const FusedFieldArgs& p, const float (&xu)[3], uint32_t w0, uint32_t U,
+                                                 const Row& trow)
+{
+    const uint32_t n_sin = 3 + 6 * p.n_freqs, e0 = w0 - U;
+    float v[WC];
+#pragma unroll
+    for (uint32_t j = 0; j < WC; j++) {
+        const uint32_t e = e0 + j, t = e - 3u;                    // t wraps for the raw columns: masked below
+        const uint32_t k = t / 6u, r = t - 6u * k, a = r >= 3u ? r - 3u : r;
+        const bool     is_sin = e >= 3u && e < n_sin;
+        const float    xa = a == 0 ? xu[0] : (a == 1 ? xu[1] : xu[2]);
+        const float    fr = p.freqs[is_sin ? k : 0u];
+        float sn, cs;
+        if constexpr (Row::kFastSin) fast_sincos(xa * fr, &sn, &cs);
+        else sincosf(xa * fr, &sn, &cs);
+        const float raw = Row::clamp_raw(e == 0 ? xu[0] : (e == 1 ? xu[1] : xu[2]));
+        v[j] = is_sin ? (r < 3u ? sn : cs) : (e < 3u ? raw : 0.0f);
+    }
+    constexpr uint32_t V = 4;
+#pragma unroll
+    for (uint32_t j = 0; j < WC; j += V) {
+        float q[V];
+#pragma unroll
+        for (uint32_t i = 0; i < V; i++) q[i] = v[j + i];
+        trow.template put<V>((w0 & 31u) + j, q);
+    }
+}
+
 // The units of a window that holds only D-dimensional units (the caller knows: a wave-uniform fact, so the other
 // dimension's code is not even issued).
 template <uint32_t F, uint32_t D>
