@@ -654,7 +654,10 @@ extern "C" int cnc_field_fused_forward(const cnc_fused_field_t* f, const float* 
             if (per_cu > 8) per_cu = 8;                                                                       \
             slot = Slot{dev, (uint32_t)(per_cu * cus)};                                                       \
         }                                                                                                     \
-        const uint32_t blocks = tiles < slot.n ? tiles : slot.n;                                              \
+        uint32_t blocks = tiles < slot.n ? tiles : slot.n;                                                    \
+        /* the guard's conditional launch returns at once in all but pathological calls: a quarter of the     \
+           resident grid keeps the empty launch short (its waves loop over the tiles when it does run) */     \
+        if (p.only_if_flagged && blocks > slot.n / 4) blocks = slot.n / 4;                                    \
         hipLaunchKernelGGL(K, dim3(blocks), dim3(64), LDS, s, p);                                             \
     } while (0)
 #define CNC_FF(FV, NTV)                                                                                 \
