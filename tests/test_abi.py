@@ -77,3 +77,35 @@ def test_mirrors_refuse_cpu_tensors():
                          torch.zeros(4, dtype=torch.int16), torch.zeros(4, dtype=torch.int32), 18, 4)
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         nc.exclusive_sum(torch.zeros(1, dtype=torch.long), torch.ones(1, dtype=torch.long), torch.ones(1), False, False)
+
+
+def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
+    """The structs that cross the C ABI by pointer (cnc_fused_field_t, cnc_field_pack_t): the ctypes mirrors in
+    cnc_amd/_lib.py must have the size and the member offsets a C compiler gives the header's declarations — a member
+    added on one side only would shift everything behind it silently."""
+    import subprocess
+    from cnc_amd import _lib
+    members = {
+        "cnc_fused_field_t": (_lib.FusedField, [f[0] for f in _lib.FusedField._fields_]),
+        "cnc_field_pack_layer_t": (_lib.FieldPackLayer, [f[0] for f in _lib.FieldPackLayer._fields_]),
+        "cnc_field_pack_t": (_lib.FieldPack, [f[0] for f in _lib.FieldPack._fields_]),
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include <stdint.h>', '#include "cnc_hip.h"', 'int main(void) {']
+    for t, (_, names) in members.items():
+        lines.append(f'  printf("{t} size %zu\\n", sizeof({t}));')
+        for n in names:
+            lines.append(f'  printf("{t} {n} %zu\\n", offsetof({t}, {n}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        t, name, value = line.split()
+        cls = members[t][0]
+        want = ctypes.sizeof(cls) if name == "size" else getattr(cls, name).offset
+        assert int(value) == want, (t, name, int(value), want)
+        seen += 1
+    assert seen == sum(len(n) + 1 for _, n in members.values())
