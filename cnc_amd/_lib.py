@@ -42,7 +42,7 @@ class FieldPackLayer(C.Structure):
     """cnc_field_pack_layer_t (include/cnc_hip.h)."""
     _fields_ = [("W", _vp), ("b", _vp), ("H", _u32), ("K", _u32), ("ldw", _u32), ("n_tiles", _u32), ("n_ksteps", _u32),
                 ("n_ksteps16", _u32), ("n_colblocks", _u32), ("n_ksteps32", _u32), ("Wp", _vp), ("Bp", _vp),
-                ("Wp16", _vp), ("Wq16", _vp)]
+                ("Wp16", _vp), ("Wq16", _vp), ("k_gap", _u32)]
 
 
 class FieldPack(C.Structure):

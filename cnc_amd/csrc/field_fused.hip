@@ -607,7 +607,7 @@ extern "C" int cnc_field_fused_forward(const cnc_fused_field_t* f, const float* 
     const bool f16x3 = two_waves || (f->flags & CNC_FIELD_MFMA_F16X3) != 0;
     p.nk16_1 = p.nkb1 / 2;
     p.nk16_h = (16 + p.geo + 15) / 16;
-    p.nk32_h = (16 + p.geo + 31) / 32;
+    p.nk32_h = (17 + p.geo + 31) / 32;              // two-wave kernels: [SH4 | raw density | geo]
     if (f16x3) {
         if (p.nk16_h * 16 > H || p.nk32_h * 32 > H) return CNC_ERR_UNSUPPORTED;
         // the range guard is part of the fp16 form: without it a value above 65504 would come out as inf / NaN

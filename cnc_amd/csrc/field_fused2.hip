@@ -68,6 +68,12 @@ __device__ __forceinline__ void load_wq(wrsrc_t W, uint32_t ks, uint32_t ncbt, u
     }
 }
 
+// The products run TRANSPOSED: the weight fragment is the MFMA's A operand (rows = output features), the activation fragment
+// its B operand (columns = samples) — the fragments themselves are what they were — so that in the result lane (r, kq)
+// holds, for sample r of the row block, the FOUR CONSECUTIVE output features 4 kq .. 4 kq + 3 of the column block.  They are
+// four consecutive K of the next layer's row: bias, ReLU, split and ONE 8-byte LDS write per half plane instead of four
+// 2-byte writes per plane and value (the colour kernel's write-backs were ~1000 LDS instructions per tile), and one bias /
+// w2 vector load per column block instead of a scalar per lane.
 template <int NRB, int NCB>
 __device__ __forceinline__ void mfma3q(const half8_t (&ah)[NRB], const half8_t (&al)[NRB], const half8_t (&wh)[NCB],
                                        const half8_t (&wl)[NCB], f32x4 (&acc)[NRB][NCB])
@@ -76,16 +82,17 @@ __device__ __forceinline__ void mfma3q(const half8_t (&ah)[NRB], const half8_t (
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
-        for (int rb = 0; rb < NRB; rb++) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rb], wh[cb], acc[rb][cb], 0, 0, 0);
+        for (int rb = 0; rb < NRB; rb++) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cb], al[rb], acc[rb][cb], 0, 0, 0);
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
-        for (int rb = 0; rb < NRB; rb++) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rb], wl[cb], acc[rb][cb], 0, 0, 0);
+        for (int rb = 0; rb < NRB; rb++) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[cb], ah[rb], acc[rb][cb], 0, 0, 0);
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
-        for (int rb = 0; rb < NRB; rb++) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rb], wh[cb], acc[rb][cb], 0, 0, 0);
+        for (int rb = 0; rb < NRB; rb++) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cb], ah[rb], acc[rb][cb], 0, 0, 0);
 }
+
 
 constexpr uint32_t kMaxUnits = 64;        // rows of the unit table kept in LDS (the host refuses more)
 
@@ -169,8 +176,8 @@ __device__ __forceinline__ void layer_q(const half_t* __restrict__ a_hi, const h
     }
 }
 
-// x = acc / 2^8 + bias (ReLU) of a column-split layer -> the two half planes.  C layout of the 16x16 tile: lane (r, kq)
-// holds rows 4 kq + v, column r; (row >> 2) & 3 = kq for every element of the lane.
+// x = acc / 2^8 + bias (ReLU) of a column-split layer -> the two half planes.  Lane (r, kq) holds sample rb * 16 + r,
+// output features 16 (cb0 + cb) + 4 kq + v: four halves = 8 bytes inside one 16-byte chunk of the (swizzled) row.
 template <int NCB, int NT>
 __device__ __forceinline__ void acc_to_planes(half_t* __restrict__ d_hi, half_t* __restrict__ d_lo,
                                               const float* __restrict__ bias, const f32x4 (&acc)[2][NCB], uint32_t cb0,
@@ -180,21 +187,25 @@ __device__ __forceinline__ void acc_to_planes(half_t* __restrict__ d_hi, half_t*
     const uint32_t r = lane & 15u, kq = lane >> 4;
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) {
-        const uint32_t col = (cb0 + cb) * 16u + r;
-        const float    b = bias[col];
-        const uint32_t at = 4u * kq * P::ld + P::col_at(col, kq);
+        const uint32_t col0 = (cb0 + cb) * 16u + 4u * kq;
+        const float4   b4 = *reinterpret_cast<const float4*>(bias + col0);
+        const float    bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
+            half4_t xh, xl;
 #pragma unroll
             for (int v = 0; v < 4; v++) {
-                float x = __builtin_fmaf(acc[rb][cb][v], kWScaleInv, b);
+                float x = __builtin_fmaf(acc[rb][cb][v], kWScaleInv, bb[v]);
                 x = x > 0 ? x : 0;
                 mx = fmaxf(mx, x);
-                half_t xh, xl;
-                split_half(x, xh, xl);
-                d_hi[at + (rb * 16 + v) * P::ld] = xh;
-                d_lo[at + (rb * 16 + v) * P::ld] = xl;
+                half_t h, l;
+                split_half(x, h, l);
+                xh[v] = h;
+                xl[v] = l;
             }
+            const uint32_t at = P::at(rb * 16u + r, col0);
+            *reinterpret_cast<half4_t*>(d_hi + at) = xh;
+            *reinterpret_cast<half4_t*>(d_lo + at) = xl;
         }
     }
 }
@@ -330,42 +341,33 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
         }
 
         if constexpr (!RGB) {
-            // density_raw = b2[0] + sum_j relu(h1[j]) W2[0][j]: per lane the partial sums of its columns for its 8 rows,
-            // through LDS, summed per sample
-            float part[2][4];
-#pragma unroll
-            for (int rb = 0; rb < 2; rb++)
-#pragma unroll
-                for (int v = 0; v < 4; v++) part[rb][v] = 0.0f;
+            // density_raw = b2[0] + sum_j relu(h1[j]) W2[0][j]: lane (r, kq) holds features 4 kq + v of its column blocks for
+            // samples r and 16 + r: two partial sums per lane, eight lanes-and-waves per sample through LDS
+            float part[2] = {0.0f, 0.0f};
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) {
-                const uint32_t col = (w * NCB + cb) * 16u + r;
-                const float    b = p.Bp[0][col], w2 = p.w2row[col];
+                const uint32_t col0 = (w * NCB + cb) * 16u + 4u * kq;
+                const float4   b4 = *reinterpret_cast<const float4*>(p.Bp[0] + col0);
+                const float4   w4 = *reinterpret_cast<const float4*>(p.w2row + col0);
+                const float    bb[4] = {b4.x, b4.y, b4.z, b4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
                 for (int rb = 0; rb < 2; rb++)
 #pragma unroll
                     for (int v = 0; v < 4; v++) {
-                        float x = __builtin_fmaf(acc[rb][cb][v], kWScaleInv, b);
+                        float x = __builtin_fmaf(acc[rb][cb][v], kWScaleInv, bb[v]);
                         x = x > 0 ? x : 0;
-                        part[rb][v] = __builtin_fmaf(x, w2, part[rb][v]);
+                        part[rb] = __builtin_fmaf(x, ww[v], part[rb]);
                     }
             }
             __syncthreads();                                   // the last chunk has been read by both waves
-            constexpr uint32_t kPP = 20;                       // floats per (wave, row): 16 partial sums + padding
+            // [sample][wave * 4 + kq]: 8 partial sums per sample, 32-byte rows
 #pragma unroll
-            for (int rb = 0; rb < 2; rb++)
-#pragma unroll
-                for (int v = 0; v < 4; v++) lds[(w * 32 + rb * 16 + 4 * kq + v) * kPP + r] = part[rb][v];
+            for (int rb = 0; rb < 2; rb++) lds[(rb * 16 + r) * 8 + w * 4 + kq] = part[rb];
             __syncthreads();
             if (tid < 32) {
-                float s = 0.0f;
-#pragma unroll
-                for (int ww = 0; ww < 2; ww++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float4 v4 = *reinterpret_cast<const float4*>(lds + (ww * 32 + tid) * kPP + 4 * q);
-                        s += v4.x; s += v4.y; s += v4.z; s += v4.w;
-                    }
+                const float4 a4 = *reinterpret_cast<const float4*>(lds + tid * 8), c4 = *reinterpret_cast<const float4*>(lds + tid * 8 + 4);
+                float s = a4.x;
+                s += a4.y; s += a4.z; s += a4.w; s += c4.x; s += c4.y; s += c4.z; s += c4.w;
                 if (live) p.density[frow] = sel ? expf((s + p.Bp[1][0]) - 1.0f) : 0.0f;
             }
             __syncthreads();                                   // before the next tile's fill overwrites the sums
@@ -378,32 +380,36 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
             // ---- layer 2 (H -> 1 + geo), split by rows: wave w owns rows [16 w, 16 w + 16) ----
             f32x4 acc2[1][NB2];
             layer_q<1, NB2, NT, kDB>(h_hi, h_lo, NT, p.Wq16[1], NB2, 0, w, acc2, lane);
-            const uint32_t Kh = p.nk32_h * 32;                 // head input width: roundup32(16 + geo) <= H
+            const uint32_t Kh = p.nk32_h * 32;                 // head input width: roundup32(17 + geo) <= H
             __syncthreads();                                   // every read of h1 has been issued and waited for
             W2_MARK(5);
-            // output column 0 = density_raw -> a float per sample; columns 1..geo -> head-input columns 16 + (c - 1)
+            // Lane (r, kq) holds outputs c = 16 cb + 4 kq + v of sample 16 w + r.  Head-input layout: [SH4 (16) | column 16 + c
+            // for output c]: the geo features (c >= 1) land 4-aligned — one 8-byte write per half plane — and column 16
+            // receives density_raw (c = 0), against which the packed head weights hold a zero column (cnc_field_pack_t:
+            // k_gap = 16).  Outputs past 1 + geo are exact zeros (zero weight rows, zero bias): the padding up to Kh.
 #pragma unroll
             for (int cb = 0; cb < NB2; cb++) {
-                const uint32_t col = cb * 16u + r;
-                if (cb * 16u > p.geo) continue;
-                const float    b = p.Bp[1][col];
-                const uint32_t hc = 15u + col;
-                const uint32_t at = (w * 16u + 4u * kq) * P::ld + P::col_at(hc, kq);
+                const uint32_t c0 = cb * 16u + 4u * kq;
+                if (16u + c0 >= Kh) continue;
+                const float4 b4 = *reinterpret_cast<const float4*>(p.Bp[1] + c0);
+                const float  bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                half4_t xh, xl;
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
-                    const float x = __builtin_fmaf(acc2[0][cb][v], kWScaleInv, b);
-                    if (col == 0) {
-                        dens[w * 16 + 4 * kq + v] = x;
-                    } else if (col <= p.geo) {
-                        mx = fmaxf(mx, fabsf(x));
-                        half_t xh, xl;
-                        split_half(x, xh, xl);
-                        h_hi[at + v * P::ld] = xh;
-                        h_lo[at + v * P::ld] = xl;
-                    }
+                    const float x = __builtin_fmaf(acc2[0][cb][v], kWScaleInv, bb[v]);
+                    if (cb == 0 && v == 0 && kq == 0) dens[w * 16 + r] = x;
+                    mx = fmaxf(mx, (c0 + v >= 1u && c0 + v <= p.geo) ? fabsf(x) : 0.0f);
+                    // density_raw may be anything finite or not: what goes into its (zero-weight) column is 0
+                    half_t h, l;
+                    split_half((c0 + v == 0u) ? 0.0f : x, h, l);
+                    xh[v] = h;
+                    xl[v] = l;
                 }
+                const uint32_t at = P::at(w * 16u + r, 16u + c0);
+                *reinterpret_cast<half4_t*>(h_hi + at) = xh;
+                *reinterpret_cast<half4_t*>(h_lo + at) = xl;
             }
-            {   // SH4 of sample fi's direction: thread (fi, fq) writes harmonics 4 fq .. 4 fq + 3; zero padding
+            {   // SH4 of sample fi's direction: thread (fi, fq) writes harmonics 4 fq .. 4 fq + 3
                 // (requesting the direction before layer 2, to take its round trip out of this phase, was built: the compiler
                 // waits for it on the spot, nothing gained — and that build returned wrong colours for rows 16..31 of about
                 // one tile per call, cause not found; tests/test_gpu_field_fused.py::test_fused_field_is_repeatable is the
@@ -421,7 +427,6 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                 }
                 const RowF16 hrow{h_hi, h_lo};
                 hrow.put<4>(P::at(fi, 4 * fq), v4);                  // 4 halves inside one 16-byte chunk
-                for (uint32_t c = 16 + p.geo + fq; c < Kh; c += 4) hrow.put1(P::at(fi, c), 0.0f);
             }
             __syncthreads();
             W2_MARK(6);
@@ -441,13 +446,14 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
             W2_MARK(10);
             f32x4 acc5[1][1];
             layer_q<1, 1, NT, kDB>(h_hi, h_lo, NT, p.Wq16[4], 1, 0, w, acc5, lane);
-            if (r < 3) {
-                const float b = p.Bp[4][r];
+            if (kq == 0) {                                     // outputs 0..2 of sample 16 w + r: 12 contiguous bytes per lane
+                const uint32_t row = row0 + w * 16 + r;
+                if (row < p.N) {
 #pragma unroll
-                for (int v = 0; v < 4; v++) {
-                    const uint32_t row = row0 + w * 16 + 4 * kq + v;
-                    const float    x = __builtin_fmaf(acc5[0][0][v], kWScaleInv, b);
-                    if (row < p.N) p.rgb[(size_t)row * 3 + r] = 1.0f / (1.0f + expf(-x));
+                    for (int v = 0; v < 3; v++) {
+                        const float x = __builtin_fmaf(acc5[0][0][v], kWScaleInv, p.Bp[4][v]);
+                        p.rgb[(size_t)row * 3 + v] = 1.0f / (1.0f + expf(-x));
+                    }
                 }
             }
             __syncthreads();                                   // the next tile's fill overwrites the planes
@@ -470,12 +476,15 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
 // stamps `flag` with the pack's id (the range guard).
 __device__ __forceinline__ void pack16x32_element(const float* __restrict__ W, uint32_t H, uint32_t K, uint32_t ldw,
                                                   uint32_t ncb, uint32_t idx, half_t* __restrict__ Wq, uint32_t* flag,
-                                                  uint32_t pack_id)
+                                                  uint32_t pack_id, uint32_t k_gap)
 {
     const uint32_t e = idx & 7u, lane = (idx >> 3) & 63u, q = idx >> 9;
     const uint32_t cb = q % ncb, ks = q / ncb;
-    const uint32_t out = cb * 16 + (lane & 15u), k = ks * 32 + 8 * (lane >> 4) + e;
-    const float    wv = (out < H && k < K) ? W[(size_t)out * ldw + k] * 256.0f : 0.0f;
+    const uint32_t out = cb * 16 + (lane & 15u), kp = ks * 32 + 8 * (lane >> 4) + e;
+    // k_gap > 0: packed column k_gap is a zero column, the source columns from k_gap on sit one to the right
+    const bool     gap = k_gap != 0u && kp == k_gap;
+    const uint32_t k = (k_gap != 0u && kp > k_gap) ? kp - 1u : kp;
+    const float    wv = (out < H && k < K && !gap) ? W[(size_t)out * ldw + k] * 256.0f : 0.0f;
     if (flag && !(fabsf(wv) <= kHalfMax)) atomicMax(flag, pack_id);
     half_t hi, lo;
     split_half(wv, hi, lo);
@@ -488,7 +497,7 @@ struct PackAllArgs {
     const float* b[5];
     uint32_t     H[5], K[5], ldw[5];
     uint32_t     nt32[5], nk8[5], nk16[5];      // fp32 fragments (and biases), 32x32x16 half fragments
-    uint32_t     ncb[5], nk32[5];               // 16x16x32 half fragments
+    uint32_t     ncb[5], nk32[5], k_gap[5];     // 16x16x32 half fragments
     float*       Wp[5];
     float*       Bp[5];
     half_t*      Wp16[5];                       // nullable
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(256) void k_field_pack_all(PackAllArgs a)
     }
     if (a.Wq16[l]) {
         const uint32_t total = a.nk32[l] * a.ncb[l] * 512;
-        if (idx < total) pack16x32_element(W, H, K, ldw, a.ncb[l], idx, a.Wq16[l], flag, a.pack_id);
+        if (idx < total) pack16x32_element(W, H, K, ldw, a.ncb[l], idx, a.Wq16[l], flag, a.pack_id, a.k_gap[l]);
     }
 }
 
@@ -634,11 +643,12 @@ extern "C" int cnc_field_pack_all(const cnc_field_pack_t* d, void* stream)
             return CNC_ERR_INVALID_VALUE;
         if (L.H > L.n_tiles * 32 || L.K > L.n_ksteps * 8) return CNC_ERR_INVALID_VALUE;
         if (L.Wp16 && (L.n_ksteps16 == 0 || L.K > L.n_ksteps16 * 16)) return CNC_ERR_INVALID_VALUE;
-        if (L.Wq16 && (L.n_colblocks == 0 || L.n_ksteps32 == 0 || L.H > L.n_colblocks * 16 || L.K > L.n_ksteps32 * 32))
+        if (L.Wq16 && (L.n_colblocks == 0 || L.n_ksteps32 == 0 || L.H > L.n_colblocks * 16 ||
+                       L.K + (L.k_gap ? 1u : 0u) > L.n_ksteps32 * 32 || L.k_gap >= L.K))
             return CNC_ERR_INVALID_VALUE;
         a.W[l] = L.W; a.b[l] = L.b; a.H[l] = L.H; a.K[l] = L.K; a.ldw[l] = L.ldw;
         a.nt32[l] = L.n_tiles; a.nk8[l] = L.n_ksteps; a.nk16[l] = L.n_ksteps16;
-        a.ncb[l] = L.n_colblocks; a.nk32[l] = L.n_ksteps32;
+        a.ncb[l] = L.n_colblocks; a.nk32[l] = L.n_ksteps32; a.k_gap[l] = L.k_gap;
         a.Wp[l] = L.Wp; a.Bp[l] = L.Bp;
         a.Wp16[l] = reinterpret_cast<half_t*>(L.Wp16);
         a.Wq16[l] = reinterpret_cast<half_t*>(L.Wq16);

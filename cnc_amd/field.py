@@ -344,7 +344,7 @@ class FusedFieldForward:
                 and all(e.ste_binary and e.fused_ste and e.bitplane and e.n_features == F_ for e in encs)
                 and encs[0].num_dim == 3 and all(e.num_dim == 2 for e in encs[1:])
                 and len({e.n_levels for e in encs[1:]}) == 1
-                and F_ in (2, 4, 8) and H in (64, 160) and 1 + geo <= 32 * nt2 and (16 + geo + 7) // 8 * 8 <= H
+                and F_ in (2, 4, 8) and H in (64, 160) and 1 + geo <= 32 * nt2 and (17 + geo + 31) // 32 * 32 <= H
                 and len(mb.network) == 3 and len(field.mlp_head) == 5
                 and all(l.out_features == H for l in (field.mlp_head[0], field.mlp_head[2]))
                 # the kernel derives the first layer's K from the unit table and the frequency count
@@ -378,7 +378,7 @@ class FusedFieldForward:
         #             16-column blocks, K-steps of 32 [16x16x32 halves: the two-wave kernels])
         shapes = [(T, r32(K0) * 4, r32(K0) * 2, H // 16, r32(K0)),
                   (T2, H // 8, H // 16, 5 if H == 160 else 4, H // 32),
-                  (T, (16 + geo + 7) // 8, (16 + geo + 15) // 16, H // 16, r32(16 + geo)),
+                  (T, (16 + geo + 7) // 8, (16 + geo + 15) // 16, H // 16, r32(17 + geo)),     # Wq16: a zero column at k = 16
                   (T, H // 8, H // 16, H // 16, H // 32),
                   (1, H // 8, H // 16, 1, H // 32)]
         if self._buffers is None or self._buffers["dev"] != str(dev):
@@ -405,6 +405,7 @@ class FusedFieldForward:
             L.n_tiles, L.n_ksteps, L.n_ksteps16, L.n_colblocks, L.n_ksteps32 = nt, nk, nk16, ncb, nk32
             L.Wp, L.Bp = buf["w"][k].data_ptr(), buf["b"][k].data_ptr()
             L.Wp16, L.Wq16 = buf["w16"][k].data_ptr(), buf["wq16"][k].data_ptr()
+            L.k_gap = 16 if k == 2 else 0          # head.0: [SH4 | raw density (zero weights) | geo], field_fused2.hip
         d.row0, d.row0_len = buf["row0"].data_ptr(), H
         d.guard, d.pack_id = buf["guard"].data_ptr(), self._pack_id
         import ctypes

@@ -725,7 +725,8 @@ int cnc_field_pack_layer16(const float* W, uint32_t H, uint32_t K, uint32_t ldw,
  * Wp16 (nullable) as cnc_field_pack_layer16 (n_ksteps16); Wq16 (nullable): n_ksteps32 * n_colblocks * 1024 halves — per
  * (K-step of 32, column block of 16): 64 x 8 halves hi, then lo, of 2^8 W[16 cb + (lane & 15)][32 ks + 8 (lane >> 4)
  * + 0..7].  Column blocks for CNC_FIELD_TWO_WAVES: base.0 / head.0 / head.2: H / 16; base.2: 5 (H = 160) or 4 (H = 64);
- * head.4: 1.  K-steps of 32: roundup32(K) / 32.  row0 / row0_len: base.2's row 0 as in cnc_field_pack_layer.
+ * head.4: 1.  K-steps of 32: roundup32(K) / 32 (head.0: roundup32(K + 1) / 32 with k_gap = 16).  row0 / row0_len: base.2's row 0 as
+ * in cnc_field_pack_layer.
  * guard / pack_id: a layer holding a weight with |2^8 w| > 65504 gets guard[1 + layer] = pack_id (see the guard). */
 typedef struct {
     const float* W;
@@ -736,6 +737,9 @@ typedef struct {
     float*       Bp;
     void*        Wp16;
     void*        Wq16;
+    uint32_t     k_gap;     /* Wq16 only: != 0 inserts a zero column at packed k = k_gap (the source columns from k_gap on
+                               move one to the right).  head.0 takes 16: the two-wave kernel lays the head's input out as
+                               [SH4 (16) | base output c at column 16 + c], and output 0 is the raw density            */
 } cnc_field_pack_layer_t;
 typedef struct {
     cnc_field_pack_layer_t layer[5];
