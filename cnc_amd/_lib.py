@@ -38,11 +38,19 @@ class FusedField(C.Structure):
                 ("debug_features", _vp), ("debug_ld", _u32)]
 
 
+class FieldBwd(C.Structure):
+    """cnc_field_bwd_t (include/cnc_hip.h)."""
+    _fields_ = [("N", _u32), ("n_neurons", _u32), ("n_features", _u32), ("n_enc_columns", _u32), ("geo_feat_dim", _u32),
+                ("ld_base", _u32), ("ld_g2", _u32), ("ld_x", _u32), ("grad_rgb", _vp), ("grad_density", _vp), ("rgb", _vp),
+                ("base_out", _vp), ("selector", _vp), ("h1", _vp), ("h3", _vp), ("h4", _vp), ("packed_weights_t", _vp * 5),
+                ("G5", _vp), ("G4", _vp), ("G3", _vp), ("G2", _vp), ("G1", _vp), ("dX", _vp)]
+
+
 class FieldPackLayer(C.Structure):
     """cnc_field_pack_layer_t (include/cnc_hip.h)."""
     _fields_ = [("W", _vp), ("b", _vp), ("H", _u32), ("K", _u32), ("ldw", _u32), ("n_tiles", _u32), ("n_ksteps", _u32),
                 ("n_ksteps16", _u32), ("n_colblocks", _u32), ("n_ksteps32", _u32), ("Wp", _vp), ("Bp", _vp),
-                ("Wp16", _vp), ("Wq16", _vp), ("k_gap", _u32)]
+                ("Wp16", _vp), ("Wq16", _vp), ("k_gap", _u32), ("flags", _u32), ("src_off", _u32)]
 
 
 class FieldPack(C.Structure):
@@ -116,6 +124,7 @@ SIGNATURES = {
     "cnc_field_pack_layer": [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _u32, _vp],
     "cnc_field_pack_layer16": [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp],
     "cnc_field_pack_all": [C.POINTER(FieldPack), _vp],
+    "cnc_field_backward_chain": [C.POINTER(FieldBwd), _vp],
     "cnc_field_fused_forward": [C.POINTER(FusedField), _vp, _vp, _u32, _vp, _vp, _vp],
     "cnc_ste_binary_forward": [_vp, _vp, C.c_uint64, _vp],
     "cnc_ste_binary_backward": [_vp, _vp, _vp, C.c_uint64, _vp],
@@ -147,6 +156,8 @@ CNC_FIELD_SH_FP16 = 1
 CNC_FIELD_MFMA_F16X3 = 2
 CNC_FIELD_TWO_WAVES = 4
 CNC_FIELD_WAVES4 = 8
+CNC_PACK_TRANSPOSE = 1
+CNC_PACK_ZERO_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
 ABI_VERSION = 26          # cnc_abi_version() of the library this table was written for

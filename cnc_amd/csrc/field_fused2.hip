@@ -21,78 +21,11 @@
 // Values: the features are those of k_grid_encode_fwd_bits (bit-identical: same Corners / fmaf chain); the layers are
 // the three-product scheme of field_fused.hip with a different summation order (k in steps of 32 instead of 16).
 // The fp16 range guard (field_fused_common.hpp) covers every value that is split into halves here.
-#include "field_fused_common.hpp"
+#include "field_mma.hpp"
 
 #include <type_traits>
 
 namespace cnc {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr uint32_t kCP = 40;              // halves per row of a chunk plane (80 bytes: conflict-free b128 rows)
-constexpr float kWScaleInv = 1.0f / 256.0f;
-
-// Activation planes: 32 rows x H halves.  H = 160: unpadded, 16-byte chunks XOR-swizzled by (row >> 2) & 3 (rows are
-// 320 bytes apart: rows r and r + 4 would start on the same banks); H = 64: rows padded by 8 halves.
-template <int NT>
-struct Plane2 {
-    static constexpr uint32_t ld = NT == 5 ? 160u : NT * 32u + 8u;
-    static constexpr bool     swz = NT == 5;
-    static __device__ __forceinline__ uint32_t at(uint32_t r, uint32_t c)
-    {
-        if constexpr (swz) return r * ld + ((((c >> 3) ^ ((r >> 2) & 3u)) << 3) | (c & 7u));
-        else return r * ld + c;
-    }
-    // column part of `at` for a row whose (row >> 2) & 3 is `s`
-    static __device__ __forceinline__ uint32_t col_at(uint32_t c, uint32_t s)
-    {
-        if constexpr (swz) return (((c >> 3) ^ s) << 3) | (c & 7u);
-        else return c;
-    }
-};
-
-// Weight fragments of the 16x16x32 form (cnc_field_pack_all): per (K-step of 32, column
-// block of 16): 64 lanes x 8 halves hi, then lo, of 2^8 W[16 cb + (lane & 15)][32 ks + 8 (lane >> 4) + 0..7].
-// voff = 16 lane + 2048 (first column block of this wave).
-template <int NCB>
-__device__ __forceinline__ void load_wq(wrsrc_t W, uint32_t ks, uint32_t ncbt, uint32_t voff, half8_t (&hi)[NCB],
-                                        half8_t (&lo)[NCB])
-{
-    const int32_t soff = (int32_t)(ks * ncbt * 2048u);
-#pragma unroll
-    for (int cb = 0; cb < NCB; cb++) {
-        const f32x4_t a = llvm_raw_buffer_load_f32x4(W, (int32_t)(voff + cb * 2048), soff, 0);
-        const f32x4_t b = llvm_raw_buffer_load_f32x4(W, (int32_t)(voff + cb * 2048 + 1024), soff, 0);
-        hi[cb] = __builtin_bit_cast(half8_t, a);
-        lo[cb] = __builtin_bit_cast(half8_t, b);
-    }
-}
-
-// The products run TRANSPOSED: the weight fragment is the MFMA's A operand (rows = output features), the activation fragment
-// its B operand (columns = samples) — the fragments themselves are what they were — so that in the result lane (r, kq)
-// holds, for sample r of the row block, the FOUR CONSECUTIVE output features 4 kq .. 4 kq + 3 of the column block.  They are
-// four consecutive K of the next layer's row: bias, ReLU, split and ONE 8-byte LDS write per half plane instead of four
-// 2-byte writes per plane and value (the colour kernel's write-backs were ~1000 LDS instructions per tile), and one bias /
-// w2 vector load per column block instead of a scalar per lane.
-template <int NRB, int NCB>
-__device__ __forceinline__ void mfma3q(const half8_t (&ah)[NRB], const half8_t (&al)[NRB], const half8_t (&wh)[NCB],
-                                       const half8_t (&wl)[NCB], f32x4 (&acc)[NRB][NCB])
-{
-    // the two small products first; consecutive instructions go to different accumulators
-#pragma unroll
-    for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-        for (int rb = 0; rb < NRB; rb++) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cb], al[rb], acc[rb][cb], 0, 0, 0);
-#pragma unroll
-    for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-        for (int rb = 0; rb < NRB; rb++) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[cb], ah[rb], acc[rb][cb], 0, 0, 0);
-#pragma unroll
-    for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-        for (int rb = 0; rb < NRB; rb++) acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[cb], ah[rb], acc[rb][cb], 0, 0, 0);
-}
-
 
 constexpr uint32_t kMaxUnits = 64;        // rows of the unit table kept in LDS (the host refuses more)
 
@@ -107,73 +40,6 @@ __host__ __device__ constexpr uint32_t kUnitTableAt()
         if (planes > n) n = planes;
     }
     return (n + 7u) & ~7u;
-}
-
-template <int NRB, int NCB>
-__device__ __forceinline__ void zero_q(f32x4 (&acc)[NRB][NCB])
-{
-#pragma unroll
-    for (int rb = 0; rb < NRB; rb++)
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++) acc[rb][cb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-}
-
-// acc[rb][cb] (rows 16 (row_block0 + rb) + ..., this wave's NCB column blocks) = A * W^T with A in the activation planes,
-// K = 32 nks.
-template <int NRB, int NCB, int NT, bool DB>
-__device__ __forceinline__ void layer_q(const half_t* __restrict__ a_hi, const half_t* __restrict__ a_lo, uint32_t nks,
-                                        const half_t_* __restrict__ Wq, uint32_t ncbt, uint32_t cb0, uint32_t row_block0,
-                                        f32x4 (&acc)[NRB][NCB], uint32_t lane)
-{
-    using P = Plane2<NT>;
-    const uint32_t r = lane & 15u, kq = lane >> 4;
-    const wrsrc_t  W = weight_rsrc(reinterpret_cast<const float*>(Wq), nks * ncbt * 2048u);
-    const uint32_t voff = lane * 16u + cb0 * 2048u;
-    const uint32_t abase = (row_block0 * 16u + r) * P::ld + (P::swz ? ((kq ^ ((r >> 2) & 3u)) << 3) : (kq << 3));
-    zero_q<NRB, NCB>(acc);
-    if constexpr (DB) {
-        // the next K-step's fragments are requested before the current one's products (two register sets)
-        half8_t wh0[NCB], wl0[NCB], wh1[NCB], wl1[NCB];
-        load_wq<NCB>(W, 0, ncbt, voff, wh0, wl0);
-        for (uint32_t ks = 0; ks < nks; ks += 2) {
-            const bool second = ks + 1 < nks;
-            if (second) load_wq<NCB>(W, ks + 1, ncbt, voff, wh1, wl1);
-            {
-                half8_t ah[NRB], al[NRB];
-#pragma unroll
-                for (int rb = 0; rb < NRB; rb++) {
-                    ah[rb] = *reinterpret_cast<const half8_t*>(a_hi + abase + rb * 16 * P::ld + ks * 32);
-                    al[rb] = *reinterpret_cast<const half8_t*>(a_lo + abase + rb * 16 * P::ld + ks * 32);
-                }
-                mfma3q<NRB, NCB>(ah, al, wh0, wl0, acc);
-            }
-            if (second) {
-                if (ks + 2 < nks) load_wq<NCB>(W, ks + 2, ncbt, voff, wh0, wl0);
-                half8_t ah[NRB], al[NRB];
-#pragma unroll
-                for (int rb = 0; rb < NRB; rb++) {
-                    ah[rb] = *reinterpret_cast<const half8_t*>(a_hi + abase + rb * 16 * P::ld + ks * 32 + 32);
-                    al[rb] = *reinterpret_cast<const half8_t*>(a_lo + abase + rb * 16 * P::ld + ks * 32 + 32);
-                }
-                mfma3q<NRB, NCB>(ah, al, wh1, wl1, acc);
-            }
-        }
-    } else {
-        // one register set: a K-step's fragments are requested as soon as the products of the step before have been
-        // issued (they read their operands at issue); the other waves of the SIMD cover the round trip
-        half8_t wh[NCB], wl[NCB];
-        load_wq<NCB>(W, 0, ncbt, voff, wh, wl);
-        for (uint32_t ks = 0; ks < nks; ks++) {
-            half8_t ah[NRB], al[NRB];
-#pragma unroll
-            for (int rb = 0; rb < NRB; rb++) {
-                ah[rb] = *reinterpret_cast<const half8_t*>(a_hi + abase + rb * 16 * P::ld + ks * 32);
-                al[rb] = *reinterpret_cast<const half8_t*>(a_lo + abase + rb * 16 * P::ld + ks * 32);
-            }
-            mfma3q<NRB, NCB>(ah, al, wh, wl, acc);
-            if (ks + 1 < nks) load_wq<NCB>(W, ks + 1, ncbt, voff, wh, wl);
-        }
-    }
 }
 
 // x = acc / 2^8 + bias (ReLU) of a column-split layer -> the two half planes.  Lane (r, kq) holds sample rb * 16 + r,
@@ -476,7 +342,7 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
 // stamps `flag` with the pack's id (the range guard).
 __device__ __forceinline__ void pack16x32_element(const float* __restrict__ W, uint32_t H, uint32_t K, uint32_t ldw,
                                                   uint32_t ncb, uint32_t idx, half_t* __restrict__ Wq, uint32_t* flag,
-                                                  uint32_t pack_id, uint32_t k_gap)
+                                                  uint32_t pack_id, uint32_t k_gap, uint32_t tflags, uint32_t src_off)
 {
     const uint32_t e = idx & 7u, lane = (idx >> 3) & 63u, q = idx >> 9;
     const uint32_t cb = q % ncb, ks = q / ncb;
@@ -484,7 +350,12 @@ __device__ __forceinline__ void pack16x32_element(const float* __restrict__ W, u
     // k_gap > 0: packed column k_gap is a zero column, the source columns from k_gap on sit one to the right
     const bool     gap = k_gap != 0u && kp == k_gap;
     const uint32_t k = (k_gap != 0u && kp > k_gap) ? kp - 1u : kp;
-    const float    wv = (out < H && k < K && !gap) ? W[(size_t)out * ldw + k] * 256.0f : 0.0f;
+    // the gradient chain's layers (field_bwd.hip) are the forward's transposed: packed W'[out][k] = W[k][src], with an
+    // optional all-zero output 0 (the raw density's slot) in front and a first source column
+    const bool     tr = (tflags & CNC_PACK_TRANSPOSE) != 0u, zf = (tflags & CNC_PACK_ZERO_FIRST) != 0u;
+    const bool     live = out < H && k < K && !gap && !(zf && out == 0u);
+    const uint32_t src = src_off + out - (zf ? 1u : 0u);
+    const float    wv = live ? (tr ? W[(size_t)k * ldw + src] : W[(size_t)src * ldw + k]) * 256.0f : 0.0f;
     if (flag && !(fabsf(wv) <= kHalfMax)) atomicMax(flag, pack_id);
     half_t hi, lo;
     split_half(wv, hi, lo);
@@ -498,6 +369,7 @@ struct PackAllArgs {
     uint32_t     H[5], K[5], ldw[5];
     uint32_t     nt32[5], nk8[5], nk16[5];      // fp32 fragments (and biases), 32x32x16 half fragments
     uint32_t     ncb[5], nk32[5], k_gap[5];     // 16x16x32 half fragments
+    uint32_t     tflags[5], src_off[5];
     float*       Wp[5];
     float*       Bp[5];
     half_t*      Wp16[5];                       // nullable
@@ -519,7 +391,7 @@ __global__ __launch_bounds__(256) void k_field_pack_all(PackAllArgs a)
     const uint32_t idx = (blockIdx.x - a.first_block[l]) * 256 + threadIdx.x;
     const float*   W = a.W[l];
     const uint32_t H = a.H[l], K = a.K[l], ldw = a.ldw[l];
-    {   // fp32 fragments, biases, row 0 (k_field_pack_layer)
+    if (a.Wp[l]) {   // fp32 fragments, biases, row 0 (k_field_pack_layer)
         const uint32_t NT = a.nt32[l], total = a.nk8[l] * NT * 256;
         if (idx < total) {
             const uint32_t m = idx & 3u, lane = (idx >> 2) & 63u, q = idx >> 8;
@@ -547,7 +419,8 @@ __global__ __launch_bounds__(256) void k_field_pack_all(PackAllArgs a)
     }
     if (a.Wq16[l]) {
         const uint32_t total = a.nk32[l] * a.ncb[l] * 512;
-        if (idx < total) pack16x32_element(W, H, K, ldw, a.ncb[l], idx, a.Wq16[l], flag, a.pack_id, a.k_gap[l]);
+        if (idx < total)
+            pack16x32_element(W, H, K, ldw, a.ncb[l], idx, a.Wq16[l], flag, a.pack_id, a.k_gap[l], a.tflags[l], a.src_off[l]);
     }
 }
 
@@ -639,9 +512,15 @@ extern "C" int cnc_field_pack_all(const cnc_field_pack_t* d, void* stream)
     uint32_t blocks = 0;
     for (int l = 0; l < 5; l++) {
         const cnc_field_pack_layer_t& L = d->layer[l];
-        if (!L.W || !L.b || !L.Wp || !L.Bp || L.H == 0 || L.K == 0 || L.ldw < L.K || L.n_tiles == 0 || L.n_ksteps == 0)
+        const bool tr = (L.flags & CNC_PACK_TRANSPOSE) != 0u;
+        if (!L.W || L.H == 0 || L.K == 0 || (!tr && L.ldw < L.K)) return CNC_ERR_INVALID_VALUE;
+        if (L.Wp) {          // the fp32 fragments (and the biases): the forward's layers
+            if (tr || !L.b || !L.Bp || L.n_tiles == 0 || L.n_ksteps == 0 || L.H > L.n_tiles * 32 || L.K > L.n_ksteps * 8)
+                return CNC_ERR_INVALID_VALUE;
+        } else if (!L.Wq16) {
             return CNC_ERR_INVALID_VALUE;
-        if (L.H > L.n_tiles * 32 || L.K > L.n_ksteps * 8) return CNC_ERR_INVALID_VALUE;
+        }
+        if (tr && (L.Wp16 || L.ldw < L.src_off + L.H - ((L.flags & CNC_PACK_ZERO_FIRST) ? 1u : 0u))) return CNC_ERR_INVALID_VALUE;
         if (L.Wp16 && (L.n_ksteps16 == 0 || L.K > L.n_ksteps16 * 16)) return CNC_ERR_INVALID_VALUE;
         if (L.Wq16 && (L.n_colblocks == 0 || L.n_ksteps32 == 0 || L.H > L.n_colblocks * 16 ||
                        L.K + (L.k_gap ? 1u : 0u) > L.n_ksteps32 * 32 || L.k_gap >= L.K))
@@ -649,10 +528,11 @@ extern "C" int cnc_field_pack_all(const cnc_field_pack_t* d, void* stream)
         a.W[l] = L.W; a.b[l] = L.b; a.H[l] = L.H; a.K[l] = L.K; a.ldw[l] = L.ldw;
         a.nt32[l] = L.n_tiles; a.nk8[l] = L.n_ksteps; a.nk16[l] = L.n_ksteps16;
         a.ncb[l] = L.n_colblocks; a.nk32[l] = L.n_ksteps32; a.k_gap[l] = L.k_gap;
+        a.tflags[l] = L.flags; a.src_off[l] = L.src_off;
         a.Wp[l] = L.Wp; a.Bp[l] = L.Bp;
         a.Wp16[l] = reinterpret_cast<half_t*>(L.Wp16);
         a.Wq16[l] = reinterpret_cast<half_t*>(L.Wq16);
-        uint32_t total = L.n_ksteps * L.n_tiles * 256;
+        uint32_t total = L.Wp ? L.n_ksteps * L.n_tiles * 256 : 0u;
         if (L.Wp16 && L.n_ksteps16 * L.n_tiles * 512 > total) total = L.n_ksteps16 * L.n_tiles * 512;
         if (L.Wq16 && L.n_ksteps32 * L.n_colblocks * 512 > total) total = L.n_ksteps32 * L.n_colblocks * 512;
         if (l == 1 && d->row0 && d->row0_len > total) total = d->row0_len;

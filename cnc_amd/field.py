@@ -485,6 +485,84 @@ class FusedFieldForward:
         return self._buffers is not None and int(self._buffers["guard"][0].item()) == self._call_id
 
 
+class _FieldChain(Function):
+    """base MLP -> density activation / head input -> head MLP -> sigmoid on a [Np, ld] feature matrix, with the WHOLE
+    input-gradient chain of its backward as one kernel (cnc_field_backward_chain, cnc_amd/csrc/field_bwd.hip).
+
+    Forward: the library GEMMs with bias + ReLU epilogues and the fused post kernel, exactly the ops of the layer-by-layer
+    path (`run_layers`, `_FieldPost`) — same values.  Backward: autograd through ngp.py:506-547 from (d rgb, d density)
+    to the gradient of the feature matrix's encoder columns in one launch — sigmoid', Linear^T, ReLU', Linear^T, ReLU',
+    Linear^T, geo split + trunc_exp's clamped derivative, Linear^T, ReLU', Linear^T — which also leaves the gradients
+    with respect to every Linear's output in HBM for the five weight gradients (split-K batched GEMMs, as before) and
+    bias gradients.  Replaces five `g @ W` GEMMs, three ReLU-backward passes, the post kernel's backward, the sigmoid's
+    backward and the slices between them."""
+
+    @staticmethod
+    def forward(ctx, feat, selector, dirs, field, W1, b1, W2, b2, W3, b3, W4, b4, W5, b5):
+        from . import _lib
+        geo, Np, ld = field.geo_feat_dim, feat.shape[0], feat.shape[1]
+        K0 = W1.shape[1]
+        W1p = F.pad(W1, (0, ld - K0)) if ld != K0 else W1
+        h1 = torch._addmm_activation(b1, feat, W1p.t())
+        base_out = F.linear(h1, W2, b2)
+        density = torch.empty((Np, 1), dtype=torch.float32, device=feat.device)
+        ld_h = (16 + geo + 3) // 4 * 4
+        head_in = torch.empty((Np, ld_h), dtype=torch.float32, device=feat.device)
+        dirs = dirs.contiguous()
+        _lib.check(_lib.lib().cnc_field_post(base_out.data_ptr(), base_out.shape[1], geo, _lib.ptr(selector), dirs.data_ptr(), Np,
+                                             density.data_ptr(), head_in.data_ptr(), ld_h,
+                                             _lib.CNC_FIELD_SH_FP16 if field.sh_fp16_round else 0, _lib.stream(feat.device)),
+                   "field_post")
+        W3p = F.pad(W3, (0, ld_h - W3.shape[1])) if ld_h != W3.shape[1] else W3
+        h3 = torch._addmm_activation(b3, head_in, W3p.t())
+        h4 = torch._addmm_activation(b4, h3, W4.t())
+        rgb = torch.sigmoid(F.linear(h4, W5, b5))
+        ctx.save_for_backward(feat, selector, h1, base_out, head_in, h3, h4, rgb, W1, W2, W3, W4, W5)
+        ctx.field = field
+        return rgb, density
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_density):
+        from . import _lib
+        from .mlp import splitk_weight_grad
+        feat, selector, h1, base_out, head_in, h3, h4, rgb, W1, W2, W3, W4, W5 = ctx.saved_tensors
+        field = ctx.field
+        dev, Np, ld = feat.device, feat.shape[0], feat.shape[1]
+        H, geo, K0 = W1.shape[0], field.geo_feat_dim, W1.shape[1]
+        n_enc = sum(e.n_output_dims for e in field.mlp_base._encoders())
+        wt = field._chain_weights_t(W1, W2, W3, W4, W5, n_enc)
+        ld2 = (1 + geo + 3) // 4 * 4
+        G5 = torch.empty((Np, 4), dtype=torch.float32, device=dev)
+        G4, G3, G1 = (torch.empty((Np, H), dtype=torch.float32, device=dev) for _ in range(3))
+        G2 = torch.empty((Np, ld2), dtype=torch.float32, device=dev)
+        dX = torch.empty((Np, ld), dtype=torch.float32, device=dev)       # only the encoder columns are written — and read
+        st = _lib.FieldBwd()
+        st.N, st.n_neurons, st.n_features, st.n_enc_columns, st.geo_feat_dim = Np, H, field.mlp_base.encoding_xyz.n_features, n_enc, geo
+        st.ld_base, st.ld_g2, st.ld_x = base_out.shape[1], ld2, ld
+        gr = None if g_rgb is None else g_rgb.contiguous()
+        gd = None if g_density is None else g_density.contiguous()
+        st.grad_rgb, st.grad_density, st.rgb, st.base_out = _lib.ptr(gr), _lib.ptr(gd), rgb.data_ptr(), base_out.data_ptr()
+        st.selector, st.h1, st.h3, st.h4 = selector.data_ptr(), h1.data_ptr(), h3.data_ptr(), h4.data_ptr()
+        for k in range(5):
+            st.packed_weights_t[k] = wt[k].data_ptr()
+        st.G5, st.G4, st.G3, st.G2, st.G1, st.dX = (t.data_ptr() for t in (G5, G4, G3, G2, G1, dX))
+        import ctypes
+        _lib.check(_lib.lib().cnc_field_backward_chain(ctypes.byref(st), _lib.stream(dev)), "field_backward_chain")
+        need = ctx.needs_input_grad
+        out = [dX if need[0] else None, None, None, None]
+        for i, (G, A, width) in enumerate(((G1, feat, K0), (G2[:, :1 + geo], h1, H), (G3, head_in, 16 + geo), (G4, h3, H),
+                                            (G5[:, :3], h4, H))):
+            gw = gb = None
+            if need[4 + 2 * i]:
+                gw = splitk_weight_grad(G, A)
+                if gw.shape[1] != width:
+                    gw = gw[:, :width]
+            if need[5 + 2 * i]:
+                gb = G.sum(0)
+            out += [gw, gb]
+        return tuple(out)
+
+
 class NGPRadianceField_mygrid_2D3D(nn.Module):
     def __init__(self, aabb: Union[torch.Tensor, List[float]], num_dim: int = 3, use_viewdirs: bool = True,
                  density_activation: Callable = _default_density_activation, unbounded: bool = False,
@@ -527,6 +605,10 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
             raise ValueError("CNC_FUSED_FIELD_KERNEL must be w1 or w2")
         self.fused_field_waves = int(os.environ.get("CNC_FUSED_FIELD_WAVES", "0"))     # 0: per kernel (4 density, 3 colour)
         self._field_fused = None
+        # the gradient pass's input-gradient chain as one kernel (`_FieldChain`; CNC_FUSED_CHAIN=0: layer by layer)
+        self.fused_chain = fused_features and os.environ.get("CNC_FUSED_CHAIN", "1") == "1"
+        self._chain_supported = None
+        self._chain_key = self._chain_wt = self._chain_src = None
         # sample counts from here on run at a bucketed row count (`_bucket_rows`); CNC_ROW_BUCKET_MIN=0 pads every call
         self.row_bucket_min = int(os.environ.get("CNC_ROW_BUCKET_MIN", "4096"))
         self._head_shape_ok = n_neurons == 160       # the 32-row kernel is instantiated for 160-wide layers
@@ -567,6 +649,51 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
     def _glue_ok(self, x):
         return (self.fused_glue and x.is_cuda and x.dtype == torch.float32 and not self.unbounded and self.num_dim == 3
                 and self.density_activation is _default_density_activation and 1 + self.geo_feat_dim <= 128)
+
+    def _chain_ok(self, x_unit) -> bool:
+        """The fused gradient chain (`_FieldChain`) applies: gradients wanted, the shapes the kernels are built for."""
+        if not (self.fused_chain and torch.is_grad_enabled() and x_unit.is_cuda and self.mlp_base._can_fuse(x_unit)):
+            return False
+        if self._chain_supported is None:
+            self._chain_supported = bool(FusedFieldForward.supported(self)
+                                         and sum(e.n_output_dims for e in self.mlp_base._encoders()) % 4 == 0
+                                         and sum(e.n_output_dims for e in self.mlp_base._encoders()) <= 192
+                                         and (1 + self.geo_feat_dim + 31) // 32 * 32 <= self.mlp_base.network[0].out_features)
+        return self._chain_supported
+
+    def _chain_weights_t(self, W1, W2, W3, W4, W5, n_enc):
+        """The five layers TRANSPOSED in the 16x16x32 fragment order (cnc_field_pack_all, one launch), cached on the
+        weights' versions: what cnc_field_backward_chain multiplies the gradients with."""
+        from . import _lib
+        ws = (W5, W4, W3, W2, W1)
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        if self._chain_key == key:
+            return self._chain_wt
+        H, geo = W1.shape[0], self.geo_feat_dim
+        r32 = lambda k: (k + 31) // 32
+        nb2 = 5 if H == 160 else 4
+        # (W, packed outputs, K, column blocks, K-steps of 32, flags, src_off)
+        T, ZF = _lib.CNC_PACK_TRANSPOSE, _lib.CNC_PACK_ZERO_FIRST
+        layers = [(W5, H, 3, H // 16, 1, T, 0), (W4, H, H, H // 16, H // 32, T, 0),
+                  (W3, 1 + geo, H, nb2, H // 32, T | ZF, 16), (W2, H, 1 + geo, H // 16, r32(1 + geo), T, 0),
+                  (W1, n_enc, H, (n_enc + 15) // 16, H // 32, T, 0)]
+        if self._chain_wt is None or self._chain_wt[0].device != W1.device:
+            self._chain_wt = [torch.empty(nk * ncb * 1024, dtype=torch.float16, device=W1.device) for _, _, _, ncb, nk, _, _ in layers]
+        d = _lib.FieldPack()
+        keep = []
+        for k, (w, Hp, K, ncb, nk, fl, off) in enumerate(layers):
+            wc = w.detach()
+            if not wc.is_contiguous():
+                wc = wc.contiguous()
+            keep.append(wc)
+            L = d.layer[k]
+            L.W, L.H, L.K, L.ldw = wc.data_ptr(), Hp, K, wc.stride(0)
+            L.n_colblocks, L.n_ksteps32, L.flags, L.src_off = ncb, nk, fl, off
+            L.Wq16 = self._chain_wt[k].data_ptr()
+        import ctypes
+        _lib.check(_lib.lib().cnc_field_pack_all(ctypes.byref(d), _lib.stream(W1.device)), "field_pack_all(transposed)")
+        self._chain_key, self._chain_src = key, ws
+        return self._chain_wt
 
     def _bucket_rows(self, n: int) -> int:
         """Row count the field's kernels and GEMMs run at for `n` samples: `n` rounded up to a multiple of ~3 % of
@@ -687,9 +814,16 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
             dirs = directions.reshape(-1, 3)
             if Np != N:          # rows of padding (`_bucket_rows`): any direction will do
                 dirs = torch.cat([dirs, dirs.new_zeros((Np - N, 3))])
-            h = self.mlp_base(x_unit, rows=Np)
-            density, head_in = _FieldPost.apply(h, selector, dirs, self.geo_feat_dim, self.sh_fp16_round)
-            rgb = torch.sigmoid(self._head(head_in))
+            if self._chain_ok(x_unit):
+                # the gradient pass: library GEMMs forward, ONE kernel for the whole input-gradient chain backward
+                feat = self.mlp_base.features_fused(x_unit, Np)
+                mb, mh = self.mlp_base.network, self.mlp_head
+                rgb, density = _FieldChain.apply(feat, selector, dirs, self, mb[0].weight, mb[0].bias, mb[2].weight, mb[2].bias,
+                                                 mh[0].weight, mh[0].bias, mh[2].weight, mh[2].bias, mh[4].weight, mh[4].bias)
+            else:
+                h = self.mlp_base(x_unit, rows=Np)
+                density, head_in = _FieldPost.apply(h, selector, dirs, self.geo_feat_dim, self.sh_fp16_round)
+                rgb = torch.sigmoid(self._head(head_in))
             if Np != N:
                 rgb, density = rgb[:N], density[:N]
             return rgb.view(lead + [3]), density.view(lead + [1])

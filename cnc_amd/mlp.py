@@ -27,6 +27,20 @@ def _split(n_rows: int) -> int:
     return s
 
 
+def splitk_weight_grad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """g^T x ([out, in]) as a batched GEMM over row slabs + a sum over the slabs (see the module docstring)."""
+    n = x.shape[0]
+    s = _split(n)
+    if s == 1:
+        return g.t() @ x
+    m = n // s
+    head = m * s
+    gw = torch.bmm(g[:head].reshape(s, m, -1).transpose(1, 2), x[:head].reshape(s, m, -1)).sum(0)
+    if head < n:
+        gw = gw + g[head:].t() @ x[head:]
+    return gw
+
+
 class _LinearSplitK(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):

@@ -740,7 +740,15 @@ typedef struct {
     uint32_t     k_gap;     /* Wq16 only: != 0 inserts a zero column at packed k = k_gap (the source columns from k_gap on
                                move one to the right).  head.0 takes 16: the two-wave kernel lays the head's input out as
                                [SH4 (16) | base output c at column 16 + c], and output 0 is the raw density            */
+    uint32_t     flags;     /* Wq16 only.  CNC_PACK_TRANSPOSE: packed W'[out][k] = W[k][src_off + out] (W: K rows of ldw
+                               floats) — the layers of the gradient chain (cnc_field_backward_chain) are the forward's
+                               transposed; Wp / Bp / Wp16 / b must be NULL then (Wp == NULL skips the fp32 fragments for
+                               any layer).  CNC_PACK_ZERO_FIRST: packed output 0 is all zero and output o >= 1 reads source
+                               src_off + o - 1 (the raw density's slot in front of the geo features)                 */
+    uint32_t     src_off;
 } cnc_field_pack_layer_t;
+#define CNC_PACK_TRANSPOSE 1u
+#define CNC_PACK_ZERO_FIRST 2u
 typedef struct {
     cnc_field_pack_layer_t layer[5];
     float*                 row0;
@@ -754,6 +762,45 @@ int cnc_field_pack_all(const cnc_field_pack_t* desc, void* stream);
  * CNC_ERR_UNSUPPORTED for shapes outside the table above (the caller then runs the unfused chain).            */
 int cnc_field_fused_forward(const cnc_fused_field_t* field, const float* positions, const float* dirs, uint32_t N,
                             float* density, float* rgb, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (extension, ABI v26) The gradient chain of the field's two MLPs as one kernel: autograd through mlp_head and mlp_base of
+ * NGPRadianceField_mygrid_2D3D (ngp.py:506-547) from (d loss / d rgb, d loss / d density) down to the gradient of the
+ * base network's INPUT columns that belong to the grid encoders — sigmoid', Linear^T, ReLU', Linear^T, ReLU', Linear^T,
+ * the geo split + trunc_exp's clamped derivative (ngp.py:318-334), Linear^T, ReLU', Linear^T — and, on the way, the
+ * gradients with respect to every Linear's output (G5 .. G1): what the weight gradients dW_l = G_l^T A_l and the bias
+ * gradients need.  Replaces five `g @ W` GEMMs, three ReLU-backward passes, cnc_field_post_backward and the sigmoid's
+ * backward.  Arithmetic: three fp16 products per term with fp32 accumulation (as CNC_FIELD_MFMA_F16X3) on operands
+ * scaled per 32-sample tile by a power of two (gradients are small); ~5e-7 relative per term.
+ * All matrices row-major float32; 16-byte aligned rows (ld multiples of 4).  packed_weights_t: cnc_field_pack_all with
+ * CNC_PACK_TRANSPOSE of, in this order: head.4 (H outputs, K = 3), head.2 (H, K = H), head.0's geo columns (1 + geo outputs:
+ * CNC_PACK_ZERO_FIRST, src_off = 16; K = H; 5 (H = 160) or 4 column blocks), base.2 (H outputs, K = 1 + geo), base.0's
+ * first n_enc_columns columns (n_enc_columns outputs in roundup16(n_enc_columns) / 16 column blocks, K = H).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t       N;                 /* rows                                                                         */
+    uint32_t       n_neurons;         /* H: 64 or 160                                                                 */
+    uint32_t       n_features;        /* F: 2, 4, 8 (names the instantiation; n_enc_columns is what is used)           */
+    uint32_t       n_enc_columns;     /* encoder columns of the feature row (a multiple of 4, <= 192)                  */
+    uint32_t       geo_feat_dim;
+    uint32_t       ld_base, ld_g2, ld_x;
+    const float*   grad_rgb;          /* [N, 3]  (nullable: zero)                                                     */
+    const float*   grad_density;      /* [N]     (nullable: zero)                                                     */
+    const float*   rgb;               /* [N, 3]  the forward's sigmoid output                                         */
+    const float*   base_out;          /* [N, ld_base] base.2's output: column 0 = raw density                         */
+    const uint8_t* selector;          /* [N]                                                                          */
+    const float*   h1;                /* [N, H] relu(base.0), relu(head.0), relu(head.2): only their signs are read    */
+    const float*   h3;
+    const float*   h4;
+    const void*    packed_weights_t[5];
+    float*         G5;                /* [N, 4]     out: gradient w.r.t. head.4's output (column 3 = 0)               */
+    float*         G4;                /* [N, H]     ... head.2's                                                      */
+    float*         G3;                /* [N, H]     ... head.0's                                                      */
+    float*         G2;                /* [N, ld_g2] ... base.2's (columns 0 .. geo; up to 16 * blocks zero-filled)     */
+    float*         G1;                /* [N, H]     ... base.0's                                                      */
+    float*         dX;                /* [N, ld_x]  out: columns [0, n_enc_columns) of the base network's input gradient */
+} cnc_field_bwd_t;
+int cnc_field_backward_chain(const cnc_field_bwd_t* chain, void* stream);
 
 /* STE_binary of ngp.py:22-39 over n floats (16-byte aligned buffers), one pass each way:
  *   forward : out = (c >= 0) * 1 + (c < 0) * -1 with c = clamp(x, -1, 1)   (+1 / -1; NaN -> 0)

@@ -89,6 +89,7 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
         "cnc_fused_field_t": (_lib.FusedField, [f[0] for f in _lib.FusedField._fields_]),
         "cnc_field_pack_layer_t": (_lib.FieldPackLayer, [f[0] for f in _lib.FieldPackLayer._fields_]),
         "cnc_field_pack_t": (_lib.FieldPack, [f[0] for f in _lib.FieldPack._fields_]),
+        "cnc_field_bwd_t": (_lib.FieldBwd, [f[0] for f in _lib.FieldBwd._fields_]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include <stdint.h>', '#include "cnc_hip.h"', 'int main(void) {']
     for t, (_, names) in members.items():
