@@ -43,7 +43,7 @@ class FieldBwd(C.Structure):
     _fields_ = [("N", _u32), ("n_neurons", _u32), ("n_features", _u32), ("n_enc_columns", _u32), ("geo_feat_dim", _u32),
                 ("ld_base", _u32), ("ld_g2", _u32), ("ld_x", _u32), ("grad_rgb", _vp), ("grad_density", _vp), ("rgb", _vp),
                 ("base_out", _vp), ("selector", _vp), ("h1", _vp), ("h3", _vp), ("h4", _vp), ("packed_weights_t", _vp * 5),
-                ("G5", _vp), ("G4", _vp), ("G3", _vp), ("G2", _vp), ("G1", _vp), ("dX", _vp)]
+                ("G5", _vp), ("G4", _vp), ("G3", _vp), ("G2", _vp), ("G1", _vp), ("dX", _vp), ("bias_grads", _vp)]
 
 
 class FieldPackLayer(C.Structure):

@@ -42,7 +42,25 @@ struct FieldBwdArgs {
     float*         G1;              // [N, H]
     float*         dX;              // [N, ld_x] columns [0, n_enc)
     uint32_t       ld_x;
+    float*         bias_grads;      // [3 H + 84] zero-initialised by the caller: column sums of G4 | G3 | G1 | G2 (80) | G5 (4)
 };
+
+// Row-major [N, ld] float matrices through buffer resources: SGPR base + ONE 32-bit lane offset + constants — a flat pointer
+// per (row block, column block) cost 20 address registers per matrix and the kernel its third wave per SIMD — and with the
+// record count set to the matrix's size a row past N reads zeros / drops its store: no bounds branches.
+__device__ void llvm_raw_buffer_store_f32x4(f32x4_t data, i32x4_t rsrc, int32_t voffset, int32_t soffset, int32_t aux)
+    __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+
+__device__ __forceinline__ float4 buf_load4(wrsrc_t m, uint32_t byte_off)
+{
+    const f32x4_t v = llvm_raw_buffer_load_f32x4(m, (int32_t)byte_off, 0, 0);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ void buf_store4(wrsrc_t m, uint32_t byte_off, float a, float b, float c, float d)
+{
+    llvm_raw_buffer_store_f32x4(f32x4_t{a, b, c, d}, m, (int32_t)byte_off, 0, 0);
+}
 
 // largest magnitude of the tile -> the power of two that puts it into [2^13, 2^14)
 __device__ __forceinline__ float tile_scale(float m)
@@ -84,13 +102,41 @@ __device__ __forceinline__ void vals_to_planes(half_t* __restrict__ d_hi, half_t
         }
 }
 
-// One column-split stage with a ReLU mask: X = (acc / (2^8 s_in)) where act > 0 else 0; to HBM (G) and, scaled by the new
-// tile scale, into the planes.  Returns the new scale.  Barriers: [all reads of the planes done + maxima exchanged] ...
-// writes ... [visible].
+// Sum over the 16 lanes of a DPP row (the 16 samples r of a row block that share kq): four v_add_f32 with row_shr, the
+// total ends up in lane 15 of the row.
+__device__ __forceinline__ float row16_sum_to_lane15(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   // row_shr:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));   // row_shr:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   // row_shr:8
+    return v;
+}
+
+// The ReLU operand of a column-split stage (post-activation values: only their sign is used), requested right behind the
+// ISSUE of the stage's products — the weight registers are free by then and the round trip runs while the matrix pipe
+// drains (requested in front of the products it costs 40 more live registers: two waves per SIMD instead of three):
+// lane (r, kq) -> rows rb * 16 + r, columns 16 (w NCB + cb) + 4 kq ..
+template <int NCB>
+struct ActTile {
+    float4 a[2][NCB];
+    // `lane_off`: byte offset of (row0 + r, 16 w NCB + 4 kq) in a [N, H] matrix
+    __device__ __forceinline__ void load(wrsrc_t act, uint32_t H, uint32_t lane_off)
+    {
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) a[rb][cb] = buf_load4(act, lane_off + (rb * 16u * H + cb * 16u) * 4u);
+    }
+};
+
+// One column-split stage with a ReLU mask: X = (acc / (2^8 s_in)) where act > 0 else 0; to HBM (G), its column sums (the
+// bias gradient) into the workgroup's LDS accumulators `bsum`, and, scaled by the new tile scale, into the planes.  Returns
+// the new scale.  Barriers: [all reads of the planes done + maxima exchanged] ... writes ... [visible].
 template <int NCB, int NT>
-__device__ __forceinline__ float masked_stage_out(const f32x4 (&acc)[2][NCB], float inv_in, const float* __restrict__ act,
-                                                  float* __restrict__ G, uint32_t H, uint32_t row0, uint32_t N, uint32_t w,
-                                                  uint32_t lane, half_t* h_hi, half_t* h_lo, float* xch)
+__device__ __forceinline__ float masked_stage_out(const f32x4 (&acc)[2][NCB], float inv_in, const ActTile<NCB>& act,
+                                                  wrsrc_t G, uint32_t H, uint32_t lane_off, uint32_t w,
+                                                  uint32_t lane, half_t* h_hi, half_t* h_lo, float* xch, float* bsum)
 {
     const uint32_t r = lane & 15u, kq = lane >> 4;
     float x[2][NCB][4];
@@ -100,17 +146,20 @@ __device__ __forceinline__ float masked_stage_out(const f32x4 (&acc)[2][NCB], fl
         const uint32_t col0 = (w * NCB + cb) * 16u + 4u * kq;
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
-            const uint32_t row = row0 + rb * 16u + r;
-            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < N) a4 = *reinterpret_cast<const float4*>(act + (size_t)row * H + col0);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+            const float4   a4 = act.a[rb][cb];
+            const float    av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 const float g = av[v] > 0.0f ? acc[rb][cb][v] * inv_in : 0.0f;
                 x[rb][cb][v] = g;
                 m = fmaxf(m, fabsf(g));
             }
-            if (row < N) *reinterpret_cast<float4*>(G + (size_t)row * H + col0) = make_float4(x[rb][cb][0], x[rb][cb][1], x[rb][cb][2], x[rb][cb][3]);
+            buf_store4(G, lane_off + (rb * 16u * H + cb * 16u) * 4u, x[rb][cb][0], x[rb][cb][1], x[rb][cb][2], x[rb][cb][3]);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const float t = row16_sum_to_lane15(x[0][cb][v] + x[1][cb][v]);
+            if (r == 15u) atomicAdd(bsum + col0 + v, t);          // ds_add_f32: four lanes, distinct addresses
         }
     }
     m = wave_max(m);
@@ -123,10 +172,10 @@ __device__ __forceinline__ float masked_stage_out(const f32x4 (&acc)[2][NCB], fl
 }
 
 #ifndef CNC_BWD_WAVES
-#define CNC_BWD_WAVES 2
+#define CNC_BWD_WAVES 3
 #endif
 #ifndef CNC_BWD_DB
-#define CNC_BWD_DB true
+#define CNC_BWD_DB false
 #endif
 template <int NT>
 __global__ __launch_bounds__(128, CNC_BWD_WAVES) void k_field_bwd_chain(FieldBwdArgs p)
@@ -142,8 +191,15 @@ __global__ __launch_bounds__(128, CNC_BWD_WAVES) void k_field_bwd_chain(FieldBwd
     half_t* const h_hi = lds16;
     half_t* const h_lo = lds16 + 32 * P::ld;
     float* const  xch = reinterpret_cast<float*>(lds16 + 2 * 32 * P::ld);       // two maxima (+ two spare words)
+    // the workgroup's bias-gradient accumulators: column sums of G4 | G3 | G1 (H each) | G2 (80) | G5 (4), flushed at the end
+    float* const  bs4 = xch + 4, * const bs3 = bs4 + H, * const bs1 = bs3 + H, * const bs2 = bs1 + H, * const bs5 = bs2 + 80;
+    for (uint32_t i = tid; i < 3 * H + 84; i += 128) bs4[i] = 0.0f;
     const uint32_t tiles = (p.N + 31u) / 32u;
     const uint32_t K2 = ((1u + p.geo + 31u) / 32u) * 32u;                        // stage 1's K: 1 + geo padded to 32
+    const uint32_t bytes_h = p.N * H * 4u;
+    const wrsrc_t  rH1 = weight_rsrc(p.h1, bytes_h), rH3 = weight_rsrc(p.h3, bytes_h), rH4 = weight_rsrc(p.h4, bytes_h);
+    const wrsrc_t  rG1 = weight_rsrc(p.G1, bytes_h), rG3 = weight_rsrc(p.G3, bytes_h), rG4 = weight_rsrc(p.G4, bytes_h);
+    const wrsrc_t  rG2 = weight_rsrc(p.G2, p.N * p.ld_g2 * 4u), rX = weight_rsrc(p.dX, p.N * p.ld_x * 4u);
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const uint32_t row0 = tile * 32, frow = row0 + fi;
         const bool     live = frow < p.N;
@@ -159,6 +215,13 @@ __global__ __launch_bounds__(128, CNC_BWD_WAVES) void k_field_bwd_chain(FieldBwd
         if (live && fq == 0) *reinterpret_cast<float4*>(p.G5 + (size_t)frow * 4) = make_float4(g5[0], g5[1], g5[2], 0.0f);
         float m5 = fmaxf(fmaxf(fabsf(g5[0]), fabsf(g5[1])), fabsf(g5[2]));
         m5 = wave_max(m5);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {                   // column sums of G5 (head.4's bias gradient)
+            float t = g5[c];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+            if (lane == 0) atomicAdd(bs5 + c, t);
+        }
         if (lane == 0) xch[w] = m5;
         __syncthreads();                               // (also: the previous tile's last reads of the planes are done)
         float s_in = tile_scale(fmaxf(xch[0], xch[1]));
@@ -171,12 +234,18 @@ __global__ __launch_bounds__(128, CNC_BWD_WAVES) void k_field_bwd_chain(FieldBwd
         }
         __syncthreads();
         f32x4 acc[2][NCB];
+        ActTile<NCB> act;
+        const uint32_t lane_off = ((row0 + r) * H + w * NCB * 16u + 4u * kq) * 4u;    // (row0 + r, this wave's first column + 4 kq)
         // ---- stage 4: G4 = (g5 W5) where h4 > 0 ----
         layer_q<2, NCB, NT, CNC_BWD_DB>(h_hi, h_lo, 1, p.Wt[0], NCBT, w * NCB, 0, acc, lane);
-        s_in = masked_stage_out<NCB, NT>(acc, kWScaleInv / s_in, p.h4, p.G4, H, row0, p.N, w, lane, h_hi, h_lo, xch);
+        __builtin_amdgcn_sched_barrier(0);
+        act.load(rH4, H, lane_off);                      // behind the products' issue: in flight while the matrix pipe drains
+        s_in = masked_stage_out<NCB, NT>(acc, kWScaleInv / s_in, act, rG4, H, lane_off, w, lane, h_hi, h_lo, xch, bs4);
         // ---- stage 3: G3 = (G4 W4) where h3 > 0 ----
         layer_q<2, NCB, NT, CNC_BWD_DB>(h_hi, h_lo, NT, p.Wt[1], NCBT, w * NCB, 0, acc, lane);
-        s_in = masked_stage_out<NCB, NT>(acc, kWScaleInv / s_in, p.h3, p.G3, H, row0, p.N, w, lane, h_hi, h_lo, xch);
+        __builtin_amdgcn_sched_barrier(0);
+        act.load(rH3, H, lane_off);                      // behind the products' issue: in flight while the matrix pipe drains
+        s_in = masked_stage_out<NCB, NT>(acc, kWScaleInv / s_in, act, rG3, H, lane_off, w, lane, h_hi, h_lo, xch, bs3);
         // ---- stage 2: G2[:, c] = (G3 W3[:, 15 + c]) for the geo features c >= 1; G2[:, 0] = g_density * d density / d raw ----
         {
             f32x4 acc2[1][NB2];
@@ -200,8 +269,12 @@ __global__ __launch_bounds__(128, CNC_BWD_WAVES) void k_field_bwd_chain(FieldBwd
                     x2[cb][v] = g;
                     m = fmaxf(m, fabsf(g));
                 }
-                if (row < p.N && c0 < p.ld_g2)
-                    *reinterpret_cast<float4*>(p.G2 + (size_t)row * p.ld_g2 + c0) = make_float4(x2[cb][0], x2[cb][1], x2[cb][2], x2[cb][3]);
+                if (c0 < p.ld_g2) buf_store4(rG2, (row * p.ld_g2 + c0) * 4u, x2[cb][0], x2[cb][1], x2[cb][2], x2[cb][3]);
+#pragma unroll
+                for (int v = 0; v < 4; v++) {
+                    const float t = row16_sum_to_lane15(x2[cb][v]);
+                    if (r == 15u && c0 + v < 80u) atomicAdd(bs2 + c0 + v, t);
+                }
             }
             m = wave_max(m);
             if (lane == 0) xch[w] = m;
@@ -233,7 +306,9 @@ __global__ __launch_bounds__(128, CNC_BWD_WAVES) void k_field_bwd_chain(FieldBwd
         }
         // ---- stage 1: G1 = (G2 W2) where h1 > 0 ----
         layer_q<2, NCB, NT, CNC_BWD_DB>(h_hi, h_lo, K2 / 32, p.Wt[3], NCBT, w * NCB, 0, acc, lane);
-        s_in = masked_stage_out<NCB, NT>(acc, kWScaleInv / s_in, p.h1, p.G1, H, row0, p.N, w, lane, h_hi, h_lo, xch);
+        __builtin_amdgcn_sched_barrier(0);
+        act.load(rH1, H, lane_off);                      // behind the products' issue: in flight while the matrix pipe drains
+        s_in = masked_stage_out<NCB, NT>(acc, kWScaleInv / s_in, act, rG1, H, lane_off, w, lane, h_hi, h_lo, xch, bs1);
         // ---- stage 0: dX[:, :n_enc] = G1 W1[:, :n_enc], rows split between the waves, the column blocks in passes of six
         // (a pass's blocks past the last one multiply whatever follows in the fragment stream: their results are dropped) ----
         {
@@ -247,14 +322,21 @@ __global__ __launch_bounds__(128, CNC_BWD_WAVES) void k_field_bwd_chain(FieldBwd
 #pragma unroll
                 for (int cb = 0; cb < PASS; cb++) {
                     const uint32_t c0 = (pass * PASS + cb) * 16u + 4u * kq;
-                    if (row < p.N && c0 < p.n_enc)
-                        *reinterpret_cast<float4*>(p.dX + (size_t)row * p.ld_x + c0) =
-                            make_float4(acc0[0][cb][0] * inv_in, acc0[0][cb][1] * inv_in, acc0[0][cb][2] * inv_in, acc0[0][cb][3] * inv_in);
+                    if (c0 < p.n_enc)
+                        buf_store4(rX, (row * p.ld_x + c0) * 4u, acc0[0][cb][0] * inv_in, acc0[0][cb][1] * inv_in, acc0[0][cb][2] * inv_in,
+                                   acc0[0][cb][3] * inv_in);
                 }
             }
         }
         // the next tile's first barrier (after its stage-5 maxima) orders its plane writes behind these reads
     }
+    // ---- the bias gradients: this workgroup's column sums into the global accumulators (zeroed by the caller) ----
+    __syncthreads();
+    if (p.bias_grads)
+        for (uint32_t i = tid; i < 3 * H + 84; i += 128) {
+            const float v = bs4[i];
+            if (v != 0.0f) unsafeAtomicAdd(p.bias_grads + i, v);
+        }
 }
 
 }  // namespace cnc
@@ -270,6 +352,8 @@ extern "C" int cnc_field_backward_chain(const cnc_field_bwd_t* f, void* stream)
     const uint32_t NT = H / 32, n_enc = f->n_enc_columns;
     if (n_enc == 0 || n_enc % 4 != 0 || (n_enc + 15) / 16 > 12 || 1 + f->geo_feat_dim > (NT == 5 ? 80u : 64u)) return CNC_ERR_UNSUPPORTED;
     if (((1 + f->geo_feat_dim + 31) / 32) * 32 > H) return CNC_ERR_UNSUPPORTED;
+    // the matrices are addressed with 32-bit byte offsets (buffer resources)
+    if ((uint64_t)f->N * (f->ld_x > H ? f->ld_x : H) * 4u >= (1ull << 32)) return CNC_ERR_UNSUPPORTED;
     if (!f->rgb || !f->base_out || !f->selector || !f->h1 || !f->h3 || !f->h4 || !f->G5 || !f->G4 || !f->G3 || !f->G2 || !f->G1 ||
         !f->dX || f->ld_base < 1 + f->geo_feat_dim || f->ld_g2 < 1 + f->geo_feat_dim || f->ld_g2 % 4 != 0 || f->ld_x < n_enc ||
         f->ld_x % 4 != 0)
@@ -284,11 +368,30 @@ extern "C" int cnc_field_backward_chain(const cnc_field_bwd_t* f, void* stream)
     }
     p.G5 = f->G5; p.G4 = f->G4; p.G3 = f->G3; p.G2 = f->G2; p.ld_g2 = f->ld_g2; p.G1 = f->G1; p.dX = f->dX; p.ld_x = f->ld_x;
     const uint32_t ld = NT == 5 ? 160u : NT * 32u + 8u;
-    const size_t   lds_bytes = (size_t)2 * 32 * ld * sizeof(half_t) + 16;
+    const size_t   lds_bytes = (size_t)2 * 32 * ld * sizeof(half_t) + 16 + (size_t)(3 * H + 84) * sizeof(float);
+    p.bias_grads = f->bias_grads;
     const uint32_t tiles = (p.N + 31u) / 32u;
     hipStream_t    s = (hipStream_t)stream;
-    // a few tiles per workgroup: the grid covers the chip several times over at the training step's 2^18 samples
-    const uint32_t blocks = tiles < 256u * 6u ? tiles : 256u * 6u;
+    // the grid is what is resident at once (the workgroups loop over the tiles); asked once per thread and device
+    static thread_local int cached_dev = -1;
+    static thread_local uint32_t cached_n[2] = {0, 0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return CNC_ERR_LAUNCH;
+    if (cached_dev != dev) {
+        int cus = 0, per5 = 0, per2 = 0;
+        const size_t lds5 = (size_t)2 * 32 * 160 * sizeof(half_t) + 16 + (size_t)(3 * 160 + 84) * sizeof(float);
+        const size_t lds2 = (size_t)2 * 32 * 72 * sizeof(half_t) + 16 + (size_t)(3 * 64 + 84) * sizeof(float);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per5, k_field_bwd_chain<5>, 128, lds5) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per2, k_field_bwd_chain<2>, 128, lds2) != hipSuccess || cus <= 0 ||
+            per5 <= 0 || per2 <= 0)
+            return CNC_ERR_LAUNCH;
+        cached_n[0] = (uint32_t)(per5 * cus);
+        cached_n[1] = (uint32_t)(per2 * cus);
+        cached_dev = dev;
+    }
+    const uint32_t resident = cached_n[NT == 5 ? 0 : 1];
+    const uint32_t blocks = tiles < resident ? tiles : resident;
     if (NT == 5) hipLaunchKernelGGL((k_field_bwd_chain<5>), dim3(blocks), dim3(128), lds_bytes, s, p);
     else hipLaunchKernelGGL((k_field_bwd_chain<2>), dim3(blocks), dim3(128), lds_bytes, s, p);
     return launch_status();

@@ -546,6 +546,9 @@ class _FieldChain(Function):
         for k in range(5):
             st.packed_weights_t[k] = wt[k].data_ptr()
         st.G5, st.G4, st.G3, st.G2, st.G1, st.dX = (t.data_ptr() for t in (G5, G4, G3, G2, G1, dX))
+        bsum = torch.zeros(3 * H + 84, dtype=torch.float32, device=dev)       # column sums of G4 | G3 | G1 | G2 | G5
+        st.bias_grads = bsum.data_ptr()
+        gb_of = (bsum[2 * H:3 * H], bsum[3 * H:3 * H + 1 + geo], bsum[H:2 * H], bsum[:H], bsum[3 * H + 80:3 * H + 83])
         import ctypes
         _lib.check(_lib.lib().cnc_field_backward_chain(ctypes.byref(st), _lib.stream(dev)), "field_backward_chain")
         need = ctx.needs_input_grad
@@ -558,7 +561,7 @@ class _FieldChain(Function):
                 if gw.shape[1] != width:
                     gw = gw[:, :width]
             if need[5 + 2 * i]:
-                gb = G.sum(0)
+                gb = gb_of[i]
             out += [gw, gb]
         return tuple(out)
 
@@ -609,6 +612,8 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         self.fused_chain = fused_features and os.environ.get("CNC_FUSED_CHAIN", "1") == "1"
         self._chain_supported = None
         self._chain_key = self._chain_wt = self._chain_src = None
+        from . import _caches
+        _caches.register(self)          # the transposed fragments: fused Adam updates weights without bumping `_version`
         # sample counts from here on run at a bucketed row count (`_bucket_rows`); CNC_ROW_BUCKET_MIN=0 pads every call
         self.row_bucket_min = int(os.environ.get("CNC_ROW_BUCKET_MIN", "4096"))
         self._head_shape_ok = n_neurons == 160       # the 32-row kernel is instantiated for 160-wide layers
@@ -649,6 +654,10 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
     def _glue_ok(self, x):
         return (self.fused_glue and x.is_cuda and x.dtype == torch.float32 and not self.unbounded and self.num_dim == 3
                 and self.density_activation is _default_density_activation and 1 + self.geo_feat_dim <= 128)
+
+    def invalidate_caches(self):
+        """After an optimizer step (cnc_amd._caches): the packed transposed weights of the gradient chain are stale."""
+        self._chain_key = None
 
     def _chain_ok(self, x_unit) -> bool:
         """The fused gradient chain (`_FieldChain`) applies: gradients wanted, the shapes the kernels are built for."""

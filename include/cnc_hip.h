@@ -799,6 +799,8 @@ typedef struct {
     float*         G2;                /* [N, ld_g2] ... base.2's (columns 0 .. geo; up to 16 * blocks zero-filled)     */
     float*         G1;                /* [N, H]     ... base.0's                                                      */
     float*         dX;                /* [N, ld_x]  out: columns [0, n_enc_columns) of the base network's input gradient */
+    float*         bias_grads;        /* (nullable) [3 H + 84] ZERO-INITIALISED by the caller; receives (atomic adds) the column
+                                         sums of G4 | G3 | G1 (H each) | G2 (80 slots) | G5 (4 slots): the bias gradients   */
 } cnc_field_bwd_t;
 int cnc_field_backward_chain(const cnc_field_bwd_t* chain, void* stream);
 
