@@ -19,6 +19,8 @@ def switch(on):
             tr._cs = tr.ctx_stream
         tr.ctx_stream = tr._cs if on else None
         tr.ctx_thread = False
+    elif what == "chain":
+        tr.field.fused_chain, tr.field._chain_supported = on, None
     elif what == "vbits":
         for e in tr.field.mlp_base._encoders():
             e.vertex_bits = on
