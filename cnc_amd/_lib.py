@@ -28,6 +28,12 @@ class CtxWindow(C.Structure):
                 ("row0", _i64 * 16), ("level", _i32 * 16), ("res", _i32 * 16), ("n_win", _i32)]
 
 
+class FieldSave(C.Structure):
+    """cnc_field_save_t (include/cnc_hip.h)."""
+    _fields_ = [("feat", _vp), ("ld_feat", _u32), ("h1", _vp), ("h3", _vp), ("h4", _vp), ("head_in", _vp), ("ld_head", _u32),
+                ("raw", _vp), ("selector", _vp), ("xyz", _vp), ("xy", _vp), ("xz", _vp), ("yz", _vp), ("n_live", _u32)]
+
+
 class FusedField(C.Structure):
     """cnc_fused_field_t (include/cnc_hip.h)."""
     _fields_ = [("aabb", _vp), ("bits", _vp * 4), ("offsets", _vp * 4), ("resolutions", _vp * 4), ("freqs", _vp),
@@ -35,7 +41,7 @@ class FusedField(C.Structure):
                 ("units", _vp), ("n_levels", _u32 * 4),
                 ("n_features", _u32), ("n_freqs", _u32), ("n_neurons", _u32), ("geo_feat_dim", _u32), ("flags", _u32),
                 ("packed_weights16q", _vp * 5), ("guard", _vp), ("call_id", _u32), ("pack_id", _u32),
-                ("debug_features", _vp), ("debug_ld", _u32)]
+                ("debug_features", _vp), ("debug_ld", _u32), ("save", FieldSave)]
 
 
 class FieldBwd(C.Structure):
@@ -160,7 +166,7 @@ CNC_PACK_TRANSPOSE = 1
 CNC_PACK_ZERO_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 26          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 27          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

@@ -355,7 +355,7 @@ extern "C" int cnc_field_backward_chain(const cnc_field_bwd_t* f, void* stream)
     // the matrices are addressed with 32-bit byte offsets (buffer resources)
     if ((uint64_t)f->N * (f->ld_x > H ? f->ld_x : H) * 4u >= (1ull << 32)) return CNC_ERR_UNSUPPORTED;
     if (!f->rgb || !f->base_out || !f->selector || !f->h1 || !f->h3 || !f->h4 || !f->G5 || !f->G4 || !f->G3 || !f->G2 || !f->G1 ||
-        !f->dX || f->ld_base < 1 + f->geo_feat_dim || f->ld_g2 < 1 + f->geo_feat_dim || f->ld_g2 % 4 != 0 || f->ld_x < n_enc ||
+        !f->dX || f->ld_base < 1 || f->ld_g2 < 1 + f->geo_feat_dim || f->ld_g2 % 4 != 0 || f->ld_x < n_enc ||
         f->ld_x % 4 != 0)
         return CNC_ERR_INVALID_VALUE;
     FieldBwdArgs p{};

@@ -624,6 +624,16 @@ extern "C" int cnc_field_fused_forward(const cnc_fused_field_t* f, const float* 
         }
         if (two_waves && 1 + p.geo > (NT == 5 ? 80u : 64u)) return CNC_ERR_UNSUPPORTED;
     }
+    const bool saving = f->save.feat != nullptr;
+    if (saving) {                        // the gradient pass's forward: the two-wave colour kernel, saving variant
+        const cnc_field_save_t& sv = f->save;
+        if (!two_waves || !want_rgb || f->debug_features) return CNC_ERR_UNSUPPORTED;
+        if (!sv.h1 || !sv.h3 || !sv.h4 || !sv.head_in || !sv.raw || !sv.selector || !sv.xyz || !sv.xy || !sv.xz || !sv.yz ||
+            sv.ld_feat < p.nkb1 * 8 || sv.ld_feat % 4 != 0 || sv.ld_head != p.nk32_h * 32 || sv.n_live > N)
+            return CNC_ERR_INVALID_VALUE;
+        p.save = FieldSave{sv.feat, sv.ld_feat, sv.h1, sv.h3, sv.h4, sv.head_in, sv.ld_head, sv.raw, sv.selector,
+                           sv.xyz, sv.xy, sv.xz, sv.yz, sv.n_live};
+    }
     const uint32_t tiles = (N + 31) / 32;
     uint32_t lds_floats = 32 * kChunkPitch;
     if (want_rgb) lds_floats = 32 * (H + kPadH);
@@ -665,7 +675,7 @@ extern "C" int cnc_field_fused_forward(const cnc_fused_field_t* f, const float* 
         if (two_waves) rc = launch_field_fused_w2(p, want_rgb, FV, H, (f->flags & CNC_FIELD_WAVES4) ? 4 : 3, s); \
         else if (f16x3 && want_rgb) CNC_FF_GRID((k_field_fused16<FV, NTV, true>), lds16);               \
         else if (f16x3) CNC_FF_GRID((k_field_fused16<FV, NTV, false>), lds16);                          \
-        if (rc != CNC_OK) break;                                                                        \
+        if (rc != CNC_OK || saving) break;           /* the saving variant saturates: nothing runs behind it */ \
         /* the exact form: the whole call without the fp16 flag, the guard's conditional fallback with it */ \
         p.only_if_flagged = f16x3 ? 1u : 0u;                                                            \
         if (want_rgb) CNC_FF_GRID((k_field_fused<FV, NTV, true>), lds32);                               \

@@ -44,10 +44,13 @@ __host__ __device__ constexpr uint32_t kUnitTableAt()
 
 // x = acc / 2^8 + bias (ReLU) of a column-split layer -> the two half planes.  Lane (r, kq) holds sample rb * 16 + r,
 // output features 16 (cb0 + cb) + 4 kq + v: four halves = 8 bytes inside one 16-byte chunk of the (swizzled) row.
-template <int NCB, int NT>
+// `save` (the gradient pass's forward): the same values as float32 into rows [row0, row0 + 32) of an [n_rows, 32 NT]
+// matrix, 16 bytes per lane and column block.
+template <int NCB, int NT, bool SAVE = false>
 __device__ __forceinline__ void acc_to_planes(half_t* __restrict__ d_hi, half_t* __restrict__ d_lo,
                                               const float* __restrict__ bias, const f32x4 (&acc)[2][NCB], uint32_t cb0,
-                                              uint32_t lane, float& mx)
+                                              uint32_t lane, float& mx, float* __restrict__ save = nullptr, uint32_t row0 = 0,
+                                              uint32_t n_rows = 0)
 {
     using P = Plane2<NT>;
     const uint32_t r = lane & 15u, kq = lane >> 4;
@@ -59,15 +62,23 @@ __device__ __forceinline__ void acc_to_planes(half_t* __restrict__ d_hi, half_t*
 #pragma unroll
         for (int rb = 0; rb < 2; rb++) {
             half4_t xh, xl;
+            float   xs[4];
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 float x = __builtin_fmaf(acc[rb][cb][v], kWScaleInv, bb[v]);
-                x = x > 0 ? x : 0;
-                mx = fmaxf(mx, x);
+                mx = fmaxf(mx, x);                                   // mx >= 0: the maximum of the ReLU's outputs
+                // the gradient pass has no exact-fp32 kernel behind it: a value beyond fp16's range saturates (same
+                // instruction count: one v_med3 for the v_max) and the guard word reports it
+                x = SAVE ? __builtin_amdgcn_fmed3f(x, 0.0f, kHalfMax) : (x > 0 ? x : 0);
                 half_t h, l;
                 split_half(x, h, l);
                 xh[v] = h;
                 xl[v] = l;
+                xs[v] = x;
+            }
+            if constexpr (SAVE) {
+                const uint32_t row = row0 + rb * 16u + r;
+                if (row < n_rows) store_vec<4>(save + (size_t)row * (32u * NT) + col0, xs);
             }
             const uint32_t at = P::at(rb * 16u + r, col0);
             *reinterpret_cast<half4_t*>(d_hi + at) = xh;
@@ -89,10 +100,15 @@ __device__ __forceinline__ void acc_to_planes(half_t* __restrict__ d_hi, half_t*
 #define W2_MARK(k) do { } while (0)
 #endif
 
-template <uint32_t F, int NT, bool RGB, int WPE, bool DUMP = false>
+// MODE 0: the gradient-free evaluator.  1 (density, test hook): + the first layer's input rows into p.dbg_features.
+// 2 (colour): the gradient pass's forward — + everything the backward reads into p.save (FieldSave), rows [n_live, N)
+// evaluated as points outside the box, values beyond fp16's range saturated instead of recomputed.
+template <uint32_t F, int NT, bool RGB, int WPE, int MODE = 0>
 __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
 {
-    using RowT = std::conditional_t<DUMP, RowDump<RowF16>, RowF16>;
+    constexpr bool DUMP = MODE == 1, SAVE = MODE == 2;
+    static_assert(!SAVE || RGB, "the saving variant is the colour kernel");
+    using RowT = std::conditional_t<DUMP, RowDump<RowF16>, std::conditional_t<SAVE, RowSave<RowF16>, RowF16>>;
 #ifdef CNC_W2_PROF
     uint64_t prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t t_prev = __builtin_amdgcn_s_memtime();
@@ -116,7 +132,9 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
         amin[a] = p.aabb[a];
         aext[a] = p.aabb[3 + a] - p.aabb[a];
     }
-    if (guard_weights_flagged(p, RGB)) return;
+    // (a flagged weight: the exact-fp32 kernel behind this one computes the call.  The saving form has none behind it
+    // and goes on: its outputs are non-finite then, and the caller finds the flag — cnc_field_save_t.)
+    if (!SAVE && guard_weights_flagged(p, RGB)) return;
     // the unit table (one 16-byte record per (encoder, level)) in LDS, behind everything else
     uint4* const unit_lds = reinterpret_cast<uint4*>(lds16 + kUnitTableAt<NT, RGB>());
     for (uint32_t u = tid; u < p.n_units; u += 128) unit_lds[u] = p.units[u];
@@ -132,15 +150,26 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
     constexpr bool kDB = WPE <= 3;                       // hidden layers: two sets of weight registers
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const uint32_t row0 = tile * 32, frow = row0 + fi;
-        const bool     live = frow < p.N;
+        const bool     live = frow < p.N;                                    // the row exists: its results are stored
+        const bool     live_in = SAVE ? frow < p.save.n_live : live;         // ... and has a position / direction
         float xu[3] = {-1.0f, -1.0f, -1.0f};
-        bool  sel = live;
-        if (live) {
+        bool  sel = live_in;
+        if (live_in) {
 #pragma unroll
             for (int a = 0; a < 3; a++) {
                 const float v = (p.pos[(size_t)frow * 3 + a] - amin[a]) / aext[a];
                 xu[a] = v;
                 sel = sel && v > 0.0f && v < 1.0f;
+            }
+        }
+        if constexpr (SAVE) {
+            if (live && fq == 0) {                                           // what k_field_prepare writes, + the plane pairs
+                p.save.selector[frow] = sel ? 1 : 0;
+#pragma unroll
+                for (int a = 0; a < 3; a++) p.save.xyz[(size_t)frow * 3 + a] = xu[a];
+                *reinterpret_cast<float2*>(p.save.xy + (size_t)frow * 2) = make_float2(xu[0], xu[1]);
+                *reinterpret_cast<float2*>(p.save.xz + (size_t)frow * 2) = make_float2(xu[0], xu[2]);
+                *reinterpret_cast<float2*>(p.save.yz + (size_t)frow * 2) = make_float2(xu[1], xu[2]);
             }
         }
 
@@ -160,6 +189,7 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                 trow.hi = c_hi + fi * kCP;
                 trow.lo = c_lo + fi * kCP;
                 if constexpr (DUMP) trow.dbg = live ? p.dbg_features + (size_t)frow * p.dbg_ld + c * 32 : nullptr;
+                if constexpr (SAVE) trow.out = live ? p.save.feat + (size_t)frow * p.save.ld_feat + c * 32 : nullptr;
                 const uint32_t w0 = c * 32 + 8 * fq, col0 = c * 32 + 16 * wu;
                 const uint32_t u_first = col0 / F, u_last = (col0 + 15) / F;
                 uint32_t       kind = 3;                                         // 3: mixed -> the general fill
@@ -240,7 +270,7 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
             W2_MARK(3);
         } else {
             __syncthreads();                                   // the last chunk has been read: the planes alias it
-            acc_to_planes<NCB, NT>(h_hi, h_lo, p.Bp[0], acc, w * NCB, lane, mx);
+            acc_to_planes<NCB, NT, SAVE>(h_hi, h_lo, p.Bp[0], acc, w * NCB, lane, mx, p.save.h1, row0, p.N);
             __syncthreads();
             W2_MARK(4);
             // ---- layer 2 (H -> 1 + geo), split by rows: wave w owns rows [16 w, 16 w + 16) ----
@@ -260,16 +290,24 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                 const float4 b4 = *reinterpret_cast<const float4*>(p.Bp[1] + c0);
                 const float  bb[4] = {b4.x, b4.y, b4.z, b4.w};
                 half4_t xh, xl;
+                float   xs[4];
 #pragma unroll
                 for (int v = 0; v < 4; v++) {
-                    const float x = __builtin_fmaf(acc2[0][cb][v], kWScaleInv, bb[v]);
+                    float x = __builtin_fmaf(acc2[0][cb][v], kWScaleInv, bb[v]);
                     if (cb == 0 && v == 0 && kq == 0) dens[w * 16 + r] = x;
                     mx = fmaxf(mx, (c0 + v >= 1u && c0 + v <= p.geo) ? fabsf(x) : 0.0f);
                     // density_raw may be anything finite or not: what goes into its (zero-weight) column is 0
+                    x = (c0 + v == 0u) ? 0.0f : x;
+                    if constexpr (SAVE) x = __builtin_amdgcn_fmed3f(x, -kHalfMax, kHalfMax);
                     half_t h, l;
-                    split_half((c0 + v == 0u) ? 0.0f : x, h, l);
+                    split_half(x, h, l);
                     xh[v] = h;
                     xl[v] = l;
+                    xs[v] = x;
+                }
+                if constexpr (SAVE) {
+                    const uint32_t row = row0 + w * 16u + r;
+                    if (row < p.N) store_vec<4>(p.save.head_in + (size_t)row * p.save.ld_head + 16u + c0, xs);
                 }
                 const uint32_t at = P::at(w * 16u + r, 16u + c0);
                 *reinterpret_cast<half4_t*>(h_hi + at) = xh;
@@ -281,7 +319,7 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                 // one tile per call, cause not found; tests/test_gpu_field_fused.py::test_fused_field_is_repeatable is the
                 // detector that caught it)
                 float d3[3] = {0.0f, 0.0f, 1.0f};
-                if (live) {
+                if (live_in) {
 #pragma unroll
                     for (int a = 0; a < 3; a++) d3[a] = ((p.dirs[(size_t)frow * 3 + a] + 1.0f) / 2.0f) * 2.0f - 1.0f;
                 }
@@ -293,21 +331,27 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                 }
                 const RowF16 hrow{h_hi, h_lo};
                 hrow.put<4>(P::at(fi, 4 * fq), v4);                  // 4 halves inside one 16-byte chunk
+                if constexpr (SAVE) {
+                    if (live) store_vec<4>(p.save.head_in + (size_t)frow * p.save.ld_head + 4 * fq, v4);
+                }
             }
             __syncthreads();
             W2_MARK(6);
-            if (tid < 32 && live) p.density[frow] = sel ? expf(dens[tid] - 1.0f) : 0.0f;
+            if (tid < 32 && live) {
+                p.density[frow] = sel ? expf(dens[tid] - 1.0f) : 0.0f;
+                if constexpr (SAVE) p.save.raw[frow] = dens[tid];
+            }
             // ---- head: (16 + geo) -> H -> H -> 3 ----
             layer_q<2, NCB, NT, kDB>(h_hi, h_lo, Kh / 32, p.Wq16[2], NCBT, w * NCB, 0, acc, lane);
             __syncthreads();
             W2_MARK(7);
-            acc_to_planes<NCB, NT>(h_hi, h_lo, p.Bp[2], acc, w * NCB, lane, mx);
+            acc_to_planes<NCB, NT, SAVE>(h_hi, h_lo, p.Bp[2], acc, w * NCB, lane, mx, p.save.h3, row0, p.N);
             __syncthreads();
             W2_MARK(8);
             layer_q<2, NCB, NT, kDB>(h_hi, h_lo, NT, p.Wq16[3], NCBT, w * NCB, 0, acc, lane);
             __syncthreads();
             W2_MARK(9);
-            acc_to_planes<NCB, NT>(h_hi, h_lo, p.Bp[3], acc, w * NCB, lane, mx);
+            acc_to_planes<NCB, NT, SAVE>(h_hi, h_lo, p.Bp[3], acc, w * NCB, lane, mx, p.save.h4, row0, p.N);
             __syncthreads();
             W2_MARK(10);
             f32x4 acc5[1][1];
@@ -476,8 +520,11 @@ int launch_field_fused_w2(const FusedFieldArgs& p, bool rgb, uint32_t F, uint32_
 #define CNC_W2_RGB(FV, NTV)                 \
     do {                                    \
         if (p.dbg_features) {               \
-            rc = resident_grid(k_field_fused16w2<FV, NTV, false, 3, true>, lds_bytes, tiles, 16, &blocks); \
-            if (rc == CNC_OK) hipLaunchKernelGGL((k_field_fused16w2<FV, NTV, false, 3, true>), dim3(blocks), dim3(128), lds_bytes, s, p); \
+            rc = resident_grid(k_field_fused16w2<FV, NTV, false, 3, 1>, lds_bytes, tiles, 16, &blocks); \
+            if (rc == CNC_OK) hipLaunchKernelGGL((k_field_fused16w2<FV, NTV, false, 3, 1>), dim3(blocks), dim3(128), lds_bytes, s, p); \
+        } else if (p.save.feat) {           \
+            rc = resident_grid(k_field_fused16w2<FV, NTV, true, 3, 2>, lds_bytes, tiles, 16, &blocks); \
+            if (rc == CNC_OK) hipLaunchKernelGGL((k_field_fused16w2<FV, NTV, true, 3, 2>), dim3(blocks), dim3(128), lds_bytes, s, p); \
         } else if (rgb) CNC_W2_W(FV, NTV, true); \
         else CNC_W2_W(FV, NTV, false);      \
     } while (0)

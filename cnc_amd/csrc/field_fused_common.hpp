@@ -21,6 +21,26 @@ struct FieldEnc {
     uint32_t       n_levels;
 };
 
+// The gradient pass's forward (k_field_fused16w2<.., SAVE>): everything the backward reads, written by the one kernel that
+// computes it.  Row-major float32, `N` rows each (N = the bucketed row count: rows [n_live, N) are rows of padding,
+// evaluated as a point outside the box — zero grid features, selector 0 — so that what is stored for them is finite).
+struct FieldSave {
+    float*   feat;        // [N, ld_feat] the first layer's input: [grid features | x | sinusoids | 0]
+    uint32_t ld_feat;     // >= 32 * chunks, a multiple of 4
+    float*   h1;          // [N, H] relu(layer 1)
+    float*   h3;          // [N, H] relu(head layer 1)
+    float*   h4;          // [N, H] relu(head layer 2)
+    float*   head_in;     // [N, ld_head] [SH4 (16) | 0 | geo features | 0]: the kernel's own head-input layout
+    uint32_t ld_head;     // roundup32(17 + geo)
+    float*   raw;         // [N] density before its activation
+    uint8_t* selector;    // [N]
+    float*   xyz;         // [N, 3] unit-cube positions; [N, 2] their xy / xz / yz pairs (the four encoders' inputs)
+    float*   xy;
+    float*   xz;
+    float*   yz;
+    uint32_t n_live;      // positions / directions are read for rows < n_live only
+};
+
 struct FusedFieldArgs {
     const float* pos;
     const float* dirs;
@@ -54,6 +74,7 @@ struct FusedFieldArgs {
     const half_t_* Wq16[5];       // fragments of the 16x16x32 form (cnc_field_pack_all), k_field_fused16w2
     float*         dbg_features;  // test hook (cnc_fused_field_t.debug_features): [N, dbg_ld] first-layer input rows
     uint32_t       dbg_ld;
+    FieldSave      save;          // cnc_fused_field_t.save (feat != nullptr: the gradient pass's forward)
 };
 
 constexpr uint32_t kChunkPitch = 36;     // floats per row of the 32 x 32 chunk tile (+4: conflict-free b128 accesses)
@@ -324,6 +345,24 @@ struct RowDump : Base {
     }
 };
 
+// RowF16 that also writes the values as float32 into the saved feature matrix (FieldSave::feat), vector stores: `out` =
+// the sample's row at this chunk's first column (16-byte aligned: ld_feat % 4 == 0), nullptr for a row that is not stored
+template <typename Base>
+struct RowSave : Base {
+    float* out;
+    template <uint32_t V>
+    __device__ __forceinline__ void put(uint32_t col, const float (&v)[V]) const
+    {
+        Base::template put<V>(col, v);
+        if (out) store_vec<V>(out + col, v);
+    }
+    __device__ __forceinline__ void put1(uint32_t col, float v) const
+    {
+        Base::put1(col, v);
+        if (out) out[col] = v;
+    }
+};
+
 struct RowF16 {
     static constexpr bool kFastSin = true;
     // a raw unit-cube coordinate of a sample far outside the box (selector 0: its density is exactly zero whatever
@@ -372,6 +411,9 @@ __device__ __forceinline__ void fast_sincos(float x, float* s, float* c)
     *s = __builtin_amdgcn_sinf(r);
     *c = __builtin_amdgcn_cosf(r);
 }
+
+template <typename Row, uint32_t WC>
+__device__ __forceinline__ void fill_tail(const FusedFieldArgs& p, const float (&xu)[3], uint32_t w0, uint32_t U, const Row& trow);
 
 // Columns [w0, w0 + WC) of the feature row of one sample into its row of the chunk tile (`trow`, chunk-relative
 // column w0 & 31).  Feature row = [units: n_units x F | x (3) | sin(f_k x) (3), cos(f_k x) (3) for k < n_freqs | 0 ...].

@@ -1100,4 +1100,4 @@ extern "C" const char* cnc_error_string(int code)
     }
 }
 
-extern "C" int cnc_abi_version(void) { return 26; }
+extern "C" int cnc_abi_version(void) { return 27; }

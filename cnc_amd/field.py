@@ -176,17 +176,23 @@ class _FusedFeatures(Function):
 
     @staticmethod
     def backward(ctx, grad):
-        from .backends import gridencoder_backend as be
-        owner = ctx.owner
-        encs = owner._encoders()
         t = ctx.saved_tensors
         xs, params, clips = t[0:4], t[4:8], t[8:12]
+        # rows of padding behind the N samples (`rows`) carry none
+        grads = _FusedFeatures.scatter(ctx.owner, grad.contiguous(), xs, params, clips, xs[0].shape[0], ctx.sink)
+        return (None, None, None, *grads)
+
+    @staticmethod
+    def scatter(owner, grad, xs, params, clips, N, sink):
+        """The four encoders' backward on the gradient of the feature matrix `grad` [>= N, ld] (read in place: the
+        encoders' columns of the first N rows): per table the gradient tensor, or None when it went into `sink` (the
+        training step's per-table gradient buffers, cnc_amd._gradsink)."""
+        from .backends import gridencoder_backend as be
         ld, cols = owner._layout()
-        grad = grad.contiguous()
-        N = xs[0].shape[0]                 # rows of padding behind them (`rows`) carry no sample
-        sink = ctx.sink                    # the training step's per-table gradient buffers (cnc_amd._gradsink)
+        if grad.shape[1] != ld:
+            raise RuntimeError("feature gradient: wrong row length")
         grads = []
-        for enc, p, xi, clip, col in zip(encs, params, xs, clips, cols):
+        for enc, p, xi, clip, col in zip(owner._encoders(), params, xs, clips, cols):
             sunk = None if sink is None else sink.table(p)
             g = torch.zeros_like(p) if sunk is None else sunk
             be.grid_encode_backward(grad, xi, p, enc.offsets_list, enc.resolutions_list, g, N,
@@ -194,7 +200,7 @@ class _FusedFeatures(Function):
                                     None, None, ste_binary=True, ste_clip_count=clip,
                                     grad_ld=ld, grad_col=col, binned=enc._binned_plan(N))
             grads.append(g if sunk is None else None)
-        return (None, None, None, *grads)
+        return grads
 
 
 class compose_3D_2D_embed(nn.Module):
@@ -414,30 +420,21 @@ class FusedFieldForward:
         self._src = [(l.weight, l.bias) for l in layers]        # keep (data_ptr, version) unique while cached
         return buf
 
-    @torch.no_grad()
-    def __call__(self, positions: torch.Tensor, directions=None, debug_features=None):
-        """density [N, 1] (and rgb [N, 3] when `directions` is given) of world positions [N, 3].  `debug_features` (test
-        hook, density-only two-wave calls): a float32 [N, >= roundup32(K0)] tensor that receives the first layer's input
-        rows as the kernel computed them."""
+    def _descriptor(self, dev, want_rgb: bool, params=None):
+        """(cnc_fused_field_t filled in for a call on `dev`, the tensors it points to, the encoders' clip counts).
+        `params`: the four tables to read (default: the encoders' own)."""
         from . import _lib
         f = self.field
         mb = f.mlp_base
-        x = positions.reshape(-1, 3)
-        if x.dtype != torch.float32 or not x.is_cuda:
-            raise RuntimeError("FusedFieldForward: positions must be a float32 CUDA tensor")
-        x = x.contiguous()
-        N, dev = x.shape[0], x.device
-        d = None
-        if directions is not None:
-            d = directions.reshape(-1, 3).to(torch.float32).contiguous()
         buf = self._pack(dev)
         st = _lib.FusedField()
         aabb = f.aabb if f.aabb.is_contiguous() else f.aabb.contiguous()
         st.aabb = aabb.data_ptr()
-        keep = [aabb]
+        keep, clips = [aabb], []
         for k, e in enumerate(mb._encoders()):
-            bits, _ = e._bit_plane(e.params)
+            bits, clip = e._bit_plane(e.params if params is None else params[k])
             keep.append(bits)
+            clips.append(clip)
             st.bits[k], st.offsets[k], st.resolutions[k] = bits.data_ptr(), e.offsets_list.data_ptr(), e.resolutions_list.data_ptr()
             st.n_levels[k] = e.n_levels
         if mb._freqs.device != dev or mb._freqs.dtype != torch.float32:
@@ -463,12 +460,29 @@ class FusedFieldForward:
             if f.fused_field_kernel == "w2":
                 # two cooperating waves per tile; the density-only kernel fits four waves per SIMD, the colour kernel three
                 flags |= _lib.CNC_FIELD_TWO_WAVES
-                waves = f.fused_field_waves or (4 if d is None else 3)
+                waves = f.fused_field_waves or (3 if want_rgb else 4)
                 if waves >= 4:
                     flags |= _lib.CNC_FIELD_WAVES4
         st.flags = flags
         self._call_id = self._call_id % 0xFFFFFFF0 + 1
         st.guard, st.call_id, st.pack_id = buf["guard"].data_ptr(), self._call_id, self._pack_id
+        return st, keep, clips
+
+    @torch.no_grad()
+    def __call__(self, positions: torch.Tensor, directions=None, debug_features=None):
+        """density [N, 1] (and rgb [N, 3] when `directions` is given) of world positions [N, 3].  `debug_features` (test
+        hook, density-only two-wave calls): a float32 [N, >= roundup32(K0)] tensor that receives the first layer's input
+        rows as the kernel computed them."""
+        from . import _lib
+        x = positions.reshape(-1, 3)
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise RuntimeError("FusedFieldForward: positions must be a float32 CUDA tensor")
+        x = x.contiguous()
+        N, dev = x.shape[0], x.device
+        d = None
+        if directions is not None:
+            d = directions.reshape(-1, 3).to(torch.float32).contiguous()
+        st, keep, _ = self._descriptor(dev, d is not None)
         if debug_features is not None:
             assert debug_features.dtype == torch.float32 and debug_features.is_contiguous() and debug_features.shape[0] == N
             st.debug_features, st.debug_ld = debug_features.data_ptr(), debug_features.shape[1]
@@ -478,6 +492,47 @@ class FusedFieldForward:
         _lib.check(_lib.lib().cnc_field_fused_forward(ctypes.byref(st), x.data_ptr(), _lib.ptr(d), N, density.data_ptr(),
                                                       _lib.ptr(rgb), _lib.stream(dev)), "field_fused_forward")
         return (density, rgb) if d is not None else density
+
+    @torch.no_grad()
+    def save_forward(self, positions: torch.Tensor, directions: torch.Tensor, rows: int, params=None):
+        """The gradient pass's forward (cnc_field_save_t): rgb [rows, 3], density [rows, 1] of the N <= `rows` world
+        positions — rows behind them are evaluated as points outside the box — and, in a dict, everything the backward
+        reads, written by the same kernel: feat, h1, h3, h4, head_in, raw, selector, xyz / xy / xz / yz, + the encoders'
+        clip counts.  Needs the two-wave three-product kernel (the default)."""
+        from . import _lib
+        f = self.field
+        if f.fused_field_precision != "f16x3" or f.fused_field_kernel != "w2":
+            raise RuntimeError("save_forward: the two-wave fp16 kernel only")
+        x = positions.reshape(-1, 3).contiguous()
+        d = directions.reshape(-1, 3).contiguous()
+        if x.dtype != torch.float32 or d.dtype != torch.float32 or not x.is_cuda or x.shape != d.shape:
+            raise RuntimeError("save_forward: float32 CUDA positions and directions of one shape")
+        N, dev = x.shape[0], x.device
+        Np = max(int(rows), N)
+        st, keep, clips = self._descriptor(dev, True, params)
+        mb = f.mlp_base
+        H, geo = mb.network[0].out_features, f.geo_feat_dim
+        ld = (mb.network[0].in_features + 31) // 32 * 32
+        ldh = (17 + geo + 31) // 32 * 32
+        new = lambda *shape, dtype=torch.float32: torch.empty(shape, dtype=dtype, device=dev)
+        out = {"feat": new(Np, ld), "h1": new(Np, H), "h3": new(Np, H), "h4": new(Np, H), "head_in": new(Np, ldh),
+               "raw": new(Np, 1), "selector": new(Np, dtype=torch.uint8), "xyz": new(Np, 3), "xy": new(Np, 2),
+               "xz": new(Np, 2), "yz": new(Np, 2)}
+        sv = st.save
+        sv.feat, sv.ld_feat, sv.h1, sv.h3, sv.h4 = out["feat"].data_ptr(), ld, out["h1"].data_ptr(), out["h3"].data_ptr(), out["h4"].data_ptr()
+        sv.head_in, sv.ld_head, sv.raw, sv.selector = out["head_in"].data_ptr(), ldh, out["raw"].data_ptr(), out["selector"].data_ptr()
+        sv.xyz, sv.xy, sv.xz, sv.yz, sv.n_live = out["xyz"].data_ptr(), out["xy"].data_ptr(), out["xz"].data_ptr(), out["yz"].data_ptr(), N
+        density, rgb = new(Np, 1), new(Np, 3)
+        import ctypes
+        _lib.check(_lib.lib().cnc_field_fused_forward(ctypes.byref(st), x.data_ptr(), d.data_ptr(), Np, density.data_ptr(),
+                                                      rgb.data_ptr(), _lib.stream(dev)), "field_fused_forward(save)")
+        self._train_calls = True
+        out["clips"] = clips
+        return rgb, density, out
+
+    def guard_words(self):
+        """The range guard's words on the host (a synchronisation): [last call that saturated / overflowed, layer flags]."""
+        return None if self._buffers is None else self._buffers["guard"][:6].tolist()
 
     def range_guard_fired(self) -> bool:
         """True when the LAST call left fp16's range and was recomputed by the exact kernel (reads one word back: a
@@ -523,11 +578,21 @@ class _FieldChain(Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_density):
+        feat, selector, h1, base_out, head_in, h3, h4, rgb, W1, W2, W3, W4, W5 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dX, layer_grads = _FieldChain.chain(ctx.field, g_rgb, g_density, feat, selector, h1, base_out, head_in, h3, h4, rgb,
+                                            (W1, W2, W3, W4, W5), need[4:14], ctx.field.mlp_base._layout()[0], gap=False)
+        return (dX if need[0] else None, None, None, None, *layer_grads)
+
+    @staticmethod
+    def chain(field, g_rgb, g_density, feat, selector, h1, base_out, head_in, h3, h4, rgb, Ws, need, ld_x, gap):
+        """(dX [Np, ld_x]: the gradient of the feature matrix's encoder columns; [dW1, db1, ..., dW5, db5], None where
+        `need` says so) from the gradients of rgb / density and what the forward kept.  `base_out`: [Np, >= 1], column 0
+        = the raw density.  `gap`: `head_in` is in the fused kernel's layout [SH4 | 0 | geo] (cnc_field_save_t)."""
         from . import _lib
         from .mlp import splitk_weight_grad
-        feat, selector, h1, base_out, head_in, h3, h4, rgb, W1, W2, W3, W4, W5 = ctx.saved_tensors
-        field = ctx.field
-        dev, Np, ld = feat.device, feat.shape[0], feat.shape[1]
+        W1, W2, W3, W4, W5 = Ws
+        dev, Np = feat.device, feat.shape[0]
         H, geo, K0 = W1.shape[0], field.geo_feat_dim, W1.shape[1]
         n_enc = sum(e.n_output_dims for e in field.mlp_base._encoders())
         wt = field._chain_weights_t(W1, W2, W3, W4, W5, n_enc)
@@ -535,10 +600,10 @@ class _FieldChain(Function):
         G5 = torch.empty((Np, 4), dtype=torch.float32, device=dev)
         G4, G3, G1 = (torch.empty((Np, H), dtype=torch.float32, device=dev) for _ in range(3))
         G2 = torch.empty((Np, ld2), dtype=torch.float32, device=dev)
-        dX = torch.empty((Np, ld), dtype=torch.float32, device=dev)       # only the encoder columns are written — and read
+        dX = torch.empty((Np, ld_x), dtype=torch.float32, device=dev)     # only the encoder columns are written — and read
         st = _lib.FieldBwd()
         st.N, st.n_neurons, st.n_features, st.n_enc_columns, st.geo_feat_dim = Np, H, field.mlp_base.encoding_xyz.n_features, n_enc, geo
-        st.ld_base, st.ld_g2, st.ld_x = base_out.shape[1], ld2, ld
+        st.ld_base, st.ld_g2, st.ld_x = base_out.shape[1], ld2, ld_x
         gr = None if g_rgb is None else g_rgb.contiguous()
         gd = None if g_density is None else g_density.contiguous()
         st.grad_rgb, st.grad_density, st.rgb, st.base_out = _lib.ptr(gr), _lib.ptr(gd), rgb.data_ptr(), base_out.data_ptr()
@@ -551,19 +616,58 @@ class _FieldChain(Function):
         gb_of = (bsum[2 * H:3 * H], bsum[3 * H:3 * H + 1 + geo], bsum[H:2 * H], bsum[:H], bsum[3 * H + 80:3 * H + 83])
         import ctypes
         _lib.check(_lib.lib().cnc_field_backward_chain(ctypes.byref(st), _lib.stream(dev)), "field_backward_chain")
-        need = ctx.needs_input_grad
-        out = [dX if need[0] else None, None, None, None]
+        out = []
         for i, (G, A, width) in enumerate(((G1, feat, K0), (G2[:, :1 + geo], h1, H), (G3, head_in, 16 + geo), (G4, h3, H),
                                             (G5[:, :3], h4, H))):
             gw = gb = None
-            if need[4 + 2 * i]:
+            if need[2 * i]:
                 gw = splitk_weight_grad(G, A)
-                if gw.shape[1] != width:
+                if i == 2 and gap:            # [SH4 | the raw density's slot | geo]: the slot is not an input of the layer
+                    gw = torch.cat([gw[:, :16], gw[:, 17:17 + geo]], dim=1)
+                elif gw.shape[1] != width:
                     gw = gw[:, :width]
-            if need[5 + 2 * i]:
+            if need[2 * i + 1]:
                 gb = gb_of[i]
             out += [gw, gb]
-        return tuple(out)
+        return dX, out
+
+
+class _FieldTrain(Function):
+    """The radiance field of the gradient pass, world positions + view directions -> (rgb, density), as TWO kernels and
+    the weight gradients: forward = the fused evaluator in its saving form (cnc_field_save_t: the four encoders, the
+    sinusoids, both MLPs, the activations — one launch that also writes what the backward reads), backward =
+    cnc_field_backward_chain, the five weight gradients, and the four encoders' scatter (`_FusedFeatures.scatter`).
+    Replaces `_prepare` + `_FusedFeatures` + `_FieldChain`: 4 encoder launches, the sinusoid kernel, 5 library GEMMs, the
+    post kernel, the sigmoid, 3 slice copies and their fills.
+
+    Values: the layers in the three-product fp16 form (~5e-7 per term) where the op chain runs fp32
+    library GEMMs; the encoders' features are bit-identical.  Rows [N, Np) are rows of padding (`_bucket_rows`)."""
+
+    @staticmethod
+    def forward(ctx, positions, dirs, field, Np, *params_and_layers):
+        params, layers = params_and_layers[:4], params_and_layers[4:]
+        rgb, density, kept = field._field_fused.save_forward(positions, dirs, Np, params)
+        ctx.save_for_backward(kept["feat"], kept["selector"], kept["h1"], kept["raw"], kept["head_in"], kept["h3"], kept["h4"],
+                              rgb, kept["xyz"], kept["xy"], kept["xz"], kept["yz"], *params, *kept["clips"], *layers[0::2])
+        ctx.field, ctx.N = field, positions.shape[0]
+        from . import _gradsink
+        ctx.sink = _gradsink.current()     # the caller thread's sink; the backward runs on autograd's own thread
+        ctx.mark_non_differentiable(kept["selector"])
+        return rgb, density
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_density):
+        t = ctx.saved_tensors
+        feat, selector, h1, raw, head_in, h3, h4, rgb = t[:8]
+        xs, params, clips, Ws = t[8:12], t[12:16], t[16:20], t[20:25]
+        field, need = ctx.field, ctx.needs_input_grad
+        owner = field.mlp_base
+        dX, layer_grads = _FieldChain.chain(field, g_rgb, g_density, feat, selector, h1, raw, head_in, h3, h4, rgb, Ws,
+                                            need[8:18], owner._layout()[0], gap=True)
+        grads = [None] * 4
+        if any(need[4:8]):
+            grads = _FusedFeatures.scatter(owner, dX, xs, params, clips, ctx.N, ctx.sink)
+        return (None, None, None, None, *grads, *layer_grads)
 
 
 class NGPRadianceField_mygrid_2D3D(nn.Module):
@@ -610,6 +714,9 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         self._field_fused = None
         # the gradient pass's input-gradient chain as one kernel (`_FieldChain`; CNC_FUSED_CHAIN=0: layer by layer)
         self.fused_chain = fused_features and os.environ.get("CNC_FUSED_CHAIN", "1") == "1"
+        # ... and its forward as the fused evaluator in its saving form (`_FieldTrain`; CNC_FUSED_TRAIN=0: library GEMMs)
+        self.fused_train = self.fused_chain and os.environ.get("CNC_FUSED_TRAIN", "1") == "1"
+        self._guard_seen = 1
         self._chain_supported = None
         self._chain_key = self._chain_wt = self._chain_src = None
         from . import _caches
@@ -669,6 +776,36 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
                                          and sum(e.n_output_dims for e in self.mlp_base._encoders()) <= 192
                                          and (1 + self.geo_feat_dim + 31) // 32 * 32 <= self.mlp_base.network[0].out_features)
         return self._chain_supported
+
+    def _train_ok(self, positions, directions) -> bool:
+        """The gradient pass as the saving fused kernel + the gradient chain (`_FieldTrain`) applies."""
+        if not (self.fused_train and self.fused_field and torch.is_grad_enabled() and positions.is_cuda
+                and positions.dtype == torch.float32 and not positions.requires_grad and not directions.requires_grad
+                and self.fused_field_precision == "f16x3" and self.fused_field_kernel == "w2" and self._glue_ok(positions)):
+            return False
+        if not self._chain_ok(positions.reshape(-1, 3)):
+            return False
+        if self._field_fused is None:
+            self._field_fused = FusedFieldForward(self) if FusedFieldForward.supported(self) else False
+        return bool(self._field_fused)
+
+    def check_range_guard(self) -> bool:
+        """For the training loop, at a point where it synchronises anyway: True when a saving forward since the last check
+        met a value beyond fp16's range (it saturated: cnc_field_save_t).  The gradient pass then leaves the fused kernel
+        for the library-GEMM forward (`_FieldChain`), which has no such range."""
+        ff = self._field_fused
+        if not ff or not getattr(ff, "_train_calls", False) or not self.fused_train:
+            return False
+        words = ff.guard_words()
+        ff._train_calls = False
+        if words and (words[0] != 0 and words[0] >= self._guard_seen or any(w == ff._pack_id for w in words[1:6])):
+            import warnings
+            warnings.warn("cnc_amd: a value left fp16's range in the fused training forward; the gradient pass continues "
+                          "on the fp32 library path")
+            self.fused_train = False
+            return True
+        self._guard_seen = ff._call_id + 1
+        return False
 
     def _chain_weights_t(self, W1, W2, W3, W4, W5, n_enc):
         """The five layers TRANSPOSED in the 16x16x32 fragment order (cnc_field_pack_all, one launch), cached on the
@@ -818,6 +955,20 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         if directions is not None and self.use_viewdirs and self.geo_feat_dim > 0 and self._glue_ok(positions) \
                 and directions.is_cuda and directions.dtype == torch.float32:
             lead = list(positions.shape[:-1])
+            if self._train_ok(positions, directions):
+                # the gradient pass: ONE kernel forward (the fused evaluator, saving what the backward reads), the
+                # gradient chain kernel + weight gradients + the encoders' scatter backward (`_FieldTrain`)
+                p = positions.reshape(-1, 3)
+                N = p.shape[0]
+                Np = self._bucket_rows(N)
+                mb, mh = self.mlp_base.network, self.mlp_head
+                rgb, density = _FieldTrain.apply(p, directions.reshape(-1, 3), self, Np,
+                                                 *(e.params for e in self.mlp_base._encoders()),
+                                                 mb[0].weight, mb[0].bias, mb[2].weight, mb[2].bias, mh[0].weight, mh[0].bias,
+                                                 mh[2].weight, mh[2].bias, mh[4].weight, mh[4].bias)
+                if Np != N:
+                    rgb, density = rgb[:N], density[:N]
+                return rgb.view(lead + [3]), density.view(lead + [1])
             x_unit, selector, Np = self._prepare(positions)
             N = x_unit.shape[0]
             dirs = directions.reshape(-1, 3)

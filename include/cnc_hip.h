@@ -654,6 +654,33 @@ int cnc_field_post(const float* base_out, uint32_t ld_base, uint32_t geo_feat_di
  * Values: the encoders' features are bit-identical to cnc_grid_encode_forward_bits; each layer is an exact fp32 fmaf
  * chain in k order (v_mfma_f32_32x32x2_f32), i.e. equal to the op chain up to the summation order of a GEMM.
  * ---------------------------------------------------------------------------------------- */
+/* (ABI v27) The forward of the GRADIENT pass as the same one kernel: with `save.feat` set, cnc_field_fused_forward
+ * (CNC_FIELD_TWO_WAVES, rgb != NULL) also writes everything the backward reads — what the op chain's autograd would have
+ * kept (ngp.py:506-547: the MLPs' inputs and ReLU outputs) plus the inputs of the four encoders' backward — so that a
+ * training step's render pass is: this kernel, cnc_field_backward_chain, cnc_field_weight_grads, the encoders' backward.
+ * All matrices row-major float32 with N rows, N = the call's N (the caller's bucketed row count); positions / dirs are
+ * read for rows < n_live only, rows [n_live, N) are evaluated as a point outside the box (zero grid features, selector
+ * 0, density 0): what is stored for them is finite, and they receive zero gradient.
+ * No exact-fp32 kernel runs behind this call: a hidden activation beyond fp16's range SATURATES at 65504 (and
+ * guard[0] = call_id reports it; the caller reads the word when it next synchronises and leaves the fused path).   */
+typedef struct {
+    float*   feat;        /* [N, ld_feat] the first layer's input: [grid features | x | sin/cos | zeros to ld_feat]   */
+    uint32_t ld_feat;     /* >= roundup32(K0), a multiple of 4                                                       */
+    float*   h1;          /* [N, H] relu(base.0)                                                                     */
+    float*   h3;          /* [N, H] relu(head.0)                                                                     */
+    float*   h4;          /* [N, H] relu(head.2)                                                                     */
+    float*   head_in;     /* [N, ld_head] = [SH4 (16) | 0 | geo features | 0 ...]: column 16 is the slot the kernel
+                             keeps for the raw density (always 0 here); head.0's weight gradient drops it              */
+    uint32_t ld_head;     /* roundup32(17 + geo)                                                                     */
+    float*   raw;         /* [N] density before the activation (base.2's output 0)                                   */
+    uint8_t* selector;    /* [N]                                                                                     */
+    float*   xyz;         /* [N, 3] unit-cube positions (cnc_field_prepare's x_unit)                                 */
+    float*   xy;          /* [N, 2] their (x, y) / (x, z) / (y, z) pairs: the plane encoders' inputs                 */
+    float*   xz;
+    float*   yz;
+    uint32_t n_live;      /* <= N                                                                                    */
+} cnc_field_save_t;
+
 typedef struct {
     const float*   aabb;               /* 6 floats on the device: the field's box (ngp.py:516-519)                */
     const uint8_t* bits[4];            /* sign bit planes (cnc_pack_sign_bits) of the xyz | xy | xz | yz tables    */
@@ -684,6 +711,8 @@ typedef struct {
                                           the raw coordinates, the sinusoids, zero padding to a multiple of 32 — before
                                           it is split into halves.  CNC_FIELD_TWO_WAVES density-only calls only.        */
     uint32_t       debug_ld;           /* >= roundup32(K0)                                                         */
+    /* ---- ABI v27 ---- */
+    cnc_field_save_t save;             /* save.feat != NULL: the gradient pass's forward (above)                   */
 } cnc_fused_field_t;
 
 /* The layers' products on the fp16 matrix pipe, three per term: every operand split x = hi + lo into two halves
@@ -787,7 +816,7 @@ typedef struct {
     const float*   grad_rgb;          /* [N, 3]  (nullable: zero)                                                     */
     const float*   grad_density;      /* [N]     (nullable: zero)                                                     */
     const float*   rgb;               /* [N, 3]  the forward's sigmoid output                                         */
-    const float*   base_out;          /* [N, ld_base] base.2's output: column 0 = raw density                         */
+    const float*   base_out;          /* [N, ld_base] base.2's output: only column 0 (raw density) is read; ld_base >= 1   */
     const uint8_t* selector;          /* [N]                                                                          */
     const float*   h1;                /* [N, H] relu(base.0), relu(head.0), relu(head.2): only their signs are read    */
     const float*   h3;

@@ -12,8 +12,9 @@ from test_gpu_field_fused import CONFIGS, _field, _inputs
 pytestmark = pytest.mark.gpu
 
 
-def _grads(f, x, d, wr, wd, chain):
-    f.fused_chain = chain
+def _grads(f, x, d, wr, wd, chain, train=False):
+    """chain False: layer by layer; True: library forward + the chain kernel; + train: the saving fused forward too."""
+    f.fused_chain, f.fused_train = chain, train
     f._chain_supported = None
     for p in f.parameters():
         p.grad = None
@@ -51,7 +52,7 @@ def test_chain_handles_missing_output_gradients(cuda):
     for which in ("rgb", "density"):
         res = {}
         for chain in (False, True):
-            f.fused_chain, f._chain_supported = chain, None
+            f.fused_chain, f.fused_train, f._chain_supported = chain, False, None
             for p in f.parameters():
                 p.grad = None
             rgb, den = f(x, d)
@@ -60,3 +61,54 @@ def test_chain_handles_missing_output_gradients(cuda):
         for name, b in res[False].items():
             a = res[True][name]
             assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-30), (which, name)
+
+
+@pytest.mark.parametrize("n", [1, 33, 5000, 70001])
+@pytest.mark.parametrize("cfg", ["f8_full", "f4_default", "f2_toy", "f8_toy", "f4_h64"])
+def test_fused_training_forward_and_its_gradients(cuda, cfg, n):
+    """`_FieldTrain`: the gradient pass's forward as the saving form of the fused evaluator (cnc_field_save_t) — the
+    outputs within the fused kernel's 2e-5 of the op chain's, every parameter gradient within 1e-4 of its largest entry
+    of the layer-by-layer autograd path (the forward's 5e-7 per term carried through the chain)."""
+    f = _field(cuda, CONFIGS[cfg], seed=8)
+    x, d = _inputs(cuda, n, seed=n + 1)
+    g = torch.Generator(device=cuda).manual_seed(3)
+    scale = torch.exp(torch.randn(n, 1, device=cuda, generator=g) * 3.0 - 6.0)
+    wr = torch.randn(n, 3, device=cuda, generator=g) * scale
+    wd = torch.randn(n, 1, device=cuda, generator=g) * scale * 0.1
+    rgb0, den0, g0 = _grads(f, x, d, wr, wd, chain=False)
+    rgb1, den1, g1 = _grads(f, x, d, wr, wd, chain=True, train=True)
+    assert f._train_ok(x, d), "the fused training forward did not run"
+    assert float((rgb1 - rgb0).abs().max()) <= 2e-5
+    assert float((den1 - den0).abs().max()) <= 2e-5 * max(1.0, float(den0.abs().max()))
+    assert set(g0) == set(g1) and len(g0) == 14
+    for name in g0:
+        a, b = g1[name].double(), g0[name].double()
+        scale_ = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * max(scale_, 1e-30), (name, float((a - b).abs().max()), scale_)
+    assert not f.check_range_guard()
+
+
+def test_fused_training_forward_row_padding_and_saved_tensors(cuda):
+    """Rows of padding (`_bucket_rows`): the saved matrices are finite there, the outputs of the live rows do not depend
+    on the padding, and what the kernel saved is what the op chain computes (features bit for bit)."""
+    f = _field(cuda, CONFIGS["f8_full"], seed=5)
+    x, d = _inputs(cuda, 5000, seed=9)
+    f._train_ok(x, d)
+    ff = f._field_fused
+    rgb_a, den_a, kept_a = ff.save_forward(x, d, 5000)
+    rgb_b, den_b, kept_b = ff.save_forward(x, d, 5000 + 777)
+    assert torch.equal(rgb_a, rgb_b[:5000]) and torch.equal(den_a, den_b[:5000])
+    for k, v in kept_b.items():
+        if k != "clips":
+            assert v.shape[0] == 5777 and bool(torch.isfinite(v.float()).all()), k
+            assert torch.equal(kept_a[k], v[:5000]), k
+    assert float(den_b[5000:].abs().max()) == 0.0 and int(kept_b["selector"][5000:].sum()) == 0
+    x_unit, selector, _ = f._prepare(x)
+    assert torch.equal(kept_a["xyz"], x_unit) and torch.equal(kept_a["selector"], selector[:5000])
+    assert torch.equal(kept_a["xy"], x_unit[:, :2]) and torch.equal(kept_a["xz"], x_unit[:, ::2]) and torch.equal(kept_a["yz"], x_unit[:, 1:])
+    with torch.no_grad():
+        feat = f.mlp_base.features_fused(x_unit)
+    n_enc = sum(e.n_output_dims for e in f.mlp_base._encoders())
+    assert torch.equal(kept_a["feat"][:, :n_enc], feat[:, :n_enc])
+    assert float((kept_a["feat"][:, n_enc:feat.shape[1]] - feat[:, n_enc:]).abs().max()) <= 1e-6      # fast sincos
+    assert float(kept_a["head_in"][:, 16].abs().max()) == 0.0

@@ -122,13 +122,21 @@ def test_fused_field_at_full_size_and_after_a_weight_update(cuda, precision):
     assert float((den1 - den0).abs().max()) >= 0.0
 
 
-def test_fused_field_is_not_used_with_gradients_or_outside_its_shapes(cuda):
+def test_fused_field_with_gradients_and_outside_its_shapes(cuda):
     from cnc_amd.field import FusedFieldForward
     f = _field(cuda, CONFIGS["f2_toy"], seed=1)
     x, d = _inputs(cuda, 500, seed=2)
-    rgb, sig = f(x, d)                              # gradients enabled: the autograd chain
+    f.fused_train = False
+    rgb, sig = f(x, d)                              # gradients enabled, the saving kernel switched off: the op chain
     assert rgb.requires_grad and not f._field_fused
     (rgb.sum() + sig.sum()).backward()
+    f.fused_train = True
+    rgb, sig = f(x, d)                              # ... switched on (the default): the fused kernel in its saving form
+    assert rgb.requires_grad and f._field_fused and f._field_fused._train_calls
+    (rgb.sum() + sig.sum()).backward()
+    x.requires_grad_(True)                          # gradients with respect to positions: the op chain again
+    assert not f._train_ok(x, d)
+    x.requires_grad_(False)
     g = _field(cuda, dict(CONFIGS["f2_toy"], n_neurons=48), seed=1)
     assert not FusedFieldForward.supported(g)
     with torch.no_grad():
