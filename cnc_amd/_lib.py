@@ -49,7 +49,15 @@ class FieldBwd(C.Structure):
     _fields_ = [("N", _u32), ("n_neurons", _u32), ("n_features", _u32), ("n_enc_columns", _u32), ("geo_feat_dim", _u32),
                 ("ld_base", _u32), ("ld_g2", _u32), ("ld_x", _u32), ("grad_rgb", _vp), ("grad_density", _vp), ("rgb", _vp),
                 ("base_out", _vp), ("selector", _vp), ("h1", _vp), ("h3", _vp), ("h4", _vp), ("packed_weights_t", _vp * 5),
-                ("G5", _vp), ("G4", _vp), ("G3", _vp), ("G2", _vp), ("G1", _vp), ("dX", _vp), ("bias_grads", _vp)]
+                ("G5", _vp), ("G4", _vp), ("G3", _vp), ("G2", _vp), ("G1", _vp), ("dX", _vp), ("bias_grads", _vp),
+                ("g_max", _vp)]
+
+
+class FieldWGrad(C.Structure):
+    """cnc_field_wgrad_t (include/cnc_hip.h)."""
+    _fields_ = [("N", _u32), ("G", _vp * 5), ("ldG", _u32 * 5), ("n_out", _u32 * 5), ("A", _vp * 5), ("ldA", _u32 * 5),
+                ("n_in", _u32 * 5), ("head_gap_col", _u32), ("dW", _vp * 5), ("ld_dW", _u32 * 5), ("g_max", _vp),
+                ("workspace", _vp), ("workspace_bytes", C.c_uint64), ("n_workgroups", _u32)]
 
 
 class FieldPackLayer(C.Structure):
@@ -131,6 +139,8 @@ SIGNATURES = {
     "cnc_field_pack_layer16": [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp],
     "cnc_field_pack_all": [C.POINTER(FieldPack), _vp],
     "cnc_field_backward_chain": [C.POINTER(FieldBwd), _vp],
+    "cnc_field_weight_grads_workspace": [C.POINTER(FieldWGrad), C.POINTER(C.c_uint64)],
+    "cnc_field_weight_grads": [C.POINTER(FieldWGrad), _vp],
     "cnc_field_fused_forward": [C.POINTER(FusedField), _vp, _vp, _u32, _vp, _vp, _vp],
     "cnc_ste_binary_forward": [_vp, _vp, C.c_uint64, _vp],
     "cnc_ste_binary_backward": [_vp, _vp, _vp, C.c_uint64, _vp],

@@ -43,6 +43,7 @@ struct FieldBwdArgs {
     float*         dX;              // [N, ld_x] columns [0, n_enc)
     uint32_t       ld_x;
     float*         bias_grads;      // [3 H + 84] zero-initialised by the caller: column sums of G4 | G3 | G1 | G2 (80) | G5 (4)
+    uint32_t*      g_max;           // [5] zero-initialised (nullable): float bits of max |G1| .. max |G5| (atomic max)
 };
 
 // Row-major [N, ld] float matrices through buffer resources: SGPR base + ONE 32-bit lane offset + constants — a flat pointer
@@ -136,7 +137,8 @@ struct ActTile {
 template <int NCB, int NT>
 __device__ __forceinline__ float masked_stage_out(const f32x4 (&acc)[2][NCB], float inv_in, const ActTile<NCB>& act,
                                                   wrsrc_t G, uint32_t H, uint32_t lane_off, uint32_t w,
-                                                  uint32_t lane, half_t* h_hi, half_t* h_lo, float* xch, float* bsum)
+                                                  uint32_t lane, half_t* h_hi, half_t* h_lo, float* xch, float* bsum,
+                                                  uint32_t& run_max)
 {
     const uint32_t r = lane & 15u, kq = lane >> 4;
     float x[2][NCB][4];
@@ -165,7 +167,9 @@ __device__ __forceinline__ float masked_stage_out(const f32x4 (&acc)[2][NCB], fl
     m = wave_max(m);
     if (lane == 0) xch[w] = m;
     __syncthreads();                                   // every read of the planes issued and done; both maxima written
-    const float s = tile_scale(fmaxf(xch[0], xch[1]));
+    const float tmax = fmaxf(xch[0], xch[1]);
+    run_max = max(run_max, (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tmax)));    // >= 0: ordered as integers
+    const float s = tile_scale(tmax);
     vals_to_planes<NCB, NT>(h_hi, h_lo, x, w * NCB, lane, s);
     __syncthreads();
     return s;
@@ -200,6 +204,7 @@ __global__ __launch_bounds__(128, CNC_BWD_WAVES) void k_field_bwd_chain(FieldBwd
     const wrsrc_t  rH1 = weight_rsrc(p.h1, bytes_h), rH3 = weight_rsrc(p.h3, bytes_h), rH4 = weight_rsrc(p.h4, bytes_h);
     const wrsrc_t  rG1 = weight_rsrc(p.G1, bytes_h), rG3 = weight_rsrc(p.G3, bytes_h), rG4 = weight_rsrc(p.G4, bytes_h);
     const wrsrc_t  rG2 = weight_rsrc(p.G2, p.N * p.ld_g2 * 4u), rX = weight_rsrc(p.dX, p.N * p.ld_x * 4u);
+    uint32_t gm1 = 0, gm2 = 0, gm3 = 0, gm4 = 0, gm5 = 0;     // float bits of the largest |G_l| this workgroup has seen (scalar)
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const uint32_t row0 = tile * 32, frow = row0 + fi;
         const bool     live = frow < p.N;
@@ -224,7 +229,9 @@ __global__ __launch_bounds__(128, CNC_BWD_WAVES) void k_field_bwd_chain(FieldBwd
         }
         if (lane == 0) xch[w] = m5;
         __syncthreads();                               // (also: the previous tile's last reads of the planes are done)
-        float s_in = tile_scale(fmaxf(xch[0], xch[1]));
+        const float t5 = fmaxf(xch[0], xch[1]);
+        gm5 = max(gm5, (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t5)));
+        float s_in = tile_scale(t5);
         {
             const RowF16 row{h_hi, h_lo};
             float v8[4] = {g5[0] * s_in, g5[1] * s_in, g5[2] * s_in, 0.0f}, z4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -240,12 +247,12 @@ __global__ __launch_bounds__(128, CNC_BWD_WAVES) void k_field_bwd_chain(FieldBwd
         layer_q<2, NCB, NT, CNC_BWD_DB>(h_hi, h_lo, 1, p.Wt[0], NCBT, w * NCB, 0, acc, lane);
         __builtin_amdgcn_sched_barrier(0);
         act.load(rH4, H, lane_off);                      // behind the products' issue: in flight while the matrix pipe drains
-        s_in = masked_stage_out<NCB, NT>(acc, kWScaleInv / s_in, act, rG4, H, lane_off, w, lane, h_hi, h_lo, xch, bs4);
+        s_in = masked_stage_out<NCB, NT>(acc, kWScaleInv / s_in, act, rG4, H, lane_off, w, lane, h_hi, h_lo, xch, bs4, gm4);
         // ---- stage 3: G3 = (G4 W4) where h3 > 0 ----
         layer_q<2, NCB, NT, CNC_BWD_DB>(h_hi, h_lo, NT, p.Wt[1], NCBT, w * NCB, 0, acc, lane);
         __builtin_amdgcn_sched_barrier(0);
         act.load(rH3, H, lane_off);                      // behind the products' issue: in flight while the matrix pipe drains
-        s_in = masked_stage_out<NCB, NT>(acc, kWScaleInv / s_in, act, rG3, H, lane_off, w, lane, h_hi, h_lo, xch, bs3);
+        s_in = masked_stage_out<NCB, NT>(acc, kWScaleInv / s_in, act, rG3, H, lane_off, w, lane, h_hi, h_lo, xch, bs3, gm3);
         // ---- stage 2: G2[:, c] = (G3 W3[:, 15 + c]) for the geo features c >= 1; G2[:, 0] = g_density * d density / d raw ----
         {
             f32x4 acc2[1][NB2];
@@ -279,7 +286,9 @@ __global__ __launch_bounds__(128, CNC_BWD_WAVES) void k_field_bwd_chain(FieldBwd
             m = wave_max(m);
             if (lane == 0) xch[w] = m;
             __syncthreads();
-            s_in = tile_scale(fmaxf(xch[0], xch[1]));
+            const float t2 = fmaxf(xch[0], xch[1]);
+            gm2 = max(gm2, (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t2)));
+            s_in = tile_scale(t2);
 #pragma unroll
             for (int cb = 0; cb < NB2; cb++) {
                 const uint32_t c0 = cb * 16u + 4u * kq;
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(128, CNC_BWD_WAVES) void k_field_bwd_chain(FieldBwd
         layer_q<2, NCB, NT, CNC_BWD_DB>(h_hi, h_lo, K2 / 32, p.Wt[3], NCBT, w * NCB, 0, acc, lane);
         __builtin_amdgcn_sched_barrier(0);
         act.load(rH1, H, lane_off);                      // behind the products' issue: in flight while the matrix pipe drains
-        s_in = masked_stage_out<NCB, NT>(acc, kWScaleInv / s_in, act, rG1, H, lane_off, w, lane, h_hi, h_lo, xch, bs1);
+        s_in = masked_stage_out<NCB, NT>(acc, kWScaleInv / s_in, act, rG1, H, lane_off, w, lane, h_hi, h_lo, xch, bs1, gm1);
         // ---- stage 0: dX[:, :n_enc] = G1 W1[:, :n_enc], rows split between the waves, the column blocks in passes of six
         // (a pass's blocks past the last one multiply whatever follows in the fragment stream: their results are dropped) ----
         {
@@ -337,6 +346,13 @@ __global__ __launch_bounds__(128, CNC_BWD_WAVES) void k_field_bwd_chain(FieldBwd
             const float v = bs4[i];
             if (v != 0.0f) unsafeAtomicAdd(p.bias_grads + i, v);
         }
+    if (p.g_max && tid == 0) {                          // what cnc_field_weight_grads scales the gradient matrices by
+        atomicMax(p.g_max + 0, gm1);
+        atomicMax(p.g_max + 1, gm2);
+        atomicMax(p.g_max + 2, gm3);
+        atomicMax(p.g_max + 3, gm4);
+        atomicMax(p.g_max + 4, gm5);
+    }
 }
 
 }  // namespace cnc
@@ -370,6 +386,7 @@ extern "C" int cnc_field_backward_chain(const cnc_field_bwd_t* f, void* stream)
     const uint32_t ld = NT == 5 ? 160u : NT * 32u + 8u;
     const size_t   lds_bytes = (size_t)2 * 32 * ld * sizeof(half_t) + 16 + (size_t)(3 * H + 84) * sizeof(float);
     p.bias_grads = f->bias_grads;
+    p.g_max = f->g_max;
     const uint32_t tiles = (p.N + 31u) / 32u;
     hipStream_t    s = (hipStream_t)stream;
     // the grid is what is resident at once (the workgroups loop over the tiles); asked once per thread and device

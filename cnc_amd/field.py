@@ -611,24 +611,46 @@ class _FieldChain(Function):
         for k in range(5):
             st.packed_weights_t[k] = wt[k].data_ptr()
         st.G5, st.G4, st.G3, st.G2, st.G1, st.dX = (t.data_ptr() for t in (G5, G4, G3, G2, G1, dX))
-        bsum = torch.zeros(3 * H + 84, dtype=torch.float32, device=dev)       # column sums of G4 | G3 | G1 | G2 | G5
+        # column sums of G4 | G3 | G1 | G2 | G5 (the bias gradients), + 8 words: the largest |G_l| (the weight gradients' scales)
+        bsum = torch.zeros(3 * H + 84 + 8, dtype=torch.float32, device=dev)
         st.bias_grads = bsum.data_ptr()
+        st.g_max = bsum.data_ptr() + (3 * H + 84) * 4
         gb_of = (bsum[2 * H:3 * H], bsum[3 * H:3 * H + 1 + geo], bsum[H:2 * H], bsum[:H], bsum[3 * H + 80:3 * H + 83])
         import ctypes
         _lib.check(_lib.lib().cnc_field_backward_chain(ctypes.byref(st), _lib.stream(dev)), "field_backward_chain")
+        pairs = ((G1, feat, K0, H), (G2, h1, H, 1 + geo), (G3, head_in, 16 + geo, H), (G4, h3, H, H), (G5, h4, H, 3))
+        gws = [None] * 5
+        if any(need[0::2]):
+            if field.fused_wgrad:
+                # the five weight gradients: ONE kernel over the G_l and the layers' inputs + one reduction
+                d = _lib.FieldWGrad()
+                d.N, d.head_gap_col, d.g_max = Np, (16 if gap else 0xFFFFFFFF), st.g_max
+                gws = [torch.empty((n_out, n_in), dtype=torch.float32, device=dev) for _, _, n_in, n_out in pairs]
+                for i, (G, A, n_in, n_out) in enumerate(pairs):
+                    d.G[i], d.ldG[i], d.n_out[i] = G.data_ptr(), G.shape[1], n_out
+                    d.A[i], d.ldA[i], d.n_in[i] = A.data_ptr(), A.shape[1], n_in
+                    d.dW[i], d.ld_dW[i] = gws[i].data_ptr(), n_in
+                ws = field._wgrad_ws
+                if ws is None or ws[0] != (dev, tuple(A.shape[1] for _, A, _, _ in pairs)):
+                    nbytes = ctypes.c_uint64(0)
+                    _lib.check(_lib.lib().cnc_field_weight_grads_workspace(ctypes.byref(d), ctypes.byref(nbytes)),
+                               "field_weight_grads_workspace")
+                    ws = field._wgrad_ws = ((dev, tuple(A.shape[1] for _, A, _, _ in pairs)),
+                                            torch.empty(nbytes.value // 4, dtype=torch.float32, device=dev))
+                d.workspace, d.workspace_bytes = ws[1].data_ptr(), ws[1].numel() * 4
+                _lib.check(_lib.lib().cnc_field_weight_grads(ctypes.byref(d), _lib.stream(dev)), "field_weight_grads")
+            else:
+                for i, (G, A, n_in, n_out) in enumerate(pairs):
+                    if need[2 * i]:
+                        gw = splitk_weight_grad(G[:, :n_out] if G.shape[1] != n_out else G, A)
+                        if i == 2 and gap:        # [SH4 | the raw density's slot | geo]: the slot is not an input of the layer
+                            gw = torch.cat([gw[:, :16], gw[:, 17:17 + geo]], dim=1)
+                        elif gw.shape[1] != n_in:
+                            gw = gw[:, :n_in]
+                        gws[i] = gw
         out = []
-        for i, (G, A, width) in enumerate(((G1, feat, K0), (G2[:, :1 + geo], h1, H), (G3, head_in, 16 + geo), (G4, h3, H),
-                                            (G5[:, :3], h4, H))):
-            gw = gb = None
-            if need[2 * i]:
-                gw = splitk_weight_grad(G, A)
-                if i == 2 and gap:            # [SH4 | the raw density's slot | geo]: the slot is not an input of the layer
-                    gw = torch.cat([gw[:, :16], gw[:, 17:17 + geo]], dim=1)
-                elif gw.shape[1] != width:
-                    gw = gw[:, :width]
-            if need[2 * i + 1]:
-                gb = gb_of[i]
-            out += [gw, gb]
+        for i in range(5):
+            out += [gws[i] if need[2 * i] else None, gb_of[i] if need[2 * i + 1] else None]
         return dX, out
 
 
@@ -717,6 +739,9 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         # ... and its forward as the fused evaluator in its saving form (`_FieldTrain`; CNC_FUSED_TRAIN=0: library GEMMs)
         self.fused_train = self.fused_chain and os.environ.get("CNC_FUSED_TRAIN", "1") == "1"
         self._guard_seen = 1
+        # the five weight gradients as one kernel (cnc_field_weight_grads; CNC_FUSED_WGRAD=0: split-K library GEMMs)
+        self.fused_wgrad = os.environ.get("CNC_FUSED_WGRAD", "1") == "1"
+        self._wgrad_ws = None
         self._chain_supported = None
         self._chain_key = self._chain_wt = self._chain_src = None
         from . import _caches

@@ -374,6 +374,10 @@ class Trainer:
         self.estimator.update_every_n_steps(
             step=step, occ_eval_fn=lambda x: self.field.query_density(x) * c.render_step_size,
             occ_thre=1e-2, n=c.step_update)
+        if step % c.step_update == 0 and step > 0:
+            # the occupancy refresh has just synchronised the host: the moment to read the fused training forward's fp16
+            # range guard (a saturated activation since the last look: the gradient pass leaves that kernel, with a warning)
+            self.field.check_range_guard()
         if self.dp and step % c.step_update == 0:
             cdist.broadcast_module_buffers(self.estimator, ["occs", "binaries"])
         ctx_future = None

@@ -830,8 +830,42 @@ typedef struct {
     float*         dX;                /* [N, ld_x]  out: columns [0, n_enc_columns) of the base network's input gradient */
     float*         bias_grads;        /* (nullable) [3 H + 84] ZERO-INITIALISED by the caller; receives (atomic adds) the column
                                          sums of G4 | G3 | G1 (H each) | G2 (80 slots) | G5 (4 slots): the bias gradients   */
+    /* ---- ABI v27 ---- */
+    uint32_t*      g_max;             /* (nullable) 5 ZERO-INITIALISED words; receive (atomic max) the float bits of
+                                         max |G1|, max |G2|, max |G3|, max |G4|, max |G5|: cnc_field_weight_grads' scales   */
 } cnc_field_bwd_t;
 int cnc_field_backward_chain(const cnc_field_bwd_t* chain, void* stream);
+
+/* (extension, ABI v27) The five weight gradients of the field's Linears, dW_l = G_l^T A_l  (autograd's LinearBackward,
+ * ngp.py:506-547), from the gradient matrices cnc_field_backward_chain left in HBM and the layers' inputs — one kernel
+ * that streams both once (a layer's operands are read by that layer only: the grid is split between the layers by bytes),
+ * products on the fp16 matrix pipe in the three-product form with G_l scaled by a power of two taken from g_max, fp32
+ * accumulation in registers over a workgroup's samples, + one reduction over the workgroups' partial sums.
+ * Layer order: base.0, base.2, head.0, head.2, head.4.  Row-major float32, N rows:
+ *   G[l] [N, ldG[l]]: columns [0, n_out[l]) (ldG % 4 == 0, >= roundup4(n_out); n_out <= 160)
+ *   A[l] [N, ldA[l]]: ALL ldA[l] columns are read (ldA % 4 == 0, <= 256; columns that are padding must hold finite values)
+ *   dW[l] [n_out[l], ld_dW[l]]: columns [0, n_in[l]) are written = input columns [0, n_in[l]) — for head.0 (l = 2) with
+ *     input column head_gap_col skipped (cnc_field_save_t.head_in: 16; 0xFFFFFFFF: none)
+ * workspace: cnc_field_weight_grads_workspace bytes (the workgroups' partial sums), no initialisation needed.
+ * n_workgroups: 0 = one per CU.  Values: within ~1e-6 of the largest entry of each dW of the float64 product.        */
+typedef struct {
+    uint32_t        N;
+    const float*    G[5];
+    uint32_t        ldG[5];
+    uint32_t        n_out[5];
+    const float*    A[5];
+    uint32_t        ldA[5];
+    uint32_t        n_in[5];
+    uint32_t        head_gap_col;
+    float*          dW[5];
+    uint32_t        ld_dW[5];
+    const uint32_t* g_max;            /* cnc_field_bwd_t.g_max after the chain kernel, same stream                         */
+    float*          workspace;
+    uint64_t        workspace_bytes;
+    uint32_t        n_workgroups;
+} cnc_field_wgrad_t;
+int cnc_field_weight_grads_workspace(const cnc_field_wgrad_t* d, uint64_t* bytes);
+int cnc_field_weight_grads(const cnc_field_wgrad_t* d, void* stream);
 
 /* STE_binary of ngp.py:22-39 over n floats (16-byte aligned buffers), one pass each way:
  *   forward : out = (c >= 0) * 1 + (c < 0) * -1 with c = clamp(x, -1, 1)   (+1 / -1; NaN -> 0)

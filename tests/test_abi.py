@@ -90,6 +90,8 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
         "cnc_field_pack_layer_t": (_lib.FieldPackLayer, [f[0] for f in _lib.FieldPackLayer._fields_]),
         "cnc_field_pack_t": (_lib.FieldPack, [f[0] for f in _lib.FieldPack._fields_]),
         "cnc_field_bwd_t": (_lib.FieldBwd, [f[0] for f in _lib.FieldBwd._fields_]),
+        "cnc_field_save_t": (_lib.FieldSave, [f[0] for f in _lib.FieldSave._fields_]),
+        "cnc_field_wgrad_t": (_lib.FieldWGrad, [f[0] for f in _lib.FieldWGrad._fields_]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include <stdint.h>', '#include "cnc_hip.h"', 'int main(void) {']
     for t, (_, names) in members.items():

@@ -112,3 +112,39 @@ def test_fused_training_forward_row_padding_and_saved_tensors(cuda):
     assert torch.equal(kept_a["feat"][:, :n_enc], feat[:, :n_enc])
     assert float((kept_a["feat"][:, n_enc:feat.shape[1]] - feat[:, n_enc:]).abs().max()) <= 1e-6      # fast sincos
     assert float(kept_a["head_in"][:, 16].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n", [1, 63, 4097, 100001])
+@pytest.mark.parametrize("shape", ["f8_full", "h64"])
+def test_weight_gradient_kernel_against_float64(cuda, shape, n):
+    """cnc_field_weight_grads on its own: dW_l = G_l^T A_l of random matrices whose rows differ by orders of magnitude
+    (a rendering loss's gradients do), against the float64 product: within 2e-6 of each dW's largest entry."""
+    import ctypes
+    from cnc_amd import _lib
+    H, geo, ldf, K0 = (160, 79, 256, 251) if shape == "f8_full" else (64, 15, 96, 91)
+    g = torch.Generator(device=cuda).manual_seed(n)
+    rnd = lambda *s: torch.randn(*s, device=cuda, generator=g)
+    row_scale = torch.exp(rnd(n, 1) * 3.0 - 8.0)
+    ld2, ldh = (1 + geo + 3) // 4 * 4, (17 + geo + 31) // 32 * 32
+    Gs = [rnd(n, H) * row_scale, rnd(n, ld2) * row_scale, rnd(n, H) * row_scale * 10, rnd(n, H) * row_scale * 0.01, rnd(n, 4) * row_scale]
+    As = [rnd(n, ldf), rnd(n, H).relu() * 3, rnd(n, ldh), rnd(n, H).relu() * 30, rnd(n, H).relu()]
+    As[2][:, 16] = 0
+    n_out, n_in = [H, 1 + geo, H, H, 3], [K0, H, 16 + geo, H, H]
+    gmax = torch.tensor([float(G[:, :o].abs().max()) for G, o in zip(Gs, n_out)] + [0.0] * 3, device=cuda).view(torch.int32)
+    d = _lib.FieldWGrad()
+    d.N, d.head_gap_col, d.g_max = n, 16, gmax.data_ptr()
+    out = [torch.full((o, i), float("nan"), device=cuda) for o, i in zip(n_out, n_in)]
+    for l in range(5):
+        d.G[l], d.ldG[l], d.n_out[l] = Gs[l].data_ptr(), Gs[l].shape[1], n_out[l]
+        d.A[l], d.ldA[l], d.n_in[l] = As[l].data_ptr(), As[l].shape[1], n_in[l]
+        d.dW[l], d.ld_dW[l] = out[l].data_ptr(), n_in[l]
+    nbytes = ctypes.c_uint64(0)
+    _lib.check(_lib.lib().cnc_field_weight_grads_workspace(ctypes.byref(d), ctypes.byref(nbytes)), "workspace")
+    ws = torch.empty(nbytes.value // 4, device=cuda)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes.value
+    _lib.check(_lib.lib().cnc_field_weight_grads(ctypes.byref(d), _lib.stream(cuda)), "field_weight_grads")
+    for l in range(5):
+        ref = Gs[l][:, :n_out[l]].double().t() @ As[l].double()
+        ref = torch.cat([ref[:, :16], ref[:, 17:17 + geo]], 1) if l == 2 else ref[:, :n_in[l]]
+        err, scale = float((out[l].double() - ref).abs().max()), float(ref.abs().max())
+        assert err <= 2e-6 * scale, (l, err, scale)

@@ -21,6 +21,8 @@ def switch(on):
         tr.ctx_thread = False
     elif what == "chain":
         tr.field.fused_chain, tr.field._chain_supported = on, None
+    elif what == "wgrad":
+        tr.field.fused_wgrad = on
     elif what == "train":
         tr.field.fused_train = on
     elif what == "vbits":

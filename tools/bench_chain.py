@@ -35,8 +35,9 @@ def main():
         rgb, den = f(x, d)
         ((rgb * wr).sum() + (den * wd).sum()).backward()
 
-    for chain in (True, False):
-        f.fused_chain, f._chain_supported = chain, None
+    # (chain kernel, saving fused forward, weight-gradient kernel)
+    for chain, train, wgrad in ((True, True, True), (True, True, False), (True, False, True), (True, False, False), (False, False, False)):
+        f.fused_chain, f.fused_train, f.fused_wgrad, f._chain_supported = chain, train, wgrad, None
         for _ in range(5):
             step()
         torch.cuda.synchronize()
@@ -46,8 +47,8 @@ def main():
             e0.record(); step(); e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
-        print(f"chain={chain}: {sorted(ts)[len(ts) // 2]:.3f} ms per forward + backward at N = {a.n}", flush=True)
-        if a.profile:
+        print(f"chain={chain} train={train} wgrad={wgrad}: {sorted(ts)[len(ts) // 2]:.3f} ms per forward + backward at N = {a.n}", flush=True)
+        if a.profile and (chain, train, wgrad) == (True, True, True):
             from torch.profiler import ProfilerActivity, profile
             with profile(activities=[ProfilerActivity.CUDA]) as prof:
                 for _ in range(3):
