@@ -139,6 +139,7 @@ SIGNATURES = {
     "cnc_field_pack_layer16": [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp],
     "cnc_field_pack_all": [C.POINTER(FieldPack), _vp],
     "cnc_field_backward_chain": [C.POINTER(FieldBwd), _vp],
+    "cnc_set_persistent_share": [C.c_float],
     "cnc_field_weight_grads_workspace": [C.POINTER(FieldWGrad), C.POINTER(C.c_uint64)],
     "cnc_field_weight_grads": [C.POINTER(FieldWGrad), _vp],
     "cnc_field_fused_forward": [C.POINTER(FusedField), _vp, _vp, _u32, _vp, _vp, _vp],

@@ -23,9 +23,10 @@ import ctypes as C
 import os
 from typing import Optional
 
+import contextlib
+
 import numpy as np
 import torch
-import contextlib
 import torch.nn as nn
 import torch.nn.functional as nnf
 from torch.autograd import Function
@@ -992,9 +993,17 @@ class CNC_context_models(nn.Module):
 
     # ------------------------------------------------------------------------------- training
     def forward_binary_vxl_mixPg_3D2D(self, Encoding_xyz, Encoding_xy, Encoding_xz, Encoding_yz,
-                                      binary_vxl=None, verbose=False, sample_num=None, step=0, sync_MB=True):
+                                      binary_vxl=None, verbose=False, sample_num=None, step=0, sync_MB=True,
+                                      stream_2D=None):
         """Entropy estimate (bits per parameter) of the four binarised tables under the context
-        models; differentiable w.r.t. tables and context models (utils_bpp_acc.py:533-706)."""
+        models; differentiable w.r.t. tables and context models (utils_bpp_acc.py:533-706).
+
+        `stream_2D` (extension): a second HIP stream for the three planes' part.  The planes' bits and the 3-D table's
+        bits share nothing but their inputs: with a stream given, the planes' forward is enqueued there (forked from the
+        current stream behind the STE of the tables) and the 3-D part on the current stream next to it; autograd runs
+        each node's backward on its forward's stream, so one backward call runs the two halves side by side as well.
+        Same values: the partial sums are added in the order of the one-stream pass.  The caller orders its stream
+        after `stream_2D` once the backward has been enqueued (the trainer's `_context_pass`)."""
         with _range("ctx/ste_params"):
             params_q_xy = self.get_STE_params(Encoding_xy)
             params_q_xz = self.get_STE_params(Encoding_xz)
@@ -1053,6 +1062,25 @@ class CNC_context_models(nn.Module):
                 self.batched_inputs_list = self._slot_lists_2D(binary_2D)
                 self._plane_cat = [None, None, None]
 
+        fork_2D = None
+        if stream_2D is not None and params_q_xyz.is_cuda and refresh is False:
+            # (a refresh step builds the planes' structures with host round trips inside the loop below: one stream)
+            fork_2D = torch.cuda.current_stream(params_q_xyz.device)
+            stream_2D.wait_stream(fork_2D)
+            for t in (params_q_xy, params_q_xz, params_q_yz, params_q_xyz):
+                t.record_stream(stream_2D)
+        with (torch.cuda.stream(stream_2D) if fork_2D is not None else contextlib.nullcontext()):
+            ttl_bit_sum, ttl_num_sum = self._bits_2D(Encoding_xy, Encoding_xz, Encoding_yz, params_q_xy, params_q_xz, params_q_yz,
+                                                     params_q_xyz, binary_vxl, binary_2D, idx_coords2, refresh)
+
+        return self._bits_3D_and_total(Encoding_xyz, params_q_xyz, binary_vxl, sample_num, ttl_bit_sum, ttl_num_sum, fork_2D,
+                                       stream_2D, sync_MB)
+
+    def _bits_2D(self, Encoding_xy, Encoding_xz, Encoding_yz, params_q_xy, params_q_xz, params_q_yz, params_q_xyz,
+                 binary_vxl, binary_2D, idx_coords2, refresh):
+        """(bits of the three planes' tables, their parameter count): utils_bpp_acc.py:560-617."""
+        axes = ("xy", "xz", "yz")
+        ttl_bit_sum, ttl_num_sum = 0, 0
         finest_3D = params_q_xyz[self._off3_host[-2]:self._off3_host[-1]]
         pn_fracs = None
         if self.use_dimension_wise and self.vote_plan is not None and finest_3D.shape[0] <= self.vote_plan.hashmap_size:
@@ -1105,8 +1133,13 @@ class CNC_context_models(nn.Module):
                         self._rows_2D_cat[k] = torch.cat(rows_of)          # fixed until the next refresh
                     ttl_bit_sum = ttl_bit_sum + self._bits(p_q, self._rows_2D_cat[k], torch.cat(means_of))
             ttl_num_sum += p_q.numel()
+        return ttl_bit_sum, ttl_num_sum
 
-        # 3-D: a random contiguous window of hash slots per level (:619-634)
+    def _bits_3D_and_total(self, Encoding_xyz, params_q_xyz, binary_vxl, sample_num, bits_2D, ttl_num_sum, fork_2D, stream_2D,
+                           sync_MB):
+        """The 3-D table's bits (a random contiguous window of hash slots per level, :619-634) + the planes' -> (bits per
+        parameter, estimated MB)."""
+        later = []           # the 3-D terms, added to the planes' bits at the end in the one-stream pass's order
         if sample_num is not None:
             sample_num_levels = self._sample_allocation(sample_num)
             ttl_sample_valid = sum(int(sample_num_levels[n].item()) for n in range(self.n_levels) if self._coded_3D(n))
@@ -1126,7 +1159,7 @@ class CNC_context_models(nn.Module):
             if self._noncoded_3D is None or self._noncoded_3D.device != bits_all.device:
                 self._noncoded_3D = torch.tensor([0.0 if n in coded else 1.0 for n in range(self.n_levels)],
                                                  dtype=bits_all.dtype, device=bits_all.device)
-            ttl_bit_sum = ttl_bit_sum + torch.dot(bits_all, self._noncoded_3D)      # the zero-order levels, one op
+            later.append(torch.dot(bits_all, self._noncoded_3D))      # the zero-order levels, one op
         fused = self.fused_heads and params_q_xyz.is_cuda and len(coded) <= 16
         L = self.max_context_layer_num
         if coded and fused:
@@ -1153,7 +1186,7 @@ class CNC_context_models(nn.Module):
             with _range("ctx/3D_entropy"):
                 coded_rows = rows_3D[mask_exist] if mask_exist.dtype == torch.bool else rows_3D.index_select(0, mask_exist)
                 bits = self._bits(params_q_xyz, coded_rows, mean)
-            ttl_bit_sum = ttl_bit_sum + bits / ttl_sample_valid * self.ttl_hashparams_num_valid_levels
+            later.append(bits / ttl_sample_valid * self.ttl_hashparams_num_valid_levels)
         elif coded:
             pts_orig, pts_n, Pg_cols, lvl_ids, cnts, values_q = [], [], [], [], [], []
             for n in coded:
@@ -1174,8 +1207,15 @@ class CNC_context_models(nn.Module):
             context = torch.cat([context, Pg_cols[mask]], dim=-1)
             mean = self._fuse_3D(self.context_model_3D(context), mask_cnt, overlap_w)
             bits = self._bits(params_q_xyz, rows_3D[mask_exist], mean)
-            ttl_bit_sum = ttl_bit_sum + bits / ttl_sample_valid * self.ttl_hashparams_num_valid_levels
+            later.append(bits / ttl_sample_valid * self.ttl_hashparams_num_valid_levels)
 
+        if fork_2D is not None:
+            fork_2D.wait_stream(stream_2D)
+            if isinstance(bits_2D, torch.Tensor):
+                bits_2D.record_stream(fork_2D)
+        ttl_bit_sum = bits_2D
+        for t in later:
+            ttl_bit_sum = ttl_bit_sum + t
         ttl_num_sum += params_q_xyz.numel()
         bits_per_param = ttl_bit_sum / ttl_num_sum
         # second value: the estimate in MB as a Python float like the reference (a device->host sync), or — with

@@ -524,6 +524,7 @@ int launch_field_fused_w2(const FusedFieldArgs& p, bool rgb, uint32_t F, uint32_
             if (rc == CNC_OK) hipLaunchKernelGGL((k_field_fused16w2<FV, NTV, false, 3, 1>), dim3(blocks), dim3(128), lds_bytes, s, p); \
         } else if (p.save.feat) {           \
             rc = resident_grid(k_field_fused16w2<FV, NTV, true, 3, 2>, lds_bytes, tiles, 16, &blocks); \
+            blocks = exp_scaled_grid(blocks); \
             if (rc == CNC_OK) hipLaunchKernelGGL((k_field_fused16w2<FV, NTV, true, 3, 2>), dim3(blocks), dim3(128), lds_bytes, s, p); \
         } else if (rgb) CNC_W2_W(FV, NTV, true); \
         else CNC_W2_W(FV, NTV, false);      \

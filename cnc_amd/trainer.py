@@ -254,10 +254,16 @@ class Trainer:
         self.build_optimizers()
         self.loss_scale = 2.0 ** 10          # GradScaler(2**10), never unscaled (train:211,361-362)
 
+        self.prefetch = os.environ.get("CNC_PREFETCH_BATCH", "1") == "1"
+        self._next_data = None
         # The entropy pass (context forward and backward) runs on its own stream next to the render pass — see train_step
         self.ctx_stream = None
         if self.device.type == "cuda" and os.environ.get("CNC_CTX_STREAM", "1") == "1":
             self.ctx_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CNC_CTX_STREAM_PRIORITY", "0")))
+        # ... and its planes' half on a third one (CNC_CTX_STREAM_2D=0: both halves on the side stream, one after the other)
+        self.ctx_stream_2D = None
+        if self.ctx_stream is not None and os.environ.get("CNC_CTX_STREAM_2D", "1") == "1":
+            self.ctx_stream_2D = torch.cuda.Stream(device=self.device)
         # leaves are accumulated on the main stream, the entropy pass produces its gradients on the side stream: intended.
         # The switch is process-global, so it is held only for the duration of a train_step (see there).
         self._warn_switch = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None) \
@@ -350,9 +356,11 @@ class Trainer:
         e = self.field.mlp_base
         side.wait_event(fork)
         with torch.cuda.stream(side), _gradsink.activate(self.sink_ctx):
+            # the planes' half of the pass on a stream of its own, next to the 3-D half (both directions: autograd runs a
+            # node's backward on its forward's stream)
             bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(
                 e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
-                sample_num=None, step=step, sync_MB=False)
+                sample_num=None, step=step, sync_MB=False, stream_2D=self.ctx_stream_2D)
             # issued from the side stream: the root gradient of a backward call is created on the ambient stream and
             # every node waits for it
             root = c.lmbda * bits_per_param * self.loss_scale
@@ -361,6 +369,8 @@ class Trainer:
                 root.backward()
             else:
                 grads = torch.autograd.grad(root, params, allow_unused=True)
+            if self.ctx_stream_2D is not None:
+                side.wait_stream(self.ctx_stream_2D)       # the planes' backward kernels: part of what `done` marks
             done = side.record_event()
         return bits_per_param, mb, done, grads
 
@@ -370,7 +380,10 @@ class Trainer:
         train:368-381) — `n_rendering_samples` and `num_rays` are always there."""
         c = self.cfg
         self.field.train(); self.estimator.train(); self.context.train()
-        data = self.dataset.fetch()
+        # the batch: drawn at the end of the step before (`_prefetch`), while that step's backward kept the GPU busy
+        data, self._next_data = self._next_data, None
+        if data is None:
+            data = self.dataset.fetch()
         self.estimator.update_every_n_steps(
             step=step, occ_eval_fn=lambda x: self.field.query_density(x) * c.render_step_size,
             occ_thre=1e-2, n=c.step_update)
@@ -436,6 +449,16 @@ class Trainer:
             if self._warn_switch is not None:
                 self._warn_switch(warn_before)
 
+    def _prefetch(self) -> None:
+        """The NEXT step's batch, drawn now: the ray count it depends on has just been set (`update_num_rays`, from this
+        step's sample count), this thread would otherwise wait for the entropy pass, and the ~25 small kernels of the draw
+        run in the shadow of this step's backward instead of at the head of the next step, in front of everything (the
+        entropy pass — the longer of the two — could not start before them: 0.5 ms).  The dataset draws from its own
+        generator: the sequence of batches is the one `fetch()` at the top of each step produces.  Single-process steps
+        only (data parallel: the ray count of the next step is known at ITS start, `_lagged_sample_count`)."""
+        if self.prefetch and not self.dp:
+            self._next_data = self.dataset.fetch()
+
     def _lagged_sample_count(self, num_rays_now: int, n_samples: int) -> None:
         """Data-parallel ray budget without a collective of its own.  The reference resizes the next batch from this
         step's sample count (train:340-344); with N ranks the count that matters is the mean over the ranks, and asking
@@ -488,6 +511,7 @@ class Trainer:
         if self.bucket is None:
             if ctx_future is not None:
                 (mse * self.loss_scale).backward()
+                self._prefetch()
                 bpp, mb, _ = join(ctx_future.result())
             elif self.ctx_stream is not None and c.lmbda > 0 and mse.requires_grad:
                 # The sequential schedule of the same idea (one host thread; the reference's order of random draws):

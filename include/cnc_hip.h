@@ -864,6 +864,13 @@ typedef struct {
     uint64_t        workspace_bytes;
     uint32_t        n_workgroups;
 } cnc_field_wgrad_t;
+/* (ABI v27) Share in (0, 1] of the GPU's wave slots that the gradient pass's persistent kernels take — the saving form of
+ * cnc_field_fused_forward, cnc_field_backward_chain, cnc_field_weight_grads: their grid is what is resident at once, and a
+ * resident workgroup keeps its slot until the kernel ends.  1 (default): all of them — right when nothing else runs.  A
+ * caller that runs a second stream next to these kernels (the training step's entropy pass) sets a smaller share so that
+ * the other stream's kernels find free slots instead of waiting for the whole kernel.  Process-wide; not thread-safe
+ * against concurrent launches (set it once).                                                                       */
+int cnc_set_persistent_share(float share);
 int cnc_field_weight_grads_workspace(const cnc_field_wgrad_t* d, uint64_t* bytes);
 int cnc_field_weight_grads(const cnc_field_wgrad_t* d, void* stream);
 
