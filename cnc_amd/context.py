@@ -615,6 +615,7 @@ class CNC_context_models(nn.Module):
         # a refresh whose occupancy grid equals the one the structures were built from keeps them (forward_..._3D2D)
         self.skip_unchanged_refresh = os.environ.get("CNC_SKIP_UNCHANGED_REFRESH", "1") == "1"
         self.refresh_stats = {"refreshes": 0, "skipped": 0}
+        self.structures_version = 0          # + 1 whenever a refresh rebuilds the vote plan / the planes' vertex lists
         self._occ_built_from, self._occ_built_how = None, None
         self.idx_coords2_tmp = None
         self.vote_plan = None
@@ -976,7 +977,9 @@ class CNC_context_models(nn.Module):
                                            pb["segs"])
             mean = _segment_reduce.apply(mean_pts, pb["cum"], None, 2, pb["order"])
         with _range("ctx/2D_entropy"):
-            return torch.dot(bits_all, self._noncoded_2D) + self._bits(p_q, pb["rows"], mean)
+            # (the zero-order levels' bits: an elementwise product and a sum, not torch.dot — the BLAS call cannot be
+            # recorded into a HIP graph, cnc_amd._planes_graph)
+            return (bits_all * self._noncoded_2D).sum() + self._bits(p_q, pb["rows"], mean)
 
     def _bits(self, table_q, rows, mean):
         """Rate of the coded rows of a binarised table under the predicted P(+1): sum of
@@ -994,7 +997,7 @@ class CNC_context_models(nn.Module):
     # ------------------------------------------------------------------------------- training
     def forward_binary_vxl_mixPg_3D2D(self, Encoding_xyz, Encoding_xy, Encoding_xz, Encoding_yz,
                                       binary_vxl=None, verbose=False, sample_num=None, step=0, sync_MB=True,
-                                      stream_2D=None):
+                                      stream_2D=None, planes=None):
         """Entropy estimate (bits per parameter) of the four binarised tables under the context
         models; differentiable w.r.t. tables and context models (utils_bpp_acc.py:533-706).
 
@@ -1003,14 +1006,25 @@ class CNC_context_models(nn.Module):
         current stream behind the STE of the tables) and the 3-D part on the current stream next to it; autograd runs
         each node's backward on its forward's stream, so one backward call runs the two halves side by side as well.
         Same values: the partial sums are added in the order of the one-stream pass.  The caller orders its stream
-        after `stream_2D` once the backward has been enqueued (the trainer's `_context_pass`)."""
+        after `stream_2D` once the backward has been enqueued (the trainer's `_context_pass`).
+
+        `planes` (extension) = (bits, parameter count) of the three planes' tables computed elsewhere — the training
+        step's captured graph of the planes' half (cnc_amd._planes_graph) — : only the 3-D half runs here, and the
+        planes' bits enter the totals as given (no gradient through them: the graph has back-propagated their share)."""
+        axes = ("xy", "xz", "yz")
+        if planes is not None:
+            if step % self.step_update == 0:
+                raise RuntimeError("planes: not on a refresh step (the planes' structures are rebuilt inside the pass)")
+            with _range("ctx/ste_params"):
+                params_q_xyz = self.get_STE_params(Encoding_xyz)
+            return self._bits_3D_and_total(Encoding_xyz, params_q_xyz, binary_vxl, sample_num, planes[0], planes[1], None,
+                                           None, sync_MB)
         with _range("ctx/ste_params"):
             params_q_xy = self.get_STE_params(Encoding_xy)
             params_q_xz = self.get_STE_params(Encoding_xz)
             params_q_yz = self.get_STE_params(Encoding_yz)
             params_q_xyz = self.get_STE_params(Encoding_xyz)
         ttl_bit_sum, ttl_num_sum = 0, 0
-        axes = ("xy", "xz", "yz")
 
         refresh = step % self.step_update == 0
         if refresh and binary_vxl is not None:
@@ -1030,6 +1044,7 @@ class CNC_context_models(nn.Module):
                 self.refresh_stats["skipped"] += 1
             else:
                 self._occ_built_from, self._occ_built_how = binary_vxl.clone(), how
+                self.structures_version += 1        # what a captured graph of the planes' half is valid for
         if refresh and self.use_dimension_wise:
             occ = binary_vxl.squeeze(0)
             R_fine = self.dimension_wise_resolution
@@ -1070,18 +1085,19 @@ class CNC_context_models(nn.Module):
             for t in (params_q_xy, params_q_xz, params_q_yz, params_q_xyz):
                 t.record_stream(stream_2D)
         with (torch.cuda.stream(stream_2D) if fork_2D is not None else contextlib.nullcontext()):
+            finest_3D = params_q_xyz[self._off3_host[-2]:self._off3_host[-1]]
             ttl_bit_sum, ttl_num_sum = self._bits_2D(Encoding_xy, Encoding_xz, Encoding_yz, params_q_xy, params_q_xz, params_q_yz,
-                                                     params_q_xyz, binary_vxl, binary_2D, idx_coords2, refresh)
+                                                     finest_3D, binary_vxl, binary_2D, idx_coords2, refresh)
 
         return self._bits_3D_and_total(Encoding_xyz, params_q_xyz, binary_vxl, sample_num, ttl_bit_sum, ttl_num_sum, fork_2D,
                                        stream_2D, sync_MB)
 
-    def _bits_2D(self, Encoding_xy, Encoding_xz, Encoding_yz, params_q_xy, params_q_xz, params_q_yz, params_q_xyz,
+    def _bits_2D(self, Encoding_xy, Encoding_xz, Encoding_yz, params_q_xy, params_q_xz, params_q_yz, finest_3D,
                  binary_vxl, binary_2D, idx_coords2, refresh):
-        """(bits of the three planes' tables, their parameter count): utils_bpp_acc.py:560-617."""
+        """(bits of the three planes' tables, their parameter count): utils_bpp_acc.py:560-617.  `finest_3D`: the
+        binarised finest level of the 3-D table (the dimension-wise votes' source)."""
         axes = ("xy", "xz", "yz")
         ttl_bit_sum, ttl_num_sum = 0, 0
-        finest_3D = params_q_xyz[self._off3_host[-2]:self._off3_host[-1]]
         pn_fracs = None
         if self.use_dimension_wise and self.vote_plan is not None and finest_3D.shape[0] <= self.vote_plan.hashmap_size:
             with _range("ctx/pn_frac"):
@@ -1213,7 +1229,7 @@ class CNC_context_models(nn.Module):
             fork_2D.wait_stream(stream_2D)
             if isinstance(bits_2D, torch.Tensor):
                 bits_2D.record_stream(fork_2D)
-        ttl_bit_sum = bits_2D
+        ttl_bit_sum = 0 if bits_2D is None else bits_2D
         for t in later:
             ttl_bit_sum = ttl_bit_sum + t
         ttl_num_sum += params_q_xyz.numel()

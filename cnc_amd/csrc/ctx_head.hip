@@ -691,6 +691,13 @@ __global__ __launch_bounds__(256) void k_level_stats_bwd(const double* __restric
 
 }  // namespace cnc
 
+namespace cnc {
+__global__ void k_zero_f64(double* __restrict__ p, uint32_t n)
+{
+    for (uint32_t i = threadIdx.x; i < n; i += 64) p[i] = 0.0;
+}
+}  // namespace cnc
+
 extern "C" int cnc_level_stats_forward(const float* table, const int64_t* offsets_host, uint32_t n_levels, uint32_t F,
                                        double* sums, float* Pg, float* bits, void* stream)
 {
@@ -700,7 +707,10 @@ extern "C" int cnc_level_stats_forward(const float* table, const int64_t* offset
     lo.n_levels = (int32_t)n_levels;
     for (uint32_t i = 0; i <= n_levels; i++) lo.off[i] = offsets_host[i];
     const int64_t rows = lo.off[n_levels] - lo.off[0];
-    if (hipMemsetAsync(sums, 0, n_levels * sizeof(double), (hipStream_t)stream) != hipSuccess) return CNC_ERR_LAUNCH;
+    // (a kernel, not hipMemsetAsync: recorded into a HIP graph — cnc_amd/_planes_graph.py — the memset node of these few
+    // bytes was not reliably ordered in front of the atomics that follow when other streams were busy: level sums, and
+    // with them Pg, came out as garbage once in a few dozen replays)
+    hipLaunchKernelGGL(cnc::k_zero_f64, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, n_levels);
     if (rows > 0)
         hipLaunchKernelGGL(cnc::k_level_sums, dim3((uint32_t)((rows + 2047) / 2048)), dim3(256), 0, (hipStream_t)stream,
                            table, lo, F, sums);

@@ -209,9 +209,10 @@ class GridEncoder(nn.Module):
         self.invalidate_caches()
 
     def invalidate_caches(self):
-        """Forget the packed sign plane / clip counter (call after writing `params` through `.data`; optimizer
-        steps do it through cnc_amd._caches)."""
-        self._bits = self._bits_key = self._bits_src = self._clip_count = None
+        """The packed sign plane / clip counter are stale (call after writing `params` through `.data`; optimizer
+        steps do it through cnc_amd._caches).  The buffers themselves are kept: `_bit_plane` repacks into them, so their
+        addresses are constants of the run."""
+        self._bits_key = self._bits_src = None
 
     def __repr__(self):
         return (f"GridEncoder: num_dim={self.num_dim} n_levels={self.n_levels} "
@@ -225,8 +226,15 @@ class GridEncoder(nn.Module):
         key = (params.data_ptr(), params._version, tuple(params.shape))
         if self._bits is None or self._bits_key != key:
             with torch.no_grad():
-                cc = torch.empty(1, dtype=torch.int32, device=params.device)
-                self._bits = _backend.pack_sign_bits(params.detach().contiguous(), None, cc)
+                # repacked IN PLACE when the table's shape is the one before: the plane's address is then a constant of
+                # the run, which a captured graph of kernels that read it needs (cnc_amd._planes_graph).  Every reader
+                # of the old contents has been joined to the caller's stream by then: the table itself has just been
+                # rewritten by the optimizer on that stream.
+                n_bytes = (params.shape[0] * params.shape[1] + 7) // 8
+                same = (self._bits is not None and self._bits.device == params.device and self._bits.numel() == n_bytes
+                        and self._clip_count is not None and self._clip_count.device == params.device)
+                cc = self._clip_count if same else torch.empty(1, dtype=torch.int32, device=params.device)
+                self._bits = _backend.pack_sign_bits(params.detach().contiguous(), self._bits if same else None, cc)
                 self._clip_count = cc
             self._bits_key = key
             self._bits_src = (params,)   # keep the storage alive so (data_ptr, version) stays unique (a tuple:

@@ -254,6 +254,12 @@ class Trainer:
         self.build_optimizers()
         self.loss_scale = 2.0 ** 10          # GradScaler(2**10), never unscaled (train:211,361-362)
 
+        # the planes' half of the entropy pass as one captured graph per refresh interval (CNC_PLANES_GRAPH=0: op by op)
+        self.planes_graph = None
+        self._planes_replayed = False
+        if self.device.type == "cuda" and os.environ.get("CNC_PLANES_GRAPH", "1") == "1":
+            from ._planes_graph import PlanesGraph
+            self.planes_graph = PlanesGraph(self)
         self.prefetch = os.environ.get("CNC_PREFETCH_BATCH", "1") == "1"
         self._next_data = None
         # The entropy pass (context forward and backward) runs on its own stream next to the render pass — see train_step
@@ -345,6 +351,25 @@ class Trainer:
         with torch.set_grad_enabled(grad_mode), torch.autocast(self.device.type, dtype=dtype, enabled=enabled):
             return self._context_pass(step, fork, params)
 
+    def _planes_graph_step(self, step: int, params) -> bool:
+        c = self.cfg
+        return (self.planes_graph is not None and params is None and self.ctx_stream_2D is not None and c.lmbda > 0
+                and step % c.step_update != 0 and step > c.step_update and torch.is_grad_enabled())
+
+    def _ensure_planes_graph(self, step: int, params) -> None:
+        """Capture the planes' graph if this step replays one and the structures it was recorded for are gone (the first
+        step behind an occupancy refresh).  On the thread that calls it, with NO other thread of the step running: a
+        capture puts the device's default random generator into capture mode for its duration, and a draw from another
+        thread (the sampler's jitter) fails meanwhile — so train_step calls this before it forks the entropy pass off."""
+        if self._planes_graph_step(step, params) and not self.planes_graph.ready():
+            try:
+                with torch.cuda.stream(self.ctx_stream_2D), _gradsink.activate(self.sink_ctx):
+                    self.planes_graph.capture()
+            except Exception as e:       # an operation the runtime cannot record: the step falls back to the op-by-op pass
+                import warnings
+                warnings.warn(f"cnc_amd: capturing the planes' graph failed ({e}); continuing without it")
+                self.planes_graph = None
+
     def _context_pass(self, step: int, fork, params=None):
         """Entropy loss forward + backward on the side stream (from whichever host thread calls it), ordered after the
         event `fork` of the main stream.  `params` = None: the gradient is accumulated into `.grad`; a parameter list:
@@ -356,11 +381,24 @@ class Trainer:
         e = self.field.mlp_base
         side.wait_event(fork)
         with torch.cuda.stream(side), _gradsink.activate(self.sink_ctx):
+            # The planes' half as ONE graph launch (cnc_amd._planes_graph): between occupancy refreshes, single-process
+            # steps (the data-parallel step wants the gradients returned).  Captured at the first step after a refresh.
+            pg, planes = self.planes_graph, None
+            self._planes_replayed = False
+            if self._planes_graph_step(step, params):
+                self._ensure_planes_graph(step, params)    # (captured by train_step already when this is the worker thread)
+                self.ctx_stream_2D.wait_stream(side)
+                with torch.cuda.stream(self.ctx_stream_2D):
+                    planes = (None, pg.replay()[1])        # the bits join the totals below, behind the backward
+                self._planes_replayed = True
             # the planes' half of the pass on a stream of its own, next to the 3-D half (both directions: autograd runs a
             # node's backward on its forward's stream)
+            # (Back-propagating the planes' share of the loss as soon as their forward is enqueued — a second backward call,
+            # before the 3-D half is launched — was built and measured: 8.25 -> 8.95 ms.  The first half of the step is bound
+            # by the two host threads' launches, and the extra call sits in front of the 3-D forward's.)
             bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(
                 e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
-                sample_num=None, step=step, sync_MB=False, stream_2D=self.ctx_stream_2D)
+                sample_num=None, step=step, sync_MB=False, stream_2D=self.ctx_stream_2D, planes=planes)
             # issued from the side stream: the root gradient of a backward call is created on the ambient stream and
             # every node waits for it
             root = c.lmbda * bits_per_param * self.loss_scale
@@ -371,6 +409,11 @@ class Trainer:
                 grads = torch.autograd.grad(root, params, allow_unused=True)
             if self.ctx_stream_2D is not None:
                 side.wait_stream(self.ctx_stream_2D)       # the planes' backward kernels: part of what `done` marks
+            if planes is not None:                         # the reported totals: + the planes' bits (no gradient here)
+                e_ = self.field.mlp_base
+                n_all = sum(t.params.numel() for t in e_._encoders())
+                bits_per_param = bits_per_param.detach() + pg.bits / n_all
+                mb = mb + pg.bits / 8 / 1024 / 1024
             done = side.record_event()
         return bits_per_param, mb, done, grads
 
@@ -427,6 +470,7 @@ class Trainer:
                     from concurrent.futures import ThreadPoolExecutor
                     self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cnc-context")
                 autocast = (torch.is_autocast_enabled(self.device.type), torch.get_autocast_dtype(self.device.type))
+                self._ensure_planes_graph(step, None if self.bucket is None else self.bucket.params)
                 ctx_future = self._pool.submit(self._context_pass_worker, step,
                                                torch.cuda.current_stream(self.device).record_event(),
                                                None if self.bucket is None else self.bucket.params,
@@ -538,6 +582,8 @@ class Trainer:
             for sink in (self.sink_render, self.sink_ctx):
                 if sink is not None:
                     sink.flush()
+            if self._planes_replayed:
+                self.planes_graph.flush()       # what autograd returned inside the planes' graph
         else:
             # Data-parallel step.  The ray loss differs per rank, the entropy loss does not (same tables, same
             # window draw on every rank): so only the ray-loss gradient is exchanged, and its all-reduce runs

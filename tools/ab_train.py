@@ -28,6 +28,10 @@ def switch(on):
         if not hasattr(tr, "_s2"):
             tr._s2 = tr.ctx_stream_2D
         tr.ctx_stream_2D = tr._s2 if on else None
+    elif what == "pgraph":
+        if not hasattr(tr, "_pg"):
+            tr._pg = tr.planes_graph
+        tr.planes_graph = tr._pg if on else None
     elif what == "prefetch":
         tr.prefetch = on
     elif what == "wgrad":

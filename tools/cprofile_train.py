@@ -5,6 +5,8 @@ import torch
 from cnc_amd.trainer import TrainConfig, Trainer
 cfg = TrainConfig(n_features=8, sample_num=150000, max_steps=2000, image_size=400, out_dir="/tmp/bits")
 tr = Trainer(cfg, device=torch.device("cuda:0"))
+if "--sequential" in sys.argv:       # both passes launched by this thread: the profile sees the entropy pass's host time too
+    tr.ctx_thread = False
 for step in range(245):
     tr.train_step(step, want_stats=False)
 torch.cuda.synchronize()
@@ -16,6 +18,6 @@ torch.cuda.synchronize()
 pr.disable()
 for key in ("tottime", "cumtime"):
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(45)
+    pstats.Stats(pr, stream=s).sort_stats(key).print_stats(70)
     out = s.getvalue()
-    print(out[out.index("ncalls"):][:9000])
+    print(out[out.index("ncalls"):][:14000])
