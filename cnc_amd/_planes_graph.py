@@ -128,8 +128,11 @@ class PlanesGraph:
         self.graph.replay()
         sink = _gradsink.current()
         if sink is not None:          # what the captured kernels add into: `flush` skips buffers nobody marked
-            sink._tables_used = [a or b for a, b in zip(sink._tables_used, self._tables_used)]
-            sink._small_used = sink._small_used or self._small_used
+            for k, used in enumerate(self._tables_used):      # (in place, only ever to True: the 3-D half marks the same
+                if used:                                      # list from its own thread meanwhile)
+                    sink._tables_used[k] = True
+            if self._small_used:
+                sink._small_used = True
         self.replays += 1
         return self.bits, self.n_params
 

@@ -256,6 +256,7 @@ class Trainer:
 
         # the planes' half of the entropy pass as one captured graph per refresh interval (CNC_PLANES_GRAPH=0: op by op)
         self.planes_graph = None
+        self._pool_graph = None
         self._planes_replayed = False
         if self.device.type == "cuda" and os.environ.get("CNC_PLANES_GRAPH", "1") == "1":
             from ._planes_graph import PlanesGraph
@@ -356,6 +357,13 @@ class Trainer:
         return (self.planes_graph is not None and params is None and self.ctx_stream_2D is not None and c.lmbda > 0
                 and step % c.step_update != 0 and step > c.step_update and torch.is_grad_enabled())
 
+    def _replay_planes(self, after) -> None:
+        """On the planes' thread: the graph launch on the planes' stream, ordered after the event `after`."""
+        torch.cuda.set_device(self.device)
+        with torch.cuda.stream(self.ctx_stream_2D), _gradsink.activate(self.sink_ctx):
+            self.ctx_stream_2D.wait_event(after)
+            self.planes_graph.replay()
+
     def _ensure_planes_graph(self, step: int, params) -> None:
         """Capture the planes' graph if this step replays one and the structures it was recorded for are gone (the first
         step behind an occupancy refresh).  On the thread that calls it, with NO other thread of the step running: a
@@ -383,13 +391,18 @@ class Trainer:
         with torch.cuda.stream(side), _gradsink.activate(self.sink_ctx):
             # The planes' half as ONE graph launch (cnc_amd._planes_graph): between occupancy refreshes, single-process
             # steps (the data-parallel step wants the gradients returned).  Captured at the first step after a refresh.
-            pg, planes = self.planes_graph, None
+            pg, planes, replay = self.planes_graph, None, None
             self._planes_replayed = False
             if self._planes_graph_step(step, params):
                 self._ensure_planes_graph(step, params)    # (captured by train_step already when this is the worker thread)
-                self.ctx_stream_2D.wait_stream(side)
-                with torch.cuda.stream(self.ctx_stream_2D):
-                    planes = (None, pg.replay()[1])        # the bits join the totals below, behind the backward
+            if self._planes_graph_step(step, params):      # (still: a failed capture switches the graph off)
+                # The graph launch itself is ~2 ms of HOST time (the runtime enqueues the ~110 nodes one by one, outside the
+                # interpreter lock): from a thread of its own, so that this one goes straight on to the 3-D half.
+                if self._pool_graph is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._pool_graph = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cnc-planes")
+                replay = self._pool_graph.submit(self._replay_planes, side.record_event())
+                planes = (None, pg.n_params)               # the bits join the totals below, behind the backward
                 self._planes_replayed = True
             # the planes' half of the pass on a stream of its own, next to the 3-D half (both directions: autograd runs a
             # node's backward on its forward's stream)
@@ -407,6 +420,8 @@ class Trainer:
                 root.backward()
             else:
                 grads = torch.autograd.grad(root, params, allow_unused=True)
+            if replay is not None:
+                replay.result()                            # the graph launch has been enqueued (and did not fail)
             if self.ctx_stream_2D is not None:
                 side.wait_stream(self.ctx_stream_2D)       # the planes' backward kernels: part of what `done` marks
             if planes is not None:                         # the reported totals: + the planes' bits (no gradient here)
