@@ -379,12 +379,14 @@ def test_gridencoder_bit_plane_cache_tracks_in_place_updates(cuda):
         b.params.copy_(a.params)
     x = torch.rand(3000, 3, device=cuda)
     assert torch.equal(a(x), b(x))
-    bits0 = a._bits
-    assert torch.equal(a(x), b(x)) and a._bits is bits0          # cached
+    bits0, key0, plane0 = a._bits, a._bits_key, a._bits.clone()
+    assert torch.equal(a(x), b(x)) and a._bits is bits0 and a._bits_key == key0          # cached
     with torch.no_grad():
         a.params.mul_(-1.0)                                       # optimizer-style in-place update
         b.params.mul_(-1.0)
-    assert torch.equal(a(x), b(x)) and a._bits is not bits0       # repacked
+    # repacked — in place: the plane's address is a constant of the run (captured graphs read it, cnc_amd/_planes_graph.py)
+    assert torch.equal(a(x), b(x)) and a._bits_key != key0 and a._bits.data_ptr() == bits0.data_ptr()
+    assert not torch.equal(a._bits, plane0)
     w = torch.randn(3000, 8 * len(RES3), device=cuda)
     (a(x) * w).sum().backward()
     (b(x) * w).sum().backward()
