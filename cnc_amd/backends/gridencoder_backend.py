@@ -76,7 +76,16 @@ def occupancy_vertex_bits(binary_vxl, occ_sat, resolutions, max_vertices=1 << 26
         if o >= 0:
             check(L.cnc_grid_vertex_bits(ptr(sat), D, int(Rb), int(R), words.data_ptr() + 4 * o,
                                          stream(binary_vxl.device)), "grid_vertex_bits")
-    return words, torch.tensor(offs, dtype=torch.int32, device=binary_vxl.device)
+    # the offsets depend on the resolutions only: one host->device copy (a synchronising one) per (resolutions, device),
+    # not per occupancy refresh and encoder
+    key = (tuple(offs), str(binary_vxl.device))
+    cached = _VB_OFFSETS.get(key)
+    if cached is None:
+        cached = _VB_OFFSETS[key] = torch.tensor(offs, dtype=torch.int32, device=binary_vxl.device)
+    return words, cached
+
+
+_VB_OFFSETS = {}
 
 
 def _vb(vertex_bits, binary_vxl, n_levels):

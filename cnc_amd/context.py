@@ -915,10 +915,14 @@ class CNC_context_models(nn.Module):
                 sizes.append(r.shape[0])
         keys_sorted, order = torch.sort(torch.cat(keys), stable=True)
         uv, uc = torch.unique_consecutive(keys_sorted, return_counts=True)          # sync 1: the number of slots
-        bases = torch.tensor([(k * nl) << shift for k in range(4)], dtype=uv.dtype, device=uv.device)
+        consts = self.__dict__.setdefault("_plane_cat_consts", {})
+        ck = (nl, shift, str(uv.dtype), str(uv.device))
+        if ck not in consts:          # two small host->device copies (synchronising ones), once instead of per refresh
+            consts[ck] = (torch.tensor([(k * nl) << shift for k in range(4)], dtype=uv.dtype, device=uv.device),
+                          torch.tensor(self._off2_host[:nl], dtype=torch.long, device=uv.device))
+        bases, off_lut = consts[ck]
         slot_at = torch.searchsorted(uv, bases).tolist()                            # sync 2: slots per plane
         pts_all = torch.cat(pts)
-        off_lut = torch.tensor(self._off2_host[:nl], dtype=torch.long, device=uv.device)
         at = 0
         for k in range(3):
             a, b = slot_at[k], slot_at[k + 1]
