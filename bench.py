@@ -386,6 +386,14 @@ def train_step_entry(dev, world=1, rank=0):
     out["refresh"] = {"every": cfg.step_update, "refresh_step_ms": ref_ms, "ordinary_step_ms_median_synced": ord_ms[len(ord_ms) // 2],
                       "refreshes_since_start": rs1["refreshes"], "unchanged_grid_kept_plan": rs1["skipped"],
                       "in_the_last_32_steps": {k: rs1[k] - rs0[k] for k in rs1}}
+    pg = tr.planes_graph
+    out["schedule"] = {"streams": 1 + (tr.ctx_stream is not None) + (tr.ctx_stream_2D is not None),
+                       "entropy_pass_thread": bool(tr.ctx_thread),
+                       "planes_graph": None if pg is None else {"captures": pg.captures, "replays": pg.replays},
+                       "field_forward": "fused kernel, saving form" if tr.field.fused_train else "library GEMMs",
+                       "field_weight_grads": "one kernel" if tr.field.fused_wgrad else "split-K library GEMMs",
+                       "range_guard_left_fused_forward": not tr.field.fused_train and os.environ.get("CNC_FUSED_TRAIN", "1") == "1",
+                       "batch_prefetch": bool(tr.prefetch)}
     if world == 1:
         out["extras"] = trained_model_entries(tr, dev)
     if world > 1:

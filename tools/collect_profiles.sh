@@ -34,6 +34,11 @@ if [ "$WHAT" = "all" ]; then
   timeout 600 python $ROOT/tools/step_phases.py > $OUT/step_phases.txt 2>&1
   timeout 600 python $ROOT/tools/aten_by_range.py > $OUT/aten_by_range.txt 2>&1
   timeout 600 python $ROOT/tools/bench_train.py --no-profile > $OUT/train_untraced.log 2>&1
+  # one steady-state step as a kernel timeline per queue; the field's gradient pass alone (forward + backward at 2^18 samples)
+  bash $ROOT/tools/step_kernels.sh > $OUT/step_kernels.log 2>&1
+  cp $ROOT/gpurun_out/step_kernels/timeline.txt $OUT/step_timeline.txt 2>/dev/null
+  timeout 600 python $ROOT/tools/bench_chain.py --profile > $OUT/bench_chain.log 2>&1
+  timeout 600 python $ROOT/tools/step_wall_by_kind.py > $OUT/step_wall_by_kind.txt 2>&1
 fi
 find $OUT -name "*kernel_trace.csv" -delete      # large; the stats csv is what is kept
 find $OUT -name "*.db" -delete
