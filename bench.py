@@ -68,6 +68,13 @@ class Timed:
         self.pending = []
 
 
+def reserve_training_streams(dev):
+    """Before anything else touches the GPU: the training step's two side streams (cnc_amd.trainer.reserve_streams says
+    why the order matters: four hardware queues, dealt out in order of first use)."""
+    from cnc_amd.trainer import reserve_streams
+    reserve_streams(dev)
+
+
 def build_workload(dev, rank):
     offs = synthetic.level_offsets(synthetic.RES_16L, LOG2_T, D)
     assert int(offs[-1]) == 6120776
@@ -526,6 +533,8 @@ def main():
     else:
         ranks = [{"rank": 0, "device": str(dev), "world_size": 1, "backend": backend}]
 
+    if not args.no_train_step:
+        reserve_training_streams(dev)
     w = build_workload(dev, rank)
     w["exchange_on"] = exchange_on
     timed = Timed()

@@ -176,14 +176,14 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
                 _plan(grad.device, cur), ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
                 ptr(grad_embeddings), int(N), int(num_dim), int(n_features), int(n_levels), flags, ptr(ste_clip_count),
                 int(grad_ld), int(grad_col), n_binned, level_rows, ptr(ws),
-                ws.numel(), stream(grad.device))
-            check(rc, "grid_encode_backward_overlapped")
+                nbytes, stream(grad.device))      # (the size THIS call asked for, not what an earlier, larger call left
+            check(rc, "grid_encode_backward_overlapped")     # behind: the library deepens its bins with the scratch it is given)
             return
         ws = _workspace(grad.device, nbytes, (torch.cuda.current_stream(grad.device).cuda_stream, 0))
         rc = L.cnc_grid_encode_backward_binned(
             ptr(grad), ptr(inputs), ptr(embeddings), ptr(offsets_list), ptr(resolutions_list),
             ptr(grad_embeddings), int(N), int(num_dim), int(n_features), int(n_levels), flags,
-            ptr(ste_clip_count), int(grad_ld), int(grad_col), n_binned, level_rows, ptr(ws), ws.numel(),
+            ptr(ste_clip_count), int(grad_ld), int(grad_col), n_binned, level_rows, ptr(ws), nbytes,
             stream(grad.device))
         check(rc, "grid_encode_backward_binned")
         return

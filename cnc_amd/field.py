@@ -198,7 +198,12 @@ class _FusedFeatures(Function):
             be.grid_encode_backward(grad, xi, p, enc.offsets_list, enc.resolutions_list, g, N,
                                     enc.num_dim, enc.n_features, enc.n_levels, 0, 128, None, None,
                                     None, None, ste_binary=True, ste_clip_count=clip,
-                                    grad_ld=ld, grad_col=col, binned=enc._binned_plan(N))
+                                    grad_ld=ld, grad_col=col, binned=enc._binned_plan(N),
+                                    # inside a training step (a sink is active) the scatter stays on the caller's stream: the
+                                    # step runs three streams of its own, and the library's two side streams next to them
+                                    # made streams share hardware queues — which ones depended on the order the process had
+                                    # created its streams in: 7.3 ms per step, or 9.7 after a bench frame had run first
+                                    overlap_streams=sink is None)
             grads.append(g if sunk is None else None)
         return grads
 

@@ -226,6 +226,31 @@ class LoaderDataset:
         return len(self.test)
 
 
+_STEP_STREAMS = {}
+
+
+def reserve_streams(device):
+    """The two side streams of the training step on `device` (entropy pass; its planes' half), created — and used once —
+    NOW, one pair per process and device.  Why there is such a call: the HIP runtime deals a process's streams onto four
+    hardware queues in the order they first appear, the null stream included, and two streams on one queue run one after
+    the other.  A Trainer made first gets a queue per stream (null, entropy, planes: three of four); made after other
+    code has used streams of its own (the encoder backward's two side streams in bench.py's frame loop) its planes' stream
+    landed on the null stream's queue and the step took 9.7 ms instead of 7.5.  A process that trains creates its Trainer
+    first anyway; one that does other GPU work first calls this at start-up."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return None
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _STEP_STREAMS:
+        prio = int(os.environ.get("CNC_CTX_STREAM_PRIORITY", "0"))
+        pair = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(2)]
+        for st in pair:
+            with torch.cuda.stream(st):
+                torch.zeros(1, device=dev)
+        _STEP_STREAMS[key] = pair
+    return _STEP_STREAMS[key]
+
+
 class Trainer:
     def __init__(self, cfg: TrainConfig, device="cuda", dataset=None):
         self.cfg = cfg
@@ -266,11 +291,11 @@ class Trainer:
         # The entropy pass (context forward and backward) runs on its own stream next to the render pass — see train_step
         self.ctx_stream = None
         if self.device.type == "cuda" and os.environ.get("CNC_CTX_STREAM", "1") == "1":
-            self.ctx_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("CNC_CTX_STREAM_PRIORITY", "0")))
+            self.ctx_stream = reserve_streams(self.device)[0]
         # ... and its planes' half on a third one (CNC_CTX_STREAM_2D=0: both halves on the side stream, one after the other)
         self.ctx_stream_2D = None
         if self.ctx_stream is not None and os.environ.get("CNC_CTX_STREAM_2D", "1") == "1":
-            self.ctx_stream_2D = torch.cuda.Stream(device=self.device)
+            self.ctx_stream_2D = reserve_streams(self.device)[1]
         # leaves are accumulated on the main stream, the entropy pass produces its gradients on the side stream: intended.
         # The switch is process-global, so it is held only for the duration of a train_step (see there).
         self._warn_switch = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None) \

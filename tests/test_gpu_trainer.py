@@ -281,3 +281,63 @@ def test_gradient_sinks_give_the_gradients_autograd_gives(cuda, tmp_path, mode):
         scale = float(want.abs().max())
         assert scale > 0, n
         assert float((got - want).abs().max()) <= 2e-4 * scale, (n, float((got - want).abs().max()), scale)
+
+
+def _entropy_pass_gradients(tr, step, params):
+    """One entropy pass (forward + backward through `Trainer._context_pass`) on the trainer's current state: (bits per
+    parameter, MB, the gradient of every parameter)."""
+    for p in params:
+        p.grad = None
+    for s in (tr.sink_render, tr.sink_ctx):
+        s.zero()
+    for enc in tr.field.mlp_base._encoders():
+        enc._bit_plane(enc.params)
+    torch.manual_seed(5)                                  # the 3-D half's window draw
+    main = torch.cuda.current_stream()
+    tr._ensure_planes_graph(step, None)
+    bpp, mb, done, _ = tr._context_pass(step, main.record_event())
+    main.wait_event(done)
+    tr.sink_ctx.flush()
+    if tr._planes_replayed:
+        tr.planes_graph.flush()
+    torch.cuda.synchronize()
+    return float(bpp), float(mb), [None if p.grad is None else p.grad.clone() for p in params]
+
+
+def test_planes_graph_and_planes_stream_equal_the_one_stream_entropy_pass(cuda, tmp_path):
+    """The planes' half of the entropy pass on its own stream (`stream_2D`), and as a captured HIP graph replayed across
+    parameter updates (`cnc_amd._planes_graph`), against the op-by-op pass on one stream — on the same state: the same
+    bits and the same gradient of every parameter up to the order of float atomics.  Then training goes on through the
+    graph: it is recorded once per occupancy refresh, replayed on every other step, and nothing goes non-finite."""
+    from cnc_amd.trainer import Trainer
+    tr = Trainer(_cfg(tmp_path, seed=11), device=cuda)
+    pg = tr.planes_graph
+    assert pg is not None and tr.ctx_stream_2D is not None
+    for step in range(20):                                # the graph: recorded at step 17, replayed 17, 18, 19
+        tr.train_step(step, want_stats=False)
+    torch.cuda.synchronize()
+    assert pg.captures == 1 and pg.replays == 3
+    params = list(tr.field.parameters()) + list(tr.context.parameters())
+    names = [n for n, _ in tr.field.named_parameters()] + ["ctx." + n for n, _ in tr.context.named_parameters()]
+    s2 = tr.ctx_stream_2D
+    tr.planes_graph, tr.ctx_stream_2D = None, None
+    want = _entropy_pass_gradients(tr, 20, params)       # one stream, op by op
+    tr.ctx_stream_2D = s2
+    two = _entropy_pass_gradients(tr, 20, params)        # the planes' half on its own stream
+    tr.planes_graph = pg
+    graph = _entropy_pass_gradients(tr, 20, params)      # ... as the graph recorded three updates ago
+    assert pg.captures == 1 and pg.replays == 4
+    for what, got in (("stream", two), ("graph", graph)):
+        assert abs(got[0] - want[0]) <= 1e-6 * want[0] and abs(got[1] - want[1]) <= 1e-6 * want[1], what
+        for n, a, b in zip(names, want[2], got[2]):
+            assert (a is None) == (b is None), (what, n)
+            if a is not None:
+                assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-30), (what, n)
+    for step in range(20, 70):
+        s = tr.train_step(step, want_stats=step % 10 == 0)
+        if step % 10 == 0:
+            assert math.isfinite(s["bpp"]) and math.isfinite(s["mse"])
+    torch.cuda.synchronize()
+    refreshes = tr.context.refresh_stats["refreshes"] - tr.context.refresh_stats["skipped"]
+    assert 2 <= pg.captures <= refreshes and pg.replays >= 4 + 50 - 4            # every non-refresh step replayed
+    assert all(bool(torch.isfinite(p).all()) for p in params)
