@@ -20,6 +20,8 @@ lock = threading.Lock()
 
 
 def mark(name):
+    if torch.cuda.is_current_stream_capturing():       # the planes' graph being recorded: nothing runs, nothing to time
+        return
     e = torch.cuda.Event(enable_timing=True)
     e.record()                      # on the calling thread's current stream
     with lock:
