@@ -116,6 +116,10 @@ SIGNATURES = {
                            _f32, _f32, _i32, _i32, C.POINTER(RaySegments), C.POINTER(RaySegments), _vp, _vp],
     "cnc_march_samples": [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                           _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cnc_occupancy_coarse_words": [_i32, _i32, _i32, _i32],
+    "cnc_occupancy_coarse_bits": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
+    "cnc_march_samples_coarse": [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cnc_sample_positions": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
     "cnc_inclusive_sum": [_vp, _vp, _vp, _vp, _u32, _i64, _i32, _i32, _vp],
     "cnc_exclusive_sum": [_vp, _vp, _vp, _vp, _u32, _i64, _i32, _i32, _vp],
@@ -164,7 +168,7 @@ SIGNATURES = {
 # entry points that return something other than a status code
 RESTYPES = {"cnc_grid_encode_backward_binned_workspace": C.c_uint64,
             "cnc_grid_encode_backward_overlapped_workspace": C.c_uint64, "cnc_bernoulli_bits_partials": C.c_uint32,
-            "cnc_relu_backward_bias_partials": C.c_uint32}
+            "cnc_relu_backward_bias_partials": C.c_uint32, "cnc_occupancy_coarse_words": C.c_uint32}
 
 CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2

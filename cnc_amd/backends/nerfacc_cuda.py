@@ -142,6 +142,33 @@ def traverse_grids(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indic
     return intervals, samples, terminate_planes
 
 
+_COARSE = {}
+_COARSE_ON = os.environ.get("CNC_MARCH_COARSE", "1") == "1"      # measurement / test switch
+
+
+def occupancy_coarse_bits(binaries):
+    """(extension) the coarse occupancy of `binaries` [n_grids, rx, ry, rz] for the march (cnc_occupancy_coarse_bits: one
+    bit per block of 4 x 4 x 4 cells), or None when the kernels take none for this shape.  Cached on the grid tensor
+    (address, version, shape): the estimator replaces its grid at every occupancy update."""
+    if not _COARSE_ON or binaries.dim() != 4 or binaries.dtype not in (torch.bool, torch.uint8):
+        return None
+    key = (binaries.data_ptr(), binaries._version, tuple(binaries.shape), str(binaries.device))
+    hit = _COARSE.get(key)
+    if hit is not None:
+        return hit[1]
+    L = _lib.lib()
+    nw = int(L.cnc_occupancy_coarse_words(*[int(v) for v in binaries.shape]))
+    words = None
+    if nw:
+        words = torch.empty(nw, dtype=torch.int32, device=binaries.device)
+        check(L.cnc_occupancy_coarse_bits(ptr(binaries), *[int(v) for v in binaries.shape], ptr(words), stream(binaries.device)),
+              "occupancy_coarse_bits")
+    if len(_COARSE) >= 8:
+        _COARSE.clear()
+    _COARSE[key] = (binaries, words)        # (the grid is kept: its address stays unique while the entry lives)
+    return words
+
+
 def march_samples(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indices, hits, near_planes, far_planes,
                   step_size, cone_angle, traverse_steps_limit=-1, want_terminate_planes=False, clamped_total=None,
                   extras=None):
@@ -180,13 +207,15 @@ def march_samples(rays_o, rays_d, rays_mask, binaries, aabbs, t_sorted, t_indice
         if box.dtype != torch.float32 or box.numel() != 6:
             raise RuntimeError("march_samples: extras['aabb'] must be 6 float32 values on the device")
 
+    coarse = occupancy_coarse_bits(binaries)      # empty blocks of 4^3 cells are skipped from LDS (same samples)
+
     def launch(starts, t0, t1, ri, tp, pos=None, dirs=None, ri32=None):
-        rc = L.cnc_march_samples(ptr(rays_o), ptr(rays_d), ptr(rays_mask), n_rays, ptr(binaries), binaries.shape[0],
-                                 binaries.shape[1], binaries.shape[2], binaries.shape[3], ptr(aabbs), ptr(hits),
-                                 ptr(t_sorted), ptr(t_indices), ptr(near_planes), ptr(far_planes), float(step_size),
-                                 float(cone_angle), int(traverse_steps_limit), ptr(counts), ptr(starts), ptr(t0),
-                                 ptr(t1), ptr(ri), ptr(tp), ptr(resume), ptr(pos), ptr(dirs), ptr(ri32), ptr(box),
-                                 stream(dev))
+        rc = L.cnc_march_samples_coarse(ptr(rays_o), ptr(rays_d), ptr(rays_mask), n_rays, ptr(binaries), binaries.shape[0],
+                                        binaries.shape[1], binaries.shape[2], binaries.shape[3], ptr(aabbs), ptr(hits),
+                                        ptr(t_sorted), ptr(t_indices), ptr(near_planes), ptr(far_planes), float(step_size),
+                                        float(cone_angle), int(traverse_steps_limit), ptr(counts), ptr(starts), ptr(t0),
+                                        ptr(t1), ptr(ri), ptr(tp), ptr(resume), ptr(pos), ptr(dirs), ptr(ri32), ptr(box),
+                                        ptr(coarse), stream(dev))
         check(rc, "march_samples")
 
     launch(None, None, None, None, term)

@@ -213,9 +213,19 @@ __global__ __launch_bounds__(64) void k_traverse(
     const int64_t* __restrict__ t_indices, const float* __restrict__ near_planes,
     const float* __restrict__ far_planes, float step_size, float cone_angle, int32_t limit,
     Seg iv, Seg sm, float* __restrict__ terminate_planes, int32_t rpb, uint32_t* __restrict__ rstate = nullptr,
-    SampleExtras ex = SampleExtras{nullptr, nullptr, nullptr, nullptr})
+    SampleExtras ex = SampleExtras{nullptr, nullptr, nullptr, nullptr}, const uint32_t* __restrict__ coarse = nullptr,
+    uint32_t coarse_words = 0, uint32_t coarse_lds_off = 0)
 {
     extern __shared__ float s_dyn[];
+    // Coarse occupancy (cnc_occupancy_coarse_bits: one bit per block of 4 x 4 x 4 cells = "any cell of the block is set")
+    // in LDS: a DDA step through empty space asks it first and goes to the cell's byte in memory only where the block
+    // holds something.  The march is one dependent load per step and nothing else to hide it behind; most steps of a ray
+    // are through empty blocks.  Same decisions, same values: the bit only ever answers for cells that are 0.
+    uint32_t* const s_coarse = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(s_dyn) + coarse_lds_off);
+    if (coarse != nullptr) {
+        for (uint32_t k = threadIdx.x; k < coarse_words; k += 64) s_coarse[k] = coarse[k];
+        __syncthreads();
+    }
     constexpr bool DIRECT = MODE == 3;                  // fill without staging: every lane stores its own samples
     constexpr bool FILL = MODE != 0 && !DIRECT;         // "FILL" below = the staged (resumable) fill passes
     constexpr bool PAIRS = MODE == 2;
@@ -361,9 +371,18 @@ __global__ __launch_bounds__(64) void k_traverse(
                 while (limit <= 0 || n_sm < limit) {
                     float t_trav = fminf(tdist[0], fminf(tdist[1], tdist[2]));
                     t_trav = fminf(t_trav, this_tmax);
-                    const int64_t cell = (int64_t)(cur[0] * res[1] * res[2] + cur[1] * res[2] + cur[2])
-                                         + level * res[0] * res[1] * res[2];
-                    if (!binaries[cell]) {
+                    bool occupied = true;
+                    if (coarse != nullptr) {
+                        const uint32_t cb = (uint32_t)(((level * (res[0] >> 2) + (cur[0] >> 2)) * (res[1] >> 2) + (cur[1] >> 2))
+                                                       * (res[2] >> 2) + (cur[2] >> 2));
+                        occupied = ((s_coarse[cb >> 5] >> (cb & 31u)) & 1u) != 0u;
+                    }
+                    if (occupied) {
+                        const int64_t cell = (int64_t)(cur[0] * res[1] * res[2] + cur[1] * res[2] + cur[2])
+                                             + level * res[0] * res[1] * res[2];
+                        occupied = binaries[cell] != 0;
+                    }
+                    if (!occupied) {
                         if (step_size <= 0.0f) {
                             t_last = t_trav;
                         } else {
@@ -608,6 +627,56 @@ extern "C" int cnc_traverse_grids(const float* rays_o, const float* rays_d,
     return launch_status();
 }
 
+namespace cnc {
+// words of the coarse occupancy of n_grids grids of res^3 cells, or 0 when the kernels do not take one for this shape
+static uint32_t coarse_words_of(int32_t n_grids, int32_t resx, int32_t resy, int32_t resz)
+{
+    if (n_grids <= 0 || resx < 4 || resy < 4 || resz < 4 || (resx & 3) || (resy & 3) || (resz & 3)) return 0;
+    const uint64_t bits = (uint64_t)n_grids * (uint64_t)(resx >> 2) * (uint64_t)(resy >> 2) * (uint64_t)(resz >> 2);
+    const uint64_t words = (bits + 31) / 32;
+    return words <= 2048 ? (uint32_t)words : 0u;           // 8 KB of LDS per 64-lane workgroup at most
+}
+
+// one lane per block of 4 x 4 x 4 cells: 16 aligned dwords of the byte grid, the wave's answers packed by ballot
+__global__ __launch_bounds__(64) void k_occupancy_coarse(const uint8_t* __restrict__ binaries, int32_t n_grids, int32_t resx,
+                                                         int32_t resy, int32_t resz, uint32_t* __restrict__ words)
+{
+    const uint32_t cx = resx >> 2, cy = resy >> 2, cz = resz >> 2;
+    const uint32_t n = (uint32_t)n_grids * cx * cy * cz, b = blockIdx.x * 64 + threadIdx.x;
+    bool any = false;
+    if (b < n) {
+        const uint32_t z = b % cz, y = (b / cz) % cy, x = (b / (cz * cy)) % cx, g = b / (cz * cy * cx);
+        const uint8_t* base = binaries + (size_t)g * resx * resy * resz;
+        uint32_t acc = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++)
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++)
+                acc |= *reinterpret_cast<const uint32_t*>(base + ((size_t)(4 * x + i) * resy + (4 * y + j)) * resz + 4 * z);
+        any = acc != 0;
+    }
+    const uint64_t m = __ballot(any);
+    if (threadIdx.x == 0) words[blockIdx.x * 2] = (uint32_t)m;
+    if (threadIdx.x == 32 && blockIdx.x * 2 + 1 < (n + 31) / 32) words[blockIdx.x * 2 + 1] = (uint32_t)(m >> 32);
+}
+}  // namespace cnc
+
+extern "C" uint32_t cnc_occupancy_coarse_words(int32_t n_grids, int32_t resx, int32_t resy, int32_t resz)
+{
+    return cnc::coarse_words_of(n_grids, resx, resy, resz);
+}
+
+extern "C" int cnc_occupancy_coarse_bits(const uint8_t* binaries, int32_t n_grids, int32_t resx, int32_t resy, int32_t resz,
+                                         uint32_t* words, void* stream)
+{
+    const uint32_t nw = cnc::coarse_words_of(n_grids, resx, resy, resz);
+    if (nw == 0) return CNC_ERR_UNSUPPORTED;
+    if (!binaries || !words || ((uintptr_t)binaries & 3u)) return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(cnc::k_occupancy_coarse, dim3((nw + 1) / 2), dim3(64), 0, (hipStream_t)stream, binaries, n_grids, resx, resy,
+                       resz, words);
+    return cnc::launch_status();
+}
+
 extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const uint8_t* rays_mask, int32_t n_rays,
                                  const uint8_t* binaries, int32_t n_grids, int32_t resx, int32_t resy,
                                  int32_t resz, const float* aabbs, const uint8_t* hits, const float* t_sorted,
@@ -616,6 +685,22 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
                                  int64_t* chunk_cnts, const int64_t* chunk_starts, float* t_starts, float* t_ends,
                                  int64_t* ray_indices, float* terminate_planes, uint32_t* resume_state,
                                  float* positions, float* dirs, int32_t* ray_indices32, const float* aabb, void* stream)
+{
+    return cnc_march_samples_coarse(rays_o, rays_d, rays_mask, n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted,
+                                    t_indices, near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, chunk_cnts,
+                                    chunk_starts, t_starts, t_ends, ray_indices, terminate_planes, resume_state, positions, dirs,
+                                    ray_indices32, aabb, nullptr, stream);
+}
+
+extern "C" int cnc_march_samples_coarse(const float* rays_o, const float* rays_d, const uint8_t* rays_mask, int32_t n_rays,
+                                        const uint8_t* binaries, int32_t n_grids, int32_t resx, int32_t resy,
+                                        int32_t resz, const float* aabbs, const uint8_t* hits, const float* t_sorted,
+                                        const int64_t* t_indices, const float* near_planes, const float* far_planes,
+                                        float step_size, float cone_angle, int32_t traverse_steps_limit,
+                                        int64_t* chunk_cnts, const int64_t* chunk_starts, float* t_starts, float* t_ends,
+                                        int64_t* ray_indices, float* terminate_planes, uint32_t* resume_state,
+                                        float* positions, float* dirs, int32_t* ray_indices32, const float* aabb,
+                                        const uint32_t* coarse_bits, void* stream)
 {
     if (n_rays <= 0) return CNC_OK;
     if (!rays_o || !rays_d || !binaries || !aabbs || !hits || !t_sorted || !t_indices || !near_planes ||
@@ -631,15 +716,18 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
     const uint32_t blocks = div_up((uint32_t)n_rays, (uint32_t)rpb);
     Seg none{}, sm{};
     sm.chunk_cnts = chunk_cnts;
+    const uint32_t cw = coarse_bits ? cnc::coarse_words_of(n_grids, resx, resy, resz) : 0u;
+    if (coarse_bits && cw == 0) return CNC_ERR_UNSUPPORTED;
+    const SampleExtras no_ex{nullptr, nullptr, nullptr, nullptr};
     if (!chunk_starts) {        // pass 1: counts only
-        if (cone0) hipLaunchKernelGGL((k_traverse<0, 32, true>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
+        if (cone0) hipLaunchKernelGGL((k_traverse<0, 32, true>), dim3(blocks), dim3(64), cw * 4, (hipStream_t)stream, rays_o, rays_d, rays_mask,
                            n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices,
                            near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, none, sm,
-                           terminate_planes, rpb, resume_state);
-        else hipLaunchKernelGGL(k_traverse<0>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
+                           terminate_planes, rpb, resume_state, no_ex, coarse_bits, cw, 0u);
+        else hipLaunchKernelGGL(k_traverse<0>, dim3(blocks), dim3(64), cw * 4, (hipStream_t)stream, rays_o, rays_d, rays_mask,
                            n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices,
                            near_planes, far_planes, step_size, cone_angle, traverse_steps_limit, none, sm,
-                           terminate_planes, rpb, resume_state);
+                           terminate_planes, rpb, resume_state, no_ex, coarse_bits, cw, 0u);
         return launch_status();
     }
     // the ray of a sample: int64 (the nerfacc boundary), int32 (internal consumers), or neither when the caller only
@@ -652,14 +740,14 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
     sm.ray_indices = ray_indices;
     ends.vals = t_ends;
     if (direct) {
-        if (cone0) hipLaunchKernelGGL((k_traverse<3, 32, true>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
+        if (cone0) hipLaunchKernelGGL((k_traverse<3, 32, true>), dim3(blocks), dim3(64), cw * 4, (hipStream_t)stream, rays_o, rays_d, rays_mask,
                            n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices, near_planes,
                            far_planes, step_size, cone_angle, traverse_steps_limit, ends, sm, terminate_planes, rpb,
-                           resume_state, ex);
-        else hipLaunchKernelGGL((k_traverse<3>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, rays_o, rays_d, rays_mask,
+                           resume_state, ex, coarse_bits, cw, 0u);
+        else hipLaunchKernelGGL((k_traverse<3>), dim3(blocks), dim3(64), cw * 4, (hipStream_t)stream, rays_o, rays_d, rays_mask,
                            n_rays, binaries, n_grids, resx, resy, resz, aabbs, hits, t_sorted, t_indices, near_planes,
                            far_planes, step_size, cone_angle, traverse_steps_limit, ends, sm, terminate_planes, rpb,
-                           resume_state, ex);
+                           resume_state, ex, coarse_bits, cw, 0u);
         return launch_status();
     }
     // staging row length, measured on the 800x800 bench frame (count + fill, ms).  Marching whole rays: 8 -> 3.53,
@@ -668,10 +756,11 @@ extern "C" int cnc_march_samples(const float* rays_o, const float* rays_d, const
     const char* ps = getenv("CNC_PAIR_STAGE");
     const int   row = ps ? atoi(ps) : (resume_state ? 16 : 32);
 #define CNC_LAUNCH_PAIRS_(R, C0)                                                                                    \
-    hipLaunchKernelGGL((k_traverse<2, R, C0>), dim3(blocks), dim3(64), 2 * 64 * (R + 1) * sizeof(float),          \
+    hipLaunchKernelGGL((k_traverse<2, R, C0>), dim3(blocks), dim3(64), 2 * 64 * (R + 1) * sizeof(float) + cw * 4, \
                        (hipStream_t)stream, rays_o, rays_d, rays_mask, n_rays, binaries, n_grids, resx, resy, resz, \
                        aabbs, hits, t_sorted, t_indices, near_planes, far_planes, step_size, cone_angle,            \
-                       traverse_steps_limit, ends, sm, terminate_planes, rpb, resume_state, ex)
+                       traverse_steps_limit, ends, sm, terminate_planes, rpb, resume_state, ex, coarse_bits, cw,     \
+                       (uint32_t)(2 * 64 * (R + 1) * sizeof(float)))
 #define CNC_LAUNCH_PAIRS(R)                   \
     do {                                      \
         if (cone0) CNC_LAUNCH_PAIRS_(R, true); \

@@ -411,6 +411,26 @@ int cnc_march_samples(const float* rays_o, const float* rays_d, const uint8_t* r
                       int64_t* ray_indices, float* terminate_planes, uint32_t* resume_state,
                       float* positions, float* dirs, int32_t* ray_indices32, const float* aabb, void* stream);
 
+/* (extension, ABI v27) Coarse occupancy for the march: one bit per block of 4 x 4 x 4 cells of the `binaries` byte grid
+ * ([n_grids, resx, resy, resz], every res a multiple of 4) = "some cell of the block is set", bit (((g cx + x) cy + y) cz + z)
+ * of the word array, c = res / 4.  cnc_occupancy_coarse_words: the array's length in 32-bit words, 0 when the march does
+ * not take one for this shape (a resolution that is no multiple of 4, more than 2048 words).  cnc_march_samples_coarse =
+ * cnc_march_samples with that array (nullable): a step of the march through an empty block is decided from LDS instead of
+ * a dependent load of the cell's byte — same decisions, same samples, same values; the array must have been made from the
+ * `binaries` the call is given.                                                                                   */
+uint32_t cnc_occupancy_coarse_words(int32_t n_grids, int32_t resx, int32_t resy, int32_t resz);
+int cnc_occupancy_coarse_bits(const uint8_t* binaries, int32_t n_grids, int32_t resx, int32_t resy, int32_t resz,
+                              uint32_t* words, void* stream);
+int cnc_march_samples_coarse(const float* rays_o, const float* rays_d, const uint8_t* rays_mask, int32_t n_rays,
+                             const uint8_t* binaries, int32_t n_grids, int32_t resx, int32_t resy, int32_t resz,
+                             const float* aabbs, const uint8_t* hits, const float* t_sorted,
+                             const int64_t* t_indices, const float* near_planes, const float* far_planes,
+                             float step_size, float cone_angle, int32_t traverse_steps_limit,
+                             int64_t* chunk_cnts, const int64_t* chunk_starts, float* t_starts, float* t_ends,
+                             int64_t* ray_indices, float* terminate_planes, uint32_t* resume_state,
+                             float* positions, float* dirs, int32_t* ray_indices32, const float* aabb,
+                             const uint32_t* coarse_bits, void* stream);
+
 /* (extension) Sample positions for the field in one pass: positions[s] = o[ray] + d[ray] * t_a[s], or
  * o + (d * (t_a[s] + t_b[s])) / 2 when t_b != NULL (rgb_sigma_fn, examples/utils.py:251-262, same
  * evaluation order); aabb != NULL (6 floats on the device) maps them to the unit cube,

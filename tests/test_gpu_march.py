@@ -393,3 +393,40 @@ def test_march_samples_resume_equals_whole_ray_march_on_the_bench_frame(cuda, mo
     ri, ts, te, starts, counts = outs[0]
     assert bool((ri[1:] >= ri[:-1]).all()) and bool((te > ts).all())
     assert int(counts.sum()) == ts.shape[0] and bool((starts == torch.cumsum(counts, 0) - counts).all())
+
+
+@pytest.mark.parametrize("shape", [(1, 128, 128, 128), (2, 32, 32, 32), (1, 16, 8, 12), (3, 64, 64, 64)])
+def test_coarse_occupancy_bits_and_the_march_through_them(cuda, shape, monkeypatch):
+    """cnc_occupancy_coarse_bits: bit (((g cx + x) cy + y) cz + z) = any cell of the 4 x 4 x 4 block — against torch; and
+    the march that consults it (cnc_march_samples_coarse: a step through an empty block is decided from LDS) returns
+    exactly what the march without it returns.  A shape the kernels take no coarse grid for gives None."""
+    from cnc_amd import synthetic
+    from cnc_amd.backends import nerfacc_cuda as C
+    g = torch.Generator().manual_seed(7)
+    binaries = torch.rand(shape, generator=g) < 0.003                                 # sparse: most blocks empty, some not
+    binaries[:, : shape[1] // 2, : shape[2] // 2, : shape[3] // 4] |= torch.rand((shape[0], shape[1] // 2, shape[2] // 2, shape[3] // 4), generator=g) < 0.3
+    b = binaries.to(cuda)
+    words = C.occupancy_coarse_bits(b)
+    n, rx, ry, rz = shape
+    blocks = b.view(n, rx // 4, 4, ry // 4, 4, rz // 4, 4).permute(0, 1, 3, 5, 2, 4, 6).reshape(n, rx // 4, ry // 4, rz // 4, 64).any(-1)
+    want = blocks.reshape(-1).cpu().numpy()
+    got = words.cpu().numpy().view(np.uint32)
+    bits = ((got[np.arange(want.size) // 32] >> (np.arange(want.size) % 32).astype(np.uint32)) & 1).astype(bool)
+    assert np.array_equal(bits, want) and 0 < want.sum() < want.size
+    assert C.occupancy_coarse_bits(torch.zeros((1, 30, 32, 32), dtype=torch.bool, device=cuda)) is None       # 30 % 4 != 0
+    assert C.occupancy_coarse_bits(torch.zeros((2, 256, 256, 128), dtype=torch.bool, device=cuda)) is None    # > 2048 words
+    o, d = synthetic.pinhole_rays(40, 40, 0.6911, 4.0, 0.3, 0.4)
+    aabbs = torch.tensor([[-1.5 * 2 ** k] * 3 + [1.5 * 2 ** k] * 3 for k in range(n)], device=cuda)
+    o, d = o.to(cuda), d.to(cuda)
+    t0, t1, hit = C.ray_aabb_intersect(o, d, aabbs, -float("inf"), float("inf"), float("inf"))
+    t_sorted, t_indices = torch.sort(torch.cat([t0, t1], -1), dim=-1)
+    near, far = torch.zeros(o.shape[0], device=cuda), torch.full((o.shape[0],), 1e10, device=cuda)
+    out = {}
+    for on in (True, False):
+        monkeypatch.setattr(C, "_COARSE_ON", on)
+        ex = {"positions": True}
+        out[on] = C.march_samples(o, d, None, b, aabbs, t_sorted, t_indices, hit, near, far, 1e-2, 0.0,
+                                  want_terminate_planes=True, extras=ex) + (ex["positions"],)
+    assert int(out[True][4].sum()) > 1000
+    for a, c in zip(out[True], out[False]):
+        assert torch.equal(a, c)

@@ -28,6 +28,8 @@ def switch(on):
         if not hasattr(tr, "_s2"):
             tr._s2 = tr.ctx_stream_2D
         tr.ctx_stream_2D = tr._s2 if on else None
+    elif what.startswith("switch"):         # switch0.0005: the interpreter's thread switch interval (s), on = that value
+        sys.setswitchinterval(float(what[6:]) if on else 0.005)
     elif what == "pgraph":
         if not hasattr(tr, "_pg"):
             tr._pg = tr.planes_graph
