@@ -52,6 +52,8 @@ class PlanesGraph:
         self.bits: Optional[torch.Tensor] = None
         self.n_params = 0
         self.pairs: List[Tuple[torch.Tensor, torch.Tensor, Optional[Tuple[int, int]]]] = []   # (parameter, static gradient, its rows)
+        self.step_bits: Optional[torch.Tensor] = None     # what THIS step's planes' half left (a replay's, or an eager run's)
+        self.step_pairs: List[Tuple[torch.Tensor, torch.Tensor, Optional[Tuple[int, int]]]] = []
         self._tables_used: List[bool] = []
         self._small_used = False
         self.captures = 0
@@ -69,9 +71,15 @@ class PlanesGraph:
     def drop(self) -> None:
         self.graph, self.key, self.bits, self.pairs = None, None, None, []
 
-    def capture(self) -> None:
+    def run_eager(self) -> None:
+        """The same forward + backward, op by op, NOW (an occupancy-refresh step: the structures have just been rebuilt and
+        no graph exists for them yet): the bits in `self.bits`, the tables' autograd gradients in `self.pairs` for
+        `flush()`, everything else in the sink — exactly what a replay leaves behind."""
+        self.capture(record=False)
+
+    def capture(self, record: bool = True) -> None:
         """Record the planes' forward + backward on the planes' stream (the caller's current stream must be it, with the
-        step's gradient sink active on this thread).  Nothing runs: `replay()` does."""
+        step's gradient sink active on this thread).  Nothing runs: `replay()` does.  (`record=False`: `run_eager`.)"""
         tr = self.tr
         ctxm, mb, c = tr.context, tr.field.mlp_base, tr.cfg
         encs = (mb.encoding_xy, mb.encoding_xz, mb.encoding_yz)
@@ -79,7 +87,8 @@ class PlanesGraph:
         o0, o1 = int(ctxm._off3_host[-2]), int(ctxm._off3_host[-1])
         n_total = sum(e.params.numel() for e in encs) + exyz.params.numel()
         sink = _gradsink.current()
-        self.drop()
+        if record:
+            self.drop()
         heads = [p for p in ctxm.parameters() if p.requires_grad]
         if sink is None or any(sink._small_at.get(p.data_ptr(), (0, -1))[1] != p.numel() for p in heads) \
                 or any(sink.table(e.params) is None for e in encs):
@@ -88,14 +97,12 @@ class PlanesGraph:
         # 3-D table only its finest level, so that its gradient is level-sized, not table-sized
         leaves = [e.params.detach().requires_grad_() for e in encs]
         leaf_fin = exyz.params.detach()[o0:o1].requires_grad_()
-        if sink is not None:
-            before = (list(sink._tables_used), sink._small_used)
-            sink._tables_used = [False] * len(sink._tables_used)
-            sink._small_used = False
-        g = torch.cuda.CUDAGraph()
-        # (not `with torch.cuda.graph(...)`: that synchronises the device and empties the allocator's cache on entry —
-        # the render pass is running on its own thread and stream next to this)
-        g.capture_begin(capture_error_mode="thread_local")
+        g = None
+        if record:
+            g = torch.cuda.CUDAGraph()
+            # (not `with torch.cuda.graph(...)`: that synchronises the device and empties the allocator's cache on entry —
+            # the render pass is running on its own thread and stream next to this)
+            g.capture_begin(capture_error_mode="thread_local")
         try:
             with torch.autograd.set_multithreading_enabled(False):
                 pq = [STE_binary.apply(t) for t in leaves]
@@ -108,19 +115,26 @@ class PlanesGraph:
                 grads = [t.grad for t in leaves + [leaf_fin]]
                 bits = bits.detach()
         finally:
-            g.capture_end()
-        self.graph, self.bits, self.n_params = g, bits, n2
+            if g is not None:
+                g.capture_end()
         targets = [e.params for e in encs] + [exyz.params]
-        self.pairs = []
+        pairs = []
         for k, (p, gr) in enumerate(zip(targets, grads)):
             if gr is not None:
-                self.pairs.append((p, gr, (o0, o1) if k == 3 else None))
-        if sink is not None:
-            self._tables_used, self._small_used = list(sink._tables_used), sink._small_used
-            sink._tables_used = [a or b for a, b in zip(before[0], sink._tables_used)]
-            sink._small_used = before[1] or sink._small_used
-        self.key = self._key()
-        self.captures += 1
+                pairs.append((p, gr, (o0, o1) if k == 3 else None))
+        self.n_params = n2
+        if not record:                    # this step's results; a graph recorded behind this leaves them alone
+            self.step_bits, self.step_pairs = bits, pairs
+            return
+        self.graph, self.bits, self.pairs = g, bits, pairs
+        if record:
+            # what the recorded kernels add into (`replay` marks it, `GradSink.flush` skips buffers nobody marked): the three
+            # planes' scatters and the heads' weight gradients (the check above has marked them for this step already)
+            plane_ptrs = {e.params.data_ptr() for e in encs}
+            self._tables_used = [t.data_ptr() in plane_ptrs for t in sink.tables]
+            self._small_used = True
+            self.key = self._key()
+            self.captures += 1
 
     def replay(self):
         """One graph launch on the current stream (the planes' stream, ordered after the step's fork) -> (bits, parameter
@@ -134,6 +148,7 @@ class PlanesGraph:
             if self._small_used:
                 sink._small_used = True
         self.replays += 1
+        self.step_bits, self.step_pairs = self.bits, self.pairs
         return self.bits, self.n_params
 
     @torch.no_grad()
@@ -141,7 +156,7 @@ class PlanesGraph:
         """The gradients autograd returned inside the graph -> `.grad` (after the sinks' flush, on the stream every
         pass has been joined to)."""
         add_to, add_from = [], []
-        for p, g, rows in self.pairs:
+        for p, g, rows in self.step_pairs:
             if p.grad is None:
                 p.grad = torch.zeros_like(p) if rows is not None else g.clone()
                 if rows is None:

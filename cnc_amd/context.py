@@ -1016,9 +1016,7 @@ class CNC_context_models(nn.Module):
         step's captured graph of the planes' half (cnc_amd._planes_graph) — : only the 3-D half runs here, and the
         planes' bits enter the totals as given (no gradient through them: the graph has back-propagated their share)."""
         axes = ("xy", "xz", "yz")
-        if planes is not None:
-            if step % self.step_update == 0:
-                raise RuntimeError("planes: not on a refresh step (the planes' structures are rebuilt inside the pass)")
+        if planes is not None:          # (on a refresh step the caller has rebuilt the planes' structures: `refresh_planes`)
             with _range("ctx/ste_params"):
                 params_q_xyz = self.get_STE_params(Encoding_xyz)
             return self._bits_3D_and_total(Encoding_xyz, params_q_xyz, binary_vxl, sample_num, planes[0], planes[1], None,
@@ -1030,6 +1028,30 @@ class CNC_context_models(nn.Module):
             params_q_xyz = self.get_STE_params(Encoding_xyz)
         ttl_bit_sum, ttl_num_sum = 0, 0
 
+        refresh = self.refresh_planes(binary_vxl, step, params_q_xy)
+        idx_coords2, binary_2D = self.idx_coords2_tmp, self._binary_2D
+
+        fork_2D = None
+        if stream_2D is not None and params_q_xyz.is_cuda and refresh is False:
+            # (a refresh step builds the planes' structures with host round trips inside the loop below: one stream)
+            fork_2D = torch.cuda.current_stream(params_q_xyz.device)
+            stream_2D.wait_stream(fork_2D)
+            for t in (params_q_xy, params_q_xz, params_q_yz, params_q_xyz):
+                t.record_stream(stream_2D)
+        with (torch.cuda.stream(stream_2D) if fork_2D is not None else contextlib.nullcontext()):
+            finest_3D = params_q_xyz[self._off3_host[-2]:self._off3_host[-1]]
+            ttl_bit_sum, ttl_num_sum = self._bits_2D(Encoding_xy, Encoding_xz, Encoding_yz, params_q_xy, params_q_xz, params_q_yz,
+                                                     finest_3D, binary_vxl, binary_2D, idx_coords2, refresh)
+
+        return self._bits_3D_and_total(Encoding_xyz, params_q_xyz, binary_vxl, sample_num, ttl_bit_sum, ttl_num_sum, fork_2D,
+                                       stream_2D, sync_MB)
+
+    def refresh_planes(self, binary_vxl, step, probe):
+        """What the planes' half of the pass is built on — the dimension-wise vote plan, the three projections of the
+        occupancy grid, the planes' vertex lists and slot orders — rebuilt on every `step_update`-th step (and the
+        projections whenever the grid tensor is another one).  Returns whether this step rebuilt them.  `probe`: any
+        tensor of the planes' tables' device and dtype (what `_plane_batch_ok` looks at)."""
+        axes = ("xy", "xz", "yz")
         refresh = step % self.step_update == 0
         if refresh and binary_vxl is not None:
             # Everything a refresh rebuilds (vote plan: three radix sorts and five gathers over ~2e7 vertices; the planes'
@@ -1067,7 +1089,6 @@ class CNC_context_models(nn.Module):
                 self.vote_plan = (_backend.VotePlan(self.idx_coords2_tmp.to(torch.int16).contiguous(),
                                                     self.dimension_wise_resolution, 2 ** self.log2_hashmap_size)
                                   if self.planned_votes else None)
-        idx_coords2 = self.idx_coords2_tmp
         if refresh or getattr(self, "_binary_2D_src", None) is not binary_vxl:
             # the projections (and, keyed on them, the encoders' summed-area tables) live until the occupancy changes
             self._binary_2D = [self._project(binary_vxl, a) for a in axes]
@@ -1075,26 +1096,13 @@ class CNC_context_models(nn.Module):
         binary_2D = self._binary_2D
         if refresh:
             # vertex lists, slot order and the slots' cumulative counts are fixed until the next refresh
-            if self._plane_batch_ok(params_q_xy) and self._refresh_plane_cats(binary_2D):
+            if self._plane_batch_ok(probe) and self._refresh_plane_cats(binary_2D):
                 self.batched_inputs_list = None           # the per-level lists: only the level-by-level loop wants them
             else:
                 self.batched_inputs_list = self._slot_lists_2D(binary_2D)
                 self._plane_cat = [None, None, None]
 
-        fork_2D = None
-        if stream_2D is not None and params_q_xyz.is_cuda and refresh is False:
-            # (a refresh step builds the planes' structures with host round trips inside the loop below: one stream)
-            fork_2D = torch.cuda.current_stream(params_q_xyz.device)
-            stream_2D.wait_stream(fork_2D)
-            for t in (params_q_xy, params_q_xz, params_q_yz, params_q_xyz):
-                t.record_stream(stream_2D)
-        with (torch.cuda.stream(stream_2D) if fork_2D is not None else contextlib.nullcontext()):
-            finest_3D = params_q_xyz[self._off3_host[-2]:self._off3_host[-1]]
-            ttl_bit_sum, ttl_num_sum = self._bits_2D(Encoding_xy, Encoding_xz, Encoding_yz, params_q_xy, params_q_xz, params_q_yz,
-                                                     finest_3D, binary_vxl, binary_2D, idx_coords2, refresh)
-
-        return self._bits_3D_and_total(Encoding_xyz, params_q_xyz, binary_vxl, sample_num, ttl_bit_sum, ttl_num_sum, fork_2D,
-                                       stream_2D, sync_MB)
+        return refresh
 
     def _bits_2D(self, Encoding_xy, Encoding_xz, Encoding_yz, params_q_xy, params_q_xz, params_q_yz, finest_3D,
                  binary_vxl, binary_2D, idx_coords2, refresh):

@@ -377,10 +377,32 @@ class Trainer:
         with torch.set_grad_enabled(grad_mode), torch.autocast(self.device.type, dtype=dtype, enabled=enabled):
             return self._context_pass(step, fork, params)
 
-    def _planes_graph_step(self, step: int, params) -> bool:
+    def _planes_thread_step(self, step: int, params) -> bool:
+        """The planes' half of this step's entropy pass runs apart from the 3-D half (its own root, its own thread)."""
         c = self.cfg
         return (self.planes_graph is not None and params is None and self.ctx_stream_2D is not None and c.lmbda > 0
-                and step % c.step_update != 0 and step > c.step_update and torch.is_grad_enabled())
+                and step > c.step_update and torch.is_grad_enabled())
+
+    def _planes_graph_step(self, step: int, params) -> bool:
+        """... as a replay of the recorded graph: every such step but the occupancy-refresh ones."""
+        return self._planes_thread_step(step, params) and step % self.cfg.step_update != 0
+
+    def _planes_refresh_job(self, after, step: int) -> None:
+        """On the planes' thread, an occupancy-refresh step: rebuild what the planes' half is built on (vote plan, projections,
+        vertex lists: host round trips on the planes' stream only) and run that half op by op — next to the 3-D half, which
+        needs none of it, instead of in front of it on one thread (the entropy pass's thread was the long pole of a refresh
+        step: 14 ms against 7.5; 12 this way).  The graph for the steps that follow is recorded by the next step, in front
+        of its fork: recording it here, behind this job, was built too — the 2.5 ms of host time it takes moved from the next
+        step into this one (whose long pole is this thread), the sum did not change."""
+        torch.cuda.set_device(self.device)
+        e = self.field.mlp_base
+        with torch.cuda.stream(self.ctx_stream_2D), _gradsink.activate(self.sink_ctx):
+            self.ctx_stream_2D.wait_event(after)
+            self.context.refresh_planes(self.estimator.binaries, step, e.encoding_xy.params)
+            if self.planes_graph.ready():          # the grid did not change: the recorded graph still stands
+                self.planes_graph.replay()
+            else:
+                self.planes_graph.run_eager()
 
     def _replay_planes(self, after) -> None:
         """On the planes' thread: the graph launch on the planes' stream, ordered after the event `after`."""
@@ -429,6 +451,13 @@ class Trainer:
                 replay = self._pool_graph.submit(self._replay_planes, side.record_event())
                 planes = (None, pg.n_params)               # the bits join the totals below, behind the backward
                 self._planes_replayed = True
+            elif self._planes_thread_step(step, params):   # an occupancy-refresh step: rebuilt and run op by op over there
+                if self._pool_graph is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._pool_graph = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cnc-planes")
+                replay = self._pool_graph.submit(self._planes_refresh_job, side.record_event(), step)
+                planes = (None, sum(t.params.numel() for t in e._encoders()[1:]))
+                self._planes_replayed = True
             # the planes' half of the pass on a stream of its own, next to the 3-D half (both directions: autograd runs a
             # node's backward on its forward's stream)
             # (Back-propagating the planes' share of the loss as soon as their forward is enqueued — a second backward call,
@@ -452,8 +481,8 @@ class Trainer:
             if planes is not None:                         # the reported totals: + the planes' bits (no gradient here)
                 e_ = self.field.mlp_base
                 n_all = sum(t.params.numel() for t in e_._encoders())
-                bits_per_param = bits_per_param.detach() + pg.bits / n_all
-                mb = mb + pg.bits / 8 / 1024 / 1024
+                bits_per_param = bits_per_param.detach() + pg.step_bits / n_all
+                mb = mb + pg.step_bits / 8 / 1024 / 1024
             done = side.record_event()
         return bits_per_param, mb, done, grads
 
