@@ -16,7 +16,7 @@
 //     stride n_wg.  No byte is read twice: 1268 floats per sample at the headline shape = 1.33 GB per 2^18 samples.
 //   * A workgroup is 16 waves (4 per SIMD) in a 2 x 8 grid over the (out, in) blocks of 16 x 16: 5 x 2 blocks = 40
 //     accumulator registers per wave; the whole dW_l of the workgroup's samples stays in registers until the end.
-//   * Memory-bound by design (the matrix work is ~50 us at full rate): the next tile's rows are requested into registers
+//   * Memory-bound by design (0.31 ms = 4.3 TB/s; the matrix work is ~50 us at full rate): the next tile's rows are requested into registers
 //     before the current tile's products are issued; two barriers per tile.
 //   * Gradients are small (1e-3 .. 1e-9): G_l is scaled by ONE power of two per layer — chosen from max |G_l|, which
 //     cnc_field_backward_chain leaves in g_max (no host round trip) — so that its largest entry is in [2^13, 2^14); an
@@ -50,6 +50,10 @@ struct WGradArgs {
 };
 
 constexpr int kWgWaves = 16, kWgThreads = 1024;
+#ifndef CNC_WGRAD_ROW_LANES
+#define CNC_WGRAD_ROW_LANES 4
+#endif
+constexpr uint32_t kRowLanes = CNC_WGRAD_ROW_LANES;
 constexpr int kOBW = 5, kIBW = 2, kWO = 2, kWI = kWgWaves / kWO;      // blocks per wave, wave grid (out x in)
 
 __device__ __forceinline__ float pow2_scale(uint32_t max_bits)
@@ -66,7 +70,10 @@ __device__ __forceinline__ void stage_request(wrsrc_t M, uint32_t ld, uint32_t c
 {
 #pragma unroll
     for (int k = 0; k < NIT; k++) {
-        const uint32_t it = tid + k * kWgThreads, m = it % NP, c = it / NP;
+        const uint32_t it = tid + k * kWgThreads;
+        // kRowLanes consecutive lanes read kRowLanes x 16 contiguous bytes of one row (then the next row pair).  Measured at 2^18
+        // samples (ms): 1 lane per row — the conflict-free order for the LDS writes — 0.37, 2: 0.337, 4: 0.31, 8: 0.324, 16: 0.39
+        const uint32_t m = (it / kRowLanes) % NP, c = ((it / kRowLanes) / NP) * kRowLanes + (it % kRowLanes);
         // an item past the matrix's columns reads beyond the records: zeros, never written to LDS
         const uint32_t off = c < c4 ? ((row0 + 2u * m) * ld + 4u * c) * 4u : 0xFFFFFFF0u;
         const f32x4_t  a = llvm_raw_buffer_load_f32x4(M, (int32_t)off, 0, 0);
@@ -84,7 +91,8 @@ __device__ __forceinline__ void stage_write(const float4 (&v)[NIT][2], uint32_t 
 {
 #pragma unroll
     for (int k = 0; k < NIT; k++) {
-        const uint32_t it = tid + k * kWgThreads, m = it % NP, c = it / NP;
+        const uint32_t it = tid + k * kWgThreads;
+        const uint32_t m = (it / kRowLanes) % NP, c = ((it / kRowLanes) / NP) * kRowLanes + (it % kRowLanes);
         if (c >= c4) continue;
         const float x0[4] = {v[k][0].x, v[k][0].y, v[k][0].z, v[k][0].w}, x1[4] = {v[k][1].x, v[k][1].y, v[k][1].z, v[k][1].w};
 #pragma unroll
