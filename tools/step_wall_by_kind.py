@@ -16,6 +16,8 @@ for step in range(250, 250 + 160):
     torch.cuda.synchronize()
     kind = "refresh" if step % 16 == 0 else ("after" if step % 16 == 1 else "plain")
     t[kind].append((time.perf_counter() - t0) * 1e3)
+    if kind == "plain" and t[kind][-1] > 10.0:
+        print(f"  slow plain step {step} (step % 16 = {step % 16}): {t[kind][-1]:.2f} ms", flush=True)
 for k, v in t.items():
     v = sorted(v); print(f"{k:8s} n={len(v)} median {v[len(v)//2]:.2f} ms  min {v[0]:.2f} max {v[-1]:.2f}")
 a = sum(sum(v) for v in t.values()) / 160
