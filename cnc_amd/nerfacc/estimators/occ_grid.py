@@ -87,6 +87,33 @@ class OccGridEstimator(AbstractEstimator):
         self._first_window_total = None if first is None else first.get("total")
         return ray_indices, t_starts, t_ends, starts, counts
 
+    def _march_key(self, rays_o, rays_d, near_plane, far_plane, render_step_size, stratified, cone_angle):
+        b = self.binaries
+        return (rays_o.data_ptr(), rays_d.data_ptr(), tuple(rays_o.shape), str(rays_o.device), b.data_ptr(), b._version,
+                float(near_plane), float(far_plane), float(render_step_size), bool(stratified), float(cone_angle))
+
+    @torch.no_grad()
+    def premarch(self, rays_o: Tensor, rays_d: Tensor, near_plane: float = 0.0, far_plane: float = 1e10,
+                 render_step_size: float = 1e-3, stratified: bool = False, cone_angle: float = 0.0) -> None:
+        """(extension) The march of a LATER `sampling(rays_o, rays_d, ...)` call with the same options, made now, on the
+        caller's current stream.  The march reads the rays and the occupancy grid and nothing else — not the field — so a
+        training loop can run the next batch's march (two serial traversal passes and a host round trip for the sample count:
+        ~1.1 ms at the head of the render pass, which is the step's critical chain) while this step's backward keeps the
+        GPU busy.  `sampling` takes the result when it is called with these very tensors and options and the grid has not
+        been replaced or written since; otherwise it is dropped and the call marches as usual.  The jitter of a stratified
+        call is drawn here, from the same generator, in the same way."""
+        n_rays = rays_o.shape[0]
+        near = torch.full((n_rays,), float(near_plane), dtype=rays_o.dtype, device=rays_o.device)
+        far = torch.full((n_rays,), float(far_plane), dtype=rays_o.dtype, device=rays_o.device)
+        if stratified:
+            near = near + torch.rand_like(near) * render_step_size
+        result = self._march(rays_o, rays_d, near, far, render_step_size, cone_angle)
+        event = torch.cuda.current_stream(rays_o.device).record_event() if rays_o.is_cuda else None
+        self._premarched = {"key": self._march_key(rays_o, rays_d, near_plane, far_plane, render_step_size, stratified,
+                                                   cone_angle),
+                            "result": result, "first_total": self._first_window_total, "event": event,
+                            "keep": (rays_o, rays_d, self.binaries)}      # the addresses in the key stay unique meanwhile
+
     @torch.no_grad()
     def sampling(self, rays_o: Tensor, rays_d: Tensor, sigma_fn: Optional[Callable] = None,
                  alpha_fn: Optional[Callable] = None, near_plane: float = 0.0, far_plane: float = 1e10,
@@ -114,10 +141,22 @@ class OccGridEstimator(AbstractEstimator):
             near = torch.maximum(near, t_min)
         if t_max is not None:
             far = torch.minimum(far, t_max)
-        if stratified:
-            near = near + torch.rand_like(near) * render_step_size
-        ray_indices, t_starts, t_ends, starts, counts = self._march(rays_o, rays_d, near, far, render_step_size,
-                                                                    cone_angle)
+        pre, self._premarched = getattr(self, "_premarched", None), None
+        if pre is not None and t_min is None and t_max is None and pre["key"] == self._march_key(
+                rays_o, rays_d, near_plane, far_plane, render_step_size, stratified, cone_angle):
+            # the march of exactly this call was made ahead of time (`premarch`): join its stream and take it
+            if pre["event"] is not None:
+                cur = torch.cuda.current_stream(rays_o.device)
+                cur.wait_event(pre["event"])
+                for t in pre["result"]:
+                    t.record_stream(cur)
+            ray_indices, t_starts, t_ends, starts, counts = pre["result"]
+            self._first_window_total = pre["first_total"]
+        else:
+            if stratified:
+                near = near + torch.rand_like(near) * render_step_size
+            ray_indices, t_starts, t_ends, starts, counts = self._march(rays_o, rays_d, near, far, render_step_size,
+                                                                        cone_angle)
         field = sigma_fn if sigma_fn is not None else alpha_fn
         if field is not None and (alpha_thre > 0.0 or early_stop_eps > 0.0):
             n = t_starts.shape[0]

@@ -243,7 +243,7 @@ def reserve_streams(device):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _STEP_STREAMS:
         prio = int(os.environ.get("CNC_CTX_STREAM_PRIORITY", "0"))
-        pair = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(2)]
+        pair = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(3)]      # entropy pass, its planes' half, look-ahead
         for st in pair:
             with torch.cuda.stream(st):
                 torch.zeros(1, device=dev)
@@ -288,6 +288,12 @@ class Trainer:
             self.planes_graph = PlanesGraph(self)
         self.prefetch = os.environ.get("CNC_PREFETCH_BATCH", "1") == "1"
         self._next_data = None
+        self._next_ready = None
+        # the next batch's draw and march on a stream of their own (CNC_PREMARCH=0: the batch only, on the main stream)
+        self.premarch = os.environ.get("CNC_PREMARCH", "1") == "1"
+        self.ahead_stream = None
+        if self.device.type == "cuda" and self.premarch:
+            self.ahead_stream = reserve_streams(self.device)[2]
         # The entropy pass (context forward and backward) runs on its own stream next to the render pass — see train_step
         self.ctx_stream = None
         if self.device.type == "cuda" and os.environ.get("CNC_CTX_STREAM", "1") == "1":
@@ -496,6 +502,14 @@ class Trainer:
         data, self._next_data = self._next_data, None
         if data is None:
             data = self.dataset.fetch()
+        elif self._next_ready is not None:          # drawn on the look-ahead stream: join it, hand the tensors over
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self._next_ready)
+            self._next_ready = None
+            for v in data.values():
+                for t in (v if isinstance(v, tuple) else (v,)):
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(cur)
         self.estimator.update_every_n_steps(
             step=step, occ_eval_fn=lambda x: self.field.query_density(x) * c.render_step_size,
             occ_thre=1e-2, n=c.step_update)
@@ -562,15 +576,32 @@ class Trainer:
             if self._warn_switch is not None:
                 self._warn_switch(warn_before)
 
-    def _prefetch(self) -> None:
+    def _prefetch(self, step: int = -1) -> None:
         """The NEXT step's batch, drawn now: the ray count it depends on has just been set (`update_num_rays`, from this
         step's sample count), this thread would otherwise wait for the entropy pass, and the ~25 small kernels of the draw
         run in the shadow of this step's backward instead of at the head of the next step, in front of everything (the
         entropy pass — the longer of the two — could not start before them: 0.5 ms).  The dataset draws from its own
         generator: the sequence of batches is the one `fetch()` at the top of each step produces.  Single-process steps
         only (data parallel: the ray count of the next step is known at ITS start, `_lagged_sample_count`)."""
-        if self.prefetch and not self.dp:
+        if not self.prefetch or self.dp:
+            return
+        c, pre = self.cfg, self.ahead_stream
+        if pre is None:
             self._next_data = self.dataset.fetch()
+            return
+        # ... on the look-ahead stream, and with the batch also its MARCH (OccGridEstimator.premarch): rays and occupancy grid
+        # are all the march reads, so the next step's two traversal passes and the host round trip for its sample count run
+        # here, next to this step's backward, instead of at the head of the next step's render pass — the step's critical
+        # chain.  Not in front of a refresh step: it replaces the grid.
+        with torch.cuda.stream(pre):
+            data = self.dataset.fetch()
+            if self.premarch and step >= 0 and (step + 1) % c.step_update != 0:
+                from .render import _as_ray_list
+                rays, _ = _as_ray_list(data["rays"])
+                self.estimator.premarch(rays.origins, rays.viewdirs, near_plane=c.near_plane, render_step_size=c.render_step_size,
+                                        stratified=True, cone_angle=c.cone_angle)
+            self._next_ready = pre.record_event()
+        self._next_data = data
 
     def _lagged_sample_count(self, num_rays_now: int, n_samples: int) -> None:
         """Data-parallel ray budget without a collective of its own.  The reference resizes the next batch from this
@@ -624,7 +655,7 @@ class Trainer:
         if self.bucket is None:
             if ctx_future is not None:
                 (mse * self.loss_scale).backward()
-                self._prefetch()
+                self._prefetch(step)
                 bpp, mb, _ = join(ctx_future.result())
             elif self.ctx_stream is not None and c.lmbda > 0 and mse.requires_grad:
                 # The sequential schedule of the same idea (one host thread; the reference's order of random draws):

@@ -430,3 +430,45 @@ def test_coarse_occupancy_bits_and_the_march_through_them(cuda, shape, monkeypat
     assert int(out[True][4].sum()) > 1000
     for a, c in zip(out[True], out[False]):
         assert torch.equal(a, c)
+
+
+def test_premarched_sampling_equals_the_call_that_marches_itself(cuda):
+    """OccGridEstimator.premarch (extension: the march of a later `sampling` call made ahead of time, on another stream)
+    hands `sampling` exactly what it would have marched itself — same samples for the same jitter — and is dropped when
+    the call is not the one it was made for (other rays, another grid)."""
+    from cnc_amd import synthetic
+    from cnc_amd.nerfacc import OccGridEstimator
+    est = OccGridEstimator(roi_aabb=[-1.5, -1.5, -1.5, 1.5, 1.5, 1.5], resolution=64).to(cuda)
+    est.binaries = synthetic.ball_binaries(64, radius=1.0).to(cuda).view(1, 64, 64, 64)
+    est.occs = est.binaries.reshape(-1).float()
+    o, d = synthetic.pinhole_rays(48, 48, 0.6911, 4.0, 0.3, 0.4)
+    o, d = o.to(cuda), d.to(cuda)
+    sigma = lambda t0, t1, ri: torch.full_like(t0, 3.0)
+    kw = dict(near_plane=0.1, render_step_size=1e-2, stratified=True, cone_angle=0.0, alpha_thre=0.0)
+    torch.manual_seed(11)
+    want = est.sampling(o, d, sigma_fn=sigma, **kw)
+    side = torch.cuda.Stream(device=cuda)
+    torch.manual_seed(11)
+    with torch.cuda.stream(side):
+        est.premarch(o, d, near_plane=0.1, render_step_size=1e-2, stratified=True, cone_angle=0.0)
+    assert est._premarched is not None
+    torch.manual_seed(99)                                   # the jitter was drawn by premarch: this draw is not used
+    got = est.sampling(o, d, sigma_fn=sigma, **kw)
+    assert est._premarched is None
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    assert want[0].numel() > 1000
+    # made for other rays / another grid: dropped, the call marches itself
+    with torch.cuda.stream(side):
+        est.premarch(o.clone(), d, near_plane=0.1, render_step_size=1e-2, stratified=True, cone_angle=0.0)
+    torch.manual_seed(11)
+    got = est.sampling(o, d, sigma_fn=sigma, **kw)
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+    with torch.cuda.stream(side):
+        est.premarch(o, d, near_plane=0.1, render_step_size=1e-2, stratified=True, cone_angle=0.0)
+    torch.cuda.synchronize()
+    est.binaries = est.binaries.clone()
+    est.binaries[0, 30:34, 30:34, 30:34] = False
+    torch.manual_seed(11)
+    fresh = est.sampling(o, d, sigma_fn=sigma, **kw)
+    assert fresh[0].numel() != want[0].numel()

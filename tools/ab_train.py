@@ -34,6 +34,8 @@ def switch(on):
         if not hasattr(tr, "_pg"):
             tr._pg = tr.planes_graph
         tr.planes_graph = tr._pg if on else None
+    elif what == "premarch":
+        tr.premarch = on
     elif what == "prefetch":
         tr.prefetch = on
     elif what == "wgrad":
