@@ -634,8 +634,10 @@ class CNC_context_models(nn.Module):
 
     def _query(self, points, binary_vxl, resolution=None, resolution_list=None):
         N = points.shape[0]
-        mask = torch.zeros([N], dtype=torch.int16, device=points.device)
-        overlap = torch.zeros([N], dtype=torch.int32, device=points.device)
+        # (the kernels write every entry: no zero fill of the ~10^7-entry buffers the reference allocates with zeros)
+        new = torch.empty if points.is_cuda else torch.zeros
+        mask = new([N], dtype=torch.int16, device=points.device)
+        overlap = new([N], dtype=torch.int32, device=points.device)
         vxl = binary_vxl.squeeze(0).contiguous()
         if resolution_list is None:
             pack_and_align.query_mask_3D(points.contiguous(), vxl, mask, overlap, int(resolution), N)
