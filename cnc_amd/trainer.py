@@ -241,6 +241,7 @@ def reserve_streams(device):
     if dev.type != "cuda":
         return None
     key = dev.index if dev.index is not None else torch.cuda.current_device()
+    dev = torch.device("cuda", key)
     if key not in _STEP_STREAMS:
         prio = int(os.environ.get("CNC_CTX_STREAM_PRIORITY", "0"))
         pair = [torch.cuda.Stream(device=dev, priority=prio) for _ in range(3)]      # entropy pass, its planes' half, look-ahead
@@ -260,6 +261,8 @@ class Trainer:
         self.dp = self.world > 1 or cdist.forced()       # data-parallel control flow (forced: a one-rank group, test hook)
         if self.dp and self.device.type == "cuda":
             self.device = torch.device("cuda", cdist.local_device_index())
+        elif self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())     # the worker threads select it by index
         set_random_seed(cfg.seed)
         c = cfg
         aabb = torch.tensor(c.aabb, device=self.device)
@@ -386,7 +389,9 @@ class Trainer:
     def _planes_thread_step(self, step: int, params) -> bool:
         """The planes' half of this step's entropy pass runs apart from the 3-D half (its own root, its own thread)."""
         c = self.cfg
-        return (self.planes_graph is not None and params is None and self.ctx_stream_2D is not None and c.lmbda > 0
+        # (data parallel, `params` given: the 3-D half's gradients are returned to the caller, the planes' half leaves its own
+        # in the sink and in the graph's static tensors as in a single-process step — both are added behind the collective)
+        return (self.planes_graph is not None and self.ctx_stream_2D is not None and c.lmbda > 0
                 and step > c.step_update and torch.is_grad_enabled())
 
     def _planes_graph_step(self, step: int, params) -> bool:
@@ -733,6 +738,8 @@ class Trainer:
                 torch._foreach_add_([v for v, _ in pairs], [g for _, g in pairs])
                 if self.sink_ctx is not None:
                     self.sink_ctx.flush()              # `.grad` = A's views (bound before the fork): after the mean
+                if self._planes_replayed:
+                    self.planes_graph.flush()
             elif c.lmbda > 0:
                 A.grads.add_(B.flat)
             A.bind(force=True)
