@@ -284,6 +284,7 @@ class Trainer:
 
         # the planes' half of the entropy pass as one captured graph per refresh interval (CNC_PLANES_GRAPH=0: op by op)
         self.planes_graph = None
+        self.planes_graph_dp = os.environ.get("CNC_PLANES_GRAPH_DP", "0") == "1"
         self._pool_graph = None
         self._planes_replayed = False
         if self.device.type == "cuda" and os.environ.get("CNC_PLANES_GRAPH", "1") == "1":
@@ -391,6 +392,9 @@ class Trainer:
         c = self.cfg
         # (data parallel, `params` given: the 3-D half's gradients are returned to the caller, the planes' half leaves its own
         # in the sink and in the graph's static tensors as in a single-process step — both are added behind the collective)
+        # Off by default there (CNC_PLANES_GRAPH_DP=1): exercised on a one-rank RCCL group only (tests/test_gpu_rccl.py).
+        if params is not None and not self.planes_graph_dp:
+            return False
         return (self.planes_graph is not None and self.ctx_stream_2D is not None and c.lmbda > 0
                 and step > c.step_update and torch.is_grad_enabled())
 

@@ -153,13 +153,16 @@ torch.distributed.destroy_process_group()
 
 
 @pytest.mark.timeout(1200)
-def test_data_parallel_trainer_step_on_rccl(cuda, tmp_path):
+@pytest.mark.parametrize("planes_graph", ["0", "1"], ids=["joint_entropy_pass", "planes_graph"])
+def test_data_parallel_trainer_step_on_rccl(cuda, tmp_path, planes_graph):
     """The DP training step (bucketed ray-loss gradient all-reduced asynchronously while the context pass runs on its own
     stream and host thread, sample count in the bucket's tail, occupancy broadcast, checksum resync) with RCCL as the
     communicator; against the same run without a process group: same loss trajectory up to atomic order."""
     script = tmp_path / "w.py"
     script.write_text(_TRAINER.format(root=ROOT, out=str(tmp_path / "bits")))
-    r = subprocess.run([sys.executable, str(script)], env=_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"),
+    # CNC_PLANES_GRAPH_DP=1: the planes' half of the entropy pass on its own thread / as a captured graph in the DP step too
+    r = subprocess.run([sys.executable, str(script)], env=_env(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+                                                                CNC_PLANES_GRAPH_DP=planes_graph),
                        capture_output=True, text=True, timeout=1100)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][0][7:])
