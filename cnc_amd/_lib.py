@@ -173,6 +173,8 @@ RESTYPES = {"cnc_grid_encode_backward_binned_workspace": C.c_uint64,
 CNC_FLAG_STE_BINARY = 1
 CNC_FLAG_LEVELS_FINEST_FIRST = 2
 CNC_FLAG_BIN_LANE_STORES = 4
+CNC_FLAG_CELL_MERGE = 8
+CNC_FLAG_CELL_CARRY = 16
 CNC_FIELD_SH_FP16 = 1
 CNC_FIELD_MFMA_F16X3 = 2
 CNC_FIELD_TWO_WAVES = 4

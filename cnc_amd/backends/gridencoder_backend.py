@@ -137,11 +137,13 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
                          N, num_dim, n_features, n_levels, max_level, Rb, dy_dx=None,
                          grad_inputs=None, binary_vxl=None, min_level_id=None, *, ste_binary=False,
                          ste_clip_count=None, occ_sat=None, grad_ld=0, grad_col=0, binned=None,
-                         interleave_levels=False, overlap_streams=True, vertex_bits=None):
+                         interleave_levels=False, overlap_streams=True, vertex_bits=None, cell_merge=False, cell_carry=False):
     """gridencoder.h:24-36.  `binned` (extension) = (n_binned, level_rows) from `plan_binned_levels`:
     take that many finest levels off the global-atomic path (cnc_grid_encode_backward_binned).
     `interleave_levels` (extension, same result): CNC_FLAG_LEVELS_FINEST_FIRST for the plain entry —
-    for calls whose tables are small enough to stay cached while all levels are in flight."""
+    for calls whose tables are small enough to stay cached while all levels are in flight.
+    `cell_merge` / `cell_carry` (extension, same result to fp32 summation order): CNC_FLAG_CELL_MERGE / _CARRY — the
+    masked / per-point-level calls of a training step's context pass (grid_encode_cells.hip)."""
     _common_checks([("grad", grad), ("inputs", inputs), ("embeddings", embeddings),
                     ("offsets_list", offsets_list), ("resolutions_list", resolutions_list),
                     ("grad_embeddings", grad_embeddings)])
@@ -192,7 +194,9 @@ def grid_encode_backward(grad, inputs, embeddings, offsets_list, resolutions_lis
         ptr(grad_embeddings), int(N), int(num_dim), int(n_features), int(n_levels), int(Rb),
         ptr(dy_dx), ptr(grad_inputs), ptr(binary_vxl), ptr(min_level_id),
         (_lib.CNC_FLAG_STE_BINARY if ste_binary else 0)
-        | (_lib.CNC_FLAG_LEVELS_FINEST_FIRST if interleave_levels else 0), ptr(ste_clip_count),
+        | (_lib.CNC_FLAG_LEVELS_FINEST_FIRST if interleave_levels else 0)
+        | (_lib.CNC_FLAG_CELL_MERGE if cell_merge else 0)
+        | (_lib.CNC_FLAG_CELL_CARRY if cell_merge and cell_carry else 0), ptr(ste_clip_count),
         ptr(_check_sat(occ_sat, binary_vxl)), *_vb(vertex_bits, binary_vxl, 0 if min_level_id is not None else n_levels),
         int(grad_ld), int(grad_col), stream(grad.device))
     check(rc, "grid_encode_backward")

@@ -1097,7 +1097,10 @@ class CNC_context_models(nn.Module):
             self._binary_2D_src = binary_vxl
         binary_2D = self._binary_2D
         if refresh:
-            # vertex lists, slot order and the slots' cumulative counts are fixed until the next refresh
+            # vertex lists, slot order and the slots' cumulative counts are fixed until the next refresh; the coded rows the
+            # level-by-level branch of `_bits_2D` caches belong to the OLD lists (callers that run `_bits_2D` with
+            # refresh=False behind this rebuild — the planes' graph / thread — would otherwise keep using them)
+            self._rows_2D_cat = [None, None, None]
             if self._plane_batch_ok(probe) and self._refresh_plane_cats(binary_2D):
                 self.batched_inputs_list = None           # the per-level lists: only the level-by-level loop wants them
             else:

@@ -307,6 +307,23 @@ __device__ __forceinline__ void unit_features_fast(const float (&x)[D], bool ins
     unit_finish_fast<D, F>(u, acc);
 }
 
+// One backward call as the cell-merging scatter (grid_encode_cells.hip) takes it.
+struct CellsArgs {
+    const float*    grad;
+    const float*    inputs;
+    const float*    emb;
+    const int32_t*  offsets;
+    const int32_t*  resolutions;
+    float*          grad_emb;
+    const uint8_t*  vxl;
+    const int32_t*  mli;
+    const uint32_t* clip_count;
+    const int32_t*  sat;
+    FeatLayout      lay;
+    uint32_t        N, L, Rb;
+    uint32_t        carry;           // != 0: shared vertices of x-neighbour cells go out once (CNC_FLAG_CELL_CARRY)
+};
+
 template <uint32_t D>
 __device__ __forceinline__ bool load_point(const float* __restrict__ inputs, uint32_t b,
                                            float (&x)[D])

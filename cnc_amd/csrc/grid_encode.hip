@@ -802,6 +802,9 @@ static void launch_bwd(const EncArgs& a)
     }
 }
 
+// grid_encode_cells.hip (CellsArgs: encoder_common.hpp)
+bool launch_bwd_cells(const CellsArgs& a, uint32_t D, uint32_t F, bool ste, hipStream_t s);
+
 template <bool BWD, uint32_t D, uint32_t F>
 static void dispatch_flags(const EncArgs& a, bool ste)
 {
@@ -908,7 +911,14 @@ extern "C" int cnc_grid_encode_backward(const float* grad, const float* inputs,
               FeatLayout{grad_ld, grad_col, (flags & CNC_FLAG_LEVELS_FINEST_FIRST) ? 1u : 0u}};
     if (!layout_ok(a.lay, F, L)) return CNC_ERR_INVALID_VALUE;
     if (binary_vxl && vertex_bits && vertex_bit_offsets) { a.lay.vbits = vertex_bits; a.lay.vboff = vertex_bit_offsets; }
-    int rc = dispatch_D<true>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
+    int rc = CNC_OK;
+    bool done = false;
+    if ((flags & CNC_FLAG_CELL_MERGE) && !dy_dx) {
+        const CellsArgs ca{grad, inputs, embeddings, offsets, resolutions, grad_embeddings, binary_vxl, min_level_id,
+                           ste_clip_count, a.sat, a.lay, N, L, Rb, (flags & CNC_FLAG_CELL_CARRY) ? 1u : 0u};
+        done = launch_bwd_cells(ca, D, F, (flags & CNC_FLAG_STE_BINARY) != 0, (hipStream_t)stream);
+    }
+    if (!done) rc = dispatch_D<true>(a, D, F, (flags & CNC_FLAG_STE_BINARY) != 0);
     if (rc == CNC_OK && dy_dx)   // kernel_input_backward (gridencoder.cu:588-614)
         rc = launch_input_backward(grad, dy_dx, grad_inputs, N, D, F, L, FeatLayout{grad_ld, grad_col},
                                    (hipStream_t)stream);

@@ -141,14 +141,23 @@ class _grid_encode(Function):
         sink = ctx.sink
         sunk = None if sink is None else sink.table(embeddings)
         grad_embeddings = torch.zeros_like(embeddings) if sunk is None else sunk
+        # Masked calls and per-point level windows are the context pass's: lattice vertices in hash-slot order, which
+        # share cells inside a 1024-point block but never consecutively -> the cell-merging scatter
+        # (csrc/grid_encode_cells.hip).  Its x-neighbour carry pays where the atomic requests are the call's bound — the
+        # 3-D windows (1-3 vertices per cell) and the one-level vote tables — and costs where a cell holds dozens of
+        # points (the planes' context levels): tools/replay_bwd_calls.py, one training step's calls one by one.
+        cells = _CELL_MERGE and (binary_vxl is not None or mli is not None)
         _backend.grid_encode_backward(grad, inputs, embeddings, offs, ress, grad_embeddings, N,
                                       num_dim, n_features, n_levels_calc, 0, Rb, None, None,
                                       binary_vxl, mli, ste_binary=ste, ste_clip_count=clip_count,
                                       occ_sat=occ_sat, binned=ctx.binned,
                                       grad_ld=n_levels_calc * n_features, grad_col=0,
-                                      vertex_bits=None if vb_words is None else (vb_words, vb_offs))
+                                      vertex_bits=None if vb_words is None else (vb_words, vb_offs),
+                                      cell_merge=cells, cell_carry=cells and (mli is not None or n_levels_calc == 1))
         return (None, grad_embeddings if sunk is None else None) + (None,) * 13
 
+
+_CELL_MERGE = os.environ.get("CNC_CELL_MERGE", "1") != "0"      # measurement switch (tools/ab_train.py)
 
 grid_encode = _grid_encode.apply
 

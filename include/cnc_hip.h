@@ -59,6 +59,21 @@ extern "C" {
                                        * result): the round-2 bin pass, every lane storing its own items, instead of
                                        * the default that writes a block's items in bin order (k_bwd_bin_sorted) */
 
+#define CNC_FLAG_CELL_MERGE 8u   /* cnc_grid_encode_backward (same result to fp32 summation order): the points of a
+                                 * 1024-point block that fall into one cell of a level are summed in LDS and every
+                                 * distinct (cell, corner row) goes out as ONE atomic (grid_encode_cells.hip) — with or
+                                 * without occupancy mask / per-point level windows, volumes and planes.  For the calls
+                                 * of a training step's context pass: lattice vertices in hash-slot order, which share
+                                 * cells inside a block but never consecutively (0.70 -> 0.43 ms for its 3-D call).
+                                 * D in {2, 3}, F in {2, 4, 8}, no dy_dx, fewer than 64 levels of resolution < 2^16
+                                 * (points on higher levels are scattered one by one); other shapes ignore the flag. */
+#define CNC_FLAG_CELL_CARRY 16u  /* with CNC_FLAG_CELL_MERGE: two cells of a block that are neighbours along x share
+                                 * 2^(D-1) vertices; each shared vertex is written once, next to its partner in the
+                                 * 64-byte segment, by one of the two cells, which walks the other's points as well
+                                 * (0.43 -> 0.28 ms for the context pass's 3-D call: the atomic requests are what that
+                                 * call is made of).  Costs time where the requests are not the bound (many points per
+                                 * cell: the planes' context levels).                                               */
+
 const char* cnc_error_string(int code);
 int         cnc_abi_version(void);              /* bumps when a signature below changes */
 

@@ -52,7 +52,7 @@ def _fwd_gpu(dev, x, emb, offs, res, L, vxl=None, mli=None, ste=False, vbits=Fal
     return out.cpu().numpy()
 
 
-def _bwd_gpu(dev, g, x, emb, offs, res, vxl=None, mli=None, ste=False, vbits=False):
+def _bwd_gpu(dev, g, x, emb, offs, res, vxl=None, mli=None, ste=False, vbits=False, route="runs"):
     from cnc_amd.backends import gridencoder_backend as be
     t = lambda a: None if a is None else torch.as_tensor(a, device=dev)
     L, N, F = g.shape
@@ -61,9 +61,15 @@ def _bwd_gpu(dev, g, x, emb, offs, res, vxl=None, mli=None, ste=False, vbits=Fal
     Rb = 128 if vxl is None else vxl.shape[-1]
     sat, vb = _vertex_bits(dev, vxl, res, vbits)
     be.grid_encode_backward(t(g), t(x), t(emb), t(offs), t(res), ge, N, D, F, L, 0, Rb, None, None,
-                            t(vxl), t(mli), ste_binary=ste, occ_sat=sat, vertex_bits=vb)
+                            t(vxl), t(mli), ste_binary=ste, occ_sat=sat, vertex_bits=vb,
+                            cell_merge=route != "runs", cell_carry=route == "cells+carry")
     torch.cuda.synchronize()
     return ge.cpu().numpy()
+
+
+# which scatter serves the call: the run-merging atomic kernel, or the cell-merging one (CNC_FLAG_CELL_MERGE: the context
+# pass's route), without and with its x-neighbour carry
+ROUTES = pytest.mark.parametrize("route", ["runs", "cells", "cells+carry"])
 
 
 @pytest.mark.parametrize("D", [2, 3])
@@ -195,9 +201,10 @@ def _check_bwd(got, want32, acc64, abs64, n_terms_max):
     assert np.all(got[untouched] == 0)
 
 
+@ROUTES
 @pytest.mark.parametrize("D,F", [(3, 8), (3, 2), (3, 1), (2, 8), (2, 4), (3, 16)])
 @pytest.mark.parametrize("ste", [False, True])
-def test_backward_against_float64_shadow(cuda, oracle, D, F, ste):
+def test_backward_against_float64_shadow(cuda, oracle, D, F, ste, route):
     res = RES3 if D == 3 else RES2
     offs, resl, emb = make_grid(res, 10, D, F, seed=11)
     x = _points(2049, D, seed=12)
@@ -205,14 +212,15 @@ def test_backward_against_float64_shadow(cuda, oracle, D, F, ste):
     g = rng.normal(size=(len(res), x.shape[0], F)).astype(np.float32)
     want32, acc64 = oracle.grid_encode_backward(g, x, emb, offs, resl, ste_binary=ste, want_acc64=True)
     _, abs64 = oracle.grid_encode_backward(np.abs(g), x, emb, offs, resl, ste_binary=ste, want_acc64=True)
-    got = _bwd_gpu(cuda, g, x, emb, offs, resl, ste=ste)
+    got = _bwd_gpu(cuda, g, x, emb, offs, resl, ste=ste, route=route)      # (F = 1 / 16 ignore the flag: the run kernel)
     _check_bwd(got, want32, acc64, abs64, n_terms_max=x.shape[0] * 8)
     if ste:
         assert np.all(got[np.abs(emb) > 1] == 0)
 
 
+@ROUTES
 @VBITS
-def test_backward_with_mask_and_per_point_levels(cuda, oracle, vbits):
+def test_backward_with_mask_and_per_point_levels(cuda, oracle, vbits, route):
     offs, resl, emb = make_grid(RES3, 10, 3, 8, seed=21)
     vxl = ball_occupancy(16, 3)
     x = _points(1500, 3, seed=22)
@@ -221,8 +229,49 @@ def test_backward_with_mask_and_per_point_levels(cuda, oracle, vbits):
     g = rng.normal(size=(3, x.shape[0], 8)).astype(np.float32)
     want32, acc64 = oracle.grid_encode_backward(g, x, emb, offs, resl, binary_vxl=vxl, min_level_id=mli, want_acc64=True)
     _, abs64 = oracle.grid_encode_backward(np.abs(g), x, emb, offs, resl, binary_vxl=vxl, min_level_id=mli, want_acc64=True)
-    got = _bwd_gpu(cuda, g, x, emb, offs, resl, vxl=vxl, mli=mli, vbits=vbits)
+    got = _bwd_gpu(cuda, g, x, emb, offs, resl, vxl=vxl, mli=mli, vbits=vbits, route=route)
     _check_bwd(got, want32, acc64, abs64, n_terms_max=x.shape[0] * 8)
+
+
+@pytest.mark.parametrize("route", ["cells", "cells+carry"])
+@pytest.mark.parametrize("D,F,masked", [(3, 8, True), (3, 8, False), (2, 8, True), (3, 2, True), (2, 4, False)])
+def test_cell_merging_backward_on_lattice_vertices_in_hash_order(cuda, oracle, D, F, masked, route):
+    """What the context pass hands the scatter: the lattice vertices of a fine level in hash-slot order, encoded at the
+    coarser levels below it (per-point windows for the volume) — many vertices per cell, x-neighbours a few entries apart,
+    some gradient rows all zero (levels outside a vertex's window), 2.5 blocks of points so that cells repeat across
+    blocks and the last block is ragged.  Dense and hashed levels are both in the windows."""
+    res = [6, 9, 14, 20, 31, 44] if D == 3 else [10, 18, 34, 66]
+    log2T = 10 if D == 3 else 9
+    offs, resl, emb = make_grid(res, log2T, D, F, seed=41)
+    emb[::7] *= 3.0                                         # some parameters outside [-1, 1]: the STE mask is live
+    vxl = ball_occupancy(16, D) if masked else None
+    rng = np.random.default_rng(42)
+    n = len(res) - 1                                        # the vertices of the finest level ...
+    R = res[n]
+    grid = np.stack(np.meshgrid(*[np.arange(1, R - 1)] * D, indexing="ij"), -1).reshape(-1, D)
+    primes = np.array([1, 2654435761, 805459861], np.uint64)[:D]
+    h = np.bitwise_xor.reduce((grid.astype(np.uint64) * primes) & np.uint64(0xFFFFFFFF), axis=1) % np.uint64(1 << log2T)
+    grid = grid[np.argsort(h, kind="stable")][:2600]        # ... in hash-slot order (x and x ^ 1 in neighbouring slots)
+    x = ((grid.astype(np.float32) - np.float32(0.5)) / np.float32(R - 2)).astype(np.float32)
+    L = 3
+    mli = g_levels = None
+    if D == 3:
+        mli = rng.integers(0, n - L + 1, size=x.shape[0]).astype(np.int32)
+        mli[: x.shape[0] // 2] = n - L                      # half of them right below their own level, as the windows are
+    else:
+        g_levels = slice(n - L, n)
+    g = rng.normal(size=(L, x.shape[0], F)).astype(np.float32)
+    g[:, rng.random(x.shape[0]) < 0.2] = 0                   # whole points without gradient
+    g[0, rng.random(x.shape[0]) < 0.3] = 0                   # and single level slots
+    o = offs if D == 3 else offs[n - L:n + 1]
+    r = resl if D == 3 else resl[n - L:n]
+    kw = dict(binary_vxl=vxl, min_level_id=mli, ste_binary=True, want_acc64=True)
+    want32, acc64 = oracle.grid_encode_backward(g, x, emb, o, r, **kw)
+    _, abs64 = oracle.grid_encode_backward(np.abs(g), x, emb, o, r, **kw)
+    got = _bwd_gpu(cuda, g, x, emb, o, r, vxl=vxl, mli=mli, ste=True, vbits=masked, route=route)
+    _check_bwd(got, want32, acc64, abs64, n_terms_max=x.shape[0] * (1 << D))
+    assert np.all(got[np.abs(emb) > 1] == 0)
+    assert np.abs(got).sum() > 0
 
 
 def test_backward_is_exact_without_collisions(cuda, oracle):

@@ -42,6 +42,11 @@ def switch(on):
         tr.field.fused_wgrad = on
     elif what == "train":
         tr.field.fused_train = on
+    elif what == "cells":                   # the context pass's scatters: cell-merging kernel / run kernel
+        from cnc_amd import gridencoder
+        gridencoder._CELL_MERGE = on
+        if tr.planes_graph is not None:
+            tr.planes_graph.drop()
     elif what == "vbits":
         for e in tr.field.mlp_base._encoders():
             e.vertex_bits = on
