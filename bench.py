@@ -107,27 +107,37 @@ def build_workload(dev, rank):
     return w
 
 
+def march_frame(w, box):
+    """slab test + count pass + cumsum + fill pass of (ray, t_start, t_end): cnc_march_samples, the form of the march
+    the renderer consumes (same t values and order as traverse_grids' interval edges) -> box["s"], box["ex"]."""
+    rays_o, rays_d = w["rays_o"], w["rays_d"]
+    t_lo, t_hi, hit = ngrid_cuda.ray_aabb_intersect(rays_o, rays_d, w["aabbs"], -float("inf"), float("inf"),
+                                                    float("inf"))
+    # The fill pass also emits each sample's position o + d (t_start + t_end) / 2 (rgb_sigma_fn,
+    # examples/utils.py:251-262) normalised to the unit cube (the radiance field's aabb mapping, ngp.py:518-519)
+    # — bit-equal to the separate cnc_sample_positions pass of rounds 1-3, which re-read (ray, t0, t1) per
+    # sample — and the ray id as int32 (int64 only at the nerfacc boundary).
+    box["ex"] = {"positions": True, "aabb": w["aabb0"], "ray_indices": "int32"}
+    box["s"] = ngrid_cuda.march_samples(rays_o, rays_d, None, w["binaries"], w["aabbs"],
+                                        torch.cat([t_lo, t_hi], -1), w["t_order"], hit, w["near"], w["far"],
+                                        STEP_SIZE, 0.0, extras=box["ex"])
+
+
+def probe_chunk_of(x):
+    """A chunk from the middle of the frame's sample stream (the first one is atypical: 36k grazing rays of ~30
+    samples, 2.1 ms against 1.1-1.16)."""
+    S = x.shape[0]
+    mid = (S // CHUNK // 2) * CHUNK
+    return x[mid:mid + min(CHUNK, S)]
+
+
 def step(w, timed, world):
     """One pass of the hot path over one 800x800 frame.  Returns the number of ray-samples."""
     rays_o, rays_d = w["rays_o"], w["rays_d"]
     n_rays = rays_o.shape[0]
     t0 = time.perf_counter()
     box = {}
-
-    def march():
-        # slab test + count pass + cumsum + fill pass of (ray, t_start, t_end): cnc_march_samples, the form of
-        # the march the renderer consumes (same t values and order as traverse_grids' interval edges)
-        t_lo, t_hi, hit = ngrid_cuda.ray_aabb_intersect(rays_o, rays_d, w["aabbs"], -float("inf"), float("inf"),
-                                                        float("inf"))
-        # The fill pass also emits each sample's position o + d (t_start + t_end) / 2 (rgb_sigma_fn,
-        # examples/utils.py:251-262) normalised to the unit cube (the radiance field's aabb mapping, ngp.py:518-519)
-        # — bit-equal to the separate cnc_sample_positions pass of rounds 1-3, which re-read (ray, t0, t1) per
-        # sample — and the ray id as int32 (int64 only at the nerfacc boundary).
-        box["ex"] = {"positions": True, "aabb": w["aabb0"], "ray_indices": "int32"}
-        box["s"] = ngrid_cuda.march_samples(rays_o, rays_d, None, w["binaries"], w["aabbs"],
-                                            torch.cat([t_lo, t_hi], -1), w["t_order"], hit, w["near"], w["far"],
-                                            STEP_SIZE, 0.0, extras=box["ex"])
-    timed.launch("march(ray_aabb+count+cumsum+fill incl. positions)", n_rays, march)
+    timed.launch("march(ray_aabb+count+cumsum+fill incl. positions)", n_rays, lambda: march_frame(w, box))
     ray_indices, t_starts, t_ends = box["s"][:3]
     S = t_starts.shape[0]
     x = box["ex"]["positions"]
@@ -149,8 +159,7 @@ def step(w, timed, world):
             o, xs, w["table"], w["offsets"], w["resolutions"], gt, n, D, F, L, 0, 128, None, None, None, None,
             ste_binary=True, ste_clip_count=w["clip"],
             binned=enc.plan_binned_levels(synthetic.RES_16L, w["offsets_host"], D, F, n)))
-    mid = (S // CHUNK // 2) * CHUNK              # a chunk from the middle of the frame (the first one is atypical:
-    w["probe_chunk"] = x[mid:mid + min(CHUNK, S)]    # 36k grazing rays of ~30 samples, 2.1 ms against 1.1-1.16)
+    w["probe_chunk"] = probe_chunk_of(x)
     if w.get("exchange_on", world > 1):
         # the only exchange of the path: one flat-bucket all-reduce of the table gradient, asynchronous on the
         # communicator's stream.  What the next frame does before it needs the table or its gradient again — the march
@@ -304,6 +313,131 @@ def field_entries(dev):
     out["field_density_speedup"] = out["field_density(chain)"]["avg_ms"] / out["field_density(fused)"]["avg_ms"]
     out["field_rgb_speedup"] = out["field_rgb+density(chain)"]["avg_ms"] / out["field_rgb+density(fused)"]["avg_ms"]
     return out
+
+
+RES_3D_B = (18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514)       # the reference composition (train:150-155,169)
+RES_2D_B = (130, 258, 514, 1026)
+N_INPUT_B = 1 << 18
+
+
+def input_B_bytes(Fb):
+    """SURVEY 8(d), Input B: 12 x 3-D levels + 3 planes x 4 levels.  (forward, backward) algorithmic bytes per sample."""
+    corners = len(RES_3D_B) * 8 + 3 * len(RES_2D_B) * 4
+    levels = len(RES_3D_B) + 3 * len(RES_2D_B)
+    pts = 4 * (3 + 3 * 2)
+    return pts + corners * Fb * 4 + levels * Fb * 4, pts + levels * Fb * 4 + 2 * corners * Fb * 4
+
+
+def touched_rows(x, res, offsets_host, dims):
+    """Distinct table rows the corners of the points `x` [N, dims] touch, per level (index arithmetic of
+    gridencoder.cu:45-87 in int64, uint32 wrap by masking)."""
+    primes = (1, 2654435761, 805459861)
+    touched = 0
+    for l, R in enumerate(res):
+        rows = offsets_host[l + 1] - offsets_host[l]
+        p0 = torch.floor(x * float(R - 2) + 0.5).to(torch.int64)
+        dense = R ** dims <= rows
+        keys = []
+        for corner in range(1 << dims):
+            c = p0 + torch.tensor([(corner >> d) & 1 for d in range(dims)], device=x.device)
+            if dense:
+                idx = sum(c[:, d] * R ** d for d in range(dims))
+            else:
+                idx = c[:, 0] * primes[0]
+                for d in range(1, dims):
+                    idx = idx ^ (c[:, d] * primes[d])
+                idx = idx & 0xFFFFFFFF
+            keys.append(idx % rows)
+        touched += int(torch.unique(torch.cat(keys)).numel())
+    return touched
+
+
+def input_B_entries(dev, x_unit, traffic):
+    """SURVEY 8(d) "Synthetic input B": the four encoders of the reference composition (12 x 3-D T = 2^19 + 3 planes x 4
+    levels T = 2^17) on N = 2^18 marched samples, F = 8 and F = 2, through the calls the product's training step makes —
+    forward: the bit-plane gather of each encoder writing point-major into the base network's [N, ld] input
+    (`_FusedFeatures`, cnc_amd/field.py); backward: the four scatters of the gradient of that matrix into a per-step
+    gradient sink, routed as `gridencoder_backend.grid_encode_backward` routes a 2^18-sample call (the run-aggregating
+    atomic kernel: one binned level x 2^18 samples is below `plan_binned_levels`' work threshold).  HIP events on the
+    current stream around the four launches (+ the sinusoid columns in the forward), median of 9 after 3 warm-up calls.
+    Outside the timed region."""
+    from cnc_amd.field import NGPRadianceField_mygrid_2D3D, _FusedFeatures
+    from cnc_amd._gradsink import GradSink
+    n = min(N_INPUT_B, x_unit.shape[0])
+    x = x_unit[:n].contiguous()
+    kernels, roof = {}, {}
+    for Fb in (8, 2):
+        torch.manual_seed(3)
+        f = NGPRadianceField_mygrid_2D3D(aabb=list(AABB), n_features_per_level=Fb, n_neurons=160, resolutions_list=RES_3D_B,
+                                         log2_hashmap_size=19, resolutions_list_2D=RES_2D_B, log2_hashmap_size_2D=17).to(dev)
+        mb = f.mlp_base
+        encs = mb._encoders()
+        with torch.no_grad():
+            for e in encs:
+                e.params.uniform_(-1, 1)
+        params = [e.params for e in encs]
+        sink = GradSink(params, [])
+        ld, cols = mb._layout()
+
+        xs = (x, x[:, :2].contiguous(), x[:, ::2].contiguous(), x[:, 1:].contiguous())
+        planes = [e._bit_plane(e.params) for e in encs]
+        clips = [c for _, c in planes]
+        feat = torch.zeros(n, ld, device=dev)
+
+        def fwd():          # the four launches of `_FusedFeatures.forward` (the sinusoid columns' kernel is no encoder)
+            for e_, (bits, _), xi, col in zip(encs, planes, xs, cols):
+                enc.grid_encode_forward_bits(xi, bits, e_.offsets_list, e_.resolutions_list, feat, n, e_.num_dim, e_.n_features,
+                                             e_.n_levels, 128, None, None, None, out_ld=ld, out_col=col)
+
+        fwd()
+        grad = torch.randn_like(feat)
+
+        def bwd():
+            _FusedFeatures.scatter(mb, grad, xs, params, clips, n, sink)
+
+        def median_ms(fn):
+            ts = []
+            for it in range(12):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                if it >= 3:
+                    ts.append(e0.elapsed_time(e1))
+            return sorted(ts)[len(ts) // 2]
+
+        t_f, t_b = median_ms(fwd), median_ms(bwd)
+        b_f, b_b = input_B_bytes(Fb)
+        touched = sum(touched_rows(xi, e._res_host, e._off_host, e.num_dim) for xi, e in zip(xs, encs))
+        levels = len(RES_3D_B) + 3 * len(RES_2D_B)
+        comp_b = n * 36 + n * levels * Fb * 4 + 2 * touched * Fb * 4
+        comp_f = n * 36 + n * ld * 4 + touched * Fb // 8               # points, the output rows, the touched rows' sign bits
+        for tag, ms, per, comp in (("fwd", t_f, b_f, comp_f), ("bwd", t_b, b_b, comp_b)):
+            name = f"input_B_{tag}(F={Fb})"
+            kernels[name] = {"launches": 9, "avg_ms": ms, "units_per_s": n / ms * 1e3, "timed_region": False}
+            e = traffic.get(f"input_B_{tag}_F{Fb}") if isinstance(traffic.get(f"input_B_{tag}_F{Fb}"), dict) else None
+            r = {"avg_launch_ms": ms, "samples_per_launch": n, "bytes_per_sample": per, "bound": "hbm",
+                 "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                 "achieved_algorithmic": per * n / ms / 1e6, "algorithmic_over_peak": per * n / (ms * 1e-3) / HBM_PEAK,
+                 "compulsory_bytes": comp, "touched_table_rows": touched,
+                 "traffic": None, "achieved": None, "frac": None}
+            if e:
+                r.update({"traffic": e["bytes"], "achieved": e["bytes"] / ms / 1e6, "frac": e["bytes"] / (ms * 1e-3) / HBM_PEAK,
+                          "frac_bounds": [e["bytes_min(read requests x 64 B)"] / (ms * 1e-3) / HBM_PEAK,
+                                          e["bytes_max(read requests x 128 B)"] / (ms * 1e-3) / HBM_PEAK],
+                          "traffic_over_compulsory": e["bytes"] / comp,
+                          "atomic_requests": e.get("atomic_requests"),
+                          "atomic_unit_busy_frac": None if not e.get("atomic_requests") else e["atomic_requests"] / 21.0e9 / (ms * 1e-3)})
+            roof[f"{tag}_F{Fb}"] = r
+        del f, sink, grad, feat
+    roof["note"] = ("SURVEY 8(d) Input B: 12 x 3-D (T = 2^19) + 3 x 4 planes (T = 2^17), N = 2^18 marched samples of the bench "
+                    "frame, the four encoder calls of the training step's render pass (point-major rows of the [N, ld] matrix; "
+                    "backward into a gradient sink, run-aggregating atomic kernel); traffic = HBM bytes per call set from "
+                    "separate rocprofv3 --pmc passes of tools/bench_input_b.py (profiles/traffic.json, same counter arithmetic "
+                    "as `roofline`); frac = traffic / duration / 8 TB/s; the backward's own bound is the memory side's atomic "
+                    "request rate (atomic_unit_busy_frac = TCC_ATOMIC requests / 21 G/s / duration)")
+    return kernels, roof
 
 
 def spawn_ranks(args) -> int:
@@ -771,6 +905,15 @@ def main():
                 import traceback
                 print(f"[bench rank {rank}] field entries failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
                 out["field"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if not args.no_field and w.get("probe_chunk") is not None:
+            try:
+                kb_, rb_ = input_B_entries(dev, w["probe_chunk"], tj)
+                kernels.update(kb_)
+                out["roofline_input_B"] = rb_
+            except Exception as exc:       # noqa: BLE001 - an extra block must not take the line down
+                import traceback
+                print(f"[bench rank {rank}] input B failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+                out["roofline_input_B"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_train_step:
             ts = guarded_train_step(dev) if world == 1 else ts_multi
             if isinstance(ts, dict) and "extras" in ts:

@@ -763,6 +763,9 @@ static void launch_fwd(const EncArgs& a)
                        a.inputs, a.emb, a.offsets, a.resolutions, a.out, a.N, a.Rb, a.vxl, a.mli, a.sat, a.lay);
 }
 
+// grid_encode_cells.hip (CellsArgs: encoder_common.hpp)
+bool launch_bwd_cells(const CellsArgs& a, uint32_t D, uint32_t F, bool ste, hipStream_t s);
+
 // grid_encode_merge.hip
 void launch_bwd_merge(const float* grad, const float* inputs, const float* emb, const int32_t* offsets,
                       const int32_t* resolutions, float* grad_emb, uint32_t N, uint32_t L,
@@ -802,8 +805,6 @@ static void launch_bwd(const EncArgs& a)
     }
 }
 
-// grid_encode_cells.hip (CellsArgs: encoder_common.hpp)
-bool launch_bwd_cells(const CellsArgs& a, uint32_t D, uint32_t F, bool ste, hipStream_t s);
 
 template <bool BWD, uint32_t D, uint32_t F>
 static void dispatch_flags(const EncArgs& a, bool ste)

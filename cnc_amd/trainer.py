@@ -317,11 +317,7 @@ class Trainer:
         self._pool = None
         # per-step gradient sinks (cnc_amd._gradsink): the encoder scatters and the context heads' weight gradients add
         # into ONE buffer per parameter and pass instead of a fresh zero-filled tensor per call (CNC_GRAD_SINK=0: off)
-        self.sink_render = self.sink_ctx = None
-        if self.device.type == "cuda" and os.environ.get("CNC_GRAD_SINK", "1") == "1":
-            tables = [e.params for e in self.field.mlp_base._encoders()]
-            self.sink_render = _gradsink.GradSink(tables, [])
-            self.sink_ctx = _gradsink.GradSink(tables, list(self.context.parameters()))
+        self.build_sinks()
         self.bucket = None
         self.time_comm = False          # bench hook: HIP events around the wait for the gradient all-reduce
         self._comm_events = []
@@ -364,6 +360,16 @@ class Trainer:
             step_update=c.step_update, skip_levels_3D=c.skip_levels_3D, skip_levels_2D=c.skip_levels_2D,
             device=self.device,
             dimension_wise_resolution=c.dimension_wise_resolution or c.resolutions_list[-1])
+
+    def build_sinks(self):
+        """The step's gradient sinks for the CURRENT field and context models (a caller that replaces `self.context` —
+        see `build_context` — calls this and `build_optimizers()` again: the entropy pass's sink holds one slot per
+        context-head parameter, and the planes' graph refuses to record without them)."""
+        self.sink_render = self.sink_ctx = None
+        if self.device.type == "cuda" and os.environ.get("CNC_GRAD_SINK", "1") == "1":
+            tables = [e.params for e in self.field.mlp_base._encoders()]
+            self.sink_render = _gradsink.GradSink(tables, [])
+            self.sink_ctx = _gradsink.GradSink(tables, list(self.context.parameters()))
 
     def build_optimizers(self):
         """Both Adam groups and their chained schedules (train:257-297)."""
@@ -436,6 +442,8 @@ class Trainer:
                 with torch.cuda.stream(self.ctx_stream_2D), _gradsink.activate(self.sink_ctx):
                     self.planes_graph.capture()
             except Exception as e:       # an operation the runtime cannot record: the step falls back to the op-by-op pass
+                if os.environ.get("CNC_PLANES_GRAPH_STRICT", "0") == "1":      # (the tests: a silent fallback there would
+                    raise                                                       # hide a capture regression)
                 import warnings
                 warnings.warn(f"cnc_amd: capturing the planes' graph failed ({e}); continuing without it")
                 self.planes_graph = None

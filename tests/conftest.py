@@ -11,6 +11,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a Trainer whose planes' graph cannot be recorded RAISES under test instead of warning and running op by op: the
+    # goldens are to hold the schedule that ships (cnc_amd/trainer.py `_ensure_planes_graph`)
+    os.environ.setdefault("CNC_PLANES_GRAPH_STRICT", "1")
 
 
 @pytest.fixture(scope="session")

@@ -323,6 +323,7 @@ def test_training_trajectory(cuda, tag, fused, tmp_path):
     tr.context.rand_like = lambda t: torch.rand_like(t)     # resolved at call time: the CPU replay below
     tr.context.load_state_dict({k[7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("ctx_sd_")}, strict=True)
     tr.build_optimizers()
+    tr.build_sinks()               # the entropy pass's gradient sink holds the NEW context heads: the planes' graph records
     sd = tr.field.state_dict()
     assert list(sd.keys()) == [str(k) for k in g["field_keys"]]
     filled = fill_state(sd, seed=23)
@@ -350,6 +351,10 @@ def test_training_trajectory(cuda, tag, fused, tmp_path):
                          [float(p.detach().double().norm()) for p in tr.context.parameters()])
             if step == 0:
                 assert np.array_equal(tr.estimator.binaries.cpu().numpy(), g["step0_binaries"])
+    # the schedule under test is the one that ships: the planes' half of the entropy pass replayed from its captured graph
+    # on every step between two occupancy refreshes (a capture that fails raises here: CNC_PLANES_GRAPH_STRICT)
+    assert tr.planes_graph is not None and tr.planes_graph.captures > 0 and tr.planes_graph.replays > 0, \
+        (tr.planes_graph and (tr.planes_graph.captures, tr.planes_graph.replays))
     want_shapes = [tuple(int(v) for v in s.split(",")) for s in g["rand_like_shapes"]]
     # the same draws in the same order as the reference; the per-ray jitter draw has the step's ray count
     assert len(tape.shapes) == len(want_shapes)

@@ -20,6 +20,13 @@ timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o 
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $CMD > $OUT/pmc_write.log 2>&1
 timeout 900 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT/pmc_req -o p -- $CMD > $OUT/pmc_req.log 2>&1
 timeout 900 rocprofv3 --pmc TCC_ATOMIC_sum --output-format csv -d $OUT/pmc_atomic -o p -- $CMD > $OUT/pmc_atomic.log 2>&1
+# SURVEY 8(d) Input B: the reference composition's four encoders on 2^18 marched samples (the same counters, own passes)
+CMDB="python $ROOT/tools/bench_input_b.py"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_b_fetch -o p -- $CMDB > $OUT/pmc_b_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_b_write -o p -- $CMDB > $OUT/pmc_b_write.log 2>&1
+timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum --output-format csv -d $OUT/pmc_b_req -o p -- $CMDB > $OUT/pmc_b_req.log 2>&1
+timeout 600 rocprofv3 --pmc TCC_ATOMIC_sum --output-format csv -d $OUT/pmc_b_atomic -o p -- $CMDB > $OUT/pmc_b_atomic.log 2>&1
+timeout 600 python $ROOT/tools/bench_input_b.py > $OUT/input_b.log 2>&1
 CNC_BWD_OVERLAP=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_no_overlap -o bench -- python $ROOT/bench.py --no-cpu-baseline --no-train-step > $OUT/bench_no_overlap.json 2> $OUT/stats_no_overlap.log
 if [ "$WHAT" = "all" ]; then
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_train -o train -- python $ROOT/tools/bench_train.py --no-profile > $OUT/train.log 2>&1

@@ -76,6 +76,15 @@ for ci in range(n_calls):
         if dbg == "0":
             tot_new += t_new
     os.environ["CNC_CELLS_DBG"] = "0"
+    if D == 3 and F == 8 and vxl is None and mli is None:
+        line += f" | merge(all levels): {timed(lambda: run(scratch, interleave_levels=True))*1e3:7.1f} us"
+        k = L - 1
+        def split():
+            be.grid_encode_backward(grad, x, table, offs[:k + 1], res[:k], scratch, N, D, F, k, 0, Rb, None, None, None, None, ste_binary=ste,
+                                    ste_clip_count=clip, grad_ld=L * F, grad_col=0, interleave_levels=True)
+            be.grid_encode_backward(grad, x, table, offs[k:], res[k:], scratch, N, D, F, 1, 0, Rb, None, None, None, None, ste_binary=ste,
+                                    ste_clip_count=clip, grad_ld=L * F, grad_col=k * F)
+        line += f" | merge(L-1)+runs(1): {timed(split)*1e3:7.1f} us"
     tot_old += t_old
     print(line + f" | max|diff| {err:.3e} of {scale:.3e}", flush=True)
 print(f"sum over calls: old {tot_old:.3f} ms, cells {tot_new:.3f} ms")

@@ -94,6 +94,44 @@ def entry(pats, n_calls, streamed_read_bytes, note):
             "streamed_read_bytes_known": streamed_read_bytes, "note": note}
 
 
+# ---- SURVEY 8(d) Input B (tools/bench_input_b.py under the same counters, its own passes: pmc_b_*) ----
+def input_b_entries():
+    fb = per_kernel(os.path.join(src, "pmc_b_fetch"), "FETCH_SIZE")
+    wb = per_kernel(os.path.join(src, "pmc_b_write"), "WRITE_SIZE")
+    rb = per_kernel(os.path.join(src, "pmc_b_req"), "TCC_EA0_RDREQ_sum")
+    wrb = per_kernel(os.path.join(src, "pmc_b_req"), "TCC_EA0_WRREQ_sum")
+    ab = per_kernel(os.path.join(src, "pmc_b_atomic"), "TCC_ATOMIC_sum")
+    if not fb:
+        return {}
+    nb = sorted(n for n in set(fb) | set(wb) | set(ab) if n.startswith("cnc::"))
+    cb = {n: max(fb.get(n, (0, 0))[1], wb.get(n, (0, 0))[1], ab.get(n, (0, 0))[1]) for n in nb}
+    with open(os.path.join(P, f"{TAG}_pmc_hbm_traffic_input_B.csv"), "w") as fh:
+        fh.write("kernel,FETCH_SIZE_avg_KB_raw,WRITE_SIZE_avg_KB,read_requests_avg,write_requests_avg,TCC_ATOMIC_sum_avg,dispatches\n")
+        for n in nb:
+            fh.write(f'"{n}",{get(fb, n):.1f},{get(wb, n):.1f},{get(rb, n):.0f},{get(wrb, n):.0f},{get(ab, n):.0f},{cb[n]}\n')
+    N_B, LEVELS = 1 << 18, 24
+
+    def tot(d, pats, calls):
+        return sum(get(d, n) * cb[n] for n in nb if any(re.search(p_, n) for p_ in pats)) / calls
+
+    out = {}
+    for Fb in (8, 2):
+        for tag, kern, streamed in (("fwd", "k_grid_encode_fwd_bits", N_B * 36),
+                                    ("bwd", "k_grid_encode_bwd", N_B * 36 + N_B * LEVELS * Fb * 4)):
+            pats = [rf"{kern}<3u, {Fb}u", rf"{kern}<2u, {Fb}u"]
+            calls = max(sum(cb[n] for n in nb if re.search(rf"{kern}<3u, {Fb}u", n)), 1)
+            f_b, w_b = tot(fb, pats, calls) * 1024, tot(wb, pats, calls) * 1024
+            sreq = min(streamed / 2.0, f_b)
+            out[f"input_B_{tag}_F{Fb}"] = {
+                "bytes": f_b + sreq + w_b, "bytes_min(read requests x 64 B)": f_b + w_b, "bytes_max(read requests x 128 B)": 2 * f_b + w_b,
+                "FETCH_SIZE_bytes_raw": f_b, "WRITE_SIZE_bytes": w_b, "read_requests": tot(rb, pats, calls) or f_b / 64.0,
+                "write_requests": tot(wrb, pats, calls), "atomic_requests": tot(ab, pats, calls), "streamed_read_bytes_known": streamed,
+                "call_sets": calls,
+                "note": "one call SET = the four encoders (12 x 3-D + 3 planes x 4 levels) on 2^18 marched samples, as the training "
+                        "step's render pass issues them (tools/bench_input_b.py)"}
+    return out
+
+
 items = 4 * N_CHUNK * L_BINNED * 16                       # one 16-byte item per (sample, binned level, corner pair)
 slabs = L_BINNED * (1 << 19) * F * 4                      # the owners read every table slab of the binned levels once
 traffic = {
@@ -112,6 +150,7 @@ traffic = {
     # <0, 32, false> / <1, ...> dispatches are the drop-in traverse_grids probe of bench.py's kernel table
     "march_samples(count+fill)": entry([r"k_traverse<0, \d+, true>", r"k_traverse<2"], max(cnt.get(next((n for n in names if "k_traverse<2" in n), ""), 1), 1),
                                        2 * 640000 * 24, "per 640k-ray frame; the fill pass also writes the positions (12 B / sample)"),
+    **input_b_entries(),
     "_sources": {p: blob_hash(os.path.join(ROOT, p)) for p in KERNEL_SOURCES if os.path.exists(os.path.join(ROOT, p))},
     "_fabric_request_rate_peak_G_per_s": 50.0,
     "_samples_per_call": N_CHUNK,
