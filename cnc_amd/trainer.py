@@ -284,7 +284,9 @@ class Trainer:
 
         # the planes' half of the entropy pass as one captured graph per refresh interval (CNC_PLANES_GRAPH=0: op by op)
         self.planes_graph = None
-        self.planes_graph_dp = os.environ.get("CNC_PLANES_GRAPH_DP", "0") == "1"
+        # ... in the data-parallel step as well (CNC_PLANES_GRAPH_DP=0: the joint entropy pass there), so that the step a
+        # multi-GPU run measures is the single-GPU step + the exchange
+        self.planes_graph_dp = os.environ.get("CNC_PLANES_GRAPH_DP", "1") == "1"
         self._pool_graph = None
         self._planes_replayed = False
         if self.device.type == "cuda" and os.environ.get("CNC_PLANES_GRAPH", "1") == "1":
@@ -398,7 +400,8 @@ class Trainer:
         c = self.cfg
         # (data parallel, `params` given: the 3-D half's gradients are returned to the caller, the planes' half leaves its own
         # in the sink and in the graph's static tensors as in a single-process step — both are added behind the collective)
-        # Off by default there (CNC_PLANES_GRAPH_DP=1): exercised on a one-rank RCCL group only (tests/test_gpu_rccl.py).
+        # On by default since round 6 (CNC_PLANES_GRAPH_DP=0 switches it off): RCCL at one rank (tests/test_gpu_rccl.py), 2 and
+        # 8 ranks over gloo on one device (tests/test_gpu_multi.py: bit-identical replicas across five refreshes).
         if params is not None and not self.planes_graph_dp:
             return False
         return (self.planes_graph is not None and self.ctx_stream_2D is not None and c.lmbda > 0

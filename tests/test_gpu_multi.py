@@ -61,6 +61,9 @@ def test_bench_reports_the_data_parallel_training_step(cuda):
     assert ts["allreduce_alone_ms"] > 0 and ts["allreduce_exposed_ms_per_step"] >= 0
     assert 0.0 <= ts["allreduce_hidden_frac"] <= 1.0
     assert ts["rendered_samples_per_s"] > 0 and ts["samples_per_step"] > 1e5     # both ranks' samples
+    # the data-parallel step is the single-GPU step + the exchange: same streams, the planes' graph replayed
+    sch = ts["schedule"]
+    assert sch["streams"] == 3 and sch["planes_graph"] is not None and sch["planes_graph"]["replays"] > 0, sch
 
 
 def test_bench_under_the_drivers_launcher(cuda):
@@ -110,7 +113,9 @@ absum = [float(p.detach().double().abs().sum()) for p in list(tr.field.parameter
 rays = [s["num_rays"] for s in stats if s]
 print("RESULT " + json.dumps(dict(rank=tr.rank, device=str(tr.device), sums=sums, absum=absum, rays=rays,
                                   mse=[s["mse"] for s in stats if s], samples=[s["n_rendering_samples"] for s in stats if s],
-                                  binaries=int(tr.estimator.binaries.sum()), resync=tr.resync)), flush=True)
+                                  binaries=int(tr.estimator.binaries.sum()), resync=tr.resync,
+                                  planes_graph=[tr.planes_graph.captures, tr.planes_graph.replays] if tr.planes_graph else None)),
+      flush=True)
 torch.distributed.barrier()
 torch.distributed.destroy_process_group()
 """
@@ -164,8 +169,11 @@ def _check_replicas(outs, steps, step_update=4):
 
 
 def test_two_rank_trainer_replicas_stay_identical(cuda, tmp_path):
-    outs = _run_trainer_ranks(tmp_path, 2, 8)
-    _check_replicas(outs, 8)
+    """20 data-parallel steps = five occupancy refreshes at step_update = 4, with the schedule that ships: the planes' half of
+    the entropy pass replayed from its captured graph on every rank (CNC_PLANES_GRAPH_DP defaults to on)."""
+    outs = _run_trainer_ranks(tmp_path, 2, 20)
+    _check_replicas(outs, 20)
+    assert all(o["planes_graph"][0] >= 2 and o["planes_graph"][1] >= 8 for o in outs), [o["planes_graph"] for o in outs]
 
 
 def test_eight_rank_trainer_and_bench(cuda, tmp_path):
