@@ -89,7 +89,6 @@ SIGNATURES = {
     "cnc_pack_sign_bits": [_vp, _vp, C.c_uint64, _u32, _vp, _vp],
     "cnc_grid_encode_forward_bits": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp],
     "cnc_mlp_forward32": [_vp, _u32, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _u32, _u32, _vp],
-    "cnc_mlp_set_variant": [_i32],
     "cnc_mlp_forward": [_vp, _u32, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _u32, _u32, _vp],
     "cnc_cnt_np_embed": [_vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp],
     "cnc_cnt_np_embed_backward": [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp],
@@ -143,7 +142,6 @@ SIGNATURES = {
     "cnc_field_pack_layer16": [_vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp],
     "cnc_field_pack_all": [C.POINTER(FieldPack), _vp],
     "cnc_field_backward_chain": [C.POINTER(FieldBwd), _vp],
-    "cnc_set_persistent_share": [C.c_float],
     "cnc_field_weight_grads_workspace": [C.POINTER(FieldWGrad), C.POINTER(C.c_uint64)],
     "cnc_field_weight_grads": [C.POINTER(FieldWGrad), _vp],
     "cnc_field_fused_forward": [C.POINTER(FusedField), _vp, _vp, _u32, _vp, _vp, _vp],
@@ -183,7 +181,7 @@ CNC_PACK_TRANSPOSE = 1
 CNC_PACK_ZERO_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 27          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 28          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

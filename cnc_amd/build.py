@@ -24,7 +24,13 @@ HIP_FLAGS = [
     "-ffp-contract=off",          # arithmetic policy: nothing fuses unless written as fmaf
     "-munsafe-fp-atomics",        # fp32 atomicAdd -> global_atomic_add_f32 (no CAS loop)
     "-Wall", "-Wno-unused-function",
-] + os.environ.get("CNC_HIP_EXTRA_FLAGS", "").split()      # diagnostics builds only (e.g. -DCNC_W2_PROF)
+]
+# Extra compiler flags are for diagnostics builds only and must be asked for twice: a stray CNC_HIP_EXTRA_FLAGS in the
+# environment must not produce a library that differs from the one the tests pinned.
+if os.environ.get("CNC_HIP_EXTRA_FLAGS"):
+    if os.environ.get("CNC_DIAG_BUILD") != "1":
+        raise RuntimeError("CNC_HIP_EXTRA_FLAGS is set but CNC_DIAG_BUILD=1 is not: refusing to build a non-standard libcnc_hip.so")
+    HIP_FLAGS += os.environ["CNC_HIP_EXTRA_FLAGS"].split()
 
 
 def _newer(srcs, target):

@@ -51,17 +51,6 @@ __device__ __forceinline__ size_t feat_index(FeatLayout lay, uint32_t slot, uint
     return lay.ld ? (size_t)b * lay.ld + lay.col + slot * F : ((size_t)slot * N + b) * F;
 }
 
-// Share of the wave slots that the training step's persistent kernels (saving field forward, gradient chain, weight
-// gradients: grid = what is resident at once, workgroups loop over the tiles) take: cnc_set_persistent_share (grid_encode.hip).
-// Such a kernel holds every slot it was given until it ends; at share 1 a kernel of ANOTHER stream that becomes ready
-// meanwhile waits for the whole kernel (the entropy pass lost ~0.4 ms behind each of the three).
-float& persistent_share();
-inline uint32_t exp_scaled_grid(uint32_t blocks)
-{
-    const uint32_t n = (uint32_t)(blocks * persistent_share());
-    return n < 1 ? 1 : n;
-}
-
 inline int launch_status()
 {
     return hipGetLastError() == hipSuccess ? CNC_OK : CNC_ERR_LAUNCH;

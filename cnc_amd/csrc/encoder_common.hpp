@@ -257,11 +257,7 @@ __device__ __forceinline__ void unit_issue_fast(const float (&x_)[D], bool insid
             ix ^= pa[2][b2];
             ia += pa[2][b2];
         }
-#ifdef CNC_EXP_SAMEROW      // timing experiment (tools/gpu_w2_exp.sh): every gather of a unit reads one row
-        index[i] = ((hashed ? ix : ia) & mask) & 1u;
-#else
         index[i] = (hashed ? ix : ia) & mask;
-#endif
         m[i] = (!border && inside) ? wi : 0.0f;
         wn += m[i];
     }

@@ -408,7 +408,7 @@ extern "C" int cnc_field_backward_chain(const cnc_field_bwd_t* f, void* stream)
         cached_dev = dev;
     }
     const uint32_t resident = cached_n[NT == 5 ? 0 : 1];
-    const uint32_t blocks = exp_scaled_grid(tiles < resident ? tiles : resident);
+    const uint32_t blocks = tiles < resident ? tiles : resident;
     if (NT == 5) hipLaunchKernelGGL((k_field_bwd_chain<5>), dim3(blocks), dim3(128), lds_bytes, s, p);
     else hipLaunchKernelGGL((k_field_bwd_chain<2>), dim3(blocks), dim3(128), lds_bytes, s, p);
     return launch_status();

@@ -87,19 +87,6 @@ __device__ __forceinline__ void acc_to_planes(half_t* __restrict__ d_hi, half_t*
     }
 }
 
-// -DCNC_W2_PROF (tools/field_phases.py, never in the product build): shader-clock time per phase, summed over the waves,
-// added to the 64-bit words behind the guard's eight (the caller allocates 64 words).
-#ifdef CNC_W2_PROF
-#define W2_MARK(k)                                          \
-    do {                                                    \
-        const uint64_t t_now_ = __builtin_amdgcn_s_memtime(); \
-        prof_acc[k] += t_now_ - t_prev;                     \
-        t_prev = t_now_;                                    \
-    } while (0)
-#else
-#define W2_MARK(k) do { } while (0)
-#endif
-
 // MODE 0: the gradient-free evaluator.  1 (density, test hook): + the first layer's input rows into p.dbg_features.
 // 2 (colour): the gradient pass's forward — + everything the backward reads into p.save (FieldSave), rows [n_live, N)
 // evaluated as points outside the box, values beyond fp16's range saturated instead of recomputed.
@@ -109,10 +96,6 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
     constexpr bool DUMP = MODE == 1, SAVE = MODE == 2;
     static_assert(!SAVE || RGB, "the saving variant is the colour kernel");
     using RowT = std::conditional_t<DUMP, RowDump<RowF16>, std::conditional_t<SAVE, RowSave<RowF16>, RowF16>>;
-#ifdef CNC_W2_PROF
-    uint64_t prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t t_prev = __builtin_amdgcn_s_memtime();
-#endif
     extern __shared__ float lds[];
     half_t* const lds16 = reinterpret_cast<half_t*>(lds);
     using P = Plane2<NT>;
@@ -199,41 +182,20 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                     const uint32_t e_last = __builtin_amdgcn_readfirstlane(p.units[u_last].w);
                     kind = e_last == 0 ? 0u : (e_first != 0 ? 1u : 3u);          // units are ordered 3-D first
                 }
-#ifdef CNC_EXP_NOFILL        // timing experiment: no features at all (the tile keeps whatever it held)
-                if (kind == 99) fill_tail<RowT, 8>(p, xu, w0, p.n_units * F, trow);
-#else
                 if (kind == 0) fill_units<F, 3, RowT, 8>(p, units, xu, w0, trow);
                 else if (kind == 1) fill_units<F, 2, RowT, 8>(p, units, xu, w0, trow);
                 else if (kind == 2) fill_tail_window<RowT, 8>(p, xu, w0, p.n_units * F, trow);
                 else fill_window<F, false, RowT, 8>(p, xu, w0, trow);
-#endif
             }
-            W2_MARK(0);
-#ifdef CNC_EXP_HOTWEIGHTS    // timing experiment: every chunk reads chunk 0's fragments (L1-resident)
-            load_wq<NCB>(W1, 0, NCBT, voff1, wh, wl);
-#else
             load_wq<NCB>(W1, c, NCBT, voff1, wh, wl);
-#endif
-#ifndef CNC_EXP_NOBARRIER    // timing experiment: no workgroup barrier in the chunk loop (results are garbage)
             __syncthreads();
-#endif
-            W2_MARK(1);
             half8_t ah[2], al[2];
 #pragma unroll
             for (int rb = 0; rb < 2; rb++) {
                 ah[rb] = *reinterpret_cast<const half8_t*>(c_hi + (rb * 16 + r) * kCP + 8 * kq);
                 al[rb] = *reinterpret_cast<const half8_t*>(c_lo + (rb * 16 + r) * kCP + 8 * kq);
             }
-#ifdef CNC_EXP_NOMFMA        // timing experiment: operands are loaded, one product per accumulator keeps them alive
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++)
-#pragma unroll
-                for (int rb = 0; rb < 2; rb++)
-                    acc[rb][cb][0] += (float)ah[rb][0] + (float)al[rb][0] + (float)wh[cb][0] + (float)wl[cb][0];
-#else
             mfma3q<2, NCB>(ah, al, wh, wl, acc);
-#endif
-            W2_MARK(2);
         }
 
         if constexpr (!RGB) {
@@ -267,18 +229,15 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                 if (live) p.density[frow] = sel ? expf((s + p.Bp[1][0]) - 1.0f) : 0.0f;
             }
             __syncthreads();                                   // before the next tile's fill overwrites the sums
-            W2_MARK(3);
         } else {
             __syncthreads();                                   // the last chunk has been read: the planes alias it
             acc_to_planes<NCB, NT, SAVE>(h_hi, h_lo, p.Bp[0], acc, w * NCB, lane, mx, p.save.h1, row0, p.N);
             __syncthreads();
-            W2_MARK(4);
             // ---- layer 2 (H -> 1 + geo), split by rows: wave w owns rows [16 w, 16 w + 16) ----
             f32x4 acc2[1][NB2];
             layer_q<1, NB2, NT, kDB>(h_hi, h_lo, NT, p.Wq16[1], NB2, 0, w, acc2, lane);
             const uint32_t Kh = p.nk32_h * 32;                 // head input width: roundup32(17 + geo) <= H
             __syncthreads();                                   // every read of h1 has been issued and waited for
-            W2_MARK(5);
             // Lane (r, kq) holds outputs c = 16 cb + 4 kq + v of sample 16 w + r.  Head-input layout: [SH4 (16) | column 16 + c
             // for output c]: the geo features (c >= 1) land 4-aligned — one 8-byte write per half plane — and column 16
             // receives density_raw (c = 0), against which the packed head weights hold a zero column (cnc_field_pack_t:
@@ -336,7 +295,6 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                 }
             }
             __syncthreads();
-            W2_MARK(6);
             if (tid < 32 && live) {
                 p.density[frow] = sel ? expf(dens[tid] - 1.0f) : 0.0f;
                 if constexpr (SAVE) p.save.raw[frow] = dens[tid];
@@ -344,16 +302,12 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
             // ---- head: (16 + geo) -> H -> H -> 3 ----
             layer_q<2, NCB, NT, kDB>(h_hi, h_lo, Kh / 32, p.Wq16[2], NCBT, w * NCB, 0, acc, lane);
             __syncthreads();
-            W2_MARK(7);
             acc_to_planes<NCB, NT, SAVE>(h_hi, h_lo, p.Bp[2], acc, w * NCB, lane, mx, p.save.h3, row0, p.N);
             __syncthreads();
-            W2_MARK(8);
             layer_q<2, NCB, NT, kDB>(h_hi, h_lo, NT, p.Wq16[3], NCBT, w * NCB, 0, acc, lane);
             __syncthreads();
-            W2_MARK(9);
             acc_to_planes<NCB, NT, SAVE>(h_hi, h_lo, p.Bp[3], acc, w * NCB, lane, mx, p.save.h4, row0, p.N);
             __syncthreads();
-            W2_MARK(10);
             f32x4 acc5[1][1];
             layer_q<1, 1, NT, kDB>(h_hi, h_lo, NT, p.Wq16[4], 1, 0, w, acc5, lane);
             if (kq == 0) {                                     // outputs 0..2 of sample 16 w + r: 12 contiguous bytes per lane
@@ -367,18 +321,9 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                 }
             }
             __syncthreads();                                   // the next tile's fill overwrites the planes
-            W2_MARK(11);
         }
     }
     guard_raise(p, mx);
-#ifdef CNC_W2_PROF
-    if (lane == 0 && p.guard) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(p.guard + 8);
-#pragma unroll
-        for (int k = 0; k < 12; k++) atomicAdd(out + k, (unsigned long long)prof_acc[k]);
-        atomicAdd(out + 12, 1ull);
-    }
-#endif
 }
 
 // W [H, K] -> fragments of the 16x16x32 form: index ((ks * ncb + cb) * 2 + plane) * 512 + lane * 8 + e holds the hi / lo
@@ -524,7 +469,6 @@ int launch_field_fused_w2(const FusedFieldArgs& p, bool rgb, uint32_t F, uint32_
             if (rc == CNC_OK) hipLaunchKernelGGL((k_field_fused16w2<FV, NTV, false, 3, 1>), dim3(blocks), dim3(128), lds_bytes, s, p); \
         } else if (p.save.feat) {           \
             rc = resident_grid(k_field_fused16w2<FV, NTV, true, 3, 2>, lds_bytes, tiles, 16, &blocks); \
-            blocks = exp_scaled_grid(blocks); \
             if (rc == CNC_OK) hipLaunchKernelGGL((k_field_fused16w2<FV, NTV, true, 3, 2>), dim3(blocks), dim3(128), lds_bytes, s, p); \
         } else if (rgb) CNC_W2_W(FV, NTV, true); \
         else CNC_W2_W(FV, NTV, false);      \
@@ -534,13 +478,9 @@ int launch_field_fused_w2(const FusedFieldArgs& p, bool rgb, uint32_t F, uint32_
         if (NT == 5) CNC_W2_RGB(FV, 5); \
         else CNC_W2_RGB(FV, 2);         \
     } while (0)
-#ifdef CNC_W2_PROBE          // register experiments: the headline instantiations only
-    CNC_W2_RGB(8, 5);
-#else
     if (F == 8) CNC_W2_NT(8);
     else if (F == 4) CNC_W2_NT(4);
     else CNC_W2_NT(2);
-#endif
 #undef CNC_W2_NT
 #undef CNC_W2_RGB
 #undef CNC_W2_W

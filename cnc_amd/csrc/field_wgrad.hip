@@ -300,7 +300,7 @@ static int wgrad_workgroups(uint32_t asked, uint32_t* n)
         cached_cus = (uint32_t)cus;
         cached_dev = dev;
     }
-    *n = exp_scaled_grid(cached_cus);                  // one 16-wave workgroup per CU
+    *n = cached_cus;                  // one 16-wave workgroup per CU
     return CNC_OK;
 }
 

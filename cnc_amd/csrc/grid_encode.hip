@@ -1111,19 +1111,4 @@ extern "C" const char* cnc_error_string(int code)
     }
 }
 
-extern "C" int cnc_abi_version(void) { return 27; }
-
-namespace cnc {
-float& persistent_share()
-{
-    static float share = 1.0f;
-    return share;
-}
-}  // namespace cnc
-
-extern "C" int cnc_set_persistent_share(float share)
-{
-    if (!(share > 0.0f) || share > 1.0f) return CNC_ERR_INVALID_VALUE;
-    cnc::persistent_share() = share;
-    return CNC_OK;
-}
+extern "C" int cnc_abi_version(void) { return 28; }

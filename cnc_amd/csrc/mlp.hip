@@ -206,143 +206,6 @@ __global__ __launch_bounds__(64) void k_mlp_forward(MlpArgs p)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Variant with the weights shared through LDS: a workgroup of 4 waves (64 rows).  The one-wave kernel
-// above re-fetches every 16-wide K block of the weights from L2 per wave (10 KB per 640 MFMA cycles
-// and wave: ~50 TB/s over the chip) and stalls on it at 33 % MFMA utilisation.  Here the 256 threads
-// bring each K block in once (double-buffered, one barrier per block) and all four waves read their
-// B fragments from LDS ([Hp][16 + 4] floats: 80-byte rows keep the 16-byte fragment reads of a wave
-// on distinct banks).
-// ---------------------------------------------------------------------------------------------
-constexpr int kWPitch = 20;
-
-template <bool RELU>
-__device__ __forceinline__ void layer_shared(const float* __restrict__ a_lds, uint32_t lda, uint32_t Kp,
-                                             const float* __restrict__ W, const float* __restrict__ bias,
-                                             uint32_t Hp, f32x4 (&acc)[kMaxTiles], uint32_t lane,
-                                             float* __restrict__ wbuf /* 2 x [160][kWPitch] */)
-{
-    const uint32_t tid = threadIdx.x;
-    const uint32_t r = lane & 15, g = lane >> 4;
-    const uint32_t n_tiles = Hp / 16;
-    const uint32_t n_vec = Hp * 4;                       // float4 per K block
-#pragma unroll
-    for (int t = 0; t < kMaxTiles; t++) acc[t] = f32x4{0, 0, 0, 0};
-    // block 0 straight into buffer 0
-    for (uint32_t idx = tid; idx < n_vec; idx += 256) {
-        const uint32_t row = idx >> 2, q = idx & 3u;
-        *reinterpret_cast<float4*>(wbuf + row * kWPitch + q * 4) =
-            *reinterpret_cast<const float4*>(W + (size_t)row * Kp + q * 4);
-    }
-    __syncthreads();
-    uint32_t cur = 0;
-    for (uint32_t kb = 0; kb < Kp; kb += 16) {
-        // next block: global -> registers now, registers -> LDS after this block's MFMAs
-        float4 nx[3];
-        const bool more = kb + 16 < Kp;
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const uint32_t idx = tid + j * 256;
-                if (idx < n_vec) nx[j] = *reinterpret_cast<const float4*>(W + (size_t)(idx >> 2) * Kp + kb + 16 + (idx & 3u) * 4);
-            }
-        }
-        const float4 a = *reinterpret_cast<const float4*>(a_lds + r * lda + kb + g * 4);
-        const float* wb = wbuf + cur * (160 * kWPitch);
-#pragma unroll
-        for (int t = 0; t < kMaxTiles; t++) {
-            if ((uint32_t)t < n_tiles) {
-                const float4 w = *reinterpret_cast<const float4*>(wb + (t * 16 + r) * kWPitch + g * 4);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc[t], 0, 0, 0);
-            }
-        }
-        if (more) {
-            float* wn = wbuf + (cur ^ 1u) * (160 * kWPitch);
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const uint32_t idx = tid + j * 256;
-                if (idx < n_vec) *reinterpret_cast<float4*>(wn + (idx >> 2) * kWPitch + (idx & 3u) * 4) = nx[j];
-            }
-        }
-        __syncthreads();
-        cur ^= 1u;
-    }
-#pragma unroll
-    for (int t = 0; t < kMaxTiles; t++) {
-        if ((uint32_t)t < n_tiles) {
-            const float b = bias[t * 16 + r];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float v = acc[t][i] + b;
-                if (RELU) v = v > 0 ? v : 0;
-                acc[t][i] = v;
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_mlp_forward4(MlpArgs p)
-{
-    extern __shared__ float lds[];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t ld0 = p.K0p + kPad, ld1 = p.Hp[0] + kPad, ld2 = (p.n_layers == 3 ? p.Hp[1] : 0) + kPad;
-    // per wave: [x | h2 (aliases x, dead after layer 1)] [h1]; then the two weight buffers
-    const uint32_t reg0 = 16 * (ld0 > ld2 ? ld0 : ld2), per_wave = reg0 + 16 * ld1;
-    float* x_lds = lds + wave * per_wave;
-    float* h2_lds = x_lds;
-    float* h1_lds = x_lds + reg0;
-    float* wbuf = lds + 4 * per_wave;
-
-    const uint32_t groups = (p.N + 63) / 64;
-    for (uint32_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
-        const uint32_t row0 = grp * 64 + wave * 16;
-        for (uint32_t k0 = 0; k0 < p.K0p; k0 += 64) {
-            const uint32_t k = k0 + lane;
-            float v[16];
-#pragma unroll
-            for (uint32_t r = 0; r < 16; r++) {
-                const uint32_t row = row0 + r;
-                v[r] = (row < p.N && k < p.K0) ? p.X[(size_t)row * p.ldx + k] : 0.0f;
-            }
-            if (k < p.K0p) {
-#pragma unroll
-                for (uint32_t r = 0; r < 16; r++) x_lds[r * ld0 + k] = v[r];
-            }
-        }
-        __syncthreads();
-        f32x4 acc[kMaxTiles];
-        layer_shared<true>(x_lds, ld0, p.K0p, p.W[0], p.B[0], p.Hp[0], acc, lane, wbuf);
-        acc_to_lds(h1_lds, ld1, p.Hp[0], acc, lane);
-        __syncthreads();
-        uint32_t Hlast;
-        if (p.n_layers == 3) {
-            layer_shared<true>(h1_lds, ld1, p.Hp[0], p.W[1], p.B[1], p.Hp[1], acc, lane, wbuf);
-            acc_to_lds(h2_lds, ld2, p.Hp[1], acc, lane);
-            __syncthreads();
-            layer_shared<false>(h2_lds, ld2, p.Hp[1], p.W[2], p.B[2], p.Hp[2], acc, lane, wbuf);
-            Hlast = p.Hp[2];
-        } else {
-            layer_shared<false>(h1_lds, ld1, p.Hp[0], p.W[1], p.B[1], p.Hp[1], acc, lane, wbuf);
-            Hlast = p.Hp[1];
-        }
-        const uint32_t c = lane & 15, g = lane >> 4;
-#pragma unroll
-        for (int t = 0; t < kMaxTiles; t++) {
-            if ((uint32_t)t < Hlast / 16) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t row = row0 + g * 4 + i, col = t * 16 + c;
-                    if (row < p.N && col < p.n_out) p.Y[(size_t)row * p.ldy + col] = acc[t][i];
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // 32-row variant on v_mfma_f32_32x32x2_f32: one wave owns 32 rows, so every weight fragment fetched
 // from L2 serves twice the rows, and a fragment is one float per (tile, k) instead of per 16 columns:
 // 5 tiles x 4 k = 20 weight registers per K block of 8 for a 160-wide layer (40 in the 16-row kernel).
@@ -436,56 +299,6 @@ __device__ __forceinline__ void acc_to_lds32(float* __restrict__ dst, uint32_t l
             if (RELU) x = x > 0 ? x : 0;
             dst[(8 * (v >> 2) + 4 * h + (v & 3)) * ld + t * 32 + i] = x;
         }
-    }
-}
-
-template <int NT0, int NT1, int NT2>
-__global__ __launch_bounds__(64) void k_mlp_forward32(MlpArgs p)
-{
-    extern __shared__ float lds[];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t ld1 = NT0 * 32 + kPad, ld2 = NT1 * 32 + kPad;
-    float* h_lds = lds;                       // h1, then h2 in the same place (h1 is dead by then)
-
-    const uint32_t tiles = (p.N + 31) / 32;
-    for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const uint32_t row0 = tile * 32;
-        const uint32_t my_row = row0 + (lane & 31);
-        const float*   a_row = my_row < p.N ? p.X + (size_t)my_row * p.ldx : nullptr;
-        const uint32_t kv = p.K0 | (p.a_vec ? 0x80000000u : 0u);
-
-        f32x16 acc[kMaxTiles32];
-        layer32<true, true, NT0>(nullptr, 0, p.K0p, p.W[0], p.B[0], acc, lane, a_row, kv);
-        acc_to_lds32<true, NT0>(h_lds, ld1, p.B[0], acc, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if constexpr (NT2 > 0) {
-            layer32<true, false, NT1>(h_lds, ld1, NT0 * 32, p.W[1], p.B[1], acc, lane, nullptr, 0);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            acc_to_lds32<true, NT1>(h_lds, ld2, p.B[1], acc, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            layer32<false, false, NT2>(h_lds, ld2, NT1 * 32, p.W[2], p.B[2], acc, lane, nullptr, 0);
-        } else {
-            layer32<false, false, NT1>(h_lds, ld1, NT0 * 32, p.W[1], p.B[1], acc, lane, nullptr, 0);
-        }
-        constexpr int NTL = NT2 > 0 ? NT2 : NT1;
-        const float*   b_last = NT2 > 0 ? p.B[2] : p.B[1];
-        const uint32_t i = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int t = 0; t < NTL; t++) {
-            const uint32_t col = t * 32 + i;
-            const float    b = b_last[col];
-#pragma unroll
-            for (int v = 0; v < 16; v++) {
-                const uint32_t row = row0 + 8 * (v >> 2) + 4 * h + (v & 3);
-                if (row < p.N && col < p.n_out) p.Y[(size_t)row * p.ldy + col] = acc[t][v] + b;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -625,12 +438,6 @@ __global__ __launch_bounds__(64) void k_mlp_forward64(MlpArgs p)
 
 using namespace cnc;
 
-// cnc_mlp_forward: 0 = one wave per 16 rows (default), 1 = four waves sharing the weights through LDS
-// (measured slower).  cnc_mlp_forward32: 3 = one 32-row tile per wave, anything else = two tiles sharing
-// the first layer's weights (default).
-static int g_mlp_variant = 0;
-extern "C" int cnc_mlp_set_variant(int v) { g_mlp_variant = v; return CNC_OK; }
-
 // Fused 2- or 3-layer fp32 MLP forward.  Weights must be pre-padded by the caller:
 //   W_l : [Hp_l, Kp_l] row-major, zero filled outside [H_l, K_l];  b_l : [Hp_l];
 //   Kp_0 = roundup16(K0), Kp_l = Hp_{l-1};  Hp_l = roundup16(H_l) <= 160.
@@ -658,19 +465,6 @@ extern "C" int cnc_mlp_forward(const float* X, uint32_t N, uint32_t ldx, uint32_
     p.n_layers = n_layers;
     p.Y = Y; p.ldy = ldy; p.n_out = n_out;
 
-    if (g_mlp_variant == 1) {
-        const uint32_t ld0 = K0p + kPad, ld1 = H1p + kPad, ld2 = (n_layers == 3 ? H2p : 0) + kPad;
-        const uint32_t pw = 16 * (ld0 > ld2 ? ld0 : ld2) + 16 * ld1;
-        const size_t   bytes = ((size_t)4 * pw + 2 * 160 * kWPitch) * sizeof(float);
-        if (bytes > 160 * 1024) return CNC_ERR_INVALID_VALUE;
-        if (hipFuncSetAttribute((const void*)k_mlp_forward4, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return CNC_ERR_LAUNCH;
-        uint32_t blocks4 = (N + 63) / 64;
-        if (blocks4 > 256u * 8) blocks4 = 256u * 8;
-        hipLaunchKernelGGL(k_mlp_forward4, dim3(blocks4), dim3(256), bytes, (hipStream_t)stream, p);
-        return launch_status();
-    }
     const uint32_t per_wave = 16 * ((H1p + kPad) + ((n_layers == 3 ? H2p : 0) + kPad));
     const size_t   lds_bytes = (size_t)per_wave * sizeof(float);
     if (lds_bytes > 160 * 1024) return CNC_ERR_INVALID_VALUE;
@@ -717,30 +511,14 @@ extern "C" int cnc_mlp_forward32(const float* X, uint32_t N, uint32_t ldx, uint3
     p.n_layers = n_layers;
     p.Y = Y; p.ldy = ldy; p.n_out = n_out;
     p.a_vec = (ldx % 4 == 0 && ldx >= K0p && ((uintptr_t)X % 16) == 0) ? 1u : 0u;
-    const uint32_t tiles = (N + 31) / 32;
-    uint32_t       blocks = tiles;
-    if (blocks > 256u * 32) blocks = 256u * 32;
     const size_t lds_bytes = (size_t)32 * (160 + kPad) * sizeof(float);
-    if (g_mlp_variant != 3) {   // default: several 32-row tiles share the first layer's weight fragments
-        const bool     three = g_mlp_variant == 5;                 // measurement: 96 rows per wave
-        const uint32_t rows_per_wave = three ? 96 : 64;
-        uint32_t       bw = (N + rows_per_wave - 1) / rows_per_wave;
-        if (bw > 256u * 32) bw = 256u * 32;
-        const bool base = n_layers == 2 && H1p == 160 && H2p == 96 && n_out <= 96;
-        const bool head = n_layers == 3 && H1p == 160 && H2p == 160 && H3p == 32 && n_out <= 32;
-        if (!base && !head) return CNC_ERR_UNSUPPORTED;
-        if (base && !three) hipLaunchKernelGGL((k_mlp_forward64<5, 3, 0, 2>), dim3(bw), dim3(64), lds_bytes, (hipStream_t)stream, p);
-        if (base && three) hipLaunchKernelGGL((k_mlp_forward64<5, 3, 0, 3>), dim3(bw), dim3(64), lds_bytes, (hipStream_t)stream, p);
-        if (head && !three) hipLaunchKernelGGL((k_mlp_forward64<5, 5, 1, 2>), dim3(bw), dim3(64), lds_bytes, (hipStream_t)stream, p);
-        if (head && three) hipLaunchKernelGGL((k_mlp_forward64<5, 5, 1, 3>), dim3(bw), dim3(64), lds_bytes, (hipStream_t)stream, p);
-        return launch_status();
-    }
-    if (n_layers == 2 && H1p == 160 && H2p == 96 && n_out <= 96) {
-        hipLaunchKernelGGL((k_mlp_forward32<5, 3, 0>), dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, p);
-    } else if (n_layers == 3 && H1p == 160 && H2p == 160 && H3p == 32 && n_out <= 32) {
-        hipLaunchKernelGGL((k_mlp_forward32<5, 5, 1>), dim3(blocks), dim3(64), lds_bytes, (hipStream_t)stream, p);
-    } else {
-        return CNC_ERR_UNSUPPORTED;
-    }
+    // two 32-row tiles per wave through the first layer: its weight fragments are fetched once per 64 rows
+    uint32_t bw = (N + 63) / 64;
+    if (bw > 256u * 32) bw = 256u * 32;
+    const bool base = n_layers == 2 && H1p == 160 && H2p == 96 && n_out <= 96;
+    const bool head = n_layers == 3 && H1p == 160 && H2p == 160 && H3p == 32 && n_out <= 32;
+    if (!base && !head) return CNC_ERR_UNSUPPORTED;
+    if (base) hipLaunchKernelGGL((k_mlp_forward64<5, 3, 0, 2>), dim3(bw), dim3(64), lds_bytes, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((k_mlp_forward64<5, 5, 1, 2>), dim3(bw), dim3(64), lds_bytes, (hipStream_t)stream, p);
     return launch_status();
 }

@@ -7,8 +7,9 @@
  * raw DEVICE pointers, sizes and a HIP stream (passed as void*, i.e. a hipStream_t; NULL = the
  * legacy default stream).  No torch types, no allocation inside the library, no state kept between
  * calls: all calls are re-entrant and stream-ordered (asynchronous; nothing here synchronises the
- * device).  Two exceptions, both opt-in: a cnc_backward_plan object the caller creates and owns, and the
- * measurement switch cnc_mlp_set_variant (kernel selection for tools/mlp_probe.py; results are the same).
+ * device).  One exception, opt-in: a cnc_backward_plan object the caller creates and owns.  (ABI v28 removed the two
+ * process-wide setters of earlier versions, cnc_mlp_set_variant and cnc_set_persistent_share: measurement switches whose
+ * experiments are closed — docs/engineering_log.md.)
  * Environment variables named CNC_* that a few entry points read are measurement switches too: they are
  * read on every call, never cached.
  *
@@ -304,10 +305,6 @@ int cnc_mlp_forward32(const float* X, uint32_t N, uint32_t ldx, uint32_t K0,
                       const float* W2, const float* b2, uint32_t H2p,
                       const float* W3, const float* b3, uint32_t H3p,
                       float* Y, uint32_t ldy, uint32_t n_out, void* stream);
-int cnc_mlp_set_variant(int variant);   /* measurement switch.  cnc_mlp_forward: 0 (default) one wave per 16
-                                          * rows, 1 = 4-wave workgroups sharing the weight K blocks through LDS
-                                          * (slower).  cnc_mlp_forward32: 3 = one 32-row tile per wave, else
-                                          * (default) two tiles per wave sharing the first layer's weights */
 int cnc_mlp_forward(const float* X, uint32_t N, uint32_t ldx, uint32_t K0,
                     const float* W1, const float* b1, uint32_t H1p,
                     const float* W2, const float* b2, uint32_t H2p,
@@ -899,13 +896,6 @@ typedef struct {
     uint64_t        workspace_bytes;
     uint32_t        n_workgroups;
 } cnc_field_wgrad_t;
-/* (ABI v27) Share in (0, 1] of the GPU's wave slots that the gradient pass's persistent kernels take — the saving form of
- * cnc_field_fused_forward, cnc_field_backward_chain, cnc_field_weight_grads: their grid is what is resident at once, and a
- * resident workgroup keeps its slot until the kernel ends.  1 (default): all of them — right when nothing else runs.  A
- * caller that runs a second stream next to these kernels (the training step's entropy pass) sets a smaller share so that
- * the other stream's kernels find free slots instead of waiting for the whole kernel.  Process-wide; not thread-safe
- * against concurrent launches (set it once).                                                                       */
-int cnc_set_persistent_share(float share);
 int cnc_field_weight_grads_workspace(const cnc_field_wgrad_t* d, uint64_t* bytes);
 int cnc_field_weight_grads(const cnc_field_wgrad_t* d, void* stream);
 

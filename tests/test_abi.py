@@ -3,6 +3,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 
@@ -32,6 +33,28 @@ def test_hip_library_exports_every_declared_symbol(built):
     lib.cnc_error_string.restype = ctypes.c_char_p
     assert lib.cnc_error_string(0) == b"ok"
     assert b"invalid" in lib.cnc_error_string(-1)
+
+
+def test_no_process_wide_setters(built):
+    """The header promises re-entrant, stream-ordered calls with no state between them: no `cnc_set_*` /
+    `cnc_*_set_*` entry point, and no library-side global the kernels read."""
+    assert not [n for n in _declared("cnc_hip.h") if "_set_" in n]
+    lib = ctypes.CDLL(os.path.join(ROOT, "cnc_amd", "libcnc_hip.so"))
+    for gone in ("cnc_set_persistent_share", "cnc_mlp_set_variant"):
+        assert not hasattr(lib, gone)
+    src = os.path.join(ROOT, "cnc_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".hpp")):
+            text = open(os.path.join(src, f)).read()
+            assert "static int g_" not in text and "persistent_share" not in text and "#ifdef CNC_EXP" not in text, f
+
+
+def test_build_refuses_stray_extra_flags():
+    import subprocess
+    env = dict(os.environ, CNC_HIP_EXTRA_FLAGS="-DCNC_SOMETHING")
+    env.pop("CNC_DIAG_BUILD", None)
+    r = subprocess.run([sys.executable, "-c", "import cnc_amd.build"], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "CNC_DIAG_BUILD" in r.stderr
 
 
 def test_ctypes_signature_table_covers_the_header(built):

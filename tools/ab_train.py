@@ -21,9 +21,6 @@ def switch(on):
         tr.ctx_thread = False
     elif what == "chain":
         tr.field.fused_chain, tr.field._chain_supported = on, None
-    elif what.startswith("share"):          # share0.66: the persistent kernels' share of the wave slots, on = that value
-        from cnc_amd import _lib
-        _lib.check(_lib.lib().cnc_set_persistent_share(float(what[5:]) if on else 1.0), "share")
     elif what == "stream2d":
         if not hasattr(tr, "_s2"):
             tr._s2 = tr.ctx_stream_2D

@@ -21,10 +21,9 @@ for dims in ((255,160,80),(95,160,160,3)):
         from cnc_amd import _lib
         with torch.no_grad():
             a=t(lambda: seq(x))
-            _lib.lib().cnc_mlp_set_variant(0); b=t(lambda: fused(x))
-            _lib.lib().cnc_mlp_set_variant(3); c=t(lambda: fused32(x))
-            _lib.lib().cnc_mlp_set_variant(2); d=t(lambda: fused32(x))
-            _lib.lib().cnc_mlp_set_variant(5); e5=t(lambda: fused32(x))
+            b=t(lambda: fused(x))
+            d=t(lambda: fused32(x))
             err=(fused32(x)-seq(x)).abs().max().item()
-            _lib.lib().cnc_mlp_set_variant(0)
-        print(f"{dims} N=2^{N.bit_length()-1}: torch {a:.3f} ms ({fl*N/a/1e9:.1f} TF)   1-wave {b:.3f} ms ({fl*N/b/1e9:.1f} TF)   32-row {c:.3f} ms ({fl*N/c/1e9:.1f} TF)   64-row-L1 {d:.3f} ms ({fl*N/d/1e9:.1f} TF)  96-row-L1 {e5:.3f} ms ({fl*N/e5/1e9:.1f} TF)  max err {err:.1e}")
+        # (the one-tile / 96-row / LDS-shared-weights variants of rounds 2-3 were measured with this probe and removed in
+        # round 6 together with the process-wide switch that selected them: docs/engineering_log.md 4.6)
+        print(f"{dims} N=2^{N.bit_length()-1}: torch {a:.3f} ms ({fl*N/a/1e9:.1f} TF)   1-wave {b:.3f} ms ({fl*N/b/1e9:.1f} TF)   64-row-L1 {d:.3f} ms ({fl*N/d/1e9:.1f} TF)  max err {err:.1e}")
