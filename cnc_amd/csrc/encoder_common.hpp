@@ -234,16 +234,19 @@ __device__ __forceinline__ void unit_issue_fast(const float (&x_)[D], bool insid
             pa[d][0] = g;
             pa[d][1] = q1;
         } else {
+            // q1 = g + 1 here (x in [0, 1] puts g at R - 2 at most: the clamp never bites), so its part is one ADD behind
+            // g's multiply — the same uint32 value as (g + 1) m — instead of a second quarter-rate v_mul_lo_u32
             const uint32_t m = hashed ? primes[d] : sd[d];
             pa[d][0] = g * m;
-            pa[d][1] = q1 * m;
+            pa[d][1] = pa[d][0] + m;
         }
     }
     float w01[4];
 #pragma unroll
     for (uint32_t j = 0; j < 4; j++) w01[j] = wa[0][j & 1u] * wa[1][j >> 1];
     float    wn = 0;
-    const uint8_t* const base = bits + (uint64_t)r.off * F / 8u;        // F in {2, 4, 8}: off is a multiple of 8 rows
+    // (the level's first row goes into the 32-bit row, not into the pointer: with a wave-uniform `bits` the gathers are
+    // scalar-base + 32-bit-offset loads — no 64-bit address pair per corner)
     uint32_t index[C];
 #pragma unroll
     for (uint32_t i = 0; i < C; i++) {
@@ -266,7 +269,7 @@ __device__ __forceinline__ void unit_issue_fast(const float (&x_)[D], bool insid
     // per 2^20 marched samples, fused field unchanged at 0.855 ms on uniform points; the selects and the second,
     // conditional load cost more than the lookups saved.  One byte gather per corner it stays.)
 #pragma unroll
-    for (uint32_t i = 0; i < C; i++) rb[i] = load_row_bits<F>(base, index[i]);
+    for (uint32_t i = 0; i < C; i++) rb[i] = load_row_bits<F>(bits, (uint64_t)(uint32_t)(r.off + index[i]));
     u.wn = wn;
 }
 

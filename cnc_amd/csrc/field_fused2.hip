@@ -176,14 +176,18 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                 const uint32_t w0 = c * 32 + 8 * fq, col0 = c * 32 + 16 * wu;
                 const uint32_t u_first = col0 / F, u_last = (col0 + 15) / F;
                 uint32_t       kind = 3;                                         // 3: mixed -> the general fill
+                const uint8_t* plane = nullptr;                                  // the wave's ONE sign plane, if it has one
                 if (u_first >= p.n_units) kind = 2;                              // raw coordinates / sinusoids / padding
                 else if (u_last < p.n_units) {
                     const uint32_t e_first = __builtin_amdgcn_readfirstlane(p.units[u_first].w);
                     const uint32_t e_last = __builtin_amdgcn_readfirstlane(p.units[u_last].w);
                     kind = e_last == 0 ? 0u : (e_first != 0 ? 1u : 3u);          // units are ordered 3-D first
+                    // (scalar selects: the pointer stays in SGPRs and the gathers take the scalar-base form)
+                    if (e_first == e_last) plane = e_first == 0 ? p.enc[0].bits : e_first == 1 ? p.enc[1].bits
+                                                   : e_first == 2 ? p.enc[2].bits : p.enc[3].bits;
                 }
-                if (kind == 0) fill_units<F, 3, RowT, 8>(p, units, xu, w0, trow);
-                else if (kind == 1) fill_units<F, 2, RowT, 8>(p, units, xu, w0, trow);
+                if (kind == 0) fill_units<F, 3, RowT, 8>(p, units, xu, w0, trow, plane);
+                else if (kind == 1) fill_units<F, 2, RowT, 8>(p, units, xu, w0, trow, plane);
                 else if (kind == 2) fill_tail_window<RowT, 8>(p, xu, w0, p.n_units * F, trow);
                 else fill_window<F, false, RowT, 8>(p, xu, w0, trow);
             }

@@ -562,21 +562,24 @@ __device__ __forceinline__ void fill_tail_window(const FusedFieldArgs& p, const 
 
 // The units of a window that holds only D-dimensional units (the caller knows: a wave-uniform fact, so the other
 // dimension's code is not even issued).
+// `bits_uniform`: the sign plane when the caller knows that every lane of the wave works on one encoder (nullptr: selected
+// per lane from the unit's record)
 template <uint32_t F, uint32_t D>
 __device__ __forceinline__ void window_unit_issue(const FusedFieldArgs& p, const UnitTable& units, const float (&xu)[3],
-                                                  uint32_t u, UnitFast& st)
+                                                  uint32_t u, UnitFast& st, const uint8_t* bits_uniform = nullptr)
 {
     const bool in_x = xu[0] >= 0.0f && xu[0] <= 1.0f, in_y = xu[1] >= 0.0f && xu[1] <= 1.0f,
                in_z = xu[2] >= 0.0f && xu[2] <= 1.0f;
     const UnitRec  rec = units(u);
-    const uint8_t* bits = unit_bits(p, rec.enc);
     if constexpr (D == 3) {
-        unit_issue_fast<3, F>(xu, in_x && in_y && in_z, bits, rec, st);
+        if (bits_uniform) unit_issue_fast<3, F>(xu, in_x && in_y && in_z, bits_uniform, rec, st);      // (two code paths: a
+        else unit_issue_fast<3, F>(xu, in_x && in_y && in_z, unit_bits(p, rec.enc), rec, st);           // merged pointer is a vector one)
     } else {
         const uint32_t pl = rec.enc - 1;                                  // plane 0 = xy, 1 = xz, 2 = yz
         const float    x2[2] = {pl == 2 ? xu[1] : xu[0], pl == 0 ? xu[1] : xu[2]};
         const bool     in2 = (pl == 2 ? in_y : in_x) && (pl == 0 ? in_y : in_z);
-        unit_issue_fast<2, F>(x2, in2, bits, rec, st);
+        if (bits_uniform) unit_issue_fast<2, F>(x2, in2, bits_uniform, rec, st);
+        else unit_issue_fast<2, F>(x2, in2, unit_bits(p, rec.enc), rec, st);
     }
 }
 
@@ -597,12 +600,12 @@ __device__ __forceinline__ void window_unit_finish(const UnitFast& st, uint32_t 
 
 template <uint32_t F, uint32_t D, typename Row, uint32_t WC>
 __device__ __forceinline__ void fill_units(const FusedFieldArgs& p, const UnitTable& units, const float (&xu)[3], uint32_t w0,
-                                           const Row& trow)
+                                           const Row& trow, const uint8_t* bits_uniform = nullptr)
 {
 #pragma unroll
     for (uint32_t s = 0; s < WC / F; s++) {
         UnitFast st;
-        window_unit_issue<F, D>(p, units, xu, (w0 + s * F) / F, st);
+        window_unit_issue<F, D>(p, units, xu, (w0 + s * F) / F, st, bits_uniform);
         window_unit_finish<F, D, Row>(st, w0 + s * F, trow);
     }
 }
