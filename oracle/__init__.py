@@ -184,7 +184,9 @@ def cnt_np_embed_backward(inputs, embeddings, outputs_sum, grad, resolution, has
 
 
 # ----------------------------------------------------------------------------- aligner
-def query_mask(points, binary_vxl, resolution=None, resolution_list=None):
+def query_mask(points, binary_vxl, resolution=None, resolution_list=None, contraction=3):
+    """`contraction` (3 = the oracle's reading): which multiply-add pairs of aligner_kernel.cu:57,71,233 are ONE fused
+    operation, as nvcc's default -fmad=true would make them (bit 0: the cell's upper edge, bit 1: the accumulation)."""
     points = _c(points, np.int16)
     vxl = _c(binary_vxl, np.uint8)
     N, D = points.shape
@@ -192,9 +194,9 @@ def query_mask(points, binary_vxl, resolution=None, resolution_list=None):
     mask = np.zeros(N, dtype=np.int16)
     overlap = np.zeros(N, dtype=np.int32)
     rl = _c(resolution_list, np.int64)
-    lib().orc_query_mask(_p(points), C.c_uint32(D), _p(vxl), C.c_int(vxl.shape[0]), _p(mask),
-                         _p(overlap), C.c_int(0 if resolution is None else int(resolution)),
-                         _p(rl), C.c_uint32(N))
+    lib().orc_query_mask_contraction(_p(points), C.c_uint32(D), _p(vxl), C.c_int(vxl.shape[0]), _p(mask),
+                                     _p(overlap), C.c_int(0 if resolution is None else int(resolution)),
+                                     _p(rl), C.c_uint32(N), C.c_int(int(contraction)))
     return mask, overlap
 
 

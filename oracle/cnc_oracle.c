@@ -379,9 +379,28 @@ void orc_cnt_np_embed_backward(const int16_t* inputs, const float* emb, const fl
  * a7. query_mask_3D{,_qlist} — my_cuda_backen/aligner_kernel.cu:4-326
  * res_list == NULL -> scalar `resolution`.
  * ------------------------------------------------------------------------------------------- */
+/* `contraction`: which of the reference's multiply-add pairs are taken as ONE fused operation — what nvcc's default
+ * -fmad=true does to a same-type multiply that feeds an add, and what cannot be observed without a CUDA build.
+ *   bit 0: the cell's upper edge  float(idx) * Rb_re + Rb_re          (aligner_kernel.cu:57,71,216-232)
+ *   bit 1: the accumulation       overlap += oa * ob (* oc)            (:73, :233)
+ * 3 = both fused: the oracle's (and the HIP kernels') reading.  tools/fmaf_exposure.py counts how many outputs change under
+ * the other three readings. */
+void orc_query_mask_contraction(const int16_t* points, uint32_t D, const uint8_t* vxl, int Rb, int16_t* mask,
+                                int32_t* overlap, int resolution, const int64_t* res_list, uint32_t N, int contraction);
+
 void orc_query_mask(const int16_t* points, uint32_t D, const uint8_t* vxl, int Rb, int16_t* mask,
                     int32_t* overlap, int resolution, const int64_t* res_list, uint32_t N)
 {
+    orc_query_mask_contraction(points, D, vxl, Rb, mask, overlap, resolution, res_list, N, 3);
+}
+
+static inline float edge_(float idx, float Rb_re, int fused) { return fused ? fmaf(idx, Rb_re, Rb_re) : idx * Rb_re + Rb_re; }
+static inline float acc_(float prod_a, float b, float area, int fused) { return fused ? fmaf(prod_a, b, area) : area + prod_a * b; }
+
+void orc_query_mask_contraction(const int16_t* points, uint32_t D, const uint8_t* vxl, int Rb, int16_t* mask,
+                                int32_t* overlap, int resolution, const int64_t* res_list, uint32_t N, int contraction)
+{
+    const int fe = contraction & 1, fa = (contraction >> 1) & 1;
     const float Rb_re = (float)(1.0 / (double)(float)Rb);                      /* :14 */
     for (uint32_t i = 0; i < N; i++) {
         float R = res_list ? (float)res_list[i] : (float)resolution;
@@ -405,25 +424,25 @@ void orc_query_mask(const int16_t* points, uint32_t D, const uint8_t* vxl, int R
         int m = 0;
         float area = 0;
         for (int a = (int)lo[0]; (uint32_t)a <= hi[0]; a++) {                 /* :56-73 / :213-236 */
-            float ra = fminf(fmaf((float)a, Rb_re, Rb_re), pn[0] + scale_re);
+            float ra = fminf(edge_((float)a, Rb_re, fe), pn[0] + scale_re);
             float la = fmaxf((float)a * Rb_re, pn[0] - scale_re);
             float oa = ra - la;
             for (int b = (int)lo[1]; (uint32_t)b <= hi[1]; b++) {
-                float rb = fminf(fmaf((float)b, Rb_re, Rb_re), pn[1] + scale_re);
+                float rb = fminf(edge_((float)b, Rb_re, fe), pn[1] + scale_re);
                 float lb = fmaxf((float)b * Rb_re, pn[1] - scale_re);
                 float ob = rb - lb;
                 if (D == 2) {
                     int mt = vxl[(size_t)a * Rb + b] != 0;
                     m |= mt;
-                    if (mt) area = fmaf(oa, ob, area);                        /* += oa*ob */
+                    if (mt) area = acc_(oa, ob, area, fa);                    /* += oa*ob */
                 } else {
                     for (int c = (int)lo[2]; (uint32_t)c <= hi[2]; c++) {
-                        float rc = fminf(fmaf((float)c, Rb_re, Rb_re), pn[2] + scale_re);
+                        float rc = fminf(edge_((float)c, Rb_re, fe), pn[2] + scale_re);
                         float lc = fmaxf((float)c * Rb_re, pn[2] - scale_re);
                         float oc = rc - lc;
                         int mt = vxl[((size_t)a * Rb + b) * Rb + c] != 0;
                         m |= mt;
-                        if (mt) area = fmaf(oa * ob, oc, area);               /* += oa*ob*oc */
+                        if (mt) area = acc_(oa * ob, oc, area, fa);           /* += oa*ob*oc */
                     }
                 }
             }
