@@ -148,3 +148,116 @@ def test_weight_gradient_kernel_against_float64(cuda, shape, n):
         ref = torch.cat([ref[:, :16], ref[:, 17:17 + geo]], 1) if l == 2 else ref[:, :n_in[l]]
         err, scale = float((out[l].double() - ref).abs().max()), float(ref.abs().max())
         assert err <= 2e-6 * scale, (l, err, scale)
+
+
+def _sh4_f64(d):
+    """tiny-cuda-nn's published degree-4 polynomial (spherical_harmonics.h) in float64 (tests/golden/make_golden_field.py
+    holds it against scipy's harmonics)."""
+    import numpy as np
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
+    return np.stack([
+        np.full_like(x, 0.28209479177387814), -0.48860251190291987 * y, 0.48860251190291987 * z,
+        -0.48860251190291987 * x, 1.0925484305920792 * xy, -1.0925484305920792 * yz,
+        0.94617469575755997 * z2 - 0.31539156525251999, -1.0925484305920792 * xz,
+        0.54627421529603959 * x2 - 0.54627421529603959 * y2, 0.59004358992664352 * y * (-3.0 * x2 + y2),
+        2.8906114426405538 * xy * z, 0.45704579946446572 * y * (1.0 - 5.0 * z2),
+        0.3731763325901154 * z * (5.0 * z2 - 3.0), 0.45704579946446572 * x * (1.0 - 5.0 * z2),
+        1.4453057213202769 * z * (x2 - y2), 0.59004358992664352 * x * (-x2 + 3.0 * y2)], -1)
+
+
+def _float64_field(f, feats, xu, dirs, wr, wd):
+    """The two networks of ngp.py:506-566 on given first-layer input rows, forward and backward, in float64 NumPy:
+    (rgb, density, {parameter name: gradient of sum(rgb * wr) + sum(density * wd)}, {parameter name: the same sums over the
+    ABSOLUTE values of every term — what an entry's rounding error is proportional to})."""
+    import numpy as np
+    mb, mh = f.mlp_base.network, f.mlp_head
+    P = {n: t.detach().cpu().numpy().astype(np.float64) for n, t in
+         (("W1", mb[0].weight), ("b1", mb[0].bias), ("W2", mb[2].weight), ("b2", mb[2].bias), ("W3", mh[0].weight),
+          ("b3", mh[0].bias), ("W4", mh[2].weight), ("b4", mh[2].bias), ("W5", mh[4].weight), ("b5", mh[4].bias))}
+    X = feats[:, :P["W1"].shape[1]].astype(np.float64)
+    sel = np.all((xu > 0) & (xu < 1), axis=1).astype(np.float64)
+    h1 = np.maximum(X @ P["W1"].T + P["b1"], 0.0)
+    o2 = h1 @ P["W2"].T + P["b2"]
+    raw = o2[:, 0]
+    den = sel * np.exp(raw - 1.0)                                       # trunc_exp(x - 1) * selector
+    d32 = ((dirs.astype(np.float32) + np.float32(1.0)) / np.float32(2.0)) * np.float32(2.0) - np.float32(1.0)
+    hin = np.concatenate([_sh4_f64(d32.astype(np.float64)), o2[:, 1:]], axis=1)
+    h3 = np.maximum(hin @ P["W3"].T + P["b3"], 0.0)
+    h4 = np.maximum(h3 @ P["W4"].T + P["b4"], 0.0)
+    rgb = 1.0 / (1.0 + np.exp(-(h4 @ P["W5"].T + P["b5"])))
+    g5 = wr * rgb * (1.0 - rgb)
+    g4 = (g5 @ P["W5"]) * (h4 > 0)
+    g3 = (g4 @ P["W4"]) * (h3 > 0)
+    ghin = g3 @ P["W3"]
+    g2 = np.concatenate([(wd[:, 0] * sel * np.exp(np.minimum(raw - 1.0, 15.0)))[:, None], ghin[:, 16:]], axis=1)
+    g1 = (g2 @ P["W2"]) * (h1 > 0)
+    G = {"W5": g5.T @ h4, "b5": g5.sum(0), "W4": g4.T @ h3, "b4": g4.sum(0), "W3": g3.T @ hin, "b3": g3.sum(0),
+         "W2": g2.T @ h1, "b2": g2.sum(0), "W1": g1.T @ X, "b1": g1.sum(0)}
+    # the scale every entry's rounding error is proportional to: the same chain on absolute values (sum of |terms|)
+    a5 = np.abs(g5)
+    a4 = (a5 @ np.abs(P["W5"])) * (h4 > 0)
+    a3 = (a4 @ np.abs(P["W4"])) * (h3 > 0)
+    ahin = a3 @ np.abs(P["W3"])
+    a2 = np.concatenate([np.abs(g2[:, :1]), ahin[:, 16:]], axis=1)
+    a1 = (a2 @ np.abs(P["W2"])) * (h1 > 0)
+    A = {"W5": a5.T @ np.abs(h4), "b5": a5.sum(0), "W4": a4.T @ np.abs(h3), "b4": a4.sum(0), "W3": a3.T @ np.abs(hin),
+         "b3": a3.sum(0), "W2": a2.T @ np.abs(h1), "b2": a2.sum(0), "W1": a1.T @ np.abs(X), "b1": a1.sum(0)}
+    return rgb, den, G, A
+
+
+@pytest.mark.parametrize("train", [False, True], ids=["chain", "fused_training_forward"])
+def test_gradient_pass_against_float64_at_full_size(cuda, train):
+    """The full-size anchor of the gradient pass that is NOT the repo's own layer-by-layer path: the reference composition
+    (12 x 3-D T = 2^19 + 3 x 4 planes T = 2^17, F = 8, H = 160), 2^16 samples, gradients spread over six orders of magnitude.
+    The first layer's input rows come from the two-wave kernel's dump (bit-equal to oracle.grid_encode_forward:
+    tests/test_gpu_field_fused.py); on them a float64 NumPy forward and backward of both MLPs (closed-form SH) is what rgb,
+    density and every MLP parameter gradient of `cnc_field_backward_chain` + `cnc_field_weight_grads` (and, `train`, the
+    saving fused forward in front of them) are held to — rgb / density at north_star's 1e-4; every gradient ENTRY against its
+    own scale, the sum of the absolute values of its ~6e4 terms through the chain (an entry that is a near-cancellation of
+    large terms cannot be relatively exact in any fp32 implementation; one that is not, is): |error| <= 1e-4 of that sum,
+    <= 3e-4 of the tensor's largest entry, and the entries down to 1e-5 of the largest that are not cancellations (|sum| >=
+    1 % of the sum of |terms|) relatively exact to 3e-3."""
+    import numpy as np
+    f = _field(cuda, CONFIGS["f8_full"], seed=31, sh_fp16_round=False)       # (the half-rounded SH has its own golden)
+    n = 1 << 16
+    x, d = _inputs(cuda, n, seed=77)
+    g = torch.Generator(device=cuda).manual_seed(9)
+    scale = torch.exp(torch.randn(n, 1, device=cuda, generator=g) * 3.0 - 6.0)
+    wr = torch.randn(n, 3, device=cuda, generator=g) * scale
+    wd = torch.randn(n, 1, device=cuda, generator=g) * scale * 0.1
+    feats = torch.full((n, 256), float("nan"), device=cuda)
+    with torch.no_grad():
+        f.fused_field, f.fused_field_precision, f.fused_field_kernel = True, "f16x3", "w2"
+        f.query_density(x[:8])
+        f._field_fused(x, debug_features=feats)
+    xu = ((x - f.aabb[:3]) / (f.aabb[3:] - f.aabb[:3])).cpu().numpy().astype(np.float32)
+    rgb64, den64, G64, A64 = _float64_field(f, feats.cpu().numpy(), xu, d.cpu().numpy(), wr.cpu().numpy().astype(np.float64),
+                                       wd.cpu().numpy().astype(np.float64))
+    rgb, den, grads = _grads(f, x, d, wr, wd, chain=True, train=train)
+    assert f._chain_supported and (f.fused_train or not train)
+    assert np.abs(rgb.cpu().numpy() - rgb64).max() <= 1e-4
+    assert np.abs(den.cpu().numpy()[:, 0] - den64).max() <= 1e-4 * den64.max()
+    names = {"W1": "mlp_base.network.0.weight", "b1": "mlp_base.network.0.bias", "W2": "mlp_base.network.2.weight",
+             "b2": "mlp_base.network.2.bias", "W3": "mlp_head.0.weight", "b3": "mlp_head.0.bias", "W4": "mlp_head.2.weight",
+             "b4": "mlp_head.2.bias", "W5": "mlp_head.4.weight", "b5": "mlp_head.4.bias"}
+    worst = {}
+    for k, name in names.items():
+        got = grads[name].cpu().numpy().astype(np.float64)
+        want = G64[k][:, :got.shape[1]] if got.ndim == 2 else G64[k]
+        assert got.shape == want.shape, (k, got.shape, want.shape)
+        big = float(np.abs(want).max())
+        absmax = float(np.abs(got - want).max()) / big
+        scale_ = A64[k][:, :got.shape[1]] if got.ndim == 2 else A64[k]
+        ratio = np.abs(got - want) / (scale_ + 1e-2 * big)       # (+ 1 % of the largest entry: units that are dead for all but
+                                                                 # a few samples have a scale of next to nothing)
+        # entries that are not cancellations (|sum| >= 1 % of the sum of |terms|), down to 1e-5 of the tensor's largest
+        m = (np.abs(want) >= 1e-5 * big) & (np.abs(want) >= 1e-2 * scale_)
+        rel = np.abs(got - want)[m] / np.abs(want)[m]
+        worst[k] = (absmax, float(ratio.max()), float(rel.max()) if m.any() else 0.0, int(m.sum()), int(m.size))
+    print("MLP gradients against float64: (max |error| / largest entry, max |error| / sum|terms|, max relative error of the non-cancelling entries, their count, entries):", worst)
+    for k, w in worst.items():
+        # measured (round 6, both forms): at most 1.2e-4 of the tensor's largest entry, 3.6e-5 of an entry's own sum of |terms| (+ 1 % of the largest),
+        # 1.0e-3 relative on the non-cancelling entries — ReLU units whose pre-activation is within rounding of zero switch
+        # between the float64 and the product's forward, which is what the largest of these are made of, not the products
+        assert w[0] <= 3e-4 and w[1] <= 1e-4 and w[2] <= 3e-3, (k, w)

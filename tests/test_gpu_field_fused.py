@@ -298,3 +298,26 @@ def test_fused_field_features_and_density_against_the_oracle_at_full_size(cuda, 
     got_den = den.cpu().numpy().reshape(-1).astype(np.float64)
     assert np.abs(got_den - want_den).max() <= 1e-4 * want_den.max()
     assert np.array_equal(got_den == 0, ~sel) and sel[64:].all() and not sel[:64].all()
+
+
+def test_fused_field_rgb_against_float64_at_full_size(cuda):
+    """The colour half of the full-size anchor: rgb of the two-wave colour kernel (reference composition, F = 8, 2^16 points)
+    against a float64 NumPy evaluation of both MLPs (closed-form SH) on the kernel's own first-layer input rows — which
+    `test_fused_field_features_and_density_against_the_oracle_at_full_size` holds bit-equal to the oracle's encoder."""
+    from test_gpu_field_chain import _float64_field
+    f = _field(cuda, CONFIGS["f8_full"], seed=22, sh_fp16_round=False)        # (the half-rounded SH has its own golden)
+    f.fused_field_precision, f.fused_field_kernel = "f16x3", "w2"
+    n = 1 << 16
+    x, d = _inputs(cuda, n, seed=123)
+    feats = torch.full((n, 256), float("nan"), device=cuda)
+    with torch.no_grad():
+        f.fused_field = True
+        f.query_density(x[:8])
+        f._field_fused(x, debug_features=feats)
+        rgb, den = f(x, d)
+    xu = ((x - f.aabb[:3]) / (f.aabb[3:] - f.aabb[:3])).cpu().numpy().astype(np.float32)
+    zeros = np.zeros((n, 3))
+    rgb64, den64, _, _ = _float64_field(f, feats.cpu().numpy(), xu, d.cpu().numpy(), zeros, zeros[:, :1])
+    assert np.abs(rgb.cpu().numpy() - rgb64).max() <= 1e-4
+    assert np.abs(den.cpu().numpy()[:, 0] - den64).max() <= 1e-4 * den64.max()
+    assert rgb64.std() > 0.01
