@@ -155,6 +155,8 @@ SIGNATURES = {
     "cnc_ctx_mlp_forward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp, _vp],
     "cnc_ctx_mlp_backward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp] * 10 + [_u32, _u32, _u32, _u32, _vp],
     "cnc_ctx_window_gather": [_vp] * 8,
+    "cnc_rows_scatter": [_vp, _vp, _vp, C.c_uint64, _u32, _vp],
+    "cnc_ctx_compact": [_vp, _vp, _vp, _vp, C.c_uint64, _i32, _vp, _vp, _vp, _vp, _vp],
     "cnc_plane_ring_vertices": [_vp, C.c_uint64, _u32, _u32, C.c_uint64, _vp, _vp, _vp],
     "cnc_bernoulli_bits_partials": [C.c_uint64, _u32],
     "cnc_bernoulli_bits_forward": [_vp, _vp, _vp, C.c_uint64, _u32, _vp, _vp],

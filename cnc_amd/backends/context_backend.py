@@ -251,9 +251,9 @@ class BernoulliBits(Function):
         if need_t:
             if rows is None:
                 g_table = g_x
-            else:            # rows are distinct hash slots: a plain scatter into zeros
-                g_table = torch.zeros_like(table)
-                g_table[rows] = g_x
+            else:            # rows are distinct hash slots: a plain scatter into zeros (one small kernel: the library's
+                g_table = torch.zeros_like(table)          # index_put took 0.28 ms for these 1.5e5 rows)
+                check(_lib.lib().cnc_rows_scatter(ptr(g_x), ptr(rows), ptr(g_table), S, F, stream(mean.device)), "rows_scatter")
         return g_table, None, g_mean
 
 
@@ -325,6 +325,24 @@ def plane_ring_vertices(cells, T, resolution, hashmap_size):
     check(_lib.lib().cnc_plane_ring_vertices(ptr(cells), cells.shape[0], int(T), int(resolution), int(hashmap_size),
                                              ptr(rows), ptr(points), stream(cells.device)), "plane_ring_vertices")
     return rows, points
+
+
+def compact_masked(idx, pts_n, level_ids, overlap, L):
+    """(pts_n[idx], level_ids[idx], (level_ids[idx] - L) as int32, clamp(overlap[idx], min = 1) as float32 or None) in one
+    kernel (cnc_ctx_compact); idx int64 [M] ascending, overlap int32 [N] or None."""
+    for name, t in (("idx", idx), ("pts_n", pts_n), ("level_ids", level_ids)):
+        check_input(t, name)
+    if idx.dtype != torch.int64 or level_ids.dtype != torch.int64 or pts_n.dtype != torch.float32 or pts_n.shape[-1] != 3 \
+            or (overlap is not None and overlap.dtype != torch.int32):
+        raise RuntimeError("compact_masked: idx / level_ids int64, pts_n float32 [N, 3], overlap int32")
+    M, dev = idx.shape[0], idx.device
+    pts_m = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    lvl_m = torch.empty(M, dtype=torch.int64, device=dev)
+    min_l = torch.empty(M, dtype=torch.int32, device=dev)
+    ow = torch.empty(M, dtype=torch.float32, device=dev) if overlap is not None else None
+    check(_lib.lib().cnc_ctx_compact(ptr(idx), ptr(pts_n), ptr(level_ids), ptr(overlap), M, int(L), ptr(pts_m), ptr(lvl_m),
+                                     ptr(min_l), ptr(ow), stream(dev)), "ctx_compact")
+    return pts_m, lvl_m, min_l, ow
 
 
 def window_gather(levels, device):

@@ -829,7 +829,7 @@ class CNC_context_models(nn.Module):
             return torch.sum(mean * overlap_w, dim=1)
         return torch.sum(mean, dim=1) / mask_cnt.unsqueeze(-1)
 
-    def _slot_masks(self, mask, overlap, unique_cnt, idx=None):
+    def _slot_masks(self, mask, overlap, unique_cnt, idx=None, picked=None):
         """Per slot: number of its vertices next to occupied space, whether any is, and the
         normalised overlap weights of those vertices (utils_bpp_acc.py:668-682).  With `idx` (the indices of
         the True entries of `mask`) the second result is the INDEX list of the slots rather than a bool mask."""
@@ -844,6 +844,8 @@ class CNC_context_models(nn.Module):
                 # index lists instead of boolean masks: ONE sync for the slots, reused by the caller for the table rows
                 mask_exist = torch.nonzero(mask_exist).squeeze(1)
                 mask_cnt = per_slot.to(torch.long).index_select(0, mask_exist)
+                if picked is not None:          # clamp(overlap[idx], min = 1) as float32 already (cnc_ctx_compact)
+                    return mask_cnt, mask_exist, picked
                 picked = overlap.index_select(0, idx)
             return mask_cnt, mask_exist, torch.clamp(picked, min=1).to(torch.float)
         mask_packed = align_and_pack.apply(mask.unsqueeze(-1).to(torch.float), unique_cnt, 0)
@@ -1207,11 +1209,12 @@ class CNC_context_models(nn.Module):
                 mask, overlap = self._query(pts_orig, binary_vxl, resolution_list=res_pts)
                 idx = torch.nonzero(mask).squeeze(1)          # the vertices next to occupied space (one sync)
             with _range("ctx/3D_slot_masks"):
-                mask_cnt, mask_exist, overlap_w = self._slot_masks(mask, overlap, cnts, idx)
+                # positions, levels, window starts and clamped overlaps of the masked vertices: one kernel
+                # (cnc_ctx_compact) instead of three index_selects, a subtraction, a clamp and two casts
+                pts_m, lvl_m, min_lvl, picked = _ctxk.compact_masked(idx, pts_n, lvl_ids, overlap.contiguous(), L)
+                mask_cnt, mask_exist, overlap_w = self._slot_masks(mask, overlap, cnts, idx, picked=picked)
             with _range("ctx/3D_encode"):
-                lvl_m = lvl_ids.index_select(0, idx)
-                context = Encoding_xyz.forward_diff_levels(pts_n.index_select(0, idx), (lvl_m - L).to(torch.int), L,
-                                                           binary_vxl=binary_vxl.squeeze(), PV=1001)
+                context = Encoding_xyz.forward_diff_levels(pts_m, min_lvl, L, binary_vxl=binary_vxl.squeeze(), PV=1001)
             with _range("ctx/3D_mlp_fuse"):
                 # the input row is [context | Pg of the vertex's level]: the column is read from Pg_all by level
                 mean_pts = _ctxk.context_mlp(self.context_model_3D, context, None, Pg_all, lvl_m)

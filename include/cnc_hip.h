@@ -611,6 +611,17 @@ typedef struct {
 int cnc_ctx_window_gather(const cnc_ctx_window_t* win, int16_t* pts, float* pts_n, int64_t* level_ids,
                           int64_t* resolutions, int64_t* slot_counts, int64_t* table_rows, void* stream);
 
+/* (ABI v28) The masked vertices of the 3-D context windows, compacted (utils_bpp_acc.py:680-690: `points_n[mask]`,
+ * `n_list[mask] - L`, `clamp(overlap[mask], min = 1)`): for idx [M] i64 (the ascending indices of the vertices next to
+ * occupied space) writes pts_m [M, 3] = pts_n[idx], level_m [M] = level_ids[idx], min_level [M] i32 = level_m - L and
+ * (overlap_w != NULL) overlap_w [M] f32 = max(overlap[idx], 1).                                                    */
+int cnc_ctx_compact(const int64_t* idx, const float* pts_n, const int64_t* level_ids, const int32_t* overlap, uint64_t M,
+                    int32_t L, float* pts_m, int64_t* level_m, int32_t* min_level, float* overlap_w, void* stream);
+
+/* (ABI v28) table[rows[s], 0..F) = values[s, 0..F) for n_rows DISTINCT rows (i64): the scatter behind
+ * cnc_bernoulli_bits_backward's grad_x when the caller wants the table-shaped gradient (zero-filled by the caller).   */
+int cnc_rows_scatter(const float* values, const int64_t* rows, float* table, uint64_t n_rows, uint32_t F, void* stream);
+
 /* (ABI v25) Vertices of one 2-D level inside / one ring around the occupied cells of a projected occupancy plane
  * (utils_bpp_acc.py:431-456 `fetch_2D_batches`): cells [n_cells, 2] int32 = the occupied (i, j) of the plane, T =
  * (resolution - 2) / plane size; writes, cell-major then ring row / column, n_cells (T+2)^2 entries of rows (the
