@@ -5,11 +5,12 @@
 //     -> hash fusion (:567-572, :693-701) -> clamp / log2 / masks / sum (Bernoulli_entropy :1002-1013)
 // as ~30 ATen launches forward and ~60 backward, 9 plane levels + the batched 3-D levels per step.  Here:
 //
-//   k_ctx_head{1,3}_fwd   the heads (NL = 1: Linear(C->F); NL = 3: C->32->32->F with LeakyReLU 0.01) on the matrix cores,
-//                         16 vertices per wave: the row [ctx | pn | Pg] is read in place (no cat), a layer's output is the
-//                         next layer's operand register for register (see "The three-layer head" below)
-//   k_ctx_head{1,3}_bwd   recompute the activations, back-propagate to the inputs, reduce the weight gradients over the
-//                         vertices through small LDS tiles (MFMA outer products), one flush per workgroup
+//   k_ctx_mlp_fwd<1,F>    the single-Linear heads (Linear(C->F)), one lane per vertex: the row [ctx | pn | Pg] is read in
+//                         place (no cat), weights transposed in LDS (broadcast reads)
+//   k_ctx_mlp_bwd<1,F>    back-propagates to the inputs and reduces the weight gradients over the 64 vertices of a wave
+//                         through LDS tiles (MFMA outer products), one atomicAdd per element and block at the end
+//   k_ctx_head3_fwd/bwd   the three-layer head (C->32->32->F, LeakyReLU 0.01) on the matrix cores, 16 vertices per wave: a
+//                         layer's output is the next layer's operand register for register (see below)
 //   k_bernoulli_bits      bits = sum over (slot, feature) of -log2(p) [x=+1] / -log2(1-p) [x=-1], p = clamp(mean),
 //                         x gathered from the table by row; per-block partial sums (deterministic total)
 //   k_bernoulli_bits_bwd  d bits / d mean and d bits / d x in one pass
@@ -36,6 +37,25 @@ struct MlpArgs {
     const float *W1, *b1, *W2, *b2, *W3, *b3; // nn.Linear layout [out, in]; W2 / W3 unused for NL == 1
 };
 
+// weights into LDS, TRANSPOSED ([in][out]) so that the per-input-element inner loops read consecutive words
+template <int NL, int F>
+__device__ __forceinline__ void load_weights(const MlpArgs& a, float* sW1t, float* sb1, float* sW2t, float* sb2,
+                                             float* sW3t, float* sb3)
+{
+    constexpr int H1 = NL == 1 ? F : kH;
+    for (uint32_t e = threadIdx.x; e < H1 * a.C; e += blockDim.x) {
+        const uint32_t j = e / a.C, c = e % a.C;
+        sW1t[c * H1 + j] = a.W1[e];
+    }
+    for (uint32_t e = threadIdx.x; e < H1; e += blockDim.x) sb1[e] = a.b1[e];
+    if constexpr (NL == 3) {
+        for (uint32_t e = threadIdx.x; e < kH * kH; e += blockDim.x) sW2t[(e % kH) * kH + e / kH] = a.W2[e];
+        for (uint32_t e = threadIdx.x; e < F * kH; e += blockDim.x) sW3t[(e % kH) * F + e / kH] = a.W3[e];
+        for (uint32_t e = threadIdx.x; e < kH; e += blockDim.x) sb2[e] = a.b2[e];
+        for (uint32_t e = threadIdx.x; e < F; e += blockDim.x) sb3[e] = a.b3[e];
+    }
+}
+
 __device__ __forceinline__ float input_at(const MlpArgs& a, uint32_t row, uint32_t c)
 {
     if (c < a.Ca) return a.in_a[(size_t)row * a.lda + c];
@@ -50,6 +70,88 @@ __device__ __forceinline__ bool seg_vec_ok(const float* p, uint32_t ld, uint32_t
     return (((uintptr_t)p | (uintptr_t)(ld * sizeof(float))) & 15u) == 0 && (n & 3u) == 0;
 }
 
+// calls fn(c, value) for every column of the input row [in_a | in_b | pg]; 16-byte loads where possible
+// (statically unrolled: a runtime-indexed float[4] here sent the NL = 3 kernels to scratch memory)
+template <class Fn>
+__device__ __forceinline__ void for_each_input(const MlpArgs& a, uint32_t row, Fn fn)
+{
+    uint32_t c = 0;
+    auto seg = [&](const float* base, uint32_t ld, uint32_t n) {
+        const float* r = base + (size_t)row * ld;
+        if (seg_vec_ok(base, ld, n)) {
+            for (uint32_t k = 0; k < n; k += 4, c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(r + k);
+                fn(c, v.x);
+                fn(c + 1, v.y);
+                fn(c + 2, v.z);
+                fn(c + 3, v.w);
+            }
+        } else {
+            for (uint32_t k = 0; k < n; k++, c++) fn(c, r[k]);
+        }
+    };
+    seg(a.in_a, a.lda, a.Ca);
+    if (a.Cb) seg(a.in_b, a.ldb, a.Cb);
+    if (a.pg) fn(c, a.pg[a.pg_index ? a.pg_index[row] : 0]);
+}
+
+// forward of one vertex; h1 / h2 hold the POST-activation hidden values (NL == 3)
+template <int NL, int F>
+__device__ __forceinline__ void mlp_row(const MlpArgs& a, uint32_t row, const float* sW1t, const float* sb1,
+                                        const float* sW2t, const float* sb2, const float* sW3t, const float* sb3,
+                                        float (&h1)[NL == 1 ? F : kH], float (&h2)[kH], float (&out)[F])
+{
+    constexpr int H1 = NL == 1 ? F : kH;
+#pragma unroll
+    for (int j = 0; j < H1; j++) h1[j] = sb1[j];
+    for_each_input(a, row, [&](uint32_t c, float v) {
+        const float* w = sW1t + c * H1;
+#pragma unroll
+        for (int j = 0; j < H1; j++) h1[j] = __builtin_fmaf(w[j], v, h1[j]);
+    });
+    if constexpr (NL == 1) {
+#pragma unroll
+        for (int f = 0; f < F; f++) out[f] = h1[f];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kH; j++) { h1[j] = lrelu(h1[j]); h2[j] = sb2[j]; }
+#pragma unroll
+        for (int i = 0; i < kH; i++) {
+            const float* w = sW2t + i * kH;
+#pragma unroll
+            for (int j = 0; j < kH; j++) h2[j] = __builtin_fmaf(w[j], h1[i], h2[j]);
+            // keep the scheduler from hoisting all 1024 weight reads of the unrolled layer to the top (that took
+            // 256 VGPRs + 256 AGPRs + 932 B of scratch per lane)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int f = 0; f < F; f++) out[f] = sb3[f];
+#pragma unroll
+        for (int j = 0; j < kH; j++) {
+            h2[j] = lrelu(h2[j]);
+            const float* w = sW3t + j * F;
+#pragma unroll
+            for (int f = 0; f < F; f++) out[f] = __builtin_fmaf(w[f], h2[j], out[f]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int NL, int F>
+__global__ __launch_bounds__(256) void k_ctx_mlp_fwd(MlpArgs a, float* __restrict__ out)
+{
+    constexpr int H1 = NL == 1 ? F : kH;
+    __shared__ float sW1t[kMaxC * H1], sb1[H1], sW2t[NL == 3 ? kH * kH : 1], sb2[kH], sW3t[NL == 3 ? kH * F : 1], sb3[F];
+    load_weights<NL, F>(a, sW1t, sb1, sW2t, sb2, sW3t, sb3);
+    __syncthreads();
+    for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < a.N; row += gridDim.x * blockDim.x) {
+        float h1[H1], h2[kH], o[F];
+        mlp_row<NL, F>(a, row, sW1t, sb1, sW2t, sb2, sW3t, sb3, h1, h2, o);
+#pragma unroll
+        for (int f = 0; f < F; f++) out[(size_t)row * F + f] = o[f];
+    }
+}
+
 struct MlpGrads {
     const float* g_out;                       // [N, F]
     float *g_a, *g_b, *g_pg;                  // [N, Ca], [N, Cb] or null, scalar accumulator or null
@@ -59,6 +161,42 @@ struct MlpGrads {
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One wave reduces outer products over its 64 vertices on the matrix cores:
+//     G[i][j] += sum_v P[v][i] * Q[v][j],   i < NA <= 16 TA,  j < NB <= 16 TB,
+// as 16 steps of v_mfma_f32_16x16x4_f32 per 16 x 16 tile of G (K = 4 vertices per step).  Lane l feeds vertex
+// 4 s + l / 16 with column l % 16 of P (operand A) and of Q (operand B): ONE LDS read per lane, operand and step —
+// 16 (TA + TB) reads per lane and batch where a lane-owns-elements loop read 2 x 64 words per owned element
+// (2048 reads per lane for the 32 x 32 layer: the whole kernel sat on the LDS pipe, 9-13 x its forward).
+// P / Q tiles live in the wave's LDS region ([64][pitch]); tile (ta, tb) of G ends up in acc[ta][tb]: element
+// (row, col) in lane col + 16 (row / 4), register row % 4.  `ntb` = column tiles in use (wave-uniform).
+template <int TA, int TB>
+__device__ __forceinline__ void outer_mfma(const float* tP, uint32_t pitchP, uint32_t NA, const float* tQ,
+                                           uint32_t pitchQ, uint32_t NB, uint32_t ntb, uint32_t lane,
+                                           f32x4 (&acc)[TA][TB])
+{
+    const uint32_t c = lane & 15u, k = lane >> 4;
+#pragma unroll 4
+    for (uint32_t s = 0; s < 16; s++) {
+        const uint32_t v = 4u * s + k;
+        float a[TA], b[TB];
+#pragma unroll
+        for (int ta = 0; ta < TA; ta++) {
+            const uint32_t i = 16u * ta + c;
+            a[ta] = i < NA ? tP[v * pitchP + i] : 0.0f;
+        }
+#pragma unroll
+        for (int tb = 0; tb < TB; tb++) {
+            const uint32_t j = 16u * tb + c;
+            b[tb] = j < NB ? tQ[v * pitchQ + j] : 0.0f;
+        }
+#pragma unroll
+        for (int ta = 0; ta < TA; ta++)
+#pragma unroll
+            for (int tb = 0; tb < TB; tb++)
+                if ((uint32_t)tb < ntb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+    }
+}
 
 // adds the accumulated tiles into g[NA][NB] (nn.Linear layout [out, in])
 template <int TA, int TB>
@@ -73,6 +211,185 @@ __device__ __forceinline__ void flush_mfma(float* g, uint32_t NA, uint32_t NB, u
                 const uint32_t i = 16u * ta + 4u * (lane >> 4) + r, j = 16u * tb + (lane & 15u);
                 if (i < NA && j < NB) atomicAdd(g + i * NB + j, acc[ta][tb][r]);
             }
+}
+
+constexpr int kBwdThreads = 128;    // two waves per block: each needs two 64-row LDS tiles (2 x 10.5 KB)
+
+template <int NL, int F>
+__global__ __launch_bounds__(kBwdThreads) void k_ctx_mlp_bwd(MlpArgs a, MlpGrads g)
+{
+    constexpr int H1 = NL == 1 ? F : kH;
+    constexpr int kPitch = kMaxC + 1;                         // tile pitch (words); covers 32 + 1 and C + 1
+    __shared__ float sW1t[kMaxC * H1], sb1[H1], sW2t[NL == 3 ? kH * kH : 1], sb2[kH], sW3t[NL == 3 ? kH * F : 1], sb3[F];
+    // per wave: tile A (gradients at a layer's output: <= 32 columns, F for the single-Linear heads) and tile B (that
+    // layer's inputs: <= kMaxC columns).  The narrow tile A of NL == 1 takes 25.6 instead of 42 KB per block:
+    // 6 instead of 3 blocks per CU for the nine 2-D heads of a step.
+    constexpr int kPitchA = NL == 1 ? F + 1 : kPitch;
+    __shared__ float tilesA[kBwdThreads / 64][64 * kPitchA];
+    __shared__ float tilesB[kBwdThreads / 64][64 * kPitch];
+    load_weights<NL, F>(a, sW1t, sb1, sW2t, sb2, sW3t, sb3);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* tA = tilesA[wave];
+    float* tB = tilesB[wave];
+    // weight-gradient tiles of this wave (accumulated over every batch of the block, MFMA layout: outer_mfma)
+    constexpr int T1A = (H1 + 15) / 16, T1B = (kMaxC + 15) / 16, TH = kH / 16, TF = (F + 15) / 16;
+    f32x4 aW1[T1A][T1B] = {}, aW2[NL == 3 ? TH : 1][NL == 3 ? TH : 1] = {}, aW3[NL == 3 ? TF : 1][NL == 3 ? TH : 1] = {};
+    float ab1 = 0, ab2 = 0, ab3 = 0, apg = 0;
+    const uint32_t ntb1 = (a.C + 15u) / 16u;
+    int64_t pg_at = -1;            // pg_index mode: the table entry this WAVE is accumulating for (wave-uniform)
+
+    const uint32_t n_batches = (a.N + kBwdThreads - 1) / kBwdThreads;
+    for (uint32_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
+        const uint32_t row = batch * kBwdThreads + threadIdx.x;
+        const bool     on = row < a.N;
+        float h1[H1], h2[kH], o[F], d_o[F];
+        float d1[H1];                                          // gradient at the first layer's pre-activation
+#pragma unroll
+        for (int f = 0; f < F; f++) d_o[f] = on ? g.g_out[(size_t)row * F + f] : 0.0f;
+        if (on && NL == 3) mlp_row<NL, F>(a, row, sW1t, sb1, sW2t, sb2, sW3t, sb3, h1, h2, o);   // a single Linear
+        else {                                                                                   // needs no activations
+#pragma unroll
+            for (int j = 0; j < H1; j++) h1[j] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kH; j++) h2[j] = 0.0f;
+        }
+        if constexpr (NL == 1) {
+#pragma unroll
+            for (int f = 0; f < F; f++) d1[f] = d_o[f];
+        } else {
+            float d2[kH];
+            // d2 = (W3^T d_out) * lrelu'(a2);  tiles: A = d_out [64][F], B = h2 [64][32] -> dW3
+#pragma unroll
+            for (int j = 0; j < kH; j++) {
+                float s = 0.0f;
+#pragma unroll
+                for (int f = 0; f < F; f++) s = __builtin_fmaf(sW3t[j * F + f], d_o[f], s);
+                d2[j] = h2[j] > 0.0f ? s : kSlope * s;
+                tB[lane * kPitch + j] = h2[j];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int f = 0; f < F; f++) tA[lane * kPitchA + f] = d_o[f];
+            __syncthreads();
+            outer_mfma<TF, TH>(tA, kPitchA, F, tB, kPitch, kH, TH, lane, aW3);
+            if (lane < F) {
+                float s = 0.0f;
+                for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitchA + lane];
+                ab3 += s;
+            }
+            __syncthreads();
+            // d1 = (W2^T d2) * lrelu'(a1);  tiles: A = d2, B = h1 -> dW2
+#pragma unroll
+            for (int i = 0; i < kH; i++) {
+                float s = 0.0f;
+#pragma unroll
+                for (int j = 0; j < kH; j++) s = __builtin_fmaf(sW2t[i * kH + j], d2[j], s);
+                d1[i] = h1[i] > 0.0f ? s : kSlope * s;
+                tA[lane * kPitchA + i] = d2[i];
+                tB[lane * kPitch + i] = h1[i];
+                __builtin_amdgcn_sched_barrier(0);       // as in mlp_row: do not hoist the whole layer's weight reads
+            }
+            __syncthreads();
+            outer_mfma<TH, TH>(tA, kPitchA, kH, tB, kPitch, kH, TH, lane, aW2);
+            if (lane < kH) {
+                float s = 0.0f;
+                for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitchA + lane];
+                ab2 += s;
+            }
+            __syncthreads();
+        }
+        // input gradient, and tiles A = d1 [64][H1], B = inputs [64][C] -> dW1
+#pragma unroll
+        for (int j = 0; j < H1; j++) tA[lane * kPitchA + j] = d1[j];
+        float   s_pg = 0.0f;       // this row's gradient of the Pg column
+        auto d_in = [&](uint32_t c) {      // d input[c] = sum_j W1[j][c] d1[j]
+            float        s = 0.0f;
+            const float* w = sW1t + c * H1;
+#pragma unroll
+            for (int j = 0; j < H1; j++) s = __builtin_fmaf(w[j], d1[j], s);
+            return s;
+        };
+        if (on) {
+            uint32_t c = 0;
+            auto     seg = [&](const float* base, uint32_t ld, uint32_t n, float* gout, uint32_t ldg) {
+                const float* r = base + (size_t)row * ld;
+                float*       go = gout ? gout + (size_t)row * ldg : nullptr;
+                if (seg_vec_ok(base, ld, n) && (!gout || seg_vec_ok(gout, ldg, n))) {
+                    for (uint32_t k = 0; k < n; k += 4, c += 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(r + k);
+                        tB[lane * kPitch + c] = v.x; tB[lane * kPitch + c + 1] = v.y;
+                        tB[lane * kPitch + c + 2] = v.z; tB[lane * kPitch + c + 3] = v.w;
+                        if (go) *reinterpret_cast<float4*>(go + k) = make_float4(d_in(c), d_in(c + 1), d_in(c + 2), d_in(c + 3));
+                    }
+                } else {
+                    for (uint32_t k = 0; k < n; k++, c++) {
+                        tB[lane * kPitch + c] = r[k];
+                        if (go) go[k] = d_in(c);
+                    }
+                }
+            };
+            seg(a.in_a, a.lda, a.Ca, g.g_a, g.ldga);
+            if (a.Cb) seg(a.in_b, a.ldb, a.Cb, g.g_b, g.ldgb);
+            if (a.pg) {
+                tB[lane * kPitch + c] = a.pg[a.pg_index ? a.pg_index[row] : 0];
+                const float s = d_in(c);
+                if (a.pg_index) s_pg = s;
+                else apg += s;
+            }
+        } else {
+            for (uint32_t c = 0; c < a.C; c++) tB[lane * kPitch + c] = 0.0f;
+        }
+        if (g.g_pg && a.pg_index) {
+            // rows of one level are contiguous, so a wave almost always holds ONE table entry: reduce over the
+            // wave and keep a running sum per wave, flushed with one atomic when the entry changes.  (One atomic
+            // per lane on <= 16 addresses serialised the whole kernel: 9.6 ms instead of 0.7.)
+            const int64_t  idx = on ? a.pg_index[row] : -1;
+            const uint64_t live = __ballot(on);
+            if (live) {
+                const int64_t first = __shfl(idx, __builtin_ctzll(live));
+                if (__ballot(on && idx != first) == 0) {
+                    float v = on ? s_pg : 0.0f;
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+                    if (first != pg_at) {
+                        if (pg_at >= 0 && lane == 0) atomicAdd(g.g_pg + pg_at, apg);
+                        pg_at = first;
+                        apg = 0.0f;
+                    }
+                    apg += v;
+                } else if (on) {
+                    atomicAdd(g.g_pg + idx, s_pg);       // a wave straddling two levels
+                }
+            }
+        }
+        __syncthreads();
+        outer_mfma<T1A, T1B>(tA, kPitchA, H1, tB, kPitch, a.C, ntb1, lane, aW1);
+        if (lane < H1) {
+            float s = 0.0f;
+            for (uint32_t v = 0; v < 64; v++) s += tA[v * kPitchA + lane];
+            ab1 += s;
+        }
+        __syncthreads();
+    }
+    // ~1000 blocks adding into the same few hundred addresses serialise at the memory side (21 us of a 72 us
+    // single-Linear call): the caller hands n_rep zeroed copies of the weight-gradient buffer and sums them
+    const size_t rep = (size_t)(blockIdx.x % g.n_rep) * g.rep_stride;
+    flush_mfma<T1A, T1B>(g.gW1 + rep, H1, a.C, lane, aW1);
+    if (lane < H1) atomicAdd(g.gb1 + rep + lane, ab1);
+    if constexpr (NL == 3) {
+        flush_mfma<TH, TH>(g.gW2 + rep, kH, kH, lane, aW2);
+        flush_mfma<TF, TH>(g.gW3 + rep, F, kH, lane, aW3);
+        if (lane < kH) atomicAdd(g.gb2 + rep + lane, ab2);
+        if (lane < F) atomicAdd(g.gb3 + rep + lane, ab3);
+    }
+    if (g.g_pg && a.pg_index) {
+        if (pg_at >= 0 && lane == 0) atomicAdd(g.g_pg + pg_at, apg);
+    } else if (g.g_pg) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) apg += __shfl_xor(apg, d);
+        if (lane == 0) atomicAdd(g.g_pg, apg);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -505,180 +822,6 @@ __global__ __launch_bounds__(256, 3) void k_ctx_head3_bwd(MlpArgs a, MlpGrads g)
     }
 }
 
-// ---- the single-Linear heads of the planes' context levels (C -> F) with the same machinery ----
-// 8-12 products forward, 12 + 12 backward per 16 vertices: these kernels move the rows ([N, C] in, [N, C] gradient out) and
-// nothing else.  (The lane-per-vertex backward of rounds 2-5 took 80 us per call in the training step, nine calls per step.)
-struct Head1Lds {
-    float W1[16 * kP1];          // [f][c]  forward:  A[m = f][k = c]   (rows >= F zero)
-    float W1t[48 * kP3t];        // [c][f]  d_in:     A[m = c][k = f]
-    float b1[16];
-};
-
-template <int F>
-__device__ __forceinline__ void head1_load(const MlpArgs& a, Head1Lds& w)
-{
-    for (uint32_t e = threadIdx.x; e < 16 * kP1; e += blockDim.x) {
-        const uint32_t f = e / kP1, c = e % kP1;
-        w.W1[e] = (f < F && c < a.C) ? a.W1[f * a.C + c] : 0.0f;
-    }
-    for (uint32_t e = threadIdx.x; e < 48 * kP3t; e += blockDim.x) {
-        const uint32_t c = e / kP3t, f = e % kP3t;
-        w.W1t[e] = (f < F && c < a.C) ? a.W1[f * a.C + c] : 0.0f;
-    }
-    for (uint32_t e = threadIdx.x; e < 16; e += blockDim.x) w.b1[e] = e < F ? a.b1[e] : 0.0f;
-}
-
-template <int F>
-__global__ __launch_bounds__(256) void k_ctx_head1_fwd(MlpArgs a, float* __restrict__ out)
-{
-    __shared__ __attribute__((aligned(16))) Head1Lds w;
-    head1_load<F>(a, w);
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, i16 = lane & 15u, q = lane >> 4;
-    const uint32_t tiles = (a.N + 15u) / 16u, nkb = (a.C + 15u) / 16u;
-    const bool     veca = seg_vec_ok(a.in_a, a.lda, 4), vecb = a.Cb != 0 && seg_vec_ok(a.in_b, a.ldb, 4);
-    const uint32_t per_wave = div_up(tiles, gridDim.x * 4u), t_lo = (blockIdx.x * 4u + wave) * per_wave;
-    for (uint32_t tile = t_lo; tile < min(tiles, t_lo + per_wave); tile++) {
-        const uint32_t row = tile * 16u + i16;
-        const bool     on = row < a.N;
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int b = 0; b < 3; b++)
-            if ((uint32_t)b < nkb)
-                acc = mfma4(head3_a4(w.W1, kP1, i16, 16u * b + 4u * q), head3_fetch4(a, row, 16u * b + 4u * q, on, veca, vecb), acc);
-        if (on) {
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                if (4u * q + r < (uint32_t)F) out[(size_t)row * F + 4u * q + r] = acc[r] + w.b1[4u * q + r];
-        }
-    }
-}
-
-template <int F>
-__global__ __launch_bounds__(256) void k_ctx_head1_bwd(MlpArgs a, MlpGrads g)
-{
-    __shared__ __attribute__((aligned(16))) Head1Lds w;
-    __shared__ float tilesA[4][16 * kTA], tilesB[4][16 * kTB];
-    head1_load<F>(a, w);
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, i16 = lane & 15u, q = lane >> 4;
-    float* const tA = tilesA[wave];
-    float* const tB = tilesB[wave];
-    const uint32_t tiles = (a.N + 15u) / 16u, nkb = (a.C + 15u) / 16u;
-    const bool     veca = seg_vec_ok(a.in_a, a.lda, 4), vecb = a.Cb != 0 && seg_vec_ok(a.in_b, a.ldb, 4);
-    const bool     vecga = seg_vec_ok(g.g_a, g.ldga, 4), vecgb = g.g_b != nullptr && seg_vec_ok(g.g_b, g.ldgb, 4);
-    const uint32_t c_pg = a.Ca + a.Cb;
-    f32x4 aW1[1][3] = {};
-    f32x4 ab1 = {0.0f, 0.0f, 0.0f, 0.0f};
-    float   apg = 0.0f;
-    int64_t pg_at = -1;
-    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-    const uint32_t per_wave = div_up(tiles, gridDim.x * 4u), t_lo = (blockIdx.x * 4u + wave) * per_wave;
-    for (uint32_t tile = t_lo; tile < min(tiles, t_lo + per_wave); tile++) {
-        const uint32_t row = tile * 16u + i16;
-        const bool     on = row < a.N;
-        f32x4 x[3], d_o = z;
-#pragma unroll
-        for (int b = 0; b < 3; b++) x[b] = head3_fetch4(a, row, 16u * b + 4u * q, on && (uint32_t)b < nkb, veca, vecb);
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-            if (on && 4u * q + r < (uint32_t)F) d_o[r] = g.g_out[(size_t)row * F + 4u * q + r];
-        float s_pg = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            if ((uint32_t)t >= nkb) continue;
-            const f32x4    acc = mfma4(head3_a4(w.W1t, kP3t, 16u * t + i16, 4u * q), d_o, z);
-            const uint32_t c0 = 16u * t + 4u * q;
-            if (on) {
-                if (c0 + 4u <= a.Ca && vecga) {
-                    *reinterpret_cast<float4*>(g.g_a + (size_t)row * g.ldga + c0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                } else if (c0 >= a.Ca && c0 + 4u <= a.Ca + a.Cb && vecgb && ((c0 - a.Ca) & 3u) == 0u) {
-                    *reinterpret_cast<float4*>(g.g_b + (size_t)row * g.ldgb + (c0 - a.Ca)) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const uint32_t c = c0 + r;
-                        if (c < a.Ca) g.g_a[(size_t)row * g.ldga + c] = acc[r];
-                        else if (c < a.Ca + a.Cb) { if (g.g_b) g.g_b[(size_t)row * g.ldgb + (c - a.Ca)] = acc[r]; }
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if (a.pg && c0 + r == c_pg) s_pg = acc[r];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) ab1[r] += d_o[r];
-        if (g.g_pg && a.pg) {
-            const bool mine = on && 4u * q <= c_pg % 16u && c_pg % 16u < 4u * q + 4u;
-            if (!a.pg_index) {
-                apg += mine ? s_pg : 0.0f;
-            } else {
-                const int64_t  idx = mine ? a.pg_index[row] : -1;
-                const uint64_t live = __ballot(mine);
-                if (live) {
-                    const int64_t first = __shfl(idx, __builtin_ctzll(live));
-                    if (__ballot(mine && idx != first) == 0) {
-                        float v = mine ? s_pg : 0.0f;
-#pragma unroll
-                        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-                        if (first != pg_at) {
-                            if (pg_at >= 0 && lane == 0) atomicAdd(g.g_pg + pg_at, apg);
-                            pg_at = first;
-                            apg = 0.0f;
-                        }
-                        apg += v;
-                    } else if (mine) {
-                        atomicAdd(g.g_pg + idx, s_pg);
-                    }
-                }
-            }
-        }
-        head3_put(tA, kTA, i16, 4u * q, d_o);
-#pragma unroll
-        for (int b = 0; b < 3; b++)
-            if ((uint32_t)b < nkb) head3_put(tB, kTB, i16, 16u * b + 4u * q, x[b]);
-        head3_lds_order();
-        head3_outer<1, 3>(tA, kTA, tB, kTB, nkb, i16, q, aW1);
-        head3_lds_order();
-    }
-    // the four waves' tiles summed through LDS (the tile regions are free now), one wave flushes
-    {
-        __syncthreads();
-        float* const scratch = &tilesB[0][0];                      // 4 x 784 floats: room for three waves' 768
-        if (wave) {
-#pragma unroll
-            for (int tb = 0; tb < 3; tb++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) scratch[(wave - 1u) * 784u + (tb * 4 + r) * 64 + lane] = aW1[0][tb][r];
-        }
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll
-            for (uint32_t o = 0; o < 3; o++)
-#pragma unroll
-                for (int tb = 0; tb < 3; tb++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) aW1[0][tb][r] += scratch[o * 784u + (tb * 4 + r) * 64 + lane];
-        }
-    }
-    const size_t rep = (size_t)(blockIdx.x % g.n_rep) * g.rep_stride;
-    if (wave == 0) flush_mfma<1, 3>(g.gW1 + rep, F, a.C, lane, aW1);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) ab1[r] += __shfl_xor(ab1[r], d);
-        if (i16 == 0 && 4u * q + r < (uint32_t)F) atomicAdd(g.gb1 + rep + 4u * q + r, ab1[r]);
-    }
-    if (g.g_pg && a.pg && a.pg_index) {
-        if (pg_at >= 0 && lane == 0) atomicAdd(g.g_pg + pg_at, apg);
-    } else if (g.g_pg && a.pg) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) apg += __shfl_xor(apg, d);
-        if (lane == 0) atomicAdd(g.g_pg, apg);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Bernoulli rate (utils_bpp_acc.py:1002-1013) with the table gather in front of it
 // ---------------------------------------------------------------------------------------------
@@ -751,18 +894,23 @@ __global__ __launch_bounds__(256) void k_segment_bwd(const float* __restrict__ g
 template <int NL>
 static int launch_mlp(bool backward, uint32_t F, const MlpArgs& a, float* out, const MlpGrads& g, hipStream_t s)
 {
-    // 16 vertices per wave on the matrix cores, four waves per workgroup, a contiguous range of tiles per wave
-    const uint32_t wgs = min(div_up(div_up(a.N, 16u), 4u), NL == 3 ? 768u : 1024u);     // (three-layer: 3 workgroups per CU)
-#define CNC_CTX_CASE(FF)                                                                                  \
-    if (F == FF) {                                                                                        \
-        if constexpr (NL == 3) {                                                                          \
-            if (backward) hipLaunchKernelGGL((k_ctx_head3_bwd<FF>), dim3(wgs), dim3(256), 0, s, a, g);    \
-            else hipLaunchKernelGGL((k_ctx_head3_fwd<FF>), dim3(wgs), dim3(256), 0, s, a, out);           \
-        } else {                                                                                          \
-            if (backward) hipLaunchKernelGGL((k_ctx_head1_bwd<FF>), dim3(wgs), dim3(256), 0, s, a, g);    \
-            else hipLaunchKernelGGL((k_ctx_head1_fwd<FF>), dim3(wgs), dim3(256), 0, s, a, out);           \
-        }                                                                                                 \
-        return launch_status();                                                                           \
+    // The three-layer head: 16 vertices per wave on the matrix cores, four waves per workgroup, a contiguous range of
+    // tiles per wave, three workgroups per CU resident.  The single-Linear heads stay on the lane-per-vertex kernels: built
+    // on the same machinery (8 + 24 products per 16 vertices) they came out SLOWER alone — 30 / 115 us against 24 / 90 for
+    // 0.64 M rows: those calls move rows and little else, and a lane per row moves them in fewer instructions.
+    const uint32_t wgs = min(div_up(div_up(a.N, 16u), 4u), 768u);
+    const uint32_t blocks = min(div_up(a.N, 256), 2048u);
+    const uint32_t bwd_blocks = min(div_up(a.N, (uint32_t)kBwdThreads), 1024u);
+#define CNC_CTX_CASE(FF)                                                                                              \
+    if (F == FF) {                                                                                                    \
+        if constexpr (NL == 3) {                                                                                      \
+            if (backward) hipLaunchKernelGGL((k_ctx_head3_bwd<FF>), dim3(wgs), dim3(256), 0, s, a, g);                \
+            else hipLaunchKernelGGL((k_ctx_head3_fwd<FF>), dim3(wgs), dim3(256), 0, s, a, out);                       \
+        } else {                                                                                                      \
+            if (backward) hipLaunchKernelGGL((k_ctx_mlp_bwd<1, FF>), dim3(bwd_blocks), dim3(kBwdThreads), 0, s, a, g); \
+            else hipLaunchKernelGGL((k_ctx_mlp_fwd<1, FF>), dim3(blocks), dim3(256), 0, s, a, out);                   \
+        }                                                                                                             \
+        return launch_status();                                                                                       \
     }
     CNC_CTX_CASE(1) CNC_CTX_CASE(2) CNC_CTX_CASE(4) CNC_CTX_CASE(8)
 #undef CNC_CTX_CASE
