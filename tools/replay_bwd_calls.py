@@ -1,6 +1,6 @@
 """The encoder backward calls of one training step (scratch/bwd_calls.npz from tools/dump_bwd_calls.py) replayed one
-by one on an idle GPU: the routed kernel of each call against the row-merging scatter (CNC_FLAG_CELL_MERGE) — time per
-call (HIP events, median of 20) and the largest difference between the two gradient tables.
+by one on an idle GPU: the run kernel of each call against the cell-merging scatter (CNC_FLAG_CELL_MERGE, with and without
+CNC_FLAG_CELL_CARRY) — time per call (HIP events, median of 20) and the largest difference between the two gradient tables.
 
     python tools/replay_bwd_calls.py [calls.npz] [--calls 0,4,6]
 """
@@ -69,13 +69,9 @@ for ci in range(n_calls):
     scratch = torch.zeros_like(table)
     t_old = timed(lambda: run(scratch))
     line = f"call {ci:2d} D={D} L={L} N={N:7d} masked={vxl is not None} perpoint={mli is not None} ste={ste}: old {t_old*1e3:7.1f} us"
-    for dbg in os.environ.get("DBG", "0").split(","):
-        os.environ["CNC_CELLS_DBG"] = dbg
-        t_new = timed(lambda: run(scratch, cell_merge=True))
-        line += f" | cells[{dbg}]: {t_new*1e3:7.1f} us"
-        if dbg == "0":
-            tot_new += t_new
-    os.environ["CNC_CELLS_DBG"] = "0"
+    t_new = timed(lambda: run(scratch, cell_merge=True))
+    tot_new += t_new
+    line += f" | cells: {t_new*1e3:7.1f} us | cells + carry: {timed(lambda: run(scratch, cell_merge=True, cell_carry=True))*1e3:7.1f} us"
     if D == 3 and F == 8 and vxl is None and mli is None:
         line += f" | merge(all levels): {timed(lambda: run(scratch, interleave_levels=True))*1e3:7.1f} us"
         k = L - 1
