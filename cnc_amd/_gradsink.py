@@ -84,15 +84,20 @@ class GradSink:
         return self.replicas.shape[1]
 
     @torch.no_grad()
-    def flush(self, grads_of=None) -> None:
+    def flush(self, grads_of=None, table_pieces=None) -> None:
         """Add what the sinks hold to the parameters' gradients (`.grad`, or `grads_of(p)` -> the tensor to add into —
         the data-parallel step keeps the gradient in a flat bucket).  Call after the backward passes that used the
-        sink have been joined to the current stream."""
+        sink have been joined to the current stream.  `table_pieces` (a dict): the tables' buffers are not added anywhere
+        but listed there, `id(parameter) -> [(buffer, None), ...]` — the tables' optimizer kernel sums the pieces itself
+        (cnc_amd._table_adam); they stay valid until the next `zero()`."""
         def target(p):
             return p.grad if grads_of is None else grads_of(p)
         add_to, add_from = [], []
         for p, v, used in zip(self.tables, self.table_views, self._tables_used):
             if not used:
+                continue
+            if table_pieces is not None:
+                table_pieces.setdefault(id(p), []).append((v, None))
                 continue
             g = target(p)
             if g is None:

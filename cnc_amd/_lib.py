@@ -28,6 +28,17 @@ class CtxWindow(C.Structure):
                 ("row0", _i64 * 16), ("level", _i32 * 16), ("res", _i32 * 16), ("n_win", _i32)]
 
 
+class AdamTable(C.Structure):
+    """cnc_adam_table_t (include/cnc_hip.h)."""
+    _fields_ = [("p", _vp), ("m", _vp), ("v", _vp), ("step", _vp), ("g", _vp * 4), ("g_lo", C.c_uint64 * 4),
+                ("g_hi", C.c_uint64 * 4), ("n", C.c_uint64)]
+
+
+class AdamTables(C.Structure):
+    """cnc_adam_tables_t (include/cnc_hip.h)."""
+    _fields_ = [("table", AdamTable * 4), ("n_tables", _u32), ("first_block", _u32 * 4)]
+
+
 class FieldSave(C.Structure):
     """cnc_field_save_t (include/cnc_hip.h)."""
     _fields_ = [("feat", _vp), ("ld_feat", _u32), ("h1", _vp), ("h3", _vp), ("h4", _vp), ("head_in", _vp), ("ld_head", _u32),
@@ -156,6 +167,7 @@ SIGNATURES = {
     "cnc_ctx_mlp_backward": [_vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _u32, _u32, _u32] + [_vp] * 6 + [_vp] * 10 + [_u32, _u32, _u32, _u32, _vp],
     "cnc_ctx_window_gather": [_vp] * 8,
     "cnc_rows_scatter": [_vp, _vp, _vp, C.c_uint64, _u32, _vp],
+    "cnc_table_adam": [_vp] + [C.c_double] * 6 + [_vp],
     "cnc_ctx_compact": [_vp, _vp, _vp, _vp, C.c_uint64, _i32, _vp, _vp, _vp, _vp, _vp],
     "cnc_plane_ring_vertices": [_vp, C.c_uint64, _u32, _u32, C.c_uint64, _vp, _vp, _vp],
     "cnc_bernoulli_bits_partials": [C.c_uint64, _u32],
@@ -183,7 +195,7 @@ CNC_PACK_TRANSPOSE = 1
 CNC_PACK_ZERO_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 28          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 29          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

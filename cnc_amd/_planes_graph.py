@@ -152,9 +152,14 @@ class PlanesGraph:
         return self.bits, self.n_params
 
     @torch.no_grad()
-    def flush(self) -> None:
+    def flush(self, table_pieces=None) -> None:
         """The gradients autograd returned inside the graph -> `.grad` (after the sinks' flush, on the stream every
-        pass has been joined to)."""
+        pass has been joined to) — or, with `table_pieces` (see GradSink.flush), listed there for the tables' optimizer
+        kernel: `(gradient, rows of the table it covers or None)`."""
+        if table_pieces is not None:
+            for p, g, rows in self.step_pairs:
+                table_pieces.setdefault(id(p), []).append((g, rows))
+            return
         add_to, add_from = [], []
         for p, g, rows in self.step_pairs:
             if p.grad is None:

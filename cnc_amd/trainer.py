@@ -23,7 +23,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import _gradsink
+from . import _gradsink, _table_adam
 from . import dist as cdist
 from .context import CNC_context_models
 from .field import NGPRadianceField_mygrid_2D3D
@@ -378,8 +378,21 @@ class Trainer:
         c = self.cfg
         # one kernel per parameter list instead of the ~9 passes of the foreach implementation (0.8 -> 0.2 ms per step)
         one_pass = self.device.type == "cuda" and os.environ.get("CNC_FUSED_ADAM", "1") == "1"
-        self.opt = torch.optim.Adam(self.field.parameters(), lr=c.lr, eps=1e-15, weight_decay=c.weight_decay, fused=one_pass)
+        # the four tables as a parameter group of their own (same hyper-parameters, same schedule): what `_table_adam` steps
+        tables = [e.params for e in self.field.mlp_base._encoders()]
+        tids = {id(p) for p in tables}
+        rest = [p for p in self.field.parameters() if id(p) not in tids]
+        self.opt = torch.optim.Adam([{"params": rest}, {"params": tables}], lr=c.lr, eps=1e-15, weight_decay=c.weight_decay,
+                                    fused=one_pass)
         self.opt2 = torch.optim.Adam(self.context.parameters(), lr=c.lr, eps=1e-15, fused=one_pass)
+        # Single-process steps with the gradient sinks: the tables' update reads the gradient pieces where they lie (one
+        # kernel instead of clone + multi-tensor add + the library's Adam over the sum; CNC_TABLE_ADAM=0 or
+        # `self.fused_table_adam = False`: pieces flushed into `.grad`, library step — what data-parallel steps do)
+        self.table_adam = None
+        if one_pass and not self.dp and os.environ.get("CNC_TABLE_ADAM", "1") == "1" \
+                and all(t.numel() % 4 == 0 for t in tables):
+            self.table_adam = _table_adam.TableAdam(self.opt, tables)
+        self.fused_table_adam = self.table_adam is not None
 
         def sched(o):
             return torch.optim.lr_scheduler.ChainedScheduler([
@@ -672,6 +685,7 @@ class Trainer:
                     t.record_stream(main)
             return bits_per_param, mb_, grads
 
+        table_pieces = None
         if self.bucket is None:
             if ctx_future is not None:
                 (mse * self.loss_scale).backward()
@@ -698,12 +712,14 @@ class Trainer:
                 self.opt.zero_grad(set_to_none=True)
                 self.opt2.zero_grad(set_to_none=True)
                 (loss * self.loss_scale).backward()
-            # both passes are joined to this stream: what their kernels added to the sinks goes to `.grad`, once
+            # both passes are joined to this stream: what their kernels added to the sinks goes to `.grad`, once — or, for
+            # the tables, straight into their Adam update (`_table_adam`: the pieces are summed there)
+            table_pieces = {} if (self.table_adam is not None and self.fused_table_adam) else None
             for sink in (self.sink_render, self.sink_ctx):
                 if sink is not None:
-                    sink.flush()
+                    sink.flush(table_pieces=table_pieces)
             if self._planes_replayed:
-                self.planes_graph.flush()       # what autograd returned inside the planes' graph
+                self.planes_graph.flush(table_pieces=table_pieces)       # what autograd returned inside the planes' graph
         else:
             # Data-parallel step.  The ray loss differs per rank, the entropy loss does not (same tables, same
             # window draw on every rank): so only the ray-loss gradient is exchanged, and its all-reduce runs
@@ -758,6 +774,11 @@ class Trainer:
             elif c.lmbda > 0:
                 A.grads.add_(B.flat)
             A.bind(force=True)
+        if self.table_adam is not None:
+            if table_pieces is not None:
+                self.table_adam.step(table_pieces)         # leaves the tables' `.grad` None: the library's step skips them
+            else:
+                self.table_adam.steps_done += 1            # the library steps them below
         self.opt.step()
         if c.lmbda > 0:
             self.opt2.step()

@@ -622,6 +622,32 @@ int cnc_ctx_compact(const int64_t* idx, const float* pts_n, const int64_t* level
  * cnc_bernoulli_bits_backward's grad_x when the caller wants the table-shaped gradient (zero-filled by the caller).   */
 int cnc_rows_scatter(const float* values, const int64_t* rows, float* table, uint64_t n_rows, uint32_t F, void* stream);
 
+/* (ABI v29) The optimizer's update of the feature tables — torch.optim.Adam(lr, eps, weight_decay) as the reference steps it
+ * (examples/train_CNC_nerf_synthetic.py:254-259,363: L2 decay into the gradient, no amsgrad) — for up to four tables in one
+ * launch, with the step's gradient summed from up to four PIECES on the way in (what autograd left in `.grad`, the render
+ * pass's scatter buffer, the entropy pass's, the planes' graph's static gradients): g = ((g0 + g1) + g2) + g3 in fp32, then
+ * m += (1 - b1)(g + wd p - m); v = b2 v + (1 - b2) g^2; p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps),
+ * scalar factors in double.  `step` = the count of THIS update (>= 1); table.step, when given, is the library optimizer's
+ * own device-side counter (float32) and is incremented.  Pointers 16-byte aligned; a piece covers elements [g_lo, g_hi) of
+ * its table, g_lo a multiple of 4, g_hi a multiple of 4 or n.                                                          */
+typedef struct {
+    float*       p;            /* [n] the table                                   */
+    float*       m;            /* [n] exp_avg                                     */
+    float*       v;            /* [n] exp_avg_sq                                  */
+    float*       step;         /* device float32 step counter to increment, or NULL */
+    const float* g[4];         /* gradient pieces, NULL = absent                  */
+    uint64_t     g_lo[4];
+    uint64_t     g_hi[4];
+    uint64_t     n;
+} cnc_adam_table_t;
+typedef struct {
+    cnc_adam_table_t table[4];
+    uint32_t         n_tables;
+    uint32_t         first_block[4];   /* filled by the library */
+} cnc_adam_tables_t;
+int cnc_table_adam(const cnc_adam_tables_t* tables, double lr, double beta1, double beta2, double eps, double weight_decay,
+                   double step, void* stream);
+
 /* (ABI v25) Vertices of one 2-D level inside / one ring around the occupied cells of a projected occupancy plane
  * (utils_bpp_acc.py:431-456 `fetch_2D_batches`): cells [n_cells, 2] int32 = the occupied (i, j) of the plane, T =
  * (resolution - 2) / plane size; writes, cell-major then ring row / column, n_cells (T+2)^2 entries of rows (the

@@ -271,6 +271,7 @@ def test_gradient_sinks_give_the_gradients_autograd_gives(cuda, tmp_path, mode):
         assert tr.sink_render is not None and tr.sink_ctx is not None
         if not sinks:
             tr.sink_render = tr.sink_ctx = None
+        tr.fused_table_adam = False           # the tables' pieces into `.grad` (what this test reads), library step
         tr.train_step(0)                      # same initial state, same draws: the gradients of this one step
         torch.cuda.synchronize()
         named = list(tr.field.named_parameters()) + [("ctx." + n, p) for n, p in tr.context.named_parameters()]
