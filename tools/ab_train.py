@@ -44,6 +44,8 @@ def switch(on):
         gridencoder._CELL_MERGE = on
         if tr.planes_graph is not None:
             tr.planes_graph.drop()
+    elif what == "tableadam":               # the tables' update: pieces summed inside cnc_table_adam / flushed into .grad
+        tr.fused_table_adam = on
     elif what == "vbits":
         for e in tr.field.mlp_base._encoders():
             e.vertex_bits = on
