@@ -421,7 +421,7 @@ class VotePlan:
                                        ptr(rows[2]), ptr(xyz), st), "vote_plan_fill")
         self.rows_by_pixel = rows
         rows_sorted, order = torch.sort(rows[0], stable=True)      # rows[0] is in (x, y, z) order, as xyz is
-        self.xyz_by_row = xyz[order].contiguous()
+        self.xyz_by_row = torch.index_select(xyz, 0, order)       # (the generic `xyz[order]` gather took 0.22 ms for 3.5 M)
         self.row_seg = self._segments(rows_sorted, self.hashmap_size)
         self._pixels_by_row = None
         return self

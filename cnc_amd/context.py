@@ -1093,12 +1093,30 @@ class CNC_context_models(nn.Module):
                 self.vote_plan = (_backend.VotePlan(self.idx_coords2_tmp.to(torch.int16).contiguous(),
                                                     self.dimension_wise_resolution, 2 ** self.log2_hashmap_size)
                                   if self.planned_votes else None)
+        planes_changed = True
         if refresh or getattr(self, "_binary_2D_src", None) is not binary_vxl:
-            # the projections (and, keyed on them, the encoders' summed-area tables) live until the occupancy changes
-            self._binary_2D = [self._project(binary_vxl, a) for a in axes]
+            # the projections (and, keyed on them, the encoders' summed-area tables) live until the occupancy changes.
+            # A refresh that flips cells of the 3-D grid usually leaves its three PROJECTIONS as they were (a cell appears
+            # or goes behind another one): everything the planes' half is built on below depends on the projections only, so
+            # it is kept then — with the OLD projection tensors, which is what the caches keyed on them look at.
+            new = [self._project(binary_vxl, a) for a in axes]
+            old = getattr(self, "_binary_2D", None)
+            how2 = (self.plane_batched, self.fused_heads, self.fused_segments, self._plane_batch_ok(probe))
+            if (self.skip_unchanged_refresh and old is not None and getattr(self, "_planes_built_how", None) == how2
+                    and getattr(self, "_planes_built_from", None) is old        # (what the structures were built from)
+                    and all(o.shape == n_.shape and o.device == n_.device for o, n_ in zip(old, new))
+                    and (self._plane_cat[0] is not None or self.batched_inputs_list is not None)
+                    and bool(torch.equal(torch.stack(old), torch.stack(new)))):
+                planes_changed = False
+                if refresh:
+                    self.refresh_stats["planes_kept"] = self.refresh_stats.get("planes_kept", 0) + 1
+            else:
+                self._binary_2D = new
+                self._planes_built_how = how2
             self._binary_2D_src = binary_vxl
         binary_2D = self._binary_2D
-        if refresh:
+        if refresh and planes_changed:
+            self._planes_built_from = binary_2D
             # vertex lists, slot order and the slots' cumulative counts are fixed until the next refresh; the coded rows the
             # level-by-level branch of `_bits_2D` caches belong to the OLD lists (callers that run `_bits_2D` with
             # refresh=False behind this rebuild — the planes' graph / thread — would otherwise keep using them)

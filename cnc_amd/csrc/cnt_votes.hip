@@ -364,8 +364,25 @@ __global__ __launch_bounds__(256) void k_vote_plan_lines(const uint32_t* __restr
     const uint32_t u = p / S + 1, w = p % S + 1;
     const OccLine  L = line_mask(bits, Rb, t, plane, u, w);
     int32_t*       out = plane == 0 ? rows_xy : plane == 1 ? rows_xz : rows_yz;
+    // Most lines of a projected scene are empty, and a line that is not touches a few coarse cells: coarse cell c holds the
+    // vertices [c t, (c + 1) t + 1] (coarse_range read backwards), so only the span between the first and the last set bit is
+    // walked — the same vertices in the same order (round 6: 0.58 + 0.64 -> see profiles/r06_refresh_step.md).
+    uint32_t c_min = 0, c_max = 0;
+    bool     some = false;
+#pragma unroll
+    for (uint32_t k = 0; k < kOccWords; k++)
+        if (L.m[k]) {
+            if (!some) c_min = 32 * k + (uint32_t)__builtin_ctz(L.m[k]);
+            c_max = 32 * k + 31u - (uint32_t)__builtin_clz(L.m[k]);
+            some = true;
+        }
+    if (!some) {
+        if (!FILL && lane == 0) counts[(size_t)plane * S * S + p] = 0;
+        return;
+    }
+    const uint32_t v_first = c_min * t > 1u ? c_min * t : 1u, v_last = (c_max + 1) * t + 1 < S ? (c_max + 1) * t + 1 : S;
     uint32_t       at = FILL ? (uint32_t)seg[(size_t)plane * (S * S + 1) + p] : 0u;
-    for (uint32_t v0 = 1; v0 <= S; v0 += 64) {
+    for (uint32_t v0 = v_first; v0 <= v_last; v0 += 64) {
         const uint32_t v = v0 + lane;
         bool           in = false;
         if (v <= S) {

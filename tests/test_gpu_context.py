@@ -473,5 +473,20 @@ def test_a_refresh_with_an_unchanged_occupancy_keeps_the_plan(setup):
     plan = m.vote_plan
     run(48, flipped, True)
     assert m.vote_plan is not plan and m.refresh_stats["skipped"] == before["skipped"] + 1
+    # a cell that appears BEHIND others in all three projections: the 3-D structures are rebuilt, the planes' are kept —
+    # and the pass returns what a full rebuild returns
+    occ3 = binary.reshape(binary.shape[-3:]).bool()
+    hidden = (~occ3) & occ3.any(2)[:, :, None] & occ3.any(1)[:, None, :] & occ3.any(0)[None, :, :]
+    assert bool(hidden.any())
+    deeper = binary.clone()
+    deeper.view(-1)[torch.nonzero(hidden.reshape(-1))[:2, 0]] = 1
+    run(64, binary.clone(), False)                                # planes built from `binary`'s projections
+    held = lambda: [c["rows"] for c in m._plane_cat] if m._plane_cat[0] is not None else [m.batched_inputs_list]
+    cats, plan, kept = held(), m.vote_plan, m.refresh_stats.get("planes_kept", 0)
+    got = run(80, deeper, True)
+    assert m.vote_plan is not plan and m.refresh_stats.get("planes_kept", 0) == kept + 1
+    assert all(a is b for a, b in zip(cats, held()))
+    want = run(96, deeper.clone(), False)
+    assert got == want
     m.skip_unchanged_refresh = True
     run(0, binary, True)                                          # leave the module fixture as the other tests expect it
