@@ -58,6 +58,7 @@ class PlanesGraph:
         self._small_used = False
         self.captures = 0
         self.replays = 0
+        self._pool = None
 
     def _key(self):
         tr = self.tr
@@ -102,7 +103,22 @@ class PlanesGraph:
             g = torch.cuda.CUDAGraph()
             # (not `with torch.cuda.graph(...)`: that synchronises the device and empties the allocator's cache on entry —
             # the render pass is running on its own thread and stream next to this)
-            g.capture_begin(capture_error_mode="thread_local")
+            # ONE memory pool for every recording of this object: a graph records into a private pool, and a pool of its own
+            # per recording left ~0.5 GB reserved behind every occupancy refresh (18 -> 31 GB over 24 refreshes; the
+            # allocator only returns a dead graph's pool under memory pressure) and a hipMalloc of that size inside every
+            # recording step — 25-35 ms for that step on some boxes.  The previous graph is dropped above, so its blocks are
+            # free in the pool when this one records.
+            # (A pool handle may only be passed again while a graph that records into it is alive: a one-kernel graph recorded
+            # once holds it for this object's lifetime.)
+            if self._pool is None:
+                pool, keeper = torch.cuda.graph_pool_handle(), torch.cuda.CUDAGraph()
+                keeper.capture_begin(pool=pool, capture_error_mode="thread_local")
+                try:
+                    self._keeper_out = torch.zeros(1, device=exyz.params.device)
+                finally:
+                    keeper.capture_end()
+                self._pool, self._keeper = pool, keeper
+            g.capture_begin(pool=self._pool, capture_error_mode="thread_local")
         try:
             with torch.autograd.set_multithreading_enabled(False):
                 pq = [STE_binary.apply(t) for t in leaves]

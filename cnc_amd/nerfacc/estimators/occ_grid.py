@@ -229,9 +229,37 @@ class OccGridEstimator(AbstractEstimator):
         self._update(step=step, occ_eval_fn=occ_eval_fn, occ_thre=occ_thre, ema_decay=ema_decay,
                      warmup_steps=warmup_steps)
 
+    def _all_visible(self) -> bool:
+        """No cell is marked invisible (occs >= 0 everywhere) — the state of every run that never calls
+        `mark_invisible_cells`.  Then the three boolean-index round trips of an update (each a `nonzero` with a host
+        sync) select everything and are skipped: same cells, same mean.  The answer is cached against the buffer's
+        identity and version counter: this class's own writes keep it (they never make a cell negative), anybody else's
+        write to `occs` is seen and costs one check."""
+        key = (id(self.occs), self.occs._version)
+        if getattr(self, "_vis_key", None) != key:
+            self._vis_flag = bool((self.occs >= 0).all())
+            self._vis_key = key
+        return self._vis_flag
+
+    def _stamp_visible(self) -> None:
+        """After a write of this class that cannot have changed which cells are visible."""
+        if getattr(self, "_vis_key", None) is not None:
+            self._vis_key = (id(self.occs), self.occs._version)
+
+    def _vis_flag_after_update(self) -> bool:
+        """`_all_visible()` behind the update's own writes to `occs` (which keep every cell's sign): the cached answer,
+        re-stamped with the buffer's new version."""
+        flag = getattr(self, "_vis_flag", None)
+        if flag is None or getattr(self, "_vis_key", (None,))[0] != id(self.occs):
+            return self._all_visible()
+        self._stamp_visible()
+        return flag
+
     @torch.no_grad()
     def _get_all_cells(self) -> List[Tensor]:
         """Per level: indices of the cells that are not marked invisible (occs >= 0)."""
+        if self._all_visible():
+            return [self.grid_indices for _ in range(self.levels)]
         per_level = self.occs.view(self.levels, self.cells_per_lvl)
         return [self.grid_indices[per_level[k] >= 0.0] for k in range(self.levels)]
 
@@ -240,9 +268,11 @@ class OccGridEstimator(AbstractEstimator):
         """Per level: n uniformly drawn (visible) cells followed by up to n of the occupied ones."""
         picks = []
         per_level = self.occs.view(self.levels, self.cells_per_lvl)
+        all_visible = self._all_visible()
         for k in range(self.levels):
             drawn = torch.randint(self.cells_per_lvl, (n,), device=self.device)
-            drawn = drawn[per_level[k][drawn] >= 0.0]
+            if not all_visible:
+                drawn = drawn[per_level[k][drawn] >= 0.0]
             occupied = self.binaries[k].reshape(-1).nonzero()[:, 0]
             if occupied.shape[0] > n:
                 occupied = occupied[torch.randint(occupied.shape[0], (n,), device=self.device)]
@@ -264,7 +294,9 @@ class OccGridEstimator(AbstractEstimator):
             seen = occ_eval_fn(lo + unit * (hi - lo)).squeeze(-1)
             slot = idx + k * self.cells_per_lvl
             self.occs[slot] = torch.maximum(self.occs[slot] * ema_decay, seen)
-        level = torch.clamp(self.occs[self.occs >= 0].mean(), max=occ_thre)
+        # (a visible cell stays visible: max(decay * occs, .) of a non-negative value)
+        visible = self.occs if self._vis_flag_after_update() else self.occs[self.occs >= 0]
+        level = torch.clamp(visible.mean(), max=occ_thre)
         self.binaries = (self.occs > level).view(self.binaries.shape)
 
     @torch.no_grad()
