@@ -908,6 +908,7 @@ class CNC_context_models(nn.Module):
         shift = max(int(self._off2_host[n + 1] - self._off2_host[n] - 1).bit_length() for n in coded)
         if (3 * nl) << shift >= 2 ** 31:
             return False
+        self._list_occupied_cells_2D(binary_2D)
         keys, pts, sizes = [], [], []
         for k in range(3):
             for n in coded:
@@ -927,6 +928,8 @@ class CNC_context_models(nn.Module):
         bases, off_lut = consts[ck]
         slot_at = torch.searchsorted(uv, bases).tolist()                            # sync 2: slots per plane
         pts_all = torch.cat(pts)
+        # the slots' table rows for the three planes at once (the key's level field is plane * nl + level)
+        rows_all = (uv & ((1 << shift) - 1)).to(torch.long) + off_lut[(uv >> shift) % nl]
         at = 0
         for k in range(3):
             a, b = slot_at[k], slot_at[k + 1]
@@ -934,14 +937,30 @@ class CNC_context_models(nn.Module):
             for i in range(len(coded)):
                 p_at.append(p_at[-1] + sizes[k * len(coded) + i])
             A, B = p_at[0], p_at[-1]
-            uvk = uv[a:b]
             self._plane_cat[k] = dict(
-                pts=pts_all[A:B], order=order[A:B] - A,
-                rows=(uvk & ((1 << shift) - 1)).to(torch.long) + off_lut[(uvk >> shift) - k * nl],
-                cum=_cum(uc[a:b]),
+                pts=pts_all[A:B], order=order[A:B] - A, rows=rows_all[a:b], cum=_cum(uc[a:b]),
                 segs=[(p_at[i] - A, p_at[i + 1] - A, 0, n * F, n) for i, n in enumerate(coded)])
             at = B
         return True
+
+    def _list_occupied_cells_2D(self, binary_2D):
+        """The occupied cells of the three projections from ONE `nonzero` (one host sync instead of three), left in the
+        cache `fetch_2D_batches` reads."""
+        if not all(b.is_cuda and b.shape == binary_2D[0].shape for b in binary_2D):
+            return
+        cache = self.__dict__.setdefault("_occ_cells_2D", {})
+        keys = [(b.data_ptr(), b._version, tuple(b.shape), tuple(b.stride())) for b in binary_2D]
+        if all(k in cache for k in keys):
+            return
+        flat = torch.stack([b.reshape(-1) for b in binary_2D])            # [3, Rb Rb]
+        hit = (flat == 1).nonzero()                                       # [M, 2]: (plane, cell), plane-major
+        per_plane = torch.searchsorted(hit[:, 0].contiguous(), torch.arange(4, device=hit.device)).tolist()
+        idx2 = self.binary_vxl_2D_idx.view(-1, 2)
+        cells = idx2[hit[:, 1]]
+        if len(cache) >= 8:
+            cache.clear()
+        for k, b in enumerate(binary_2D):
+            cache[keys[k]] = (b, cells[per_plane[k]:per_plane[k + 1]])
 
     def _plane_batch_ok(self, p_q):
         """The coded levels of a plane can be evaluated together when every one of them looks at the levels below it
