@@ -804,7 +804,17 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
             self._chain_supported = bool(FusedFieldForward.supported(self)
                                          and sum(e.n_output_dims for e in self.mlp_base._encoders()) % 4 == 0
                                          and sum(e.n_output_dims for e in self.mlp_base._encoders()) <= 192
-                                         and (1 + self.geo_feat_dim + 31) // 32 * 32 <= self.mlp_base.network[0].out_features)
+                                         and (1 + self.geo_feat_dim + 31) // 32 * 32 <= self.mlp_base.network[0].out_features
+                                         # cnc_field_backward_chain's own limits (field_bwd.hip): the bias-sum layout keeps
+                                         # 80 (H = 160) / 64 (H = 64) slots for the base network's last layer
+                                         and 1 + self.geo_feat_dim <= (80 if self.mlp_base.network[0].out_features == 160 else 64))
+        if not self._chain_supported:
+            return False
+        # ... and its 32-bit byte offsets: rows x the widest row it addresses (the padded feature matrix or a hidden layer)
+        H = self.mlp_base.network[0].out_features
+        ld = max(H, (sum(e.n_output_dims for e in self.mlp_base._encoders()) + 3 + 60 + 31) // 32 * 32 + 32)
+        if x_unit.shape[0] * ld * 4 >= (1 << 32):
+            return False
         return self._chain_supported
 
     def _train_ok(self, positions, directions) -> bool:

@@ -289,6 +289,7 @@ class Trainer:
         self.planes_graph_dp = os.environ.get("CNC_PLANES_GRAPH_DP", "1") == "1"
         self._pool_graph = None
         self._planes_replayed = False
+        self._fwd_enqueued = None
         if self.device.type == "cuda" and os.environ.get("CNC_PLANES_GRAPH", "1") == "1":
             from ._planes_graph import PlanesGraph
             self.planes_graph = PlanesGraph(self)
@@ -424,6 +425,20 @@ class Trainer:
         """... as a replay of the recorded graph: every such step but the occupancy-refresh ones."""
         return self._planes_thread_step(step, params) and step % self.cfg.step_update != 0
 
+    def _on_planes_thread(self, fn, *args):
+        """Submit `fn(*args)` to the planes' thread under the SUBMITTING thread's grad and autocast modes (thread-local in
+        PyTorch; a pool thread starts from the defaults)."""
+        if self._pool_graph is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool_graph = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cnc-planes")
+        grad_mode = torch.is_grad_enabled()
+        enabled, dtype = torch.is_autocast_enabled(self.device.type), torch.get_autocast_dtype(self.device.type)
+
+        def job():
+            with torch.set_grad_enabled(grad_mode), torch.autocast(self.device.type, dtype=dtype, enabled=enabled):
+                return fn(*args)
+        return self._pool_graph.submit(job)
+
     def _planes_refresh_job(self, after, step: int) -> None:
         """On the planes' thread, an occupancy-refresh step: rebuild what the planes' half is built on (vote plan, projections,
         vertex lists: host round trips on the planes' stream only) and run that half op by op — next to the 3-D half, which
@@ -484,17 +499,11 @@ class Trainer:
             if self._planes_graph_step(step, params):      # (still: a failed capture switches the graph off)
                 # The graph launch itself is ~2 ms of HOST time (the runtime enqueues the ~110 nodes one by one, outside the
                 # interpreter lock): from a thread of its own, so that this one goes straight on to the 3-D half.
-                if self._pool_graph is None:
-                    from concurrent.futures import ThreadPoolExecutor
-                    self._pool_graph = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cnc-planes")
-                replay = self._pool_graph.submit(self._replay_planes, side.record_event())
+                replay = self._on_planes_thread(self._replay_planes, side.record_event())
                 planes = (None, pg.n_params)               # the bits join the totals below, behind the backward
                 self._planes_replayed = True
             elif self._planes_thread_step(step, params):   # an occupancy-refresh step: rebuilt and run op by op over there
-                if self._pool_graph is None:
-                    from concurrent.futures import ThreadPoolExecutor
-                    self._pool_graph = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cnc-planes")
-                replay = self._pool_graph.submit(self._planes_refresh_job, side.record_event(), step)
+                replay = self._on_planes_thread(self._planes_refresh_job, side.record_event(), step)
                 planes = (None, sum(t.params.numel() for t in e._encoders()[1:]))
                 self._planes_replayed = True
             # the planes' half of the pass on a stream of its own, next to the 3-D half (both directions: autograd runs a
@@ -502,17 +511,29 @@ class Trainer:
             # (Back-propagating the planes' share of the loss as soon as their forward is enqueued — a second backward call,
             # before the 3-D half is launched — was built and measured: 8.25 -> 8.95 ms.  The first half of the step is bound
             # by the two host threads' launches, and the extra call sits in front of the 3-D forward's.)
-            bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(
-                e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
-                sample_num=None, step=step, sync_MB=False, stream_2D=self.ctx_stream_2D, planes=planes)
-            # issued from the side stream: the root gradient of a backward call is created on the ambient stream and
-            # every node waits for it
-            root = c.lmbda * bits_per_param * self.loss_scale
-            grads = None
-            if params is None:
-                root.backward()
-            else:
-                grads = torch.autograd.grad(root, params, allow_unused=True)
+            try:
+                bits_per_param, mb = self.context.forward_binary_vxl_mixPg_3D2D(
+                    e.encoding_xyz, e.encoding_xy, e.encoding_xz, e.encoding_yz, self.estimator.binaries,
+                    sample_num=None, step=step, sync_MB=False, stream_2D=self.ctx_stream_2D, planes=planes)
+                # issued from the side stream: the root gradient of a backward call is created on the ambient stream and
+                # every node waits for it
+                root = c.lmbda * bits_per_param * self.loss_scale
+                grads = None
+                if params is None:
+                    root.backward()
+                else:
+                    grads = torch.autograd.grad(root, params, allow_unused=True)
+            except BaseException:
+                # the planes' job writes the sink and the graph's static gradients: wait for it (its own error, if any, is
+                # secondary) and order this stream after what it enqueued before the error travels on
+                if replay is not None:
+                    try:
+                        replay.result()
+                    except BaseException:
+                        pass
+                    if self.ctx_stream_2D is not None:
+                        side.wait_stream(self.ctx_stream_2D)
+                raise
             if replay is not None:
                 replay.result()                            # the graph launch has been enqueued (and did not fail)
             if self.ctx_stream_2D is not None:
@@ -531,6 +552,7 @@ class Trainer:
         train:368-381) — `n_rendering_samples` and `num_rays` are always there."""
         c = self.cfg
         self.field.train(); self.estimator.train(); self.context.train()
+        self._planes_replayed = False       # (set by this step's entropy pass if the planes' half runs apart from it)
         # the batch: drawn at the end of the step before (`_prefetch`), while that step's backward kept the GPU busy
         data, self._next_data = self._next_data, None
         if data is None:
@@ -626,6 +648,11 @@ class Trainer:
         # are all the march reads, so the next step's two traversal passes and the host round trip for its sample count run
         # here, next to this step's backward, instead of at the head of the next step's render pass — the step's critical
         # chain.  Not in front of a refresh step: it replaces the grid.
+        # (ordered after this step's render FORWARD on the main stream — the march that read `binaries`, the coarse occupancy
+        # words computed lazily by whichever stream marches first; today a host sync earlier in the step already covers them —
+        # not after its backward, which is what this runs next to)
+        if self._fwd_enqueued is not None:
+            pre.wait_event(self._fwd_enqueued)
         with torch.cuda.stream(pre):
             data = self.dataset.fetch()
             if self.premarch and step >= 0 and (step + 1) % c.step_update != 0:
@@ -661,6 +688,7 @@ class Trainer:
             rgb, acc, depth, n_samples, extra = render_image_with_occgrid(
                 self.field, self.estimator, rays, near_plane=c.near_plane, render_step_size=c.render_step_size,
                 render_bkgd=bkgd, cone_angle=c.cone_angle, alpha_thre=c.alpha_thre, return_extra=True)
+        self._fwd_enqueued = torch.cuda.current_stream(self.device).record_event() if self.device.type == "cuda" else None
         if not self.dp:
             if n_samples == 0:
                 if ctx_future is not None:
