@@ -744,6 +744,7 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
         # ... and its forward as the fused evaluator in its saving form (`_FieldTrain`; CNC_FUSED_TRAIN=0: library GEMMs)
         self.fused_train = self.fused_chain and os.environ.get("CNC_FUSED_TRAIN", "1") == "1"
         self._guard_seen = 1
+        self._guard_host = self._guard_evt = self._guard_ids = None       # `snapshot_range_guard`
         # the five weight gradients as one kernel (cnc_field_weight_grads; CNC_FUSED_WGRAD=0: split-K library GEMMs)
         self.fused_wgrad = os.environ.get("CNC_FUSED_WGRAD", "1") == "1"
         self._wgrad_ws = None
@@ -845,6 +846,39 @@ class NGPRadianceField_mygrid_2D3D(nn.Module):
             self.fused_train = False
             return True
         self._guard_seen = ff._call_id + 1
+        return False
+
+    def snapshot_range_guard(self) -> None:
+        """Behind a training forward: the guard's words on their way to pinned host memory (one 24-byte copy, no
+        synchronisation); `poll_range_guard` looks at them once they have arrived — in a training loop, the step after.
+        Round 6: the check used to happen only where the loop synchronises anyway (every `step_update` steps)."""
+        ff = self._field_fused
+        if not ff or not getattr(ff, "_train_calls", False) or not self.fused_train or ff._buffers is None:
+            return
+        if self._guard_evt is not None and not self._guard_evt.query():
+            return                                      # the previous snapshot is still in flight: it will be looked at first
+        g = ff._buffers["guard"]
+        if self._guard_host is None:
+            self._guard_host = torch.zeros(6, dtype=g.dtype).pin_memory()
+        self._guard_host.copy_(g[:6], non_blocking=True)
+        self._guard_evt = torch.cuda.Event()
+        self._guard_evt.record()
+        self._guard_ids = (ff._pack_id, ff._call_id)
+
+    def poll_range_guard(self) -> bool:
+        """True (once) when a snapshot has arrived that shows a value beyond fp16's range in a saving forward: the gradient
+        pass then leaves the fused kernel for the fp32 library path, as `check_range_guard` does.  Never waits."""
+        if self._guard_evt is None or not self._guard_evt.query() or not self.fused_train:
+            return False
+        words, (pack_id, call_id) = self._guard_host.tolist(), self._guard_ids
+        self._guard_evt = None
+        if words[0] != 0 and words[0] >= self._guard_seen or any(w == pack_id for w in words[1:6]):
+            import warnings
+            warnings.warn("cnc_amd: a value left fp16's range in the fused training forward; the gradient pass continues "
+                          "on the fp32 library path")
+            self.fused_train = False
+            return True
+        self._guard_seen = max(self._guard_seen, call_id + 1)
         return False
 
     def _chain_weights_t(self, W1, W2, W3, W4, W5, n_enc):

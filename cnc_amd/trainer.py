@@ -689,6 +689,11 @@ class Trainer:
                 self.field, self.estimator, rays, near_plane=c.near_plane, render_step_size=c.render_step_size,
                 render_bkgd=bkgd, cone_angle=c.cone_angle, alpha_thre=c.alpha_thre, return_extra=True)
         self._fwd_enqueued = torch.cuda.current_stream(self.device).record_event() if self.device.type == "cuda" else None
+        if self.device.type == "cuda":
+            # the fused training forward's fp16 range guard, every step and without a wait: the words of the step before have
+            # arrived by now (the sampler has synchronised the host since), this step's are sent on their way
+            self.field.poll_range_guard()
+            self.field.snapshot_range_guard()
         if not self.dp:
             if n_samples == 0:
                 if ctx_future is not None:

@@ -88,6 +88,32 @@ def test_fused_training_forward_and_its_gradients(cuda, cfg, n):
     assert not f.check_range_guard()
 
 
+def test_range_guard_of_the_training_forward_is_looked_at_every_step_without_a_wait(cuda):
+    """`snapshot_range_guard` behind a saving forward + `poll_range_guard` at the next step: nothing for an ordinary model;
+    with hidden activations driven past fp16's 65504 the poll that follows the snapshot's arrival reports it, once, and the
+    gradient pass leaves the fused kernel."""
+    f = _field(cuda, CONFIGS["f8_full"], seed=8)
+    x, d = _inputs(cuda, 4096, seed=2)
+    wr, wd = torch.randn(4096, 3, device=cuda), torch.randn(4096, 1, device=cuda)
+    for _ in range(3):                                   # three "steps": poll what the step before sent, send this one's
+        _grads(f, x, d, wr, wd, chain=True, train=True)
+        assert not f.poll_range_guard()
+        f.snapshot_range_guard()
+    torch.cuda.synchronize()
+    assert not f.poll_range_guard() and f.fused_train
+    with torch.no_grad():
+        f.mlp_base.network[0].weight.mul_(300.0)
+        f.mlp_base.network[0].bias.fill_(7.0e4)
+        f.mlp_base.network[2].weight.mul_(1.0e-5)
+    _grads(f, x, d, wr, wd, chain=True, train=True)
+    f.snapshot_range_guard()
+    torch.cuda.synchronize()
+    with pytest.warns(UserWarning, match="left fp16's range"):
+        assert f.poll_range_guard()
+    assert not f.fused_train and not f.poll_range_guard()
+    assert not f._train_ok(x, d)                         # the next gradient pass runs the fp32 library forward
+
+
 def test_fused_training_forward_row_padding_and_saved_tensors(cuda):
     """Rows of padding (`_bucket_rows`): the saved matrices are finite there, the outputs of the live rows do not depend
     on the padding, and what the kernel saved is what the op chain computes (features bit for bit)."""
