@@ -115,6 +115,9 @@ def test_ctypes_structs_have_the_layout_of_the_header(tmp_path):
         "cnc_field_bwd_t": (_lib.FieldBwd, [f[0] for f in _lib.FieldBwd._fields_]),
         "cnc_field_save_t": (_lib.FieldSave, [f[0] for f in _lib.FieldSave._fields_]),
         "cnc_field_wgrad_t": (_lib.FieldWGrad, [f[0] for f in _lib.FieldWGrad._fields_]),
+        "cnc_adam_table_t": (_lib.AdamTable, [f[0] for f in _lib.AdamTable._fields_]),
+        "cnc_adam_tables_t": (_lib.AdamTables, [f[0] for f in _lib.AdamTables._fields_]),
+        "cnc_ctx_window_t": (_lib.CtxWindow, [f[0] for f in _lib.CtxWindow._fields_]),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include <stdint.h>', '#include "cnc_hip.h"', 'int main(void) {']
     for t, (_, names) in members.items():
