@@ -52,7 +52,7 @@ class FusedField(C.Structure):
                 ("units", _vp), ("n_levels", _u32 * 4),
                 ("n_features", _u32), ("n_freqs", _u32), ("n_neurons", _u32), ("geo_feat_dim", _u32), ("flags", _u32),
                 ("packed_weights16q", _vp * 5), ("guard", _vp), ("call_id", _u32), ("pack_id", _u32),
-                ("debug_features", _vp), ("debug_ld", _u32), ("save", FieldSave)]
+                ("debug_features", _vp), ("debug_ld", _u32), ("save", FieldSave), ("n_rows_dev", _vp)]
 
 
 class FieldBwd(C.Structure):
@@ -168,6 +168,8 @@ SIGNATURES = {
     "cnc_ctx_window_gather": [_vp] * 8,
     "cnc_rows_scatter": [_vp, _vp, _vp, C.c_uint64, _u32, _vp],
     "cnc_table_adam": [_vp] + [C.c_double] * 6 + [_vp],
+    "cnc_ray_window_positions": [_vp] * 10 + [_u32, _vp],
+    "cnc_scatter_counted": [_vp, _vp, _vp, _vp, C.c_uint64, _vp],
     "cnc_ctx_compact": [_vp, _vp, _vp, _vp, C.c_uint64, _i32, _vp, _vp, _vp, _vp, _vp],
     "cnc_plane_ring_vertices": [_vp, C.c_uint64, _u32, _u32, C.c_uint64, _vp, _vp, _vp],
     "cnc_bernoulli_bits_partials": [C.c_uint64, _u32],
@@ -195,7 +197,7 @@ CNC_PACK_TRANSPOSE = 1
 CNC_PACK_ZERO_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 29          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 30          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

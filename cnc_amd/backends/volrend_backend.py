@@ -160,6 +160,28 @@ def window_samples(starts, first, cnts, t_starts, t_ends, total, ends=None):
     return o_r, o_s, o_e, o_i
 
 
+def window_positions(starts, first, cnts, ends, t_starts, t_ends, rays_o, rays_d, capacity):
+    """(positions [capacity, 3], source_index [capacity]) of samples [first[r], first[r] + cnts[r]) of every ray, packed in
+    ray order; `ends` = cumsum(cnts) — its last element is the number of rows that are written, and it stays on the
+    device (cnc_ray_window_positions).  `capacity` >= that number (the caller's bound); rows behind it are left as they
+    are."""
+    n_rays, dev = starts.shape[0], t_starts.device
+    pos = torch.empty((capacity, 3), dtype=torch.float32, device=dev)
+    src = torch.empty(capacity, dtype=torch.int64, device=dev)
+    if capacity and n_rays:
+        check(_lib.lib().cnc_ray_window_positions(ptr(starts), ptr(first), ptr(cnts), ptr(ends), _p(t_starts), _p(t_ends),
+                                                  _p(rays_o), _p(rays_d), ptr(pos), ptr(src), n_rays, stream(dev)),
+              "ray_window_positions")
+    return pos, src
+
+
+def scatter_counted(out, src, values, n_dev):
+    """out[src[i]] = values[i] for i < min(n_dev, len(src)); `n_dev`: one int64 on the device."""
+    if src.shape[0]:
+        check(_lib.lib().cnc_scatter_counted(_p(values), ptr(src), ptr(out), ptr(n_dev), int(src.shape[0]), stream(out.device)),
+              "scatter_counted")
+
+
 def ray_transmittance(starts, cnts, t_starts, t_ends, sigmas):
     """exp(-sum sigma dt) over the first cnts[r] samples of every ray: float32 [n_rays]."""
     n_rays = starts.shape[0]

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused(FusedFieldArgs p)
     if (p.only_if_flagged && *reinterpret_cast<volatile const uint32_t*>(p.guard) != p.call_id) return;
     const uint32_t lane = threadIdx.x, i = lane & 31u, h = lane >> 5;
     constexpr uint32_t ldh = NT * 32 + kPadH;
+    p.N = rows_of(p);                          // (cnc_fused_field_t.n_rows_dev: a count the device holds)
     const uint32_t tiles = (p.N + 31u) / 32u;
     float amin[3], aext[3];
 #pragma unroll
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
     half_t* const c_lo = lds16 + 32 * kChunkPitch16;
     half_t* const h_hi = lds16;                                 // activation planes (colour variant)
     half_t* const h_lo = lds16 + 32 * ldh;
+    p.N = rows_of(p);                          // (cnc_fused_field_t.n_rows_dev: a count the device holds)
     const uint32_t tiles = (p.N + 31u) / 32u;
     float amin[3], aext[3];
 #pragma unroll
@@ -570,6 +572,7 @@ extern "C" int cnc_field_fused_forward(const cnc_fused_field_t* f, const float* 
     if (!(F == 2 || F == 4 || F == 8) || !(H == 64 || H == 160)) return CNC_ERR_UNSUPPORTED;
     FusedFieldArgs p{};
     p.pos = positions; p.dirs = dirs; p.aabb = f->aabb; p.N = N;
+    p.n_dev = f->n_rows_dev;
     uint32_t units = 0;
     for (int e = 0; e < 4; e++) {
         if (!f->bits[e] || !f->offsets[e] || !f->resolutions[e] || f->n_levels[e] == 0) return CNC_ERR_INVALID_VALUE;

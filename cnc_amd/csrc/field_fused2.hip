@@ -108,6 +108,7 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
     half_t* const h_hi = lds16;                    // activation planes (colour variant) — alias the chunk buffers
     half_t* const h_lo = lds16 + 32 * P::ld;
     float* const  dens = reinterpret_cast<float*>(lds16 + 2 * 32 * P::ld);      // colour variant: 32 raw densities
+    p.N = rows_of(p);                          // (cnc_fused_field_t.n_rows_dev: a count the device holds)
     const uint32_t tiles = (p.N + 31u) / 32u;
     float amin[3], aext[3];
 #pragma unroll

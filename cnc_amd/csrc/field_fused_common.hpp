@@ -75,7 +75,16 @@ struct FusedFieldArgs {
     float*         dbg_features;  // test hook (cnc_fused_field_t.debug_features): [N, dbg_ld] first-layer input rows
     uint32_t       dbg_ld;
     FieldSave      save;          // cnc_fused_field_t.save (feat != nullptr: the gradient pass's forward)
+    const int64_t* n_dev;         // cnc_fused_field_t.n_rows_dev: N = min(N, *n_dev) (see `rows_of`)
 };
+
+// the number of rows a launch works on: the host's N, cut to a count the device holds (cnc_fused_field_t.n_rows_dev)
+__device__ __forceinline__ uint32_t rows_of(const FusedFieldArgs& p)
+{
+    if (p.n_dev == nullptr) return p.N;
+    const int64_t n = *p.n_dev;
+    return n < 0 ? 0u : (n < (int64_t)p.N ? (uint32_t)n : p.N);
+}
 
 constexpr uint32_t kChunkPitch = 36;     // floats per row of the 32 x 32 chunk tile (+4: conflict-free b128 accesses)
 constexpr uint32_t kPadH = 4;

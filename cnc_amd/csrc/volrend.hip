@@ -324,6 +324,44 @@ __global__ __launch_bounds__(256) void k_window_samples(
     }
 }
 
+// The same window as POSITIONS for the field (cnc_ray_window_positions): o + (d (t0 + t1)) / 2, the expression of
+// k_sample_positions (march.hip), written where the running sum of the windows puts the ray — the window's sample count
+// never leaves the device.
+__global__ __launch_bounds__(256) void k_window_positions(
+    const int64_t* __restrict__ starts, const int64_t* __restrict__ win_lo, const int64_t* __restrict__ win_n,
+    const int64_t* __restrict__ win_ends, const float* __restrict__ t_starts, const float* __restrict__ t_ends,
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, float* __restrict__ positions,
+    int64_t* __restrict__ o_src, uint32_t n_rays)
+{
+    const uint32_t j = threadIdx.x & 31;
+    const uint32_t ray = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (ray >= n_rays) return;
+    const int64_t n = win_n[ray];
+    if (n <= 0) return;
+    const int64_t s0 = starts[ray] + win_lo[ray], o0 = win_ends[ray] - n;
+    float         o[3], d[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        o[a] = rays_o[(size_t)ray * 3 + a];
+        d[a] = rays_d[(size_t)ray * 3 + a];
+    }
+    for (int64_t k = j; k < n; k += 32) {
+        const float ta = t_starts[s0 + k], tb = t_ends[s0 + k];
+#pragma unroll
+        for (int a = 0; a < 3; a++) positions[(o0 + k) * 3 + a] = o[a] + (d[a] * (ta + tb)) / 2.0f;
+        o_src[o0 + k] = s0 + k;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_counted(const float* __restrict__ values, const int64_t* __restrict__ src,
+                                                         float* __restrict__ out, const int64_t* __restrict__ n_dev,
+                                                         uint64_t capacity)
+{
+    const int64_t  n_ = *n_dev;
+    const uint64_t n = n_ < 0 ? 0ull : ((uint64_t)n_ < capacity ? (uint64_t)n_ : capacity);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) out[src[i]] = values[i];
+}
+
 // exp(-sum of sigma dt over the first cnts[r] samples of ray r): what is left of the ray after them
 __global__ __launch_bounds__(256) void k_ray_transmittance(
     const int64_t* __restrict__ starts, const int64_t* __restrict__ cnts, const float* __restrict__ t_starts,
@@ -499,6 +537,30 @@ extern "C" int cnc_ray_window_samples(const int64_t* chunk_starts, const int64_t
     hipLaunchKernelGGL(k_window_samples, ray_grid(n_rays), dim3(256), 0, (hipStream_t)stream, chunk_starts, window_first,
                        window_cnts, out_starts, t_starts, t_ends, out_t_starts, out_t_ends, out_ray_indices,
                        out_source_index, n_rays);
+    return launch_status();
+}
+
+extern "C" int cnc_ray_window_positions(const int64_t* chunk_starts, const int64_t* win_lo, const int64_t* win_n,
+                                        const int64_t* win_ends, const float* t_starts, const float* t_ends,
+                                        const float* rays_o, const float* rays_d, float* positions, int64_t* src,
+                                        uint32_t n_rays, void* stream)
+{
+    if (n_rays == 0) return CNC_OK;
+    if (!chunk_starts || !win_lo || !win_n || !win_ends || !t_starts || !t_ends || !rays_o || !rays_d || !positions || !src)
+        return CNC_ERR_INVALID_VALUE;
+    hipLaunchKernelGGL(k_window_positions, ray_grid(n_rays), dim3(256), 0, (hipStream_t)stream, chunk_starts, win_lo, win_n,
+                       win_ends, t_starts, t_ends, rays_o, rays_d, positions, src, n_rays);
+    return launch_status();
+}
+
+extern "C" int cnc_scatter_counted(const float* values, const int64_t* src, float* out, const int64_t* n_dev,
+                                   uint64_t capacity, void* stream)
+{
+    if (capacity == 0) return CNC_OK;
+    if (!values || !src || !out || !n_dev) return CNC_ERR_INVALID_VALUE;
+    const uint64_t blocks = (capacity + 255) / 256;
+    hipLaunchKernelGGL(k_scatter_counted, dim3((uint32_t)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       values, src, out, n_dev, capacity);
     return launch_status();
 }
 

@@ -474,10 +474,12 @@ class FusedFieldForward:
         return st, keep, clips
 
     @torch.no_grad()
-    def __call__(self, positions: torch.Tensor, directions=None, debug_features=None):
+    def __call__(self, positions: torch.Tensor, directions=None, debug_features=None, n_rows_dev=None):
         """density [N, 1] (and rgb [N, 3] when `directions` is given) of world positions [N, 3].  `debug_features` (test
         hook, density-only two-wave calls): a float32 [N, >= roundup32(K0)] tensor that receives the first layer's input
-        rows as the kernel computed them."""
+        rows as the kernel computed them.  `n_rows_dev` (an int64 tensor of one element on the device): only the first
+        min(N, n_rows_dev) rows are evaluated — N is then the capacity of `positions`, the rows behind the count are
+        neither read nor written (cnc_fused_field_t.n_rows_dev: the sampler's depth windows)."""
         from . import _lib
         x = positions.reshape(-1, 3)
         if x.dtype != torch.float32 or not x.is_cuda:
@@ -491,6 +493,10 @@ class FusedFieldForward:
         if debug_features is not None:
             assert debug_features.dtype == torch.float32 and debug_features.is_contiguous() and debug_features.shape[0] == N
             st.debug_features, st.debug_ld = debug_features.data_ptr(), debug_features.shape[1]
+        if n_rows_dev is not None:
+            if n_rows_dev.dtype != torch.int64 or n_rows_dev.device != dev or n_rows_dev.numel() != 1:
+                raise RuntimeError("FusedFieldForward: n_rows_dev must be one int64 on the positions' device")
+            st.n_rows_dev = n_rows_dev.data_ptr()
         density = torch.empty((N, 1), dtype=torch.float32, device=dev)
         rgb = torch.empty((N, 3), dtype=torch.float32, device=dev) if d is not None else None
         import ctypes

@@ -162,7 +162,12 @@ class OccGridEstimator(AbstractEstimator):
             n = t_starts.shape[0]
             windows = self._front_to_back_pays(n) if front_to_back is None else (bool(front_to_back) and bool(self._WINDOWS))
             if n and sigma_fn is not None and early_stop_eps > 0.0 and windows:
-                values = self._density_front_to_back(sigma_fn, starts, counts, t_starts, t_ends, early_stop_eps)
+                owner = getattr(sigma_fn, "__self__", None)
+                counted = owner.density_windows() if self._COUNTED_WINDOWS and hasattr(owner, "density_windows") else None
+                if counted is not None:
+                    values = self._density_front_to_back_counted(counted, starts, counts, t_starts, t_ends, early_stop_eps)
+                else:
+                    values = self._density_front_to_back(sigma_fn, starts, counts, t_starts, t_ends, early_stop_eps)
             else:
                 values = field(t_starts, t_ends, ray_indices) if n else torch.empty((0,), device=t_starts.device)
             if values.shape != t_starts.shape:
@@ -214,6 +219,40 @@ class OccGridEstimator(AbstractEstimator):
             if values.shape != ts_w.shape:
                 raise AssertionError("sigmas must have shape of (N,)! Got {}".format(values.shape))
             sigmas.index_copy_(0, src, values.to(sigmas.dtype))
+        return sigmas
+
+    # (round 6) The same windows with their sample counts left on the device: a window's size is the last element of a
+    # running sum the host never reads; positions, density and the scatter back work on buffers of a bound's size and stop
+    # at the count (cnc_ray_window_positions, cnc_fused_field_t.n_rows_dev, cnc_scatter_counted).  Same densities for the
+    # same samples — what changes is that the host issues the three windows back to back instead of waiting for each
+    # (two round trips, ~0.3 ms of the step's critical chain).  Needs a field that takes a device-side row count
+    # (`_FieldOnRays.density_windows`); CNC_SAMPLER_COUNTED_WINDOWS=0: off.
+    _COUNTED_WINDOWS = os.environ.get("CNC_SAMPLER_COUNTED_WINDOWS", "1") == "1"
+
+    def _density_front_to_back_counted(self, counted, starts, counts, t_starts, t_ends, early_stop_eps):
+        from ...backends import volrend_backend as _K
+        rays_o, rays_d, evaluate = counted
+        n, n_rays = int(t_starts.shape[0]), int(starts.shape[0])
+        sigmas = torch.zeros_like(t_starts)
+        done = torch.zeros_like(counts)
+        take = torch.empty_like(counts)
+        threshold = early_stop_eps * (1.0 - 1e-3)
+        known = 0                      # samples the host KNOWS to be evaluated already (a lower bound)
+        for i, w in enumerate(self._WINDOWS + (None,)):
+            _K.ray_window_next(starts, counts, t_starts, t_ends, sigmas, done, take, w, threshold, first=i == 0)
+            ends = torch.cumsum(take, 0)
+            if i == 0 and self._first_window_total is not None:
+                capacity = known = int(self._first_window_total)     # came back with the march's own sample total
+            else:
+                capacity = n - known if w is None else min(n_rays * int(w), n - known)
+            if capacity <= 0:
+                break
+            pos, src = _K.window_positions(starts, done, take, ends, t_starts, t_ends, rays_o, rays_d, capacity)
+            n_dev = ends[-1:]
+            values = evaluate(pos, n_dev)
+            if values.shape[0] != capacity:
+                raise AssertionError("sigmas must have shape of (N,)! Got {}".format(tuple(values.shape)))
+            _K.scatter_counted(sigmas, src, values.to(sigmas.dtype), n_dev)
         return sigmas
 
     # ------------------------------------------------------------------------------------- upkeep

@@ -66,6 +66,19 @@ class _FieldOnRays:
         x, _ = _mid_points(self.o, self.d, ray_indices, t_starts, t_ends)
         return self.field.query_density(x).squeeze(-1)
 
+    def density_windows(self):
+        """(extension, for OccGridEstimator's front-to-back sampler) What it takes to evaluate depth windows whose sample
+        count stays on the device: (origins, directions, evaluate(positions [capacity, 3], n_rows_dev) -> density
+        [capacity]) — or None when the field has no evaluator that accepts a device-side row count (then the sampler calls
+        `density` on exactly sized batches, one host round trip per window)."""
+        probe = getattr(self.field, "_fused_forward", None)
+        if probe is None or not self.o.is_cuda or self.o.dtype != torch.float32:
+            return None
+        fused = probe(self.o)
+        if fused is None:
+            return None
+        return self.o.contiguous(), self.d.contiguous(), lambda x, n: fused(x, n_rows_dev=n).view(-1)
+
     def colour_and_density(self, t_starts, t_ends, ray_indices):
         x, v = _mid_points(self.o, self.d, ray_indices, t_starts, t_ends)
         return self.colour_and_density_at(x, v)

@@ -648,6 +648,18 @@ typedef struct {
 int cnc_table_adam(const cnc_adam_tables_t* tables, double lr, double beta1, double beta2, double eps, double weight_decay,
                    double step, void* stream);
 
+/* (ABI v30) The front-to-back sampler's depth windows without a host round trip per window (nerfacc/estimators/occ_grid.py
+ * `_density_front_to_back`; the reference evaluates sigma_fn on ALL marched samples at once, occ_grid.py:172-238).
+ * cnc_ray_window_positions: samples [win_lo[r], win_lo[r] + win_n[r]) of ray r -> positions[o + k] = o_r + (d_r (t0 + t1)) / 2
+ * (examples/utils.py:251-262, the arithmetic of cnc_sample_positions) and src[o + k] = their index in the sample stream, at
+ * o = win_ends[r] - win_n[r] (win_ends = inclusive running sum of win_n, so win_ends[n_rays - 1] is the window's sample count,
+ * on the device).  cnc_scatter_counted: out[src[i]] = values[i] for i < min(*n_dev, capacity).                        */
+int cnc_ray_window_positions(const int64_t* chunk_starts, const int64_t* win_lo, const int64_t* win_n, const int64_t* win_ends,
+                             const float* t_starts, const float* t_ends, const float* rays_o, const float* rays_d,
+                             float* positions, int64_t* src, uint32_t n_rays, void* stream);
+int cnc_scatter_counted(const float* values, const int64_t* src, float* out, const int64_t* n_dev, uint64_t capacity,
+                        void* stream);
+
 /* (ABI v25) Vertices of one 2-D level inside / one ring around the occupied cells of a projected occupancy plane
  * (utils_bpp_acc.py:431-456 `fetch_2D_batches`): cells [n_cells, 2] int32 = the occupied (i, j) of the plane, T =
  * (resolution - 2) / plane size; writes, cell-major then ring row / column, n_cells (T+2)^2 entries of rows (the
@@ -782,6 +794,10 @@ typedef struct {
     uint32_t       debug_ld;           /* >= roundup32(K0)                                                         */
     /* ---- ABI v27 ---- */
     cnc_field_save_t save;             /* save.feat != NULL: the gradient pass's forward (above)                   */
+    /* ---- ABI v30 ---- */
+    const int64_t* n_rows_dev;         /* nullable: a row count ON THE DEVICE — the call evaluates min(N, *n_rows_dev) rows
+                                          (N = the capacity of the buffers).  For callers that size a batch on the device
+                                          and must not wait for the number (the front-to-back sampler's depth windows)     */
 } cnc_fused_field_t;
 
 /* The layers' products on the fp16 matrix pipe, three per term: every operand split x = hi + lo into two halves

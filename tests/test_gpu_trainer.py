@@ -187,7 +187,7 @@ def test_front_to_back_density_gives_the_same_samples(cuda, tmp_path):
     from cnc_amd.nerfacc.estimators.occ_grid import OccGridEstimator
     from cnc_amd.render import _FieldOnRays
     from cnc_amd.trainer import Trainer
-    tr = Trainer(_cfg(tmp_path, lmbda=0.0), device=cuda)
+    tr = Trainer(_cfg(tmp_path, lmbda=0.0, n_neurons=64), device=cuda)      # (64: a width the one-kernel evaluator has)
     tr.train(steps=150, log=None)                      # a surface has formed
     tr.field.eval(); tr.estimator.eval()
     view = tr.dataset.view(0)
@@ -202,12 +202,23 @@ def test_front_to_back_density_gives_the_same_samples(cuda, tmp_path):
     kw = dict(sigma_fn=fn.density, near_plane=tr.cfg.near_plane, render_step_size=tr.cfg.render_step_size,
               stratified=False, cone_angle=tr.cfg.cone_angle, alpha_thre=tr.cfg.alpha_thre)
     outs = []
+    tr.estimator._COUNTED_WINDOWS = False              # windows through the `sigma_fn` callback (counted below)
     for mode in (False, True):                         # the public switch of `sampling`
         seen.clear()
         with torch.no_grad():
             ri, ts, te = tr.estimator.sampling(o, d, front_to_back=mode, **kw)
         outs.append((ri.clone(), ts.clone(), te.clone(), sum(seen), len(seen)))
     (ri_a, ts_a, te_a, n_a, calls_a), (ri_b, ts_b, te_b, n_b, calls_b) = outs
+    # the windows with their sample counts left on the device (no host round trip per window): the callback is not used,
+    # the field evaluates buffers of a bound's size up to a count it reads on the device — the SAME samples as the windows
+    # through the callback, exactly (a row's density does not depend on the batch it is evaluated in)
+    tr.estimator._COUNTED_WINDOWS = True
+    seen.clear()
+    with torch.no_grad():
+        assert fn.density_windows() is not None
+        ri_c, ts_c, te_c = tr.estimator.sampling(o, d, front_to_back=True, **kw)
+    assert not seen
+    assert ri_c.shape == ri_b.shape and torch.equal(ri_c, ri_b) and torch.equal(ts_c, ts_b) and torch.equal(te_c, te_b)
     assert calls_a == 1 and 1 < calls_b <= 3
     assert n_b < 0.7 * n_a                              # most of the marched samples are never evaluated
     # a GEMM row may round differently in a different batch: allow a handful of samples at the threshold to differ

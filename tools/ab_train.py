@@ -46,6 +46,8 @@ def switch(on):
             tr.planes_graph.drop()
     elif what == "tableadam":               # the tables' update: pieces summed inside cnc_table_adam / flushed into .grad
         tr.fused_table_adam = on
+    elif what == "windows":                 # the sampler's depth windows: sample counts left on the device / read per window
+        tr.estimator._COUNTED_WINDOWS = on
     elif what == "vbits":
         for e in tr.field.mlp_base._encoders():
             e.vertex_bits = on
