@@ -37,8 +37,9 @@ __global__ __launch_bounds__(64, 2) void k_field_fused(FusedFieldArgs p)
     if (p.only_if_flagged && *reinterpret_cast<volatile const uint32_t*>(p.guard) != p.call_id) return;
     const uint32_t lane = threadIdx.x, i = lane & 31u, h = lane >> 5;
     constexpr uint32_t ldh = NT * 32 + kPadH;
-    p.N = rows_of(p);                          // (cnc_fused_field_t.n_rows_dev: a count the device holds)
-    const uint32_t tiles = (p.N + 31u) / 32u;
+    const uint32_t n_rows = rows_of(p);       // p.N, or a count the device holds (cnc_fused_field_t.n_rows_dev) — a LOCAL: writing
+                                              // to the by-value argument block would move all of it into scratch memory
+    const uint32_t tiles = (n_rows + 31u) / 32u;
     float amin[3], aext[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused(FusedFieldArgs p)
     }
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const uint32_t row0 = tile * 32, row = row0 + i;
-        const bool     live = row < p.N;
+        const bool     live = row < n_rows;
         // unit-cube position and selector of sample i (k_field_prepare: same expression)
         float xu[3] = {-1.0f, -1.0f, -1.0f};
         bool  sel = live;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused(FusedFieldArgs p)
                     const uint32_t r = 8 * (v >> 2) + 4 * h + (v & 3);
                     const float    x = acc2[t][v] + b;
                     if (col == 0) {
-                        if (row0 + r < p.N) p.density[row0 + r] = ((selmask >> r) & 1ull) ? expf(x - 1.0f) : 0.0f;
+                        if (row0 + r < n_rows) p.density[row0 + r] = ((selmask >> r) & 1ull) ? expf(x - 1.0f) : 0.0f;
                     } else if (15 + col < Kh) {
                         lds[r * ldi + 15 + col] = col <= p.geo ? x : 0.0f;
                     }
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused(FusedFieldArgs p)
 #pragma unroll
                 for (int v = 0; v < 16; v++) {
                     const uint32_t r = 8 * (v >> 2) + 4 * h + (v & 3);
-                    if (row0 + r < p.N) p.rgb[(size_t)(row0 + r) * 3 + i] = 1.0f / (1.0f + expf(-(acc5[0][v] + b)));
+                    if (row0 + r < n_rows) p.rgb[(size_t)(row0 + r) * 3 + i] = 1.0f / (1.0f + expf(-(acc5[0][v] + b)));
                 }
             }
             wave_lds_order();
@@ -331,8 +332,9 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
     half_t* const c_lo = lds16 + 32 * kChunkPitch16;
     half_t* const h_hi = lds16;                                 // activation planes (colour variant)
     half_t* const h_lo = lds16 + 32 * ldh;
-    p.N = rows_of(p);                          // (cnc_fused_field_t.n_rows_dev: a count the device holds)
-    const uint32_t tiles = (p.N + 31u) / 32u;
+    const uint32_t n_rows = rows_of(p);       // p.N, or a count the device holds (cnc_fused_field_t.n_rows_dev) — a LOCAL: writing
+                                              // to the by-value argument block would move all of it into scratch memory
+    const uint32_t tiles = (n_rows + 31u) / 32u;
     float amin[3], aext[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
     float mx = 0.0f;                     // largest |value| split into halves by this lane (the range guard)
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const uint32_t row0 = tile * 32, row = row0 + i;
-        const bool     live = row < p.N;
+        const bool     live = row < n_rows;
         float xu[3] = {-1.0f, -1.0f, -1.0f};
         bool  sel = live;
         if (live) {
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(64, 2) void k_field_fused16(FusedFieldArgs p)
                 for (int v = 0; v < 16; v++) {
                     const uint32_t r = 8 * (v >> 2) + 4 * h + (v & 3);
                     const float    x = __builtin_fmaf(acc5[0][v], kWeightScaleInv, b);
-                    if (row0 + r < p.N) p.rgb[(size_t)(row0 + r) * 3 + i] = 1.0f / (1.0f + expf(-x));
+                    if (row0 + r < n_rows) p.rgb[(size_t)(row0 + r) * 3 + i] = 1.0f / (1.0f + expf(-x));
                 }
             }
             wave_lds_order();

@@ -108,8 +108,9 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
     half_t* const h_hi = lds16;                    // activation planes (colour variant) — alias the chunk buffers
     half_t* const h_lo = lds16 + 32 * P::ld;
     float* const  dens = reinterpret_cast<float*>(lds16 + 2 * 32 * P::ld);      // colour variant: 32 raw densities
-    p.N = rows_of(p);                          // (cnc_fused_field_t.n_rows_dev: a count the device holds)
-    const uint32_t tiles = (p.N + 31u) / 32u;
+    const uint32_t n_rows = rows_of(p);       // p.N, or a count the device holds (cnc_fused_field_t.n_rows_dev) — a LOCAL: writing
+                                              // to the by-value argument block would move all of it into scratch memory
+    const uint32_t tiles = (n_rows + 31u) / 32u;
     float amin[3], aext[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
     constexpr bool kDB = WPE <= 3;                       // hidden layers: two sets of weight registers
     for (uint32_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const uint32_t row0 = tile * 32, frow = row0 + fi;
-        const bool     live = frow < p.N;                                    // the row exists: its results are stored
+        const bool     live = frow < n_rows;                                    // the row exists: its results are stored
         const bool     live_in = SAVE ? frow < p.save.n_live : live;         // ... and has a position / direction
         float xu[3] = {-1.0f, -1.0f, -1.0f};
         bool  sel = live_in;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
             __syncthreads();                                   // before the next tile's fill overwrites the sums
         } else {
             __syncthreads();                                   // the last chunk has been read: the planes alias it
-            acc_to_planes<NCB, NT, SAVE>(h_hi, h_lo, p.Bp[0], acc, w * NCB, lane, mx, p.save.h1, row0, p.N);
+            acc_to_planes<NCB, NT, SAVE>(h_hi, h_lo, p.Bp[0], acc, w * NCB, lane, mx, p.save.h1, row0, n_rows);
             __syncthreads();
             // ---- layer 2 (H -> 1 + geo), split by rows: wave w owns rows [16 w, 16 w + 16) ----
             f32x4 acc2[1][NB2];
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
                 }
                 if constexpr (SAVE) {
                     const uint32_t row = row0 + w * 16u + r;
-                    if (row < p.N) store_vec<4>(p.save.head_in + (size_t)row * p.save.ld_head + 16u + c0, xs);
+                    if (row < n_rows) store_vec<4>(p.save.head_in + (size_t)row * p.save.ld_head + 16u + c0, xs);
                 }
                 const uint32_t at = P::at(w * 16u + r, 16u + c0);
                 *reinterpret_cast<half4_t*>(h_hi + at) = xh;
@@ -307,17 +308,17 @@ __global__ __launch_bounds__(128, WPE) void k_field_fused16w2(FusedFieldArgs p)
             // ---- head: (16 + geo) -> H -> H -> 3 ----
             layer_q<2, NCB, NT, kDB>(h_hi, h_lo, Kh / 32, p.Wq16[2], NCBT, w * NCB, 0, acc, lane);
             __syncthreads();
-            acc_to_planes<NCB, NT, SAVE>(h_hi, h_lo, p.Bp[2], acc, w * NCB, lane, mx, p.save.h3, row0, p.N);
+            acc_to_planes<NCB, NT, SAVE>(h_hi, h_lo, p.Bp[2], acc, w * NCB, lane, mx, p.save.h3, row0, n_rows);
             __syncthreads();
             layer_q<2, NCB, NT, kDB>(h_hi, h_lo, NT, p.Wq16[3], NCBT, w * NCB, 0, acc, lane);
             __syncthreads();
-            acc_to_planes<NCB, NT, SAVE>(h_hi, h_lo, p.Bp[3], acc, w * NCB, lane, mx, p.save.h4, row0, p.N);
+            acc_to_planes<NCB, NT, SAVE>(h_hi, h_lo, p.Bp[3], acc, w * NCB, lane, mx, p.save.h4, row0, n_rows);
             __syncthreads();
             f32x4 acc5[1][1];
             layer_q<1, 1, NT, kDB>(h_hi, h_lo, NT, p.Wq16[4], 1, 0, w, acc5, lane);
             if (kq == 0) {                                     // outputs 0..2 of sample 16 w + r: 12 contiguous bytes per lane
                 const uint32_t row = row0 + w * 16 + r;
-                if (row < p.N) {
+                if (row < n_rows) {
 #pragma unroll
                     for (int v = 0; v < 3; v++) {
                         const float x = __builtin_fmaf(acc5[0][0][v], kWScaleInv, p.Bp[4][v]);
