@@ -3,7 +3,7 @@
 //
 // k_grid_encode_bwd (grid_encode.hip) merges consecutive samples of one cell; k_grid_encode_bwd_merge
 // (grid_encode_merge.hip) the equal cells of a 1024-sample block, but only for the unmasked 3-D levels of a bench
-// frame.  What a step of the full model issues (tools/dump_bwd_calls.py + scratch/analyze_cells.py, round 6, F = 8;
+// frame.  What a step of the full model issues (tools/dump_bwd_calls.py + tools/count_bwd_calls.py, round 6, F = 8;
 // M (row, 32 B) updates per call, blocks of 1024 points):
 //
 //   call                                     corner refs   runs of a cell   distinct cells x 2^D   distinct rows
