@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from . import _lib
+from . import _caches, _lib
 
 Piece = Tuple[torch.Tensor, Optional[Tuple[int, int]]]       # (gradient piece, the ROWS of the table it covers or None = all)
 
@@ -89,3 +89,6 @@ class TableAdam:
         _lib.check(_lib.lib().cnc_table_adam(C.byref(a), float(lr), float(b1), float(b2), float(g["eps"]),
                                              float(g["weight_decay"]), float(self.steps_done),
                                              torch.cuda.current_stream(self.tables[0].device).cuda_stream), "cnc_table_adam")
+        # the kernel writes the tables through their addresses: `Tensor._version` does not move, so the copies keyed on it
+        # (the encoders' sign bit planes, packed weights) are dropped here as after any optimizer step (cnc_amd._caches)
+        _caches.invalidate_all()
