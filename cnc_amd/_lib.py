@@ -31,7 +31,7 @@ class CtxWindow(C.Structure):
 class AdamTable(C.Structure):
     """cnc_adam_table_t (include/cnc_hip.h)."""
     _fields_ = [("p", _vp), ("m", _vp), ("v", _vp), ("step", _vp), ("g", _vp * 4), ("g_lo", C.c_uint64 * 4),
-                ("g_hi", C.c_uint64 * 4), ("n", C.c_uint64)]
+                ("g_hi", C.c_uint64 * 4), ("n", C.c_uint64), ("sign_bits", _vp), ("clip_count", _vp)]
 
 
 class AdamTables(C.Structure):
@@ -197,7 +197,7 @@ CNC_PACK_TRANSPOSE = 1
 CNC_PACK_ZERO_FIRST = 2
 CNC_VOLREND_ACCUMULATE = 1
 CNC_VOLREND_FINALIZE = 2
-ABI_VERSION = 30          # cnc_abi_version() of the library this table was written for
+ABI_VERSION = 31          # cnc_abi_version() of the library this table was written for
 
 
 def lib() -> C.CDLL:

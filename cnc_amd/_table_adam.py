@@ -23,9 +23,18 @@ Piece = Tuple[torch.Tensor, Optional[Tuple[int, int]]]       # (gradient piece, 
 
 
 class TableAdam:
-    def __init__(self, opt: torch.optim.Adam, tables: Sequence[torch.nn.Parameter]):
+    def __init__(self, opt: torch.optim.Adam, tables: Sequence[torch.nn.Parameter], encoders: Optional[Sequence] = None):
+        """`encoders` (optional, one GridEncoder per table, `encoder.params is table`): the kernel then also leaves each
+        updated table's sign bit plane and clip counter in the encoder's cache buffers (what `GridEncoder._bit_plane` would
+        make by reading the table again at the next forward); `mark_planes_current()` re-validates them after the library
+        optimizers' post-step hook has dropped every cache."""
         self.opt = opt
         self.tables: List[torch.nn.Parameter] = list(tables)
+        self.encoders = list(encoders) if encoders is not None else None
+        if self.encoders is not None and (len(self.encoders) != len(self.tables)
+                                          or any(e.params is not p for e, p in zip(self.encoders, self.tables))):
+            raise ValueError("TableAdam: one encoder per table, in the tables' order")
+        self._planes_written: List = []
         if not 1 <= len(self.tables) <= 4:
             raise ValueError("TableAdam: one to four tables")
         ids = {id(p) for p in self.tables}
@@ -83,6 +92,21 @@ class TableAdam:
                 t.g[j], t.g_lo[j], t.g_hi[j] = gt.data_ptr(), lo, hi
                 keep.append(gt)
             p.grad = None
+        # the updated tables' sign planes into the encoders' own cache buffers (kept at their addresses: a recorded graph
+        # reads them there), when those exist in the size the table needs
+        self._planes_written = []
+        if self.encoders is not None:
+            counters = []
+            for k, (p, e) in enumerate(zip(self.tables, self.encoders)):
+                bits, cc = getattr(e, "_bits", None), getattr(e, "_clip_count", None)
+                if (p.numel() % 8 == 0 and bits is not None and cc is not None and bits.device == p.device
+                        and bits.dtype == torch.uint8 and bits.numel() == p.numel() // 8 and cc.device == p.device
+                        and cc.numel() == 1 and cc.dtype == torch.int32 and getattr(e, "bitplane", True)):
+                    a.table[k].sign_bits, a.table[k].clip_count = bits.data_ptr(), cc.data_ptr()
+                    counters.append(cc)
+                    self._planes_written.append((e, p))
+            if counters:
+                torch._foreach_zero_(counters)
         b1, b2 = g["betas"]
         lr = g["lr"]
         self.steps_done += 1
@@ -92,3 +116,13 @@ class TableAdam:
         # the kernel writes the tables through their addresses: `Tensor._version` does not move, so the copies keyed on it
         # (the encoders' sign bit planes, packed weights) are dropped here as after any optimizer step (cnc_amd._caches)
         _caches.invalidate_all()
+        self.mark_planes_current()
+
+    def mark_planes_current(self) -> None:
+        """The sign planes the last `step` wrote ARE the planes of the tables as they stand (nothing has written the tables
+        since): re-validate the encoders' cache entries.  Called by `step` itself, and by the Trainer once more behind the
+        library optimizers' steps — their post-step hook (cnc_amd._caches) drops every cache, it cannot know which
+        parameters a step touched."""
+        for e, p in self._planes_written:
+            e._bits_key = (p.data_ptr(), p._version, tuple(p.shape))
+            e._bits_src = (p,)

@@ -1111,4 +1111,4 @@ extern "C" const char* cnc_error_string(int code)
     }
 }
 
-extern "C" int cnc_abi_version(void) { return 30; }
+extern "C" int cnc_abi_version(void) { return 31; }

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(kAdamThreads) void k_table_adam(cnc_adam_tables_t a
     const cnc_adam_table_t& T = a.table[t];
     const uint64_t          base = (uint64_t)(blockIdx.x - a.first_block[t]) * kAdamPerBlock;
     if (blockIdx.x == a.first_block[t] && threadIdx.x == 0 && T.step) *T.step += 1.0f;    // the optimizer's step count
+    uint32_t clipped = 0;
 #pragma unroll
     for (uint32_t r = 0; r < 4; r++) {
         const uint64_t i = base + ((uint64_t)r * kAdamThreads + threadIdx.x) * kAdamVec;
@@ -72,6 +73,16 @@ __global__ __launch_bounds__(kAdamThreads) void k_table_adam(cnc_adam_tables_t a
             *reinterpret_cast<float4*>(T.p + i) = p;
             *reinterpret_cast<float4*>(T.m + i) = m;
             *reinterpret_cast<float4*>(T.v + i) = v;
+            if (T.sign_bits) {
+                // cnc_pack_sign_bits' byte: 8 consecutive elements = this lane's four and the next lane's (consecutive lanes
+                // hold consecutive float4s; n is a multiple of 8 and a block starts at a multiple of 4,096, so the pair
+                // never straddles a wave or the table's end)
+                const uint32_t nib = (p.x >= 0 ? 1u : 0u) | (p.y >= 0 ? 2u : 0u) | (p.z >= 0 ? 4u : 0u) | (p.w >= 0 ? 8u : 0u);
+                const uint32_t hi = (uint32_t)__shfl_down((int)nib, 1);
+                if ((threadIdx.x & 1u) == 0) T.sign_bits[i >> 3] = (uint8_t)(nib | hi << 4);
+                clipped += !(p.x >= -1.0f && p.x <= 1.0f) + !(p.y >= -1.0f && p.y <= 1.0f) + !(p.z >= -1.0f && p.z <= 1.0f) +
+                           !(p.w >= -1.0f && p.w <= 1.0f);
+            }
         } else {
             for (uint64_t j = i; j < T.n; j++) {
                 float g = 0.f;
@@ -88,6 +99,7 @@ __global__ __launch_bounds__(kAdamThreads) void k_table_adam(cnc_adam_tables_t a
             }
         }
     }
+    if (T.sign_bits && T.clip_count && clipped) atomicAdd(T.clip_count, clipped);      // rare: |p| > 1 after the update
 }
 
 }   // namespace cnc
@@ -102,6 +114,7 @@ extern "C" int cnc_table_adam(const cnc_adam_tables_t* tables, double lr, double
         const cnc_adam_table_t& T = a.table[t];
         if (!T.p || !T.m || !T.v || T.n == 0) return CNC_ERR_INVALID_VALUE;
         if (((uintptr_t)T.p | (uintptr_t)T.m | (uintptr_t)T.v) & 15) return CNC_ERR_INVALID_VALUE;
+        if (T.sign_bits && (T.n & 7)) return CNC_ERR_INVALID_VALUE;
         for (uint32_t k = 0; k < 4; k++) {
             if (!T.g[k]) continue;
             const bool hi_ok = (T.g_hi[k] & 3) == 0 || T.g_hi[k] == T.n;

@@ -392,7 +392,7 @@ class Trainer:
         self.table_adam = None
         if one_pass and not self.dp and os.environ.get("CNC_TABLE_ADAM", "1") == "1" \
                 and all(t.numel() % 4 == 0 for t in tables):
-            self.table_adam = _table_adam.TableAdam(self.opt, tables)
+            self.table_adam = _table_adam.TableAdam(self.opt, tables, self.field.mlp_base._encoders())
         self.fused_table_adam = self.table_adam is not None
 
         def sched(o):
@@ -815,6 +815,8 @@ class Trainer:
         self.opt.step()
         if c.lmbda > 0:
             self.opt2.step()
+        if self.table_adam is not None and table_pieces is not None:
+            self.table_adam.mark_planes_current()      # (the two steps above dropped every cache: the tables' planes stand)
         self.sched.step()
         if c.lmbda > 0:
             self.sched2.step()

@@ -629,7 +629,8 @@ int cnc_rows_scatter(const float* values, const int64_t* rows, float* table, uin
  * m += (1 - b1)(g + wd p - m); v = b2 v + (1 - b2) g^2; p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps),
  * scalar factors in double.  `step` = the count of THIS update (>= 1); table.step, when given, is the library optimizer's
  * own device-side counter (float32) and is incremented.  Pointers 16-byte aligned; a piece covers elements [g_lo, g_hi) of
- * its table, g_lo a multiple of 4, g_hi a multiple of 4 or n.                                                          */
+ * its table, g_lo a multiple of 4, g_hi a multiple of 4 or n.  (ABI v31) the kernel can also leave the updated table's sign
+ * bit plane and clip counter behind (sign_bits / clip_count below).                                                    */
 typedef struct {
     float*       p;            /* [n] the table                                   */
     float*       m;            /* [n] exp_avg                                     */
@@ -639,6 +640,12 @@ typedef struct {
     uint64_t     g_lo[4];
     uint64_t     g_hi[4];
     uint64_t     n;
+    /* ---- ABI v31 ---- */
+    uint8_t*     sign_bits;    /* nullable (n a multiple of 8): receives cnc_pack_sign_bits' plane of the UPDATED table —
+                                  byte i = the signs (>= 0) of elements 8 i .. 8 i + 7 — so that the next forward need not
+                                  read the table again to make it                                                       */
+    uint32_t*    clip_count;   /* nullable, with sign_bits: += the number of updated elements outside [-1, 1] (the
+                                  caller zeroes it first), cnc_pack_sign_bits' counter                                  */
 } cnc_adam_table_t;
 typedef struct {
     cnc_adam_table_t table[4];

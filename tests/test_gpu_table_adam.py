@@ -90,6 +90,48 @@ def test_table_adam_against_the_library_optimizer_and_float64(cuda, wd):
         assert float((mine[k] - ref[k]).detach().abs().max()) <= 8e-7 * float(ref[k].detach().abs().max())
 
 
+def test_table_adam_leaves_the_sign_planes_of_the_updated_tables(cuda):
+    """With the encoders given, the kernel writes each updated table's sign bit plane and clip counter into the encoder's
+    cache buffers: bit for bit what cnc_pack_sign_bits makes of the updated table, the count of entries outside [-1, 1],
+    at the buffers' old addresses, and `_bit_plane` takes them as current."""
+    from cnc_amd._table_adam import TableAdam
+    from cnc_amd.backends import gridencoder_backend as be
+    from cnc_amd.gridencoder import GridEncoder
+    torch.manual_seed(2)
+    encs = [GridEncoder(num_dim=3, n_features=8, resolutions_list=(10, 18, 33), log2_hashmap_size=12, ste_binary=True).to(cuda),
+            GridEncoder(num_dim=2, n_features=8, resolutions_list=(34, 130), log2_hashmap_size=10, ste_binary=True).to(cuda)]
+    with torch.no_grad():
+        for e in encs:
+            e.params.uniform_(-1.2, 1.2)                       # some beyond +-1, some that the update will carry across
+            e.invalidate_caches()
+    planes = [e._bit_plane(e.params) for e in encs]            # creates the cache buffers
+    where = [(b.data_ptr(), c.data_ptr()) for b, c in planes]
+    tables = [e.params for e in encs]
+    other = torch.nn.Parameter(torch.ones(3, device=cuda))
+    opt = torch.optim.Adam([{"params": [other]}, {"params": tables}], lr=0.3, eps=1e-15, fused=True)
+    ta = TableAdam(opt, tables, encs)
+    for step in range(3):
+        ta.step({id(p): [(torch.randn_like(p), None)] for p in tables})
+        other.grad = torch.ones_like(other)
+        opt.step()                                             # its post-step hook drops every cache ...
+        ta.mark_planes_current()                               # ... the tables' planes stand
+        torch.cuda.synchronize()
+        for e, (b_at, c_at) in zip(encs, where):
+            bits, clip = e._bit_plane(e.params)                # taken from the cache: no repack
+            assert (bits.data_ptr(), clip.data_ptr()) == (b_at, c_at)
+            want_clip = torch.zeros(1, dtype=torch.int32, device=cuda)
+            want = be.pack_sign_bits(e.params.detach(), None, want_clip)
+            assert torch.equal(bits, want) and int(clip) == int(want_clip) == int((e.params.abs() > 1).sum())
+            assert int(clip) > 0
+    # without the follow-up call the hook's invalidation stands and the plane is repacked from the table (same contents)
+    ta.step({id(p): [(torch.randn_like(p), None)] for p in tables})
+    opt.step()
+    assert all(e._bits_key is None for e in encs)
+    for e in encs:
+        bits, clip = e._bit_plane(e.params)
+        assert torch.equal(bits, be.pack_sign_bits(e.params.detach())) and int(clip) == int((e.params.abs() > 1).sum())
+
+
 def test_table_adam_refuses_what_it_cannot_do(cuda):
     from cnc_amd import _lib
     from cnc_amd._table_adam import TableAdam
