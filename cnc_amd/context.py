@@ -1293,7 +1293,7 @@ class CNC_context_models(nn.Module):
         bits_per_param = ttl_bit_sum / ttl_num_sum
         # second value: the estimate in MB as a Python float like the reference (a device->host sync), or — with
         # sync_MB=False — the 0-dim device tensor, for callers that only read it when they log
-        est_MB = ttl_bit_sum.detach() / 8 / 1024 / 1024
+        est_MB = ttl_bit_sum.detach() * (1.0 / 8388608.0)        # / 8 / 1024 / 1024: a power of two, one op, same value
         return bits_per_param, (est_MB.item() if sync_MB else est_MB)
 
     # ------------------------------------------------------------------------------- encode

@@ -542,7 +542,7 @@ class Trainer:
                 e_ = self.field.mlp_base
                 n_all = sum(t.params.numel() for t in e_._encoders())
                 bits_per_param = bits_per_param.detach() + pg.step_bits / n_all
-                mb = mb + pg.step_bits / 8 / 1024 / 1024
+                mb = mb + pg.step_bits * (1.0 / 8388608.0)         # / 8 / 1024 / 1024 (a power of two: same value)
             done = side.record_event()
         return bits_per_param, mb, done, grads
 
