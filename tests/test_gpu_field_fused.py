@@ -321,3 +321,46 @@ def test_fused_field_rgb_against_float64_at_full_size(cuda):
     assert np.abs(rgb.cpu().numpy() - rgb64).max() <= 1e-4
     assert np.abs(den.cpu().numpy()[:, 0] - den64).max() <= 1e-4 * den64.max()
     assert rgb64.std() > 0.01
+
+
+@pytest.mark.parametrize("kernel", ["w2", "w1"])
+@pytest.mark.parametrize("cfg", ["f8_full", "f2_toy"])
+def test_fused_field_with_a_row_count_on_the_device(cuda, cfg, kernel):
+    """cnc_fused_field_t.n_rows_dev: the call works on min(N, count) rows, the count read on the device — the rows in front of
+    it get the values of an exactly sized call bit for bit, nothing behind it is touched (positions there may be garbage), a
+    count beyond the capacity is the capacity, a count of zero does nothing.  Density-only and colour calls, both kernels,
+    and the exact-fp32 form."""
+    from cnc_amd import _lib
+    f = _field(cuda, CONFIGS[cfg], seed=6)
+    f.fused_field_kernel = kernel
+    cap = 7013
+    x, d = _inputs(cuda, cap, seed=8)
+    for precision in ("f16x3", "f32"):
+        f.fused_field_precision = precision
+        with torch.no_grad():
+            ff = f._fused_forward(x)
+            assert ff is not None
+            for count in (0, 1, 31, 32, 4097, cap, cap + 50):
+                n = min(count, cap)
+                xg = x.clone()
+                xg[n:] = float("nan")                           # what lies behind the count is never read
+                n_dev = torch.tensor([count], dtype=torch.int64, device=cuda)
+                want_den = ff(x[:n]) if n else x.new_zeros((0, 1))
+                want_den2, want_rgb = ff(x[:n], d[:n]) if n else (x.new_zeros((0, 1)), x.new_zeros((0, 3)))
+                # outputs are allocated by the call: poison the allocator's next blocks through a first, discarded call
+                got_den = ff(xg, n_rows_dev=n_dev)
+                got_den2, got_rgb = ff(xg, d, n_rows_dev=n_dev)
+                assert got_den.shape == (cap, 1) and got_rgb.shape == (cap, 3)
+                assert torch.equal(got_den[:n], want_den) and torch.equal(got_den2[:n], want_den2)
+                assert torch.equal(got_rgb[:n], want_rgb)
+        # rows behind the count keep what the buffers held: call the C entry on buffers of our own
+        import ctypes
+        with torch.no_grad():
+            st, keep, _ = ff._descriptor(x.device, False)
+            den = torch.full((cap, 1), -7.0, device=cuda)
+            n_dev = torch.tensor([100], dtype=torch.int64, device=cuda)
+            st.n_rows_dev = n_dev.data_ptr()
+            _lib.check(_lib.lib().cnc_field_fused_forward(ctypes.byref(st), x.data_ptr(), None, cap, den.data_ptr(), None,
+                                                          _lib.stream(x.device)), "field_fused_forward")
+            torch.cuda.synchronize()
+            assert bool((den[100:] == -7.0).all()) and torch.equal(den[:100], ff(x[:100]))

@@ -472,3 +472,44 @@ def test_premarched_sampling_equals_the_call_that_marches_itself(cuda):
     torch.manual_seed(11)
     fresh = est.sampling(o, d, sigma_fn=sigma, **kw)
     assert fresh[0].numel() != want[0].numel()
+
+
+def test_window_positions_and_counted_scatter(cuda):
+    """cnc_ray_window_positions / cnc_scatter_counted (the sampler's depth windows with their sample count left on the device):
+    positions = o + (d (t0 + t1)) / 2 of samples [first, first + n) of every ray, packed by the running sum of n, with the
+    samples' own indices — bit-equal to cnc_sample_positions on the compacted window — and the scatter back stops at the count."""
+    from cnc_amd.backends import nerfacc_cuda as C
+    from cnc_amd.backends import volrend_backend as K
+    g = torch.Generator(device=cuda).manual_seed(4)
+    n_rays = 777
+    counts = torch.randint(0, 40, (n_rays,), device=cuda, generator=g)
+    counts[5] = 0
+    starts = torch.cumsum(counts, 0) - counts
+    n = int(counts.sum())
+    t0 = torch.rand(n, device=cuda, generator=g) * 4
+    t1 = t0 + torch.rand(n, device=cuda, generator=g) * 0.01
+    o = torch.randn(n_rays, 3, device=cuda, generator=g)
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=cuda, generator=g), dim=-1)
+    first = (torch.rand(n_rays, device=cuda, generator=g) * (counts + 1)).long().clamp_max(counts)
+    take = torch.minimum(torch.full_like(counts, 9), counts - first)
+    ends = torch.cumsum(take, 0)
+    total = int(ends[-1])
+    cap = total + 123
+    pos, src = K.window_positions(starts, first, take, ends, t0, t1, o, d, cap)
+    ri, ts, te, src_ref = K.window_samples(starts, first, take, t0, t1, total, ends=ends)
+    want, _ = C.sample_positions(o, d, ri, ts, te, want_dirs=True)
+    assert torch.equal(pos[:total], want) and torch.equal(src[:total], src_ref)
+    assert torch.equal(src_ref, torch.cat([torch.arange(int(starts[r] + first[r]), int(starts[r] + first[r] + take[r]),
+                                                        device=cuda) for r in range(n_rays)]))
+    values = torch.rand(cap, device=cuda, generator=g)
+    for count in (0, 17, total, total + 1000):
+        out = torch.full((n,), -1.0, device=cuda)
+        src_all = torch.cat([src[:total], torch.zeros(cap - total, dtype=torch.int64, device=cuda)])   # garbage behind the count
+        K.scatter_counted(out, src_all, values, torch.tensor([count], dtype=torch.int64, device=cuda))
+        k = min(count, cap)                                      # a count beyond the capacity is the capacity
+        ref = torch.full((n,), -1.0, device=cuda)
+        ref[src_all[:min(k, total)]] = values[:min(k, total)]
+        if k > total:               # rows [total, k) all point at sample 0 here: which of their values lands there is open
+            assert float(out[0]) in set(values[total:k].tolist()) | {float(ref[0])}
+            out[0] = ref[0]
+        assert torch.equal(out, ref)
