@@ -166,7 +166,9 @@ __global__ __launch_bounds__(64) void k_mlp_forward(MlpArgs p)
         const float*   a_row = my_row < p.N ? p.X + (size_t)my_row * p.ldx : nullptr;
 
         f32x4 acc[kMaxTiles];
-        const uint32_t kv = p.K0 | (p.a_vec ? 0x80000000u : 0u);
+        // (the vector path reads the row's K0p floats — into the row behind it when K0 < K0p — so the matrix's LAST row,
+        // which has none, takes the guarded loads: X may be a column window of a wider matrix that ends with the buffer)
+        const uint32_t kv = p.K0 | ((p.a_vec && my_row + 1 < p.N) ? 0x80000000u : 0u);
         if constexpr (NT0 > 0) layer_nt<true, true, NT0>(nullptr, 0, p.K0p, p.W[0], p.B[0], acc, lane, a_row, kv);
         else layer<true, true>(nullptr, 0, p.K0p, p.W[0], p.B[0], p.Hp[0], acc, lane, a_row, kv);
         acc_to_lds(h1_lds, ld1, p.Hp[0], acc, lane);
@@ -311,7 +313,8 @@ __device__ __forceinline__ void acc_to_lds32(float* __restrict__ dst, uint32_t l
 template <int NT, int T>
 __device__ __forceinline__ void layer32_first_xT(uint32_t Kp, const float* __restrict__ W,
                                                  f32x16 (&acc)[T][kMaxTiles32], uint32_t lane,
-                                                 const float* const (&rows)[T], uint32_t k_valid)
+                                                 const float* const (&rows)[T], uint32_t k_valid,
+                                                 const float* __restrict__ last_row)
 {
     const uint32_t i = lane & 31, h = lane >> 5;
     const uint32_t lane_off = i * Kp + h * 4;
@@ -332,7 +335,7 @@ __device__ __forceinline__ void layer32_first_xT(uint32_t Kp, const float* __res
         float4 v{0, 0, 0, 0};
         const uint32_t k = kb + h * 4;
         if (a_row) {
-            if (a_vec) {
+            if (a_vec && a_row != last_row) {       // (the matrix's last row has no row behind it to read into)
                 v = *reinterpret_cast<const float4*>(a_row + k);
                 if (k + 4 > k_real) {
                     if (k >= k_real) v.x = 0;
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(64) void k_mlp_forward64(MlpArgs p)
         const uint32_t kv = p.K0 | (p.a_vec ? 0x80000000u : 0u);
 
         f32x16 accT[T][kMaxTiles32], acc[kMaxTiles32];
-        layer32_first_xT<NT0, T>(p.K0p, p.W[0], accT, lane, rows, kv);
+        layer32_first_xT<NT0, T>(p.K0p, p.W[0], accT, lane, rows, kv, p.X + (size_t)(p.N - 1) * p.ldx);
 #pragma unroll
         for (int half = 0; half < T; half++) {
             const uint32_t base_row = row0 + half * 32;

@@ -295,7 +295,9 @@ int cnc_cnt_np_embed_planned_masked(const uint32_t* rows_by_pixel, const int32_t
 /* Y[N, n_out] = W3 relu(W2 relu(W1 x + b1) + b2) + b3 (W3 == NULL: two layers), fp32 on
  * v_mfma_f32_16x16x4_f32, activations kept in LDS.  X [N, K0] with row stride ldx.  Weights are
  * passed PADDED: W_l [Hp_l, Kp_l] row-major zero-filled, b_l [Hp_l], Kp_0 = roundup16(K0),
- * Kp_l = Hp_{l-1}, Hp_l = roundup16(H_l) <= 160.                                                */
+ * Kp_l = Hp_{l-1}, Hp_l = roundup16(H_l) <= 160.  X may be a column window of a wider matrix: rows that are
+ * 16-byte aligned with ldx >= Kp_0 are read Kp_0 floats at a time (into the row behind them), the matrix's last row only
+ * up to K0.                                                                                    */
 /* The same network on v_mfma_f32_32x32x2_f32: 32-row tiles, two of them per wave through the first
  * layer so that its weight fragments are fetched once per 64 rows.  Padding: Hp_l multiples of
  * 32, Kp_0 = roundup8(K0), Kp_l = Hp_{l-1}.  Only (160, 96) and (160, 160, 32) are instantiated (the
