@@ -36,9 +36,10 @@ def test_fused_mlp_forward_matches_torch(cuda, dims, N):
     for l in seq:
         ref = torch.relu(ref) if isinstance(l, nn.ReLU) else ref @ l.weight.double().t() + l.bias.double()
     assert (got.double() - ref).abs().max() <= 2e-5 * scale
-    # strided input view (columns of a wider matrix) and weight update tracking.  (A fresh segment for `wide`: at N = 2^16
-    # and 16 columns it is exactly 4 MiB — the window's last row then ends with the mapping, and a kernel that read the
-    # padded K of THAT row faulted: the round-6 fix of both kernels' vector loads.)
+    # strided input view (columns of a wider matrix) and weight update tracking.  (At N = 2^16 and 16 columns `wide` is
+    # exactly 4 MiB: in a fresh segment the window's last row ends with the allocation, and a kernel that read the padded K
+    # of THAT row faulted whenever nothing was mapped behind it — behind tests/test_gpu_march.py on some boxes; round 6 took
+    # that read out of both kernels.  The fresh segment makes the case likelier, it cannot force the mapping.)
     torch.cuda.empty_cache()
     wide = torch.randn(N, dims[0] + 9, device=cuda)
     assert torch.allclose(fused(wide[:, 4:4 + dims[0]]), seq(wide[:, 4:4 + dims[0]]), rtol=0, atol=2e-5 * float(scale) + 1e-4)
