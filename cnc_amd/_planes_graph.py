@@ -99,40 +99,52 @@ class PlanesGraph:
         leaves = [e.params.detach().requires_grad_() for e in encs]
         leaf_fin = exyz.params.detach()[o0:o1].requires_grad_()
         g = None
-        if record:
-            g = torch.cuda.CUDAGraph()
-            # (not `with torch.cuda.graph(...)`: that synchronises the device and empties the allocator's cache on entry —
-            # the render pass is running on its own thread and stream next to this)
-            # ONE memory pool for every recording of this object: a graph records into a private pool, and a pool of its own
-            # per recording left ~0.5 GB reserved behind every occupancy refresh (18 -> 31 GB over 24 refreshes; the
-            # allocator only returns a dead graph's pool under memory pressure) and a hipMalloc of that size inside every
-            # recording step — 25-35 ms for that step on some boxes.  The previous graph is dropped above, so its blocks are
-            # free in the pool when this one records.
-            # (A pool handle may only be passed again while a graph that records into it is alive: a one-kernel graph recorded
-            # once holds it for this object's lifetime.)
-            if self._pool is None:
-                pool, keeper = torch.cuda.graph_pool_handle(), torch.cuda.CUDAGraph()
-                keeper.capture_begin(pool=pool, capture_error_mode="thread_local")
-                try:
-                    self._keeper_out = torch.zeros(1, device=exyz.params.device)
-                finally:
-                    keeper.capture_end()
-                self._pool, self._keeper = pool, keeper
-            g.capture_begin(pool=self._pool, capture_error_mode="thread_local")
+        # No garbage collection while the stream records: a collection that runs into ANOTHER PlanesGraph's dead cycle (a
+        # Trainer a test has dropped) destroys a graph and releases its pool from this thread in the middle of the
+        # recording, which the runtime refuses — and a destructor that fails ends the process (seen once the test files ran
+        # in another order).  Reference counts still free what this method itself lets go of.
+        import gc
+        gc_was_on = record and gc.isenabled()
+        if gc_was_on:
+            gc.disable()
         try:
-            with torch.autograd.set_multithreading_enabled(False):
-                pq = [STE_binary.apply(t) for t in leaves]
-                fin = STE_binary.apply(leaf_fin)
-                bits, n2 = ctxm._bits_2D(*encs, *pq, fin, tr.estimator.binaries, ctxm._binary_2D, ctxm.idx_coords2_tmp, False)
-                root = c.lmbda * (bits / n_total) * tr.loss_scale
-                # the WHOLE graph (torch.autograd.grad with the leaves as inputs would skip every node that does not lead to
-                # them: the encoders' and the heads' backward, whose gradients go into the sink, not to autograd)
-                root.backward()
-                grads = [t.grad for t in leaves + [leaf_fin]]
-                bits = bits.detach()
+            if record:
+                g = torch.cuda.CUDAGraph()
+                # (not `with torch.cuda.graph(...)`: that synchronises the device and empties the allocator's cache on entry —
+                # the render pass is running on its own thread and stream next to this)
+                # ONE memory pool for every recording of this object: a graph records into a private pool, and a pool of its own
+                # per recording left ~0.5 GB reserved behind every occupancy refresh (18 -> 31 GB over 24 refreshes; the
+                # allocator only returns a dead graph's pool under memory pressure) and a hipMalloc of that size inside every
+                # recording step — 25-35 ms for that step on some boxes.  The previous graph is dropped above, so its blocks are
+                # free in the pool when this one records.
+                # (A pool handle may only be passed again while a graph that records into it is alive: a one-kernel graph recorded
+                # once holds it for this object's lifetime.)
+                if self._pool is None:
+                    pool, keeper = torch.cuda.graph_pool_handle(), torch.cuda.CUDAGraph()
+                    keeper.capture_begin(pool=pool, capture_error_mode="thread_local")
+                    try:
+                        self._keeper_out = torch.zeros(1, device=exyz.params.device)
+                    finally:
+                        keeper.capture_end()
+                    self._pool, self._keeper = pool, keeper
+                g.capture_begin(pool=self._pool, capture_error_mode="thread_local")
+            try:
+                with torch.autograd.set_multithreading_enabled(False):
+                    pq = [STE_binary.apply(t) for t in leaves]
+                    fin = STE_binary.apply(leaf_fin)
+                    bits, n2 = ctxm._bits_2D(*encs, *pq, fin, tr.estimator.binaries, ctxm._binary_2D, ctxm.idx_coords2_tmp, False)
+                    root = c.lmbda * (bits / n_total) * tr.loss_scale
+                    # the WHOLE graph (torch.autograd.grad with the leaves as inputs would skip every node that does not lead to
+                    # them: the encoders' and the heads' backward, whose gradients go into the sink, not to autograd)
+                    root.backward()
+                    grads = [t.grad for t in leaves + [leaf_fin]]
+                    bits = bits.detach()
+            finally:
+                if g is not None:
+                    g.capture_end()
         finally:
-            if g is not None:
-                g.capture_end()
+            if gc_was_on:
+                gc.enable()
         targets = [e.params for e in encs] + [exyz.params]
         pairs = []
         for k, (p, gr) in enumerate(zip(targets, grads)):
